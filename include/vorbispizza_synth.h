@@ -1,0 +1,186 @@
+/*
+ * vorbispizza_synth.h -- C ABI of the MI355X-native Vorbis PCM-synthesis back end.
+ *
+ * This is the drop-in boundary for ONE hot path of TechPizzaDev/VorbisPizza (C#): everything that
+ * happens to a packet after its CPU entropy decode (Mapping.cs:109-163) until PCM leaves
+ * StreamDecoder.Read:  inverse coupling -> Floor1 curve x residue -> inverse MDCT ->
+ * window + overlap-add -> clip -> interleaved / planar store.
+ *
+ * The reference has no FFI seam for this path (the callee types are `internal`); each entry point
+ * below names the reference call it replaces.  A C# host binds these with
+ * [DllImport("vorbispizza_synth", CallingConvention = CallingConvention.Cdecl)] exactly as
+ * NVorbis.Tests/Bindings/Vorbisfile.cs:43-107 binds libvorbisfile.
+ *
+ * Conventions (mirroring that binding): cdecl, POD structs with sequential layout, `int` status
+ * returns (0 = OK, < 0 = error), caller-owned I/O buffers valid for the duration of the call, opaque
+ * handles owned by the caller (SafeHandle on the C# side).  The library never calls back into the
+ * host and never throws.  A context / decoder is used from one thread at a time; distinct contexts
+ * (one per GPU) may run concurrently.  There is NO CPU fallback: every compute entry point fails
+ * with VPZ_E_NO_DEVICE / VPZ_E_HIP when no gfx950 device is usable.
+ */
+#ifndef VORBISPIZZA_SYNTH_H
+#define VORBISPIZZA_SYNTH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPZ_ABI_VERSION 1
+
+/* ---- status codes (negative like the OV_* codes, Vorbisfile.cs:10-24) ---- */
+#define VPZ_OK                 0
+#define VPZ_E_INVALID_ARG     (-1)  /* null pointer, bad size, bad index */
+#define VPZ_E_UNSUPPORTED     (-2)  /* block size / layout this build has no kernel for */
+#define VPZ_E_HIP             (-3)  /* HIP runtime error; text via vpz_context_last_error */
+#define VPZ_E_NOMEM           (-4)
+#define VPZ_E_WINDOW_MISMATCH (-5)  /* previous tail longer than the window slope:
+                                       StreamDecoder.cs:777-778 would throw */
+#define VPZ_E_NO_DEVICE       (-6)
+#define VPZ_E_CAPACITY        (-7)  /* output buffer too small for the samples produced */
+
+/* ---- where caller pointers live ---- */
+#define VPZ_MEM_HOST   0   /* host memory (what a pinned C# array is); call is synchronous */
+#define VPZ_MEM_DEVICE 1   /* device memory on the context's GPU; call is asynchronous on the
+                              context stream, order with vpz_context_synchronize */
+
+typedef struct vpz_context vpz_context;   /* one GPU + one HIP stream + tables */
+typedef struct vpz_decoder vpz_decoder;   /* synthesis state of a group of streams */
+
+int         vpz_abi_version(void);
+const char *vpz_error_string(int status);
+
+/* Number of usable devices (0 when there is no GPU); never fails. */
+int vpz_device_count(void);
+
+/* Context = what `Mdct._setupCache` (Mdct.cs:13) and `StreamDecoder._blockSizeCache`
+ * (StreamDecoder.cs:29,226-229) are in the reference: immutable per-block-size tables, plus the
+ * device stream the work runs on. */
+int  vpz_context_create(int device_id, vpz_context **out);
+void vpz_context_destroy(vpz_context *ctx);
+int  vpz_context_synchronize(vpz_context *ctx);
+const char *vpz_context_last_error(vpz_context *ctx);
+/* hipStream_t of the context (for callers that time with their own events) */
+void *vpz_context_stream(vpz_context *ctx);
+/* HIP-event timer on the context stream: start .. stop brackets whatever was enqueued between. */
+int vpz_context_timer_start(vpz_context *ctx);
+int vpz_context_timer_stop(vpz_context *ctx, float *elapsed_ms);
+
+/* Device memory helpers so a host without its own HIP binding can keep batches resident. */
+int vpz_device_alloc(vpz_context *ctx, uint64_t bytes, void **dev_ptr);
+int vpz_device_free(vpz_context *ctx, void *dev_ptr);
+int vpz_memcpy_h2d(vpz_context *ctx, void *dev_dst, const void *host_src, uint64_t bytes);
+int vpz_memcpy_d2h(vpz_context *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * vpz_imdct_batch  ==  `Mdct.Reverse(samples, buf2, n)` (Mdct.cs:15-19) applied to `count` rows.
+ * spectra: [count][n/2] float32 (the first half of each reference `samples` span);
+ * out:     [count][n]   float32 (the whole span after the call).  n is a power of two,
+ * 64 <= n <= 8192 (Vorbis block sizes).  n = 64/128 reproduce the reference's literal (non-IMDCT)
+ * output, quirk q1 of SURVEY.md 7.2.  `mode`: VPZ_IMDCT_FAST uses the wavefront FFT factorisation
+ * (<= 1e-5 abs error for |PCM| <= 1; n = 256 and 2048 only, falls back to EXACT otherwise);
+ * VPZ_IMDCT_EXACT runs the reference's own butterfly schedule (Mdct.cs:98-414) and is bit-identical
+ * to it.
+ * ------------------------------------------------------------------------------------------ */
+#define VPZ_IMDCT_FAST  0
+#define VPZ_IMDCT_EXACT 1
+int vpz_imdct_batch(vpz_context *ctx, int n, int64_t count, const float *spectra, float *out,
+                    int mem_space, int mode);
+
+/* ------------------------------------------------------------------------------------------
+ * Stream configuration: the setup-header products the synthesis path reads.
+ * ------------------------------------------------------------------------------------------ */
+#define VPZ_MAX_FLOOR1_POSTS 65
+#define VPZ_POSTS_STRIDE     64   /* `Data.Posts = new int[64]`, Floor1.cs:17 */
+#define VPZ_MAX_CHANNELS     255
+#define VPZ_MAX_COUPLING     256
+
+typedef struct vpz_floor1_config {        /* Floor1.cs:30-31 (`_xList`, `_multiplier`) */
+    int32_t x_count;                      /* length of _xList, 2..65 */
+    int32_t multiplier;                   /* _multiplier, 1..4 (range = {256,128,86,64}) */
+    int32_t x_list[VPZ_MAX_FLOOR1_POSTS]; /* _xList in bitstream order; the library derives
+                                             _lNeigh/_hNeigh/_sortIdx as Floor1.cs:108-149 does */
+} vpz_floor1_config;
+
+typedef struct vpz_mapping_config {       /* Mapping.cs:11-15 */
+    int32_t coupling_steps;
+    uint8_t coupling_magnitude[VPZ_MAX_COUPLING];
+    uint8_t coupling_angle[VPZ_MAX_COUPLING];
+    uint8_t channel_floor[VPZ_MAX_CHANNELS + 1]; /* _submapFloor[_mux[ch]] per channel */
+} vpz_mapping_config;
+
+typedef struct vpz_stream_config {
+    int32_t channels;                     /* StreamDecoder._channels */
+    int32_t block_size0, block_size1;     /* BlockSizes.Size0 / Size1 */
+    int32_t floor_count;
+    const vpz_floor1_config *floors;
+    int32_t mapping_count;
+    const vpz_mapping_config *mappings;
+    int32_t clip_samples;                 /* StreamDecoder.ClipSamples (StreamDecoder.cs:993) */
+} vpz_stream_config;
+
+/* One audio packet as the CPU stage leaves it at Mapping.cs:163. */
+#define VPZ_PKT_BLOCK_FLAG   0x01  /* Mode._blockFlag */
+#define VPZ_PKT_PREV_FLAG    0x02  /* Mode.cs:39 first bit  (long blocks only) */
+#define VPZ_PKT_NEXT_FLAG    0x04  /* Mode.cs:39 second bit (long blocks only) */
+#define VPZ_PKT_EOS          0x08  /* packet.IsEndOfStream -> EndOfStreamFlags.PacketFlag */
+#define VPZ_PKT_NOT_DECODED  0x10  /* DecodeNextPacket returned null (StreamDecoder.cs:758-761) */
+#define VPZ_PKT_INTERLEAVED  0x20  /* residue is the Residue2 vector [n/2][channels]
+                                      (Residue2.cs:31-34) instead of planar [channels][n/2] */
+#define VPZ_PKT_NO_FLOOR     0x40  /* residue already is the floored spectrum: skip coupling and
+                                      Floor1 (boundary variant "between Mapping.cs:187 and :188") */
+typedef struct vpz_packet {
+    int32_t stream;          /* 0 .. n_streams-1 */
+    uint8_t flags;           /* VPZ_PKT_* */
+    uint8_t mapping;         /* index into vpz_stream_config.mappings (Mode._mapping) */
+    uint16_t reserved;
+    int64_t granule;         /* packet.GranulePosition, -1 if none (StreamDecoder.cs:744) */
+    int64_t residue_offset;  /* float index of this packet's residue in the `residue` buffer:
+                                channels * blocksize/2 floats */
+} vpz_packet;
+
+/* Output placement == the two public Read overloads (Contracts/IStreamDecoder.cs:126,151). */
+#define VPZ_OUT_INTERLEAVED 0   /* StoreInterleaved: dst[i*channels + ch]            */
+#define VPZ_OUT_PLANAR      1   /* StoreContiguous : dst[ch*channel_stride + off + i] */
+
+int  vpz_decoder_create(vpz_context *ctx, const vpz_stream_config *cfg, int32_t n_streams,
+                        vpz_decoder **out);
+void vpz_decoder_destroy(vpz_decoder *dec);
+/* `StreamDecoder.ResetDecoder` (StreamDecoder.cs:357-369) for one stream; stream < 0 = all. */
+int  vpz_decoder_reset(vpz_decoder *dec, int32_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * vpz_decoder_synth == for each packet, in order:  Mapping.DecodePacket tail (Mapping.cs:166-195)
+ * + StreamDecoder.ReadNextPacket / OverlapBuffers (StreamDecoder.cs:640-694, 764-791) + the
+ * Store* call of Read (:474-489), i.e. everything `while (idx == 0)` does for that packet.
+ *
+ * packets[n_packets]: packets of one stream must appear in stream order; streams may interleave.
+ * residue: float32, addressed by vpz_packet.residue_offset.
+ * posts / post_counts: per packet p and channel c, record r = p*channels + c:
+ *   post_counts[r] = Floor1.Data.PostCount (0 => ExecuteChannel false, channel outputs zeros),
+ *   posts[r*64 + i] = Floor1.Data.Posts[i] as `Unpack` left them (raw, before UnwrapPosts).
+ *   Both may be NULL when every packet has VPZ_PKT_NO_FLOOR.
+ * pcm_out: stream s writes at pcm_out + stream_out_offset[s] (float index; NULL offsets = all 0),
+ *   interleaved [sample][channel] or planar with `channel_stride` floats between channels.
+ *   At most stream_out_capacity samples per channel are written per stream.
+ * samples_written[n_streams]: samples per channel produced by this call (host memory, always).
+ *   The count is final when the call returns even in VPZ_MEM_DEVICE mode (it is computed by the
+ *   host-side state machine); the PCM itself is ready after vpz_context_synchronize.
+ * ------------------------------------------------------------------------------------------ */
+int vpz_decoder_synth(vpz_decoder *dec, int64_t n_packets, const vpz_packet *packets,
+                      const float *residue, const int16_t *posts, const uint8_t *post_counts,
+                      int mem_space,
+                      float *pcm_out, const int64_t *stream_out_offset, int64_t stream_out_capacity,
+                      int out_layout, int64_t channel_stride,
+                      int64_t *samples_written);
+
+/* `StreamDecoder.HasClipped` (StreamDecoder.cs:1001); synchronises the context. */
+int vpz_decoder_has_clipped(vpz_decoder *dec, int32_t stream, int32_t *has_clipped);
+/* `_currentPosition` after the last synth call (StreamDecoder.cs:493) */
+int vpz_decoder_position(vpz_decoder *dec, int32_t stream, int64_t *sample_position);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VORBISPIZZA_SYNTH_H */

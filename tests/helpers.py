@@ -1,0 +1,119 @@
+"""Shared test helpers: workload generators and the oracle-side driver that
+plays the role vpz_decoder_synth plays on the GPU."""
+import ctypes as C
+
+import numpy as np
+
+PKT_BLOCK_FLAG, PKT_PREV_FLAG, PKT_NEXT_FLAG, PKT_EOS = 0x01, 0x02, 0x04, 0x08
+PKT_NOT_DECODED, PKT_INTERLEAVED, PKT_NO_FLOOR = 0x10, 0x20, 0x40
+
+# X list of a libvorbis 44.1 kHz long-block floor1 (29 posts, the shape 3test.ogg's long floor has)
+LONG_XLIST = [0, 1024, 93, 23, 372, 6, 46, 186, 750, 14, 33, 65, 130, 260, 556, 3, 10, 18, 28, 39, 55,
+              79, 111, 158, 220, 312, 464, 650, 850]
+SHORT_XLIST = [0, 128, 12, 46, 4, 8, 16, 23, 33, 70, 2, 6, 10, 14, 19, 28, 39, 58, 90]
+
+
+def markov_block_flags(frames, seed, p_ls=0.1, p_sl=0.3, start_long=True):
+    """Config 3 block-flag chain: p(long->short)=0.1, p(short->long)=0.3; returns the packet flag
+    bytes with prev/next window flags made mutually consistent (StreamDecoder.cs:654,778)."""
+    rng = np.random.default_rng(seed)
+    u = rng.random(frames)
+    bf = np.zeros(frames, dtype=np.uint8)
+    cur = 1 if start_long else 0
+    for i in range(frames):
+        bf[i] = cur
+        cur = (0 if u[i] < p_ls else 1) if cur else (1 if u[i] < p_sl else 0)
+    prev = np.concatenate([[1], bf[:-1]])
+    nxt = np.concatenate([bf[1:], [1]])
+    return (bf * PKT_BLOCK_FLAG | prev * PKT_PREV_FLAG * bf | nxt * PKT_NEXT_FLAG * bf).astype(np.uint8)
+
+
+def gaussian_spectra(shape, seed, sigma=2.0 ** -8):
+    return (np.random.default_rng(seed).standard_normal(shape) * sigma).astype(np.float32)
+
+
+def oracle_decode(orc, channels, size0, size1, packets, floors=(), mappings=(), clip=False,
+                  interleave=False):
+    """Runs one stream through the oracle.  packets: list of dicts with keys
+    flags, granule (default -1), mapping (default 0), residue (np [channels*half] as laid out for the
+    ABI), posts (np [channels, <=64]), post_count (np [channels]).  Returns PCM [channels, T] or [T, channels]."""
+    L = orc.lib()
+    st = L.orc_stream_create(channels, size0, size1)
+    L.orc_stream_reset(st)
+    ofl = [orc.floor1_init(xl, mult) for (xl, mult) in floors]
+    chunks = []
+    eos_seen = False
+
+    def take():
+        n = L.orc_stream_available(st)
+        if n <= 0:
+            return
+        if interleave:
+            buf = np.zeros((n, channels), dtype=np.float32)
+            L.orc_stream_store(st, buf.ctypes.data_as(C.POINTER(C.c_float)), 0, n, 0, 1, int(clip))
+            chunks.append(buf.T.copy())
+        else:
+            buf = np.zeros((channels, n), dtype=np.float32)
+            L.orc_stream_store(st, buf.ctypes.data_as(C.POINTER(C.c_float)), 0, n, n, 0, int(clip))
+            chunks.append(buf)
+
+    for pk in packets:
+        if eos_seen and L.orc_stream_available(st) == 0:
+            break  # Read(): nothing more is read after EOS (StreamDecoder.cs:441-447)
+        flags = pk["flags"]
+        eos = 1 if flags & PKT_EOS else 0
+        if flags & PKT_NOT_DECODED:
+            L.orc_stream_read_next_packet(st, 0, None, -1, eos)
+            if eos:
+                eos_seen = True
+                L.orc_stream_drain_eos(st)
+                take()
+            continue
+        bf = 1 if flags & PKT_BLOCK_FLAG else 0
+        n = size1 if bf else size0
+        half = n // 2
+        info = orc.packet_info(size0, size1, bf, bool(flags & PKT_PREV_FLAG), bool(flags & PKT_NEXT_FLAG))
+        res = np.asarray(pk["residue"], dtype=np.float32)
+        if flags & PKT_INTERLEAVED:
+            res = res.reshape(half, channels).T.copy()
+        else:
+            res = res.reshape(channels, half)
+        if flags & PKT_NO_FLOOR:
+            pcm = np.stack([orc.mdct_reverse(res[c][None, :], n)[0] for c in range(channels)])
+        else:
+            m = mappings[pk.get("mapping", 0)]
+            pcm = orc.mapping_synth(channels, n, res, ofl, m.get("channel_floor", [0] * channels),
+                                    pk["posts"], pk["post_count"], m.get("coupling", []))
+        p = L.orc_stream_next_buffer(st)
+        view = np.ctypeslib.as_array(p, shape=(channels, size1))
+        view[:] = 0
+        view[:, :n] = pcm
+        rc = L.orc_stream_read_next_packet(st, 1, C.byref(info), int(pk.get("granule", -1)), eos)
+        if rc < 0:
+            L.orc_stream_destroy(st)
+            raise RuntimeError("window mismatch")
+        if eos:
+            eos_seen = True
+        take()
+    pos = L.orc_stream_position(st)
+    clipped = bool(L.orc_stream_has_clipped(st))
+    L.orc_stream_destroy(st)
+    pcm = np.concatenate(chunks, axis=1) if chunks else np.zeros((channels, 0), dtype=np.float32)
+    return (pcm.T.copy() if interleave else pcm), pos, clipped
+
+
+def random_posts(rng, xlist, multiplier, n_ch, silent_prob=0.0):
+    """Raw floor1 posts as `Floor1.Unpack` leaves them: two absolute values then residuals."""
+    rng_range = {1: 256, 2: 128, 3: 86, 4: 64}[multiplier]
+    posts = np.zeros((n_ch, 64), dtype=np.int16)
+    counts = np.zeros(n_ch, dtype=np.uint8)
+    for c in range(n_ch):
+        if rng.random() < silent_prob:
+            continue
+        counts[c] = len(xlist)
+        posts[c, 0] = rng.integers(rng_range // 4, rng_range // 2)
+        posts[c, 1] = rng.integers(rng_range // 8, rng_range // 3)
+        vals = rng.integers(0, 12, size=len(xlist) - 2)
+        vals[rng.random(len(vals)) < 0.35] = 0
+        posts[c, 2:len(xlist)] = vals
+    return posts, counts

@@ -1,0 +1,73 @@
+"""CPU-side checks of the C-ABI shared library: it loads, exports every symbol the header declares,
+and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as ge
+    ge.build()
+    from vorbispizza_amd import capi as m
+    m.lib()
+    return m
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "vorbispizza_synth.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vpz_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(capi):
+    syms = header_symbols()
+    assert len(syms) >= 20
+    L = C.CDLL(capi.LIB_PATH)
+    for s in syms:
+        assert hasattr(L, s), "missing export " + s
+    assert sorted(capi.EXPORTED_SYMBOLS) == syms
+
+
+def test_abi_version_and_error_strings(capi):
+    L = capi.lib()
+    assert L.vpz_abi_version() == 1
+    assert L.vpz_error_string(0) == b"ok"
+    for code in range(-7, 0):
+        assert L.vpz_error_string(code) not in (b"ok", b"unknown status")
+
+
+def test_struct_layouts_match_header(capi):
+    assert C.sizeof(capi.Packet) == 24
+    assert C.sizeof(capi.Floor1Config) == 4 * (2 + 65)
+    assert C.sizeof(capi.MappingConfig) == 4 + 256 + 256 + 256
+
+
+def test_no_cpu_fallback(capi):
+    """Without a GPU the library must fail loudly instead of computing on the host."""
+    L = capi.lib()
+    if L.vpz_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    h = C.c_void_p()
+    assert L.vpz_context_create(0, C.byref(h)) == capi.E_NO_DEVICE
+    assert not h.value
+    with pytest.raises(capi.SynthError):
+        capi.Context(0)
+    x = np.zeros((1, 1024), dtype=np.float32)
+    y = np.zeros((1, 2048), dtype=np.float32)
+    assert L.vpz_imdct_batch(None, 2048, 1, x.ctypes.data, y.ctypes.data, 0, 0) == capi.E_INVALID_ARG
+
+
+def test_product_does_not_touch_oracle():
+    """The shipped package must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "vorbispizza_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "orc_" not in text and "import oracle" not in text and "liboracle" not in text, f

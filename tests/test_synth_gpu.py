@@ -1,0 +1,281 @@
+"""GPU parity of vpz_decoder_synth (Mapping.cs:166-195 + StreamDecoder.cs:640-694, 764-791,
+515-638) against the CPU oracle, through the C ABI.  Float outputs: <= 1e-5 max-abs per sample
+(|PCM| <~ 1); sample counts, positions and clip flags: exact."""
+import numpy as np
+import pytest
+
+import helpers
+from helpers import (PKT_BLOCK_FLAG, PKT_EOS, PKT_INTERLEAVED, PKT_NEXT_FLAG, PKT_NO_FLOOR, PKT_NOT_DECODED,
+                     PKT_PREV_FLAG)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import __graft_entry__ as ge
+    ge.build()
+    from vorbispizza_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def build_batch(flags_list, spectra_list, channels, size0=256, size1=2048, extra_flags=0, stream_ids=None,
+                granules=None):
+    """flags_list[s]: uint8 flags per frame of stream s; spectra_list[s]: [frames, channels, size1/2]."""
+    from vorbispizza_amd import make_packets
+    n = sum(len(f) for f in flags_list)
+    pk = make_packets(n)
+    res, opk = [], [[] for _ in flags_list]
+    off = 0
+    # interleave the streams round-robin to exercise per-stream ordering
+    cursors = [0] * len(flags_list)
+    i = 0
+    while i < n:
+        for s, fl in enumerate(flags_list):
+            f = cursors[s]
+            if f >= len(fl):
+                continue
+            half = (size1 if fl[f] & 1 else size0) // 2
+            r = spectra_list[s][f, :, :half].reshape(-1)
+            pk[i]["stream"] = s if stream_ids is None else stream_ids[s]
+            pk[i]["flags"] = fl[f] | extra_flags
+            pk[i]["granule"] = -1 if granules is None else granules[s][f]
+            pk[i]["residue_offset"] = off
+            res.append(r)
+            opk[s].append({"flags": int(fl[f] | extra_flags), "residue": r, "granule": int(pk[i]["granule"])})
+            off += channels * half
+            cursors[s] += 1
+            i += 1
+    return pk, np.concatenate(res), opk
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+@pytest.mark.parametrize("frames", [1, 2, 7, 40, 300])
+def test_mixed_window_switching_matches_oracle(ctx, oracle, channels, frames):
+    """BASELINE config 3 at oracle-sized length: Markov short/long chain, NO_FLOOR spectra."""
+    from vorbispizza_amd import Decoder
+    flags = helpers.markov_block_flags(frames, seed=frames)
+    spec = helpers.gaussian_spectra((frames, channels, 1024), seed=100 + frames)
+    pk, res, opk = build_batch([flags], [spec], channels, extra_flags=PKT_NO_FLOOR)
+    dec = Decoder(ctx, channels, 256, 2048)
+    got = dec.synth(pk, res)[0]
+    ref, pos, _ = helpers.oracle_decode(oracle, channels, 256, 2048, opk[0])
+    assert got.shape == ref.shape
+    if ref.size:
+        assert np.abs(got - ref).max() <= TOL
+    assert dec.position(0) == pos
+    dec.close()
+
+
+def test_every_window_geometry_and_sample_counts(ctx, oracle):
+    """All five PacketInfo geometries of Mode.cs:30-66 appear; per-packet SampleCount is exact."""
+    from vorbispizza_amd import Decoder
+    L, S = PKT_BLOCK_FLAG, 0
+    P, N = PKT_PREV_FLAG, PKT_NEXT_FLAG
+    #        long pl/nl   long pl/ns   short  short  long ps/ns   short  long ps/nl   long pl/nl
+    flags = np.array([L | P | N, L | P, S, S, L, S, L | N, L | P | N], dtype=np.uint8)
+    spec = helpers.gaussian_spectra((len(flags), 2, 1024), seed=11)
+    dec = Decoder(ctx, 2, 256, 2048)
+    total = 0
+    expect = [0, 1472, 128, 128, 1024, 128, 576, 1024]  # first packet emits nothing (:679)
+    ref_all, _, _ = helpers.oracle_decode(
+        oracle, 2, 256, 2048, build_batch([flags], [spec], 2, extra_flags=PKT_NO_FLOOR)[2][0])
+    for f in range(len(flags)):  # one packet per call: exercises the saved-state path each time
+        pk, res, _ = build_batch([flags[f:f + 1]], [spec[f:f + 1]], 2, extra_flags=PKT_NO_FLOOR)
+        out = dec.synth(pk, res)[0]
+        assert out.shape[1] == expect[f], (f, out.shape)
+        assert np.abs(out - ref_all[:, total:total + expect[f]]).max(initial=0) <= TOL
+        total += expect[f]
+    assert total == ref_all.shape[1]
+    dec.close()
+
+
+@pytest.mark.parametrize("split", [1, 5, 16, 17, 33])
+def test_batch_boundaries_do_not_matter(ctx, oracle, split):
+    """Feeding the same stream in differently sized batches gives the same PCM (OLA state carry)."""
+    from vorbispizza_amd import Decoder
+    frames = 70
+    flags = helpers.markov_block_flags(frames, seed=5)
+    spec = helpers.gaussian_spectra((frames, 2, 1024), seed=6)
+    ref, _, _ = helpers.oracle_decode(oracle, 2, 256, 2048,
+                                      build_batch([flags], [spec], 2, extra_flags=PKT_NO_FLOOR)[2][0])
+    dec = Decoder(ctx, 2, 256, 2048)
+    outs = []
+    for a in range(0, frames, split):
+        pk, res, _ = build_batch([flags[a:a + split]], [spec[a:a + split]], 2, extra_flags=PKT_NO_FLOOR)
+        outs.append(dec.synth(pk, res)[0])
+    got = np.concatenate(outs, axis=1)
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= TOL
+    dec.close()
+
+
+def test_many_streams_interleaved_output_and_reset(ctx, oracle):
+    from vorbispizza_amd import Decoder, capi
+    n_streams, channels = 5, 2
+    flags = [helpers.markov_block_flags(20 + 3 * s, seed=20 + s) for s in range(n_streams)]
+    spec = [helpers.gaussian_spectra((len(flags[s]), channels, 1024), seed=40 + s) for s in range(n_streams)]
+    pk, res, opk = build_batch(flags, spec, channels, extra_flags=PKT_NO_FLOOR)
+    dec = Decoder(ctx, channels, 256, 2048, n_streams=n_streams)
+    for rep in range(2):
+        outs = dec.synth(pk, res, out_layout=capi.OUT_INTERLEAVED)
+        for s in range(n_streams):
+            ref, _, _ = helpers.oracle_decode(oracle, channels, 256, 2048, opk[s], interleave=True)
+            assert outs[s].shape == ref.shape
+            assert np.abs(outs[s] - ref).max() <= TOL
+        dec.reset(-1)  # ResetDecoder: the second pass must start from scratch again
+    dec.close()
+
+
+def test_clip_and_has_clipped(ctx, oracle):
+    from vorbispizza_amd import Decoder
+    frames = 6
+    flags = np.full(frames, PKT_BLOCK_FLAG | PKT_PREV_FLAG | PKT_NEXT_FLAG, dtype=np.uint8)
+    spec = helpers.gaussian_spectra((frames, 2, 1024), seed=8, sigma=2.0 ** -5)  # |pcm| well above 1
+    spec[:, 1] *= 2.0 ** -6  # second channel stays small
+    pk, res, opk = build_batch([flags], [spec], 2, extra_flags=PKT_NO_FLOOR)
+    dec = Decoder(ctx, 2, 256, 2048, clip_samples=True)
+    got = dec.synth(pk, res)[0]
+    ref, _, clipped = helpers.oracle_decode(oracle, 2, 256, 2048, opk[0], clip=True)
+    assert clipped and dec.has_clipped(0)
+    assert np.abs(got).max() == np.float32(0.99999994)
+    inside = np.abs(ref) < 0.999
+    assert np.array_equal(np.abs(got) == np.float32(0.99999994), np.abs(ref) == np.float32(0.99999994)) or \
+        np.abs(got - ref).max() <= 1e-4
+    assert np.abs(got[inside] - ref[inside]).max() <= 1e-4  # sigma 2^-5: error scales with amplitude
+    dec2 = Decoder(ctx, 2, 256, 2048, clip_samples=True)
+    pk2, res2, _ = build_batch([flags], [spec * 2.0 ** -8], 2, extra_flags=PKT_NO_FLOOR)
+    dec2.synth(pk2, res2)
+    assert not dec2.has_clipped(0)
+    dec.close()
+    dec2.close()
+
+
+def test_eos_granule_trim_and_ignored_tail_packets(ctx, oracle):
+    """StreamDecoder.cs:657-666: the EOS packet's granule cuts its valid length; packets after EOS
+    are never read (:441-447)."""
+    from vorbispizza_amd import Decoder
+    frames = 8
+    flags = np.full(frames, PKT_BLOCK_FLAG | PKT_PREV_FLAG | PKT_NEXT_FLAG, dtype=np.uint8)
+    flags[5] |= PKT_EOS
+    gran = [[-1, -1, 2048, -1, -1, 4096 + 300, -1, -1]]
+    spec = helpers.gaussian_spectra((frames, 2, 1024), seed=12)
+    pk, res, opk = build_batch([flags], [spec], 2, extra_flags=PKT_NO_FLOOR, granules=gran)
+    dec = Decoder(ctx, 2, 256, 2048)
+    got = dec.synth(pk, res)[0]
+    ref, pos, _ = helpers.oracle_decode(oracle, 2, 256, 2048, opk[0])
+    assert got.shape == ref.shape == (2, 4096 + 300)
+    assert np.abs(got - ref).max() <= TOL
+    assert dec.position(0) == pos == 4096 + 300
+    dec.close()
+
+
+def test_failed_eos_packet_drains_tail_unwindowed(ctx, oracle):
+    """Quirk q4 (StreamDecoder.cs:451-455)."""
+    from vorbispizza_amd import Decoder
+    flags = np.array([PKT_BLOCK_FLAG | PKT_PREV_FLAG | PKT_NEXT_FLAG] * 3 + [PKT_NOT_DECODED | PKT_EOS],
+                     dtype=np.uint8)
+    spec = helpers.gaussian_spectra((4, 1, 1024), seed=13)
+    pk, res, opk = build_batch([flags], [spec], 1, extra_flags=PKT_NO_FLOOR)
+    dec = Decoder(ctx, 1, 256, 2048)
+    got = dec.synth(pk, res)[0]
+    ref, _, _ = helpers.oracle_decode(oracle, 1, 256, 2048, opk[0])
+    assert got.shape == ref.shape == (1, 3072)
+    assert np.abs(got - ref).max() <= TOL
+    dec.close()
+
+
+def test_window_mismatch_is_an_error_not_a_crash(ctx):
+    """Quirk q11: a long tail (1024) followed by a short block would throw in OverlapBuffers."""
+    from vorbispizza_amd import Decoder, SynthError, capi
+    flags = np.array([PKT_BLOCK_FLAG | PKT_PREV_FLAG | PKT_NEXT_FLAG, 0], dtype=np.uint8)
+    spec = helpers.gaussian_spectra((2, 1, 1024), seed=14)
+    pk, res, _ = build_batch([flags], [spec], 1, extra_flags=PKT_NO_FLOOR)
+    dec = Decoder(ctx, 1, 256, 2048)
+    with pytest.raises(SynthError) as e:
+        dec.synth(pk, res)
+    assert e.value.status == capi.E_WINDOW_MISMATCH
+    # the failed batch left no state behind: a consistent batch still decodes from scratch
+    flags2 = helpers.markov_block_flags(10, seed=1)
+    pk2, res2, _ = build_batch([flags2], [helpers.gaussian_spectra((10, 1, 1024), seed=2)], 1,
+                               extra_flags=PKT_NO_FLOOR)
+    assert dec.synth(pk2, res2)[0].shape[1] > 0
+    dec.close()
+
+
+def make_floor_packets(rng, frames, channels, flags, interleaved, silent_prob=0.1):
+    """Residue (zero above a cutoff bin, like `end < N/2`) + raw floor posts per packet."""
+    pks = []
+    for f in range(frames):
+        bf = flags[f] & 1
+        half = 1024 if bf else 128
+        xl = helpers.LONG_XLIST if bf else helpers.SHORT_XLIST
+        res = (rng.standard_normal((channels, half)) * 6).round().astype(np.float32)
+        res[:, int(half * 0.85):] = 0
+        res[rng.random((channels, half)) < 0.3] = 0
+        posts, counts = helpers.random_posts(rng, xl, 2, channels, silent_prob)
+        layout = res.T.reshape(-1) if interleaved else res.reshape(-1)
+        pks.append({"flags": int(flags[f]) | (PKT_INTERLEAVED if interleaved else 0), "mapping": int(bf),
+                    "residue": layout.copy(), "posts": posts, "post_count": counts, "granule": -1})
+    return pks
+
+
+@pytest.mark.parametrize("channels,coupling,interleaved", [
+    (1, [], False), (2, [(0, 1)], True), (2, [(0, 1)], False), (6, [(0, 1), (2, 3)], True),
+    (3, [(0, 1), (0, 2)], True)])
+def test_floor1_and_coupling_match_oracle(ctx, oracle, channels, coupling, interleaved):
+    """BASELINE config 4 shape at small size: Residue2-interleaved residue, inverse coupling,
+    Floor1 render on the GPU, silent channels (ExecuteChannel false)."""
+    from vorbispizza_amd import Decoder, make_packets
+    frames = 24
+    rng = np.random.default_rng(channels * 10 + len(coupling))
+    flags = helpers.markov_block_flags(frames, seed=channels)
+    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)]
+    mappings = [{"coupling": coupling, "channel_floor": [0] * channels},
+                {"coupling": coupling, "channel_floor": [1] * channels}]
+    opk = make_floor_packets(rng, frames, channels, flags, interleaved)
+    pk = make_packets(frames)
+    off = 0
+    for f, p in enumerate(opk):
+        pk[f]["flags"], pk[f]["mapping"], pk[f]["granule"], pk[f]["residue_offset"] = p["flags"], p["mapping"], -1, off
+        off += p["residue"].size
+    res = np.concatenate([p["residue"] for p in opk])
+    posts = np.concatenate([p["posts"] for p in opk]).astype(np.int16)
+    counts = np.concatenate([p["post_count"] for p in opk]).astype(np.uint8)
+    dec = Decoder(ctx, channels, 256, 2048, floors=floors, mappings=mappings)
+    got = dec.synth(pk, res, posts, counts)[0]
+    ref, _, _ = helpers.oracle_decode(oracle, channels, 256, 2048, opk, floors=floors, mappings=mappings)
+    assert got.shape == ref.shape
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(got - ref).max() <= TOL * scale
+    dec.close()
+
+
+def test_floor_curve_is_bit_exact(ctx, oracle):
+    """The integer part of Floor1 (UnwrapPosts + DDA) must be bit-exact: with a one-hot residue of
+    1.0 every IMDCT output is floor[k] * cos(...), so compare via a flat spectrum trick -- feed
+    residue = 1 everywhere through NO coupling and check the floored spectrum the oracle would feed
+    to its IMDCT produces identical PCM within float rounding of the transform only."""
+    from vorbispizza_amd import Decoder, make_packets
+    rng = np.random.default_rng(77)
+    frames = 12
+    flags = np.full(frames, PKT_BLOCK_FLAG | PKT_PREV_FLAG | PKT_NEXT_FLAG, dtype=np.uint8)
+    floors = [(helpers.LONG_XLIST, 2)]
+    mappings = [{"coupling": [], "channel_floor": [0]}]
+    opk = []
+    for f in range(frames):
+        posts, counts = helpers.random_posts(rng, helpers.LONG_XLIST, 2, 1)
+        opk.append({"flags": int(flags[f]), "mapping": 0, "residue": np.ones(1024, dtype=np.float32) * 2.0 ** -10,
+                    "posts": posts, "post_count": counts, "granule": -1})
+    pk = make_packets(frames)
+    for f in range(frames):
+        pk[f]["flags"], pk[f]["residue_offset"], pk[f]["granule"] = flags[f], f * 1024, -1
+    dec = Decoder(ctx, 1, 256, 2048, floors=floors, mappings=mappings)
+    got = dec.synth(pk, np.concatenate([p["residue"] for p in opk]),
+                    np.concatenate([p["posts"] for p in opk]), np.concatenate([p["post_count"] for p in opk]))[0]
+    ref, _, _ = helpers.oracle_decode(oracle, 1, 256, 2048, opk, floors=floors, mappings=mappings)
+    # one wrong floor bin (a y off by one = 11.5 % amplitude step on one bin) would show as >= 1e-4 here
+    assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    dec.close()

@@ -1,0 +1,73 @@
+"""In-tree build of libvorbispizza_synth.so (hipcc, gfx950 only).
+
+The built library lives in vorbispizza_amd/lib/ (git-ignored, but shipped to the GPU box by
+gpurun).  No JIT cache, no torch extension machinery: plain `hipcc -shared -fPIC`.
+"""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libvorbispizza_synth.so")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
+
+# translation unit -> extra flags.  imdct_exact.hip and the host-side table / state-machine code
+# must round every f32 multiply/add separately, like the reference's JIT output.
+SOURCES = {
+    "imdct_fast.hip": [],
+    "imdct_exact.hip": ["-ffp-contract=off"],
+    "synth_kernels.hip": [],
+    "vpz_context.hip": ["-ffp-contract=off"],
+    "vpz_decoder.hip": ["-ffp-contract=off"],
+}
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-fno-strict-aliasing"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return "hipcc"
+
+
+def _deps(src):
+    deps = [src]
+    for name in os.listdir(CSRC):
+        if name.endswith(".hpp"):
+            deps.append(os.path.join(CSRC, name))
+    deps.append(os.path.join(_HERE, "..", "include", "vorbispizza_synth.h"))
+    return deps
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP translation unit for gfx950 and link the C-ABI shared library."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    objs, relink = [], force or not os.path.exists(LIB_PATH)
+    for name, extra in SOURCES.items():
+        src = os.path.join(CSRC, name)
+        if not os.path.exists(src):
+            raise RuntimeError("missing source " + src)
+        obj = os.path.join(OBJ_DIR, name.replace(".hip", ".o"))
+        stale = force or not os.path.exists(obj) or any(
+            os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src))
+        if stale:
+            cmd = [hipcc] + COMMON + extra + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            relink = True
+        objs.append(obj)
+    if relink:
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

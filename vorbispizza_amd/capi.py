@@ -1,0 +1,276 @@
+"""ctypes binding of include/vorbispizza_synth.h -- the same entry points a C# host P/Invokes.
+
+There is no CPU fallback: if the shared library is missing the import raises, and every compute
+call raises SynthError when no MI355X is usable.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvorbispizza_synth.so")
+
+OK = 0
+E_INVALID_ARG, E_UNSUPPORTED, E_HIP, E_NOMEM, E_WINDOW_MISMATCH, E_NO_DEVICE, E_CAPACITY = -1, -2, -3, -4, -5, -6, -7
+MEM_HOST, MEM_DEVICE = 0, 1
+IMDCT_FAST, IMDCT_EXACT = 0, 1
+OUT_INTERLEAVED, OUT_PLANAR = 0, 1
+PKT_BLOCK_FLAG, PKT_PREV_FLAG, PKT_NEXT_FLAG, PKT_EOS = 0x01, 0x02, 0x04, 0x08
+PKT_NOT_DECODED, PKT_INTERLEAVED, PKT_NO_FLOOR = 0x10, 0x20, 0x40
+MAX_FLOOR1_POSTS, POSTS_STRIDE, MAX_CHANNELS, MAX_COUPLING = 65, 64, 255, 256
+
+
+class Floor1Config(C.Structure):
+    _fields_ = [("x_count", C.c_int32), ("multiplier", C.c_int32), ("x_list", C.c_int32 * MAX_FLOOR1_POSTS)]
+
+
+class MappingConfig(C.Structure):
+    _fields_ = [("coupling_steps", C.c_int32),
+                ("coupling_magnitude", C.c_uint8 * MAX_COUPLING),
+                ("coupling_angle", C.c_uint8 * MAX_COUPLING),
+                ("channel_floor", C.c_uint8 * (MAX_CHANNELS + 1))]
+
+
+class StreamConfig(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("block_size0", C.c_int32), ("block_size1", C.c_int32),
+                ("floor_count", C.c_int32), ("floors", C.POINTER(Floor1Config)),
+                ("mapping_count", C.c_int32), ("mappings", C.POINTER(MappingConfig)),
+                ("clip_samples", C.c_int32)]
+
+
+class Packet(C.Structure):
+    _fields_ = [("stream", C.c_int32), ("flags", C.c_uint8), ("mapping", C.c_uint8),
+                ("reserved", C.c_uint16), ("granule", C.c_int64), ("residue_offset", C.c_int64)]
+
+
+PACKET_DTYPE = np.dtype([("stream", "<i4"), ("flags", "u1"), ("mapping", "u1"), ("reserved", "<u2"),
+                         ("granule", "<i8"), ("residue_offset", "<i8")])
+assert PACKET_DTYPE.itemsize == C.sizeof(Packet) == 24
+
+# every symbol include/vorbispizza_synth.h declares: (name, restype, argtypes)
+_vp = C.c_void_p
+_SIGNATURES = [
+    ("vpz_abi_version", C.c_int, []),
+    ("vpz_error_string", C.c_char_p, [C.c_int]),
+    ("vpz_device_count", C.c_int, []),
+    ("vpz_context_create", C.c_int, [C.c_int, C.POINTER(_vp)]),
+    ("vpz_context_destroy", None, [_vp]),
+    ("vpz_context_synchronize", C.c_int, [_vp]),
+    ("vpz_context_last_error", C.c_char_p, [_vp]),
+    ("vpz_context_stream", _vp, [_vp]),
+    ("vpz_context_timer_start", C.c_int, [_vp]),
+    ("vpz_context_timer_stop", C.c_int, [_vp, C.POINTER(C.c_float)]),
+    ("vpz_device_alloc", C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
+    ("vpz_device_free", C.c_int, [_vp, _vp]),
+    ("vpz_memcpy_h2d", C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    ("vpz_memcpy_d2h", C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    ("vpz_imdct_batch", C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, C.c_int, C.c_int]),
+    ("vpz_decoder_create", C.c_int, [_vp, C.POINTER(StreamConfig), C.c_int32, C.POINTER(_vp)]),
+    ("vpz_decoder_destroy", None, [_vp]),
+    ("vpz_decoder_reset", C.c_int, [_vp, C.c_int32]),
+    ("vpz_decoder_synth", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int64,
+                                    C.c_int, C.c_int64, _vp]),
+    ("vpz_decoder_has_clipped", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int32)]),
+    ("vpz_decoder_position", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64)]),
+]
+EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+_lib = None
+
+
+class SynthError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        name = lib().vpz_error_string(status).decode()
+        super().__init__("vorbispizza_synth: %s (%d)%s" % (name, status, (": " + detail) if detail else ""))
+
+
+def lib():
+    """Load libvorbispizza_synth.so (built in-tree by vorbispizza_amd._build.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libvorbispizza_synth.so is not built: run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, restype, argtypes in _SIGNATURES:
+            fn = getattr(L, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if _is_torch(x):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(x.ctypes.data)
+
+
+class Context:
+    """vpz_context: one GPU, one HIP stream, the per-block-size tables."""
+
+    def __init__(self, device=0):
+        self._h = _vp()
+        rc = lib().vpz_context_create(device, C.byref(self._h))
+        if rc != OK:
+            self._h = None
+            raise SynthError(rc, "vpz_context_create(device=%d)" % device)
+        self.device = device
+
+    def _check(self, rc):
+        if rc != OK:
+            raise SynthError(rc, lib().vpz_context_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib().vpz_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(lib().vpz_context_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return lib().vpz_context_stream(self._h)
+
+    def timer_start(self):
+        self._check(lib().vpz_context_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._check(lib().vpz_context_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def imdct_batch(self, spectra, n, mode=IMDCT_FAST, out=None):
+        """`Mdct.Reverse` (Mdct.cs:15-19) per row.  numpy in -> numpy out (host memory, synchronous);
+        torch cuda tensor in -> torch cuda tensor out (device memory, asynchronous on the context stream)."""
+        half = n // 2
+        if _is_torch(spectra):
+            import torch
+            assert spectra.is_cuda and spectra.dtype == torch.float32 and spectra.is_contiguous()
+            count = spectra.numel() // half
+            if out is None:
+                out = torch.empty((count, n), dtype=torch.float32, device=spectra.device)
+            self._check(lib().vpz_imdct_batch(self._h, n, count, _ptr(spectra), _ptr(out), MEM_DEVICE, mode))
+            return out
+        spectra = np.ascontiguousarray(spectra, dtype=np.float32).reshape(-1, half)
+        count = spectra.shape[0]
+        if out is None:
+            out = np.empty((count, n), dtype=np.float32)
+        self._check(lib().vpz_imdct_batch(self._h, n, count, _ptr(spectra), _ptr(out), MEM_HOST, mode))
+        return out
+
+
+def make_packets(count):
+    return np.zeros(count, dtype=PACKET_DTYPE)
+
+
+class Decoder:
+    """vpz_decoder: synthesis state of `n_streams` streams that share one setup header."""
+
+    def __init__(self, ctx, channels, block_size0, block_size1, floors=(), mappings=(), n_streams=1,
+                 clip_samples=False):
+        """floors: [(x_list, multiplier)], mappings: [{"coupling": [(mag, ang)], "channel_floor": [..]}]"""
+        self.ctx = ctx
+        self.channels, self.size0, self.size1, self.n_streams = channels, block_size0, block_size1, n_streams
+        fl = (Floor1Config * max(1, len(floors)))()
+        for i, (xl, mult) in enumerate(floors):
+            if len(xl) > MAX_FLOOR1_POSTS:
+                raise SynthError(E_INVALID_ARG, "floor1 X list too long")
+            fl[i].x_count = len(xl)
+            fl[i].multiplier = mult
+            for j, x in enumerate(xl):
+                fl[i].x_list[j] = int(x)
+        mp = (MappingConfig * max(1, len(mappings)))()
+        for i, m in enumerate(mappings):
+            cp = m.get("coupling", [])
+            mp[i].coupling_steps = len(cp)
+            for j, (mag, ang) in enumerate(cp):
+                mp[i].coupling_magnitude[j] = mag
+                mp[i].coupling_angle[j] = ang
+            for c, f in enumerate(m.get("channel_floor", [0] * channels)):
+                mp[i].channel_floor[c] = f
+        cfg = StreamConfig(channels, block_size0, block_size1, len(floors), fl, len(mappings), mp,
+                           1 if clip_samples else 0)
+        self._h = _vp()
+        rc = lib().vpz_decoder_create(ctx._h, C.byref(cfg), n_streams, C.byref(self._h))
+        if rc != OK:
+            self._h = None
+            raise SynthError(rc, lib().vpz_context_last_error(ctx._h).decode())
+
+    def close(self):
+        if self._h:
+            lib().vpz_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, stream=-1):
+        self.ctx._check(lib().vpz_decoder_reset(self._h, stream))
+
+    def synth_raw(self, packets, residue, posts, post_counts, pcm_out, stream_out_offset, capacity,
+                  out_layout, channel_stride, mem_space):
+        """Thin call of vpz_decoder_synth; returns samples_written (int64 array, per stream)."""
+        written = np.zeros(self.n_streams, dtype=np.int64)
+        packets = np.ascontiguousarray(packets, dtype=PACKET_DTYPE)
+        offs = None if stream_out_offset is None else np.ascontiguousarray(stream_out_offset, dtype=np.int64)
+        rc = lib().vpz_decoder_synth(self._h, len(packets), _ptr(packets), _ptr(residue), _ptr(posts),
+                                     _ptr(post_counts), mem_space, _ptr(pcm_out), _ptr(offs), capacity,
+                                     out_layout, channel_stride, _ptr(written))
+        self.ctx._check(rc)
+        return written
+
+    def synth(self, packets, residue, posts=None, post_counts=None, out_layout=OUT_PLANAR, capacity=None):
+        """Host-memory convenience: returns a list (per stream) of PCM arrays, [channels, samples]
+        for OUT_PLANAR or [samples, channels] for OUT_INTERLEAVED."""
+        packets = np.ascontiguousarray(packets, dtype=PACKET_DTYPE)
+        residue = np.ascontiguousarray(residue, dtype=np.float32)
+        if posts is not None:
+            posts = np.ascontiguousarray(posts, dtype=np.int16)
+            post_counts = np.ascontiguousarray(post_counts, dtype=np.uint8)
+        if capacity is None:
+            per = np.zeros(self.n_streams, dtype=np.int64)
+            for s, f in zip(packets["stream"], packets["flags"]):
+                per[s] += (self.size1 if f & PKT_BLOCK_FLAG else self.size0)
+            capacity = int(per.max()) + 1
+        C_ = self.channels
+        out = np.zeros(self.n_streams * C_ * capacity, dtype=np.float32)
+        offs = np.arange(self.n_streams, dtype=np.int64) * (C_ * capacity)
+        written = self.synth_raw(packets, residue, posts, post_counts, out, offs, capacity, out_layout,
+                                 capacity, MEM_HOST)
+        res = []
+        for s in range(self.n_streams):
+            blk = out[offs[s]: offs[s] + C_ * capacity]
+            if out_layout == OUT_PLANAR:
+                res.append(blk.reshape(C_, capacity)[:, :written[s]].copy())
+            else:
+                res.append(blk[: written[s] * C_].reshape(written[s], C_).copy())
+        return res
+
+    def has_clipped(self, stream=0):
+        v = C.c_int32()
+        self.ctx._check(lib().vpz_decoder_has_clipped(self._h, stream, C.byref(v)))
+        return bool(v.value)
+
+    def position(self, stream=0):
+        v = C.c_int64()
+        self.ctx._check(lib().vpz_decoder_position(self._h, stream, C.byref(v)))
+        return v.value

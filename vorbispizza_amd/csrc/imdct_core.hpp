@@ -1,0 +1,180 @@
+// Wavefront-level inverse MDCT cores for gfx950 (wave64).
+//
+// The reference computes the IMDCT with stb_vorbis' in-place radix-2 schedule (Mdct.cs:77-419).
+// Here it is re-factored for a 64-lane wavefront (DESIGN.md "IMDCT kernel"):
+//
+//   tw[k] = exp(+2*pi*i*(k + 1/8)/N)                        k in [0, N/4)
+//   z[k]  = (X[N/2-1-2k] + i*X[2k]) * tw[k]
+//   Z     = unnormalised inverse DFT of z, length N/4        (512 points for N = 2048, 64 for 256)
+//   W[j]  = Z[j] * tw[j]
+//   h[2j] = Re W[j],  h[N/2-1-2j] = -Im W[j]                 h[m] = y[N/4 + m], m in [0, N/2)
+//   y[n]  = -h[N/4-1-n] (n < N/4),  y[3N/4+m] = h[N/2-1-m] (m < N/4)     (Mdct.cs:378-381)
+//
+// N = 2048: one wavefront per channel-block, 8 complex points per lane, three radix-8 stages with
+// two transposes through wave-private LDS.  N = 256: eight channel-blocks per wavefront (8 lanes x 8
+// points each), two radix-8 stages, one transpose.  No MFMA: this is a butterfly network.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace vpz {
+
+constexpr float kSqrtHalf = 0.70710678118654752440f;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by +i
+__device__ __forceinline__ float2 cmul_i(float2 a) { return make_float2(-a.y, a.x); }
+
+// value held by lane (63 - lane)
+__device__ __forceinline__ float lane_mirror64(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((63 - lane) << 2, __float_as_int(v)));
+}
+// value held by lane (lane ^ 7): mirror inside each group of 8 lanes
+__device__ __forceinline__ float lane_mirror8(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 7) << 2, __float_as_int(v)));
+}
+
+// In-register 8-point inverse DFT: v[p] <- sum_m v[m] * exp(+2*pi*i*p*m/8)
+__device__ __forceinline__ void radix8_inverse(float2 (&v)[8])
+{
+    float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+    float2 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+    float2 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+    float2 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+    // odd branch twiddles exp(+i*pi*m/4), m = 1, 2, 3
+    a5 = make_float2((a5.x - a5.y) * kSqrtHalf, (a5.x + a5.y) * kSqrtHalf);
+    a6 = cmul_i(a6);
+    a7 = make_float2((-a7.x - a7.y) * kSqrtHalf, (a7.x - a7.y) * kSqrtHalf);
+
+    float2 b0 = cadd(a0, a2), b2 = csub(a0, a2);
+    float2 b1 = cadd(a1, a3), b3 = cmul_i(csub(a1, a3));
+    float2 c0 = cadd(a4, a6), c2 = csub(a4, a6);
+    float2 c1 = cadd(a5, a7), c3 = cmul_i(csub(a5, a7));
+
+    v[0] = cadd(b0, b1); v[4] = csub(b0, b1);
+    v[2] = cadd(b2, b3); v[6] = csub(b2, b3);
+    v[1] = cadd(c0, c1); v[5] = csub(c0, c1);
+    v[3] = cadd(c2, c3); v[7] = csub(c2, c3);
+}
+
+// LDS floats a wavefront needs for the transposes / the h staging area.
+constexpr int kWaveScratchFloat2 = 576;  // 72*8 (stage A->B), 66*7+64 = 526 (stage B->C), 512 (h)
+
+// -------------------------------------------------------------------------------------------
+// N = 2048.  xa[m] = (X[2k], X[2k+1]) for k = lane + 64*m, already floor-multiplied if needed.
+// On return the wave-private LDS area `h` holds h[0..1024) as floats in natural order.
+//   s_tw   : 512 float2  tw[k]
+//   s_twAB : 512 float2  exp(2*pi*i*l*p/512) at [p*64 + l]
+//   s_twBC :  64 float2  exp(2*pi*i*l0*q/64) at [l0*8 + q]
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void imdct2048_wave(const float2 (&xa)[8], float2 *scratch,
+                                               const float2 *s_tw, const float2 *s_twAB,
+                                               const float2 *s_twBC, int lane)
+{
+    float2 z[8];
+    float2 tw[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) tw[m] = s_tw[lane + 64 * m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        // X[N/2-1-2k] sits in the .y half of the pair loaded by lane 63-lane for point 7-m
+        float re = lane_mirror64(xa[7 - m].y, lane);
+        z[m] = cmul(make_float2(re, xa[m].x), tw[m]);
+    }
+    // stage A: DFT over the top input digit (stride 64), output digit p
+    radix8_inverse(z);
+#pragma unroll
+    for (int p = 1; p < 8; ++p) z[p] = cmul(z[p], s_twAB[p * 64 + lane]);
+    // transpose 1: (lane l = l0 + 8*l1, reg p) -> (lane l0 + 8*p, reg l1); rows padded to 72
+#pragma unroll
+    for (int p = 0; p < 8; ++p) scratch[72 * p + lane] = z[p];
+    const int l0 = lane & 7, pp = lane >> 3;
+#pragma unroll
+    for (int l1 = 0; l1 < 8; ++l1) z[l1] = scratch[72 * pp + l0 + 8 * l1];
+    // stage B: DFT over l1, output digit q1
+    radix8_inverse(z);
+#pragma unroll
+    for (int q = 1; q < 8; ++q) z[q] = cmul(z[q], s_twBC[l0 * 8 + q]);
+    // transpose 2: (lane l0 + 8*p, reg q1) -> (lane p + 8*q1, reg l0); row stride 66
+#pragma unroll
+    for (int q = 0; q < 8; ++q) scratch[66 * l0 + pp + 8 * q] = z[q];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) z[r] = scratch[66 * r + lane];
+    // stage C: DFT over l0, output digit q0;  lane now holds Z[j], j = lane + 64*q0
+    radix8_inverse(z);
+    float wim[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float2 w = cmul(z[q], tw[q]);
+        z[q].x = w.x;
+        wim[q] = -w.y;
+    }
+    // h[2j] = Re W[j];  h[2j+1] = -Im W[N/4-1-j], held by lane 63-lane in register 7-q0
+    float *h = reinterpret_cast<float *>(scratch);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float hi = lane_mirror64(wim[7 - q], lane);
+        reinterpret_cast<float2 *>(h)[lane + 64 * q] = make_float2(z[q].x, hi);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// N = 256, eight channel-blocks per wavefront: group g = lane >> 3 owns one block, l = lane & 7.
+// xa[m] = (X[2k], X[2k+1]) for k = l + 8*m of the group's block.
+// On return h[g*128 .. g*128+128) holds the group's h in natural order.
+//   s_tw   : 64 float2 tw[k] for N = 256
+//   s_twBC : 64 float2 exp(2*pi*i*l*p/64) at [l*8 + p]   (shared with the 2048 path)
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void imdct256_wave8(const float2 (&xa)[8], float2 *scratch,
+                                               const float2 *s_tw, const float2 *s_twBC, int lane)
+{
+    const int g = lane >> 3, l = lane & 7;
+    float2 z[8];
+    float2 tw[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) tw[m] = s_tw[l + 8 * m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        float re = lane_mirror8(xa[7 - m].y, lane);
+        z[m] = cmul(make_float2(re, xa[m].x), tw[m]);
+    }
+    radix8_inverse(z);  // over m (stride 8), output digit p
+#pragma unroll
+    for (int p = 1; p < 8; ++p) z[p] = cmul(z[p], s_twBC[l * 8 + p]);
+    // transpose inside the group: (lane l, reg p) -> (lane p, reg l)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) scratch[72 * g + 8 * p + l] = z[p];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) z[r] = scratch[72 * g + 8 * l + r];
+    radix8_inverse(z);  // over l, output digit q;  lane holds Z[j], j = l + 8*q
+    float wim[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float2 w = cmul(z[q], tw[q]);
+        z[q].x = w.x;
+        wim[q] = -w.y;
+    }
+    float *h = reinterpret_cast<float *>(scratch);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float hi = lane_mirror8(wim[7 - q], lane);
+        reinterpret_cast<float2 *>(h)[g * 64 + l + 8 * q] = make_float2(z[q].x, hi);
+    }
+}
+
+// Value of the full IMDCT output y[pos] given h (natural order, N/2 floats), N = 4*n4.
+__device__ __forceinline__ float y_from_h(const float *h, int pos, int n4)
+{
+    if (pos < n4) return -h[n4 - 1 - pos];
+    if (pos < 3 * n4) return h[pos - n4];
+    return h[5 * n4 - 1 - pos];
+}
+
+}  // namespace vpz

@@ -1,0 +1,150 @@
+// Batched inverse MDCT kernels (vpz_imdct_batch, VPZ_IMDCT_FAST): `Mdct.Reverse` semantics
+// (Mdct.cs:15-19) -- N/2 spectral values in, all N time-domain values out, per channel-block.
+//
+// HBM-bound: 4*N/2 bytes read + 4*N bytes written per channel-block (12 288 B at N = 2048).
+// One wavefront per channel-block (N = 2048) or per 8 channel-blocks (N = 256); persistent
+// workgroups of 4 wavefronts grid-stride over the batch with the next block's loads in flight
+// while the current one is transformed.  All global accesses are 8 or 16 bytes per lane and each
+// wave-instruction covers one contiguous 512 B / 1 KiB span.
+#include "imdct_core.hpp"
+#include "vpz_internal.hpp"
+
+namespace vpz {
+
+constexpr int kWavesPerGroup = 4;
+constexpr int kThreads = 64 * kWavesPerGroup;
+
+// Write y (N floats) from h (N/2 floats in LDS): y = [-rev(h[0:N/4]), h, rev(h[N/4:N/2])].
+// `lanes` lanes cooperate, lane index `l`; float4 granularity, N/8 float4 of h.
+template <int N, int LANES>
+__device__ __forceinline__ void store_full_block(const float *h, float *out, int l)
+{
+    constexpr int H4 = N / 8;       // float4 count of h
+    constexpr int Q4 = N / 16;      // float4 count of a quarter block
+    const float4 *h4 = reinterpret_cast<const float4 *>(h);
+    float4 *o4 = reinterpret_cast<float4 *>(out);
+#pragma unroll
+    for (int r = 0; r < H4 / LANES; ++r) {
+        const int f = l + LANES * r;
+        float4 v = h4[f];
+        o4[Q4 + f] = v;
+        float4 rv = make_float4(v.w, v.z, v.y, v.x);
+        if (r < (H4 / LANES) / 2) {  // f < Q4: first quarter, negated mirror
+            o4[Q4 - 1 - f] = make_float4(-rv.x, -rv.y, -rv.z, -rv.w);
+        } else {                     // last quarter, mirror
+            o4[3 * Q4 + (H4 - 1 - f)] = rv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void imdct2048_kernel(const float *__restrict__ spectra,
+                                                             float *__restrict__ out,
+                                                             long count,
+                                                             const float2 *__restrict__ tables)
+{
+    __shared__ float2 s_tw[512];
+    __shared__ float2 s_twAB[512];
+    __shared__ float2 s_twBC[64];
+    __shared__ float2 s_scratch[kWavesPerGroup][kWaveScratchFloat2];
+
+    for (int i = threadIdx.x; i < 512; i += kThreads) {
+        s_tw[i] = tables[kFastTwOffset + i];
+        s_twAB[i] = tables[kFastTwABOffset + i];
+    }
+    if (threadIdx.x < 64) s_twBC[threadIdx.x] = tables[kFastTwBCOffset + threadIdx.x];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float2 *scratch = s_scratch[wave];
+    const long stride = (long)gridDim.x * kWavesPerGroup;
+    long blk = (long)blockIdx.x * kWavesPerGroup + wave;
+    if (blk >= count) return;
+
+    float2 cur[8];
+    {
+        const float2 *src = reinterpret_cast<const float2 *>(spectra + blk * 1024);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) cur[m] = src[lane + 64 * m];
+    }
+    while (true) {
+        const long nxt = blk + stride;
+        float2 pre[8];
+        if (nxt < count) {
+            const float2 *src = reinterpret_cast<const float2 *>(spectra + nxt * 1024);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) pre[m] = src[lane + 64 * m];
+        }
+        imdct2048_wave(cur, scratch, s_tw, s_twAB, s_twBC, lane);
+        store_full_block<2048, 64>(reinterpret_cast<const float *>(scratch), out + blk * 2048, lane);
+        if (nxt >= count) break;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) cur[m] = pre[m];
+        blk = nxt;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void imdct256_kernel(const float *__restrict__ spectra,
+                                                            float *__restrict__ out,
+                                                            long count,
+                                                            const float2 *__restrict__ tables)
+{
+    __shared__ float2 s_tw[64];
+    __shared__ float2 s_twBC[64];
+    __shared__ float2 s_scratch[kWavesPerGroup][kWaveScratchFloat2];
+    if (threadIdx.x < 64) {
+        s_tw[threadIdx.x] = tables[kFastTwOffset + threadIdx.x];
+        s_twBC[threadIdx.x] = tables[kFastTwBCOffset + threadIdx.x];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 3, l = lane & 7;
+    float2 *scratch = s_scratch[wave];
+    const long stride = (long)gridDim.x * kWavesPerGroup * 8;
+    // every wavefront owns 8 consecutive channel-blocks per step; tail groups clamp and skip stores
+    for (long base = ((long)blockIdx.x * kWavesPerGroup + wave) * 8; base < count; base += stride) {
+        const long blk = base + g;
+        const bool live = blk < count;
+        const long ld = live ? blk : count - 1;
+        float2 xa[8];
+        const float2 *src = reinterpret_cast<const float2 *>(spectra + ld * 128);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) xa[m] = src[l + 8 * m];
+        imdct256_wave8(xa, scratch, s_tw, s_twBC, lane);
+        if (live)
+            store_full_block<256, 8>(reinterpret_cast<const float *>(scratch) + g * 128,
+                                     out + blk * 256, l);
+    }
+}
+
+static int grid_for(int64_t work_groups, int num_cu, int groups_per_cu)
+{
+    int64_t cap = (int64_t)num_cu * groups_per_cu;
+    int64_t g = work_groups < cap ? work_groups : cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+hipError_t launch_imdct_fast_2048(const float *spectra, float *out, int64_t count,
+                                  const float2 *tw, int num_cu, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    int grid = grid_for((count + kWavesPerGroup - 1) / kWavesPerGroup, num_cu, 4);
+    hipLaunchKernelGGL(imdct2048_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out,
+                       (long)count, tw);
+    return hipGetLastError();
+}
+
+hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count,
+                                 const float2 *tw, int num_cu, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    int64_t per_group = kWavesPerGroup * 8;
+    int grid = grid_for((count + per_group - 1) / per_group, num_cu, 4);
+    hipLaunchKernelGGL(imdct256_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out,
+                       (long)count, tw);
+    return hipGetLastError();
+}
+
+}  // namespace vpz

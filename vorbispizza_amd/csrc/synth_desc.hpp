@@ -1,0 +1,85 @@
+// Device-visible descriptors of one vpz_decoder_synth batch.  The host-side state machine
+// (vpz_decoder.hip: ReadNextPacket / GetPacketInfo, integers only) resolves every packet into a
+// FrameDesc; the kernels never see stream state other than these and the saved h tails.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace vpz {
+
+// frame flags
+constexpr uint32_t kFrameLong = 1u;        // block size = size1 (else size0)
+constexpr uint32_t kFrameSlope1 = 2u;      // PacketInfo.LeftUseSize1: overlap uses the size1 slope
+constexpr uint32_t kFrameNoFloor = 8u;     // spectrum is already floored (VPZ_PKT_NO_FLOOR)
+constexpr uint32_t kFrameDrain = 4u;       // no new block: emit the previous tail un-windowed
+                                           // (StreamDecoder.cs:451-455, quirk q4)
+
+struct FrameDesc {
+    int64_t spec_off;    // float offset of channel 0's spectrum; channel c at + c*(blocksize/2)
+    int64_t out_off;     // first output sample (per channel) of this frame inside its stream
+    int32_t stream;
+    int32_t rec;         // first channel record (packet_index * channels) for exec / floor data
+    int32_t left_start;  // PacketInfo.LeftStart
+    int32_t packet_len;  // overlap length = prevStop - prevEnd (0 when there is no previous block)
+    int32_t prev_end;    // position of the previous block's tail in ITS output (prevEnd)
+    int32_t out_count;   // samples emitted per channel: rightStart' - LeftStart
+    uint32_t flags;
+    int32_t reserved;
+};
+
+// how a run obtains the block that precedes its first frame
+constexpr int32_t kPreNone = 0;     // the stream has no previous block (first packet / after reset)
+constexpr int32_t kPreState = 1;    // previous block's h is in the decoder's device state
+constexpr int32_t kPreRecompute = 2;// previous block is frame first-1 of this batch: recompute it
+constexpr uint32_t kRunSaveState = 1u;  // run ends the stream's batch: save h of its last block
+
+struct RunDesc {
+    int32_t first;       // index of the first FrameDesc
+    int32_t count;       // frames in the run
+    int32_t stream;
+    int32_t pre_kind;
+    uint32_t flags;
+    int32_t prev_long;   // kPreState: 1 if the saved block was a size1 block
+    int32_t reserved0, reserved1;
+};
+
+// Floor1 static tables on the device (Floor1.cs:30-31), one per vpz_floor1_config
+struct FloorDev {
+    int32_t x_count;
+    int32_t multiplier;
+    int32_t range;
+    int32_t reserved;
+    int16_t x_list[64];
+    uint8_t l_neigh[64];
+    uint8_t h_neigh[64];
+    uint8_t sort_idx[64];
+};
+
+struct SynthArgs {
+    const FrameDesc *frames;
+    const RunDesc *runs;
+    int32_t n_runs;
+    int32_t channels;
+    int32_t size0, size1;
+    const float *spec;          // planar spectra (caller residue or the coupling temp)
+    const uint8_t *post_counts; // [rec] PostCount; nullptr => every channel executes, no floor
+    const int16_t *final_y;     // [rec][64] unwrapped posts * multiplier (from the unwrap kernel)
+    const uint8_t *step_flags;  // [rec][64]
+    const uint8_t *rec_floor;   // [rec] floor index of the record
+    const FloorDev *floors;
+    const float *inv_db;        // 256 floats
+    float *state_h;             // [stream][channel][size1/2]
+    const float2 *tw_long;      // fast tables of size1 (BlockTables::d_fast)
+    const float2 *tw_short;     // fast tables of size0
+    const float *slope0, *slope1;
+    float *out;
+    const int64_t *stream_out_off;  // nullptr => 0
+    int64_t channel_stride;
+    int32_t interleaved;
+    int32_t clip;
+    int32_t *clipped;           // [stream] sticky HasClipped
+};
+
+}  // namespace vpz

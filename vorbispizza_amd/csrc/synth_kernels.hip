@@ -1,0 +1,510 @@
+// Fused PCM-synthesis kernels behind vpz_decoder_synth:
+//
+//   floor1_unwrap_kernel   Floor1.UnwrapPosts (Floor1.cs:270-353), one LANE per channel-record,
+//                          integer only, bit-exact.
+//   coupling_kernel        Residue2 de-interleave (Residue2.cs:42-51) + inverse square-polar
+//                          coupling (Mapping.cs:166-172, 198-269), element-wise, bit-exact.
+//   synth_kernel           per channel-block: Floor1 curve render x residue (Floor1.cs:236-262,
+//                          372-397) -> inverse MDCT (Mdct.cs) -> window + overlap-add with the
+//                          previous block (StreamDecoder.cs:764-791) -> clip (Utils.cs:44-58) ->
+//                          interleaved / planar store (StreamDecoder.cs:515-638).
+//
+// synth_kernel gives one wavefront a RUN of consecutive blocks of one channel of one stream, so
+// the previous block's output stays in LDS and the only HBM traffic is the spectrum in and the
+// PCM out (8 B per sample for long blocks).  The block before a run's first is recomputed (one
+// redundant IMDCT per run) or taken from the decoder's saved state.
+#include "imdct_core.hpp"
+#include "synth_desc.hpp"
+#include "vpz_internal.hpp"
+
+namespace vpz {
+
+constexpr int kSynthWaves = 4;
+constexpr int kSynthThreads = 64 * kSynthWaves;
+constexpr int kWaveBufFloats = 1160;  // h (<=1024 floats) | transposes (1152) | floor curve + 129 ints
+
+// ---------------------------------------------------------------------------------------------
+// Floor1.UnwrapPosts, one lane per record.  posts: raw [rec][64]; writes final_y = finalY *
+// multiplier (what Apply feeds to RenderLineMulti, Floor1.cs:237,245) and the step flags.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int iabs(int x) { int s = x >> 31; return (x ^ s) - s; }
+
+__device__ __forceinline__ int render_point(int x0, int y0, int x1, int y1, int X)
+{
+    int dy = y1 - y0;
+    int adx = x1 - x0;
+    int ady = iabs(dy);
+    int err = ady * (X - x0);
+    int off = err / adx;
+    return dy < 0 ? y0 - off : y0 + off;
+}
+
+__global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int16_t *__restrict__ posts,
+                                                          const uint8_t *__restrict__ post_counts,
+                                                          const uint8_t *__restrict__ rec_floor,
+                                                          const FloorDev *__restrict__ floors,
+                                                          int16_t *__restrict__ final_y,
+                                                          uint8_t *__restrict__ step_flags)
+{
+    __shared__ int s_y[64][64];       // [post][lane]
+    __shared__ uint8_t s_f[64][64];
+    const int lane = threadIdx.x;
+    const int rec = blockIdx.x * 64 + lane;
+    if (rec >= n_rec) return;
+    const int pc_raw = post_counts[rec];
+    if (pc_raw == 0) return;  // ExecuteChannel false: nothing to unwrap
+    const FloorDev &f = floors[rec_floor[rec]];
+    const int pc = f.x_count;  // Unpack leaves PostCount == xList.Length or 0 (Floor1.cs:173-218)
+    const int16_t *p = posts + (size_t)rec * 64;
+    for (int i = 0; i < 64; ++i) s_f[i][lane] = 0;
+    s_f[0][lane] = 1;
+    s_f[1][lane] = 1;
+    s_y[0][lane] = p[0];
+    s_y[1][lane] = p[1];
+    for (int i = 2; i < pc; ++i) {
+        const int lo = f.l_neigh[i], hi = f.h_neigh[i];
+        const int predicted = render_point(f.x_list[lo], s_y[lo][lane], f.x_list[hi], s_y[hi][lane],
+                                           f.x_list[i]);
+        const int val = p[i];
+        const int highroom = f.range - predicted;
+        const int lowroom = predicted;
+        const int room = (highroom < lowroom ? highroom : lowroom) * 2;
+        int result;
+        if (val != 0) {
+            s_f[lo][lane] = 1;
+            s_f[hi][lane] = 1;
+            s_f[i][lane] = 1;
+            if (val >= room) {
+                result = (highroom > lowroom) ? val - lowroom + predicted : predicted - val + highroom - 1;
+            } else {
+                result = ((val % 2) == 1) ? predicted - ((val + 1) / 2) : predicted + (val / 2);
+            }
+        } else {
+            s_f[i][lane] = 0;
+            result = predicted;
+        }
+        s_y[i][lane] = result;
+    }
+    int16_t *fy = final_y + (size_t)rec * 64;
+    uint8_t *sf = step_flags + (size_t)rec * 64;
+    for (int i = 0; i < pc; ++i) {
+        int v = s_y[i][lane] * f.multiplier;
+        v = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+        fy[i] = (int16_t)v;
+        sf[i] = s_f[i][lane];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// De-interleave + inverse coupling into a planar temp.  One thread per (packet, bin).
+// ---------------------------------------------------------------------------------------------
+struct CouplingPacket {
+    int64_t src_off;     // float offset in the caller's residue buffer
+    int64_t dst_off;     // float offset in the planar temp (== FrameDesc.spec_off)
+    int32_t half;        // blocksize / 2
+    int32_t steps_off;   // offset into the steps array (pairs mag, ang), -1: no coupling
+    int32_t steps;
+    int32_t interleaved;
+};
+
+__device__ __forceinline__ void couple(float &m, float &a)
+{
+    // Mapping.cs:209-225, the Vector<T> form, lane-wise with the same bit operations
+    const float oldM = m, oldA = a;
+    const uint32_t posM = oldM > 0.0f ? 0xFFFFFFFFu : 0u;
+    const uint32_t posA = oldA > 0.0f ? 0xFFFFFFFFu : 0u;
+    const uint32_t signedA = __float_as_uint(oldA) ^ (0x80000000u & posM);
+    m = oldM - __uint_as_float(signedA & ~posA);
+    a = oldM + __uint_as_float(signedA & posA);
+}
+
+__global__ __launch_bounds__(256) void coupling_kernel(const CouplingPacket *__restrict__ pkts,
+                                                      const uint8_t *__restrict__ steps,
+                                                      int channels, const float *__restrict__ residue,
+                                                      float *__restrict__ temp, int max_half)
+{
+    const CouplingPacket pk = pkts[blockIdx.y];
+    const int bin = blockIdx.x * 256 + threadIdx.x;
+    if (bin >= pk.half) return;
+    const float *src = residue + pk.src_off;
+    float *dst = temp + pk.dst_off;
+    for (int c = 0; c < channels; ++c) {
+        float v = pk.interleaved ? src[(size_t)bin * channels + c] : src[(size_t)c * pk.half + bin];
+        dst[(size_t)c * pk.half + bin] = v;
+    }
+    if (pk.steps_off < 0) return;
+    const uint8_t *st = steps + pk.steps_off;
+    for (int i = pk.steps - 1; i >= 0; --i) {  // reverse order, Mapping.cs:166
+        float *pm = dst + (size_t)st[2 * i] * pk.half + bin;
+        float *pa = dst + (size_t)st[2 * i + 1] * pk.half + bin;
+        float m = *pm, a = *pa;
+        couple(m, a);
+        *pm = m;
+        *pa = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Floor1 curve render into LDS (curve[0..n) = inverse_dB_table[y(x)]), one wavefront.
+// Closed form of the reference DDA (Floor1.cs:372-397): inside a segment (x0,y0)-(x1,y1) with
+// adx = x1-x0, k = x-x0:  y = y0 + trunc(dy*k/adx);  the DDA error term after k steps is
+// (|dy|*k mod adx) - adx.  Each lane starts four runs of 4 bins with one exact integer division
+// and then steps the reference DDA.  Segment end uses min(hx, n) in the slope (quirk q2).
+// aux layout (ints): [0..32) bitmap of active post x, [32..64) exclusive prefix popcounts,
+// [64..129) compacted active posts, x in the low 16 bits, y (signed) in the high 16.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int div_floor_small(int a, int b)
+{
+    // exact floor(a/b) for 0 <= a < 2^23, 0 < b <= 8192
+    int q = (int)((float)a * __frcp_rn((float)b));
+    int r = a - q * b;
+    if (r < 0) { --q; }
+    else if (r >= b) { ++q; }
+    return q;
+}
+
+struct Seg {
+    int x0, y0, x1, adx, sy, base, rseg;
+};
+
+__device__ __forceinline__ Seg load_segment(const int *cxy, int j, int m, int n)
+{
+    Seg s;
+    const int p0 = cxy[j];
+    s.x0 = p0 & 0xFFFF;
+    s.y0 = p0 >> 16;
+    int x1raw, y1;
+    if (j + 1 < m) { const int p1 = cxy[j + 1]; x1raw = p1 & 0xFFFF; y1 = p1 >> 16; }
+    else { x1raw = n; y1 = s.y0; }  // flat tail, Floor1.cs:259-262
+    s.x1 = x1raw < n ? x1raw : n;
+    s.adx = s.x1 - s.x0;
+    const int dy = y1 - s.y0;
+    const int ady = iabs(dy);
+    s.sy = dy < 0 ? -1 : 1;
+    const int ab = div_floor_small(ady, s.adx);  // |dy / adx| (C# truncating division)
+    s.base = s.sy * ab;
+    s.rseg = ady - ab * s.adx;
+    return s;
+}
+
+__device__ __forceinline__ void render_floor_curve(float *curve, int *aux, int n, int rec,
+                                                   const SynthArgs &a, const float *s_db, int lane)
+{
+    const FloorDev &f = a.floors[a.rec_floor[rec]];
+    const int pc = f.x_count;
+    int *bitmap = aux, *prefix = aux + 32, *cxy = aux + 64;
+    if (lane < 32) bitmap[lane] = 0;
+    // compact the active posts in X order (Floor1.cs:238-252)
+    bool active = false;
+    int x = 0, y = 0;
+    if (lane < pc) {
+        const int idx = f.sort_idx[lane];
+        active = (lane == 0) || a.step_flags[(size_t)rec * 64 + idx] != 0;
+        x = f.x_list[idx];
+        y = a.final_y[(size_t)rec * 64 + idx];
+    }
+    const unsigned long long mask = __ballot(active);
+    const int m = __popcll(mask);
+    if (active) {
+        const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+        cxy[pos] = (x & 0xFFFF) | (y << 16);
+        if (x < n) atomicOr(reinterpret_cast<unsigned int *>(&bitmap[x >> 5]), 1u << (x & 31));
+    }
+    // exclusive prefix popcount over the 32 bitmap words
+    {
+        int c = (lane < 32) ? __popc((unsigned)bitmap[lane]) : 0;
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            int t = __shfl_up(incl, d);
+            if ((lane & 31) >= d) incl += t;
+        }
+        if (lane < 32) prefix[lane] = incl - c;
+    }
+    const int groups = n >> 2;  // runs of 4 bins
+    for (int g = lane; g < groups; g += 64) {
+        int xx = 4 * g;
+        const unsigned w = (unsigned)bitmap[xx >> 5];
+        int j = prefix[xx >> 5] + __popc(w & ((2u << (xx & 31)) - 1u)) - 1;
+        Seg s = load_segment(cxy, j, m, n);
+        const int k = xx - s.x0;
+        const int ady = iabs(s.base) * s.adx + s.rseg;
+        const int aa = ady * k;
+        const int q = div_floor_small(aa, s.adx);
+        int yy = s.y0 + s.sy * q;
+        int err = (aa - q * s.adx) - s.adx;
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int yi = yy < 0 ? 0 : (yy > 255 ? 255 : yy);  // the reference would throw outside 0..255
+            v[t] = s_db[yi];
+            ++xx;
+            if (xx == s.x1 && xx < n) {  // next segment starts exactly on its post
+                ++j;
+                s = load_segment(cxy, j, m, n);
+                yy = s.y0;
+                err = -s.adx;
+            } else {
+                yy += s.base;
+                err += s.rseg;
+                if (err >= 0) { err -= s.adx; yy += s.sy; }
+            }
+        }
+        reinterpret_cast<float4 *>(curve)[g] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// synth_kernel
+// ---------------------------------------------------------------------------------------------
+struct WaveCtx {
+    float *buf[2];   // ping-pong: buf[cur] receives h of the block being built, buf[cur^1] = previous h
+    int cur;
+    int prev_n4;     // n/4 of the previous block (0: none)
+};
+
+template <bool kHasFloor>
+__device__ __forceinline__ void build_block(const SynthArgs &a, const FrameDesc &fd, int ch, int lane,
+                                            const float2 (&xin)[8], float *hbuf, float *other,
+                                            const float2 *s_twL, const float2 *s_twAB,
+                                            const float2 *s_twBC, const float2 *s_twS,
+                                            const float *s_db, bool exec)
+{
+    const bool is_long = fd.flags & kFrameLong;
+    const int n = is_long ? a.size1 : a.size0;
+    const int half = n >> 1;
+    if (!exec) {  // Mapping.cs:190-194: the channel is silent, its whole block is zero
+        for (int i = lane; i < half; i += 64) hbuf[i] = 0.0f;
+        return;
+    }
+    float2 x[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) x[m] = xin[m];
+    if (kHasFloor && !(fd.flags & kFrameNoFloor)) {
+        // curve goes to the buffer that will receive h (free until the transposes start)
+        int *aux = reinterpret_cast<int *>(hbuf + 1024);
+        render_floor_curve(hbuf, aux, half, fd.rec + ch, a, s_db, lane);
+        const float2 *c2 = reinterpret_cast<const float2 *>(hbuf);
+        if (n == 2048) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { float2 c = c2[lane + 64 * m]; x[m].x *= c.x; x[m].y *= c.y; }
+        } else {
+            const int l = lane & 7;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { float2 c = c2[l + 8 * m]; x[m].x *= c.x; x[m].y *= c.y; }
+        }
+    }
+    if (n == 2048) {
+        imdct2048_wave(x, reinterpret_cast<float2 *>(hbuf), s_twL, s_twAB, s_twBC, lane);
+    } else {
+        // all eight lane groups transform the same short block; group 0's copy lands at hbuf[0..128)
+        imdct256_wave8(x, reinterpret_cast<float2 *>(hbuf), s_twS, s_twBC, lane);
+    }
+    (void)other;
+}
+
+__device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base, int n, int lane)
+{
+    const float2 *s = reinterpret_cast<const float2 *>(base);
+    if (n == 2048) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) x[m] = s[lane + 64 * m];
+    } else {
+        const int l = lane & 7;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) x[m] = s[l + 8 * m];
+    }
+}
+
+template <bool kHasFloor>
+__global__ __launch_bounds__(kSynthThreads) void synth_kernel(SynthArgs a)
+{
+    __shared__ float2 s_twL[512];
+    __shared__ float2 s_twAB[512];
+    __shared__ float2 s_twBC[64];
+    __shared__ float2 s_twS[64];
+    __shared__ float s_slope1[1024];
+    __shared__ float s_slope0[128];
+    __shared__ float s_db[kHasFloor ? 256 : 1];
+    __shared__ float s_buf[kSynthWaves][2][kWaveBufFloats];
+
+    const bool has_long = a.size1 == 2048 || a.size0 == 2048;
+    const bool has_short = a.size0 == 256 || a.size1 == 256;
+    for (int i = threadIdx.x; i < 512; i += kSynthThreads) {
+        if (has_long) {
+            s_twL[i] = a.tw_long[kFastTwOffset + i];
+            s_twAB[i] = a.tw_long[kFastTwABOffset + i];
+        }
+    }
+    {
+        const float2 *any = has_long ? a.tw_long : a.tw_short;
+        if (threadIdx.x < 64) {
+            s_twBC[threadIdx.x] = any[kFastTwBCOffset + threadIdx.x];
+            if (has_short) s_twS[threadIdx.x] = a.tw_short[kFastTwOffset + threadIdx.x];
+        }
+    }
+    for (int i = threadIdx.x; i < a.size1 / 2; i += kSynthThreads) s_slope1[i] = a.slope1[i];
+    for (int i = threadIdx.x; i < a.size0 / 2 && i < 128; i += kSynthThreads) s_slope0[i] = a.slope0[i];
+    if (kHasFloor) s_db[threadIdx.x & 255] = a.inv_db[threadIdx.x & 255];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long item = (long)blockIdx.x * kSynthWaves + wave;
+    if (item >= (long)a.n_runs * a.channels) return;
+    const int run_idx = (int)(item / a.channels);
+    const int ch = (int)(item - (long)run_idx * a.channels);
+    const RunDesc run = a.runs[run_idx];
+    const int half1 = a.size1 >> 1;
+
+    float *bufs[2] = {s_buf[wave][0], s_buf[wave][1]};
+    int cur = 0;
+    int prev_n4 = 0;
+
+    auto exec_of = [&](const FrameDesc &fd) -> bool {
+        return a.post_counts == nullptr || (fd.flags & kFrameNoFloor) || a.post_counts[fd.rec + ch] != 0;
+    };
+
+    // ---- block preceding the run
+    if (run.pre_kind == kPreState) {
+        const float *st = a.state_h + ((size_t)run.stream * a.channels + ch) * half1;
+        const int ph = run.prev_long ? (a.size1 >> 1) : (a.size0 >> 1);
+        for (int i = lane; i < ph; i += 64) bufs[1][i] = st[i];
+        prev_n4 = ph >> 1;
+    } else if (run.pre_kind == kPreRecompute) {
+        const FrameDesc fd = a.frames[run.first - 1];
+        const int n = (fd.flags & kFrameLong) ? a.size1 : a.size0;
+        const bool ex = exec_of(fd);
+        float2 x[8];
+        if (ex) load_spectrum(x, a.spec + fd.spec_off + (size_t)ch * (n >> 1), n, lane);
+        build_block<kHasFloor>(a, fd, ch, lane, x, bufs[1], bufs[0], s_twL, s_twAB, s_twBC, s_twS, s_db, ex);
+        prev_n4 = n >> 2;
+    }
+
+    float *out_base = a.out + (a.stream_out_off ? a.stream_out_off[run.stream] : 0);
+    bool clipped_any = false;
+
+    // ---- software pipeline: spectrum of frame i+1 is in flight while frame i is synthesised
+    float2 xcur[8];
+    {
+        const FrameDesc fd0 = a.frames[run.first];
+        if (!(fd0.flags & kFrameDrain) && exec_of(fd0)) {
+            const int n = (fd0.flags & kFrameLong) ? a.size1 : a.size0;
+            load_spectrum(xcur, a.spec + fd0.spec_off + (size_t)ch * (n >> 1), n, lane);
+        }
+    }
+    int last_long = 0;
+    for (int fi = 0; fi < run.count; ++fi) {
+        const FrameDesc fd = a.frames[run.first + fi];
+        float2 xnext[8];
+        if (fi + 1 < run.count) {
+            const FrameDesc fn = a.frames[run.first + fi + 1];
+            if (!(fn.flags & kFrameDrain) && exec_of(fn)) {
+                const int nn = (fn.flags & kFrameLong) ? a.size1 : a.size0;
+                load_spectrum(xnext, a.spec + fn.spec_off + (size_t)ch * (nn >> 1), nn, lane);
+            }
+        }
+        const bool drain = fd.flags & kFrameDrain;
+        const int n = (fd.flags & kFrameLong) ? a.size1 : a.size0;
+        const int n4 = n >> 2;
+        float *hcur = bufs[cur], *hprev = bufs[cur ^ 1];
+        if (!drain)
+            build_block<kHasFloor>(a, fd, ch, lane, xcur, hcur, hprev, s_twL, s_twAB, s_twBC, s_twS, s_db,
+                                   exec_of(fd));
+
+        // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 573-591)
+        const float *slope = (fd.flags & kFrameSlope1) ? s_slope1 : s_slope0;
+        const int plen = fd.packet_len;
+        for (int i = lane; i < fd.out_count; i += 64) {
+            float v;
+            if (drain) {
+                v = y_from_h(hprev, fd.prev_end + i, prev_n4);
+            } else {
+                v = y_from_h(hcur, fd.left_start + i, n4);
+                if (i < plen) {
+                    const float t = y_from_h(hprev, fd.prev_end + i, prev_n4);
+                    v = (v * slope[i]) + (t * slope[plen - 1 - i]);
+                }
+            }
+            if (a.clip) {
+                if (v > 0.99999994f) { v = 0.99999994f; clipped_any = true; }
+                else if (v < -0.99999994f) { v = -0.99999994f; clipped_any = true; }
+            }
+            const int64_t t = fd.out_off + i;
+            if (a.interleaved) out_base[t * a.channels + ch] = v;
+            else out_base[(int64_t)ch * a.channel_stride + t] = v;
+        }
+        if (!drain) {
+            cur ^= 1;
+            prev_n4 = n4;
+            last_long = (fd.flags & kFrameLong) ? 1 : 0;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) xcur[m] = xnext[m];
+    }
+
+    // ---- keep the last block for the next batch (the reference keeps _prevPacketBuf)
+    if ((run.flags & kRunSaveState) && prev_n4 > 0) {
+        float *st = a.state_h + ((size_t)run.stream * a.channels + ch) * half1;
+        const float *hl = bufs[cur ^ 1];
+        for (int i = lane; i < 2 * prev_n4; i += 64) st[i] = hl[i];
+        (void)last_long;
+    }
+    if (a.clip && __any(clipped_any) && lane == 0) atomicOr(&a.clipped[run.stream], 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *post_counts,
+                                const uint8_t *rec_floor, const FloorDev *floors, int16_t *final_y,
+                                uint8_t *step_flags, hipStream_t stream)
+{
+    if (n_rec <= 0) return hipSuccess;
+    hipLaunchKernelGGL(floor1_unwrap_kernel, dim3((n_rec + 63) / 64), dim3(64), 0, stream, n_rec, posts,
+                       post_counts, rec_floor, floors, final_y, step_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_coupling(const void *pkts, int n_pkts, const uint8_t *steps, int channels,
+                           const float *residue, float *temp, int max_half, hipStream_t stream)
+{
+    if (n_pkts <= 0) return hipSuccess;
+    // grid.y is limited to 65535: chunk the packet list
+    const CouplingPacket *p = static_cast<const CouplingPacket *>(pkts);
+    for (int done = 0; done < n_pkts; done += 65535) {
+        int cnt = n_pkts - done < 65535 ? n_pkts - done : 65535;
+        hipLaunchKernelGGL(coupling_kernel, dim3((max_half + 255) / 256, cnt), dim3(256), 0, stream,
+                           p + done, steps, channels, residue, temp, max_half);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t stream)
+{
+    const long items = (long)args.n_runs * args.channels;
+    if (items <= 0) return hipSuccess;
+    const int grid = (int)((items + kSynthWaves - 1) / kSynthWaves);
+    if (has_floor)
+        hipLaunchKernelGGL(synth_kernel<true>, dim3(grid), dim3(kSynthThreads), 0, stream, args);
+    else
+        hipLaunchKernelGGL(synth_kernel<false>, dim3(grid), dim3(kSynthThreads), 0, stream, args);
+    return hipGetLastError();
+}
+
+size_t coupling_packet_size() { return sizeof(CouplingPacket); }
+void fill_coupling_packet(void *dst, int64_t src_off, int64_t dst_off, int32_t half, int32_t steps_off,
+                          int32_t steps, int32_t interleaved)
+{
+    CouplingPacket *p = static_cast<CouplingPacket *>(dst);
+    p->src_off = src_off;
+    p->dst_off = dst_off;
+    p->half = half;
+    p->steps_off = steps_off;
+    p->steps = steps;
+    p->interleaved = interleaved;
+}
+
+}  // namespace vpz

@@ -1,0 +1,597 @@
+// vpz_decoder_*: host half of the synthesis path.  Mirrors, with integers only, what
+// StreamDecoder.ReadNextPacket / Read and Mode.GetPacketInfo decide per packet
+// (StreamDecoder.cs:418-498, 640-694; Mode.cs:30-66) and turns a batch of packets into frame /
+// run descriptors for the kernels in synth_kernels.hip.  No sample arithmetic happens here.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "synth_desc.hpp"
+#include "vpz_internal.hpp"
+
+namespace vpz {
+
+hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *post_counts,
+                                const uint8_t *rec_floor, const FloorDev *floors, int16_t *final_y,
+                                uint8_t *step_flags, hipStream_t stream);
+hipError_t launch_coupling(const void *pkts, int n_pkts, const uint8_t *steps, int channels,
+                           const float *residue, float *temp, int max_half, hipStream_t stream);
+hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t stream);
+size_t coupling_packet_size();
+void fill_coupling_packet(void *dst, int64_t src_off, int64_t dst_off, int32_t half, int32_t steps_off,
+                          int32_t steps, int32_t interleaved);
+
+static const uint32_t k_inverse_db_bits[256] = {
+#include "floor1_inverse_db_bits.inc"
+};
+
+// StreamDecoder.cs:45-49 + position / EOS bookkeeping, per stream
+struct StreamState {
+    bool has_prev = false;      // _prevPacketBuf != null
+    bool prev_long = false;     // block flag of the packet held in _prevPacketBuf
+    int prev_start = 0, prev_end = 0, prev_stop = 0;
+    int64_t current_position = 0;
+    bool has_position = false;
+    bool eos_found = false;
+    bool has_clipped = false;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct Decoder {
+    Context *ctx = nullptr;
+    int channels = 0, size0 = 0, size1 = 0, clip = 0;
+    int n_streams = 0;
+    std::vector<vpz_floor1_config> floors;
+    std::vector<vpz_mapping_config> mappings;
+    std::vector<StreamState> states;
+    BlockTables *t0 = nullptr, *t1 = nullptr;
+    FloorDev *d_floors = nullptr;
+    float *d_state_h = nullptr;
+    int32_t *d_clipped = nullptr;
+    uint8_t *d_steps = nullptr;              // coupling steps of all mappings, pairs (mag, ang)
+    std::vector<int32_t> mapping_steps_off;  // per mapping: offset into d_steps (pairs*2), -1 none
+    DevBuf b_frames, b_runs, b_recfloor, b_finaly, b_stepflags, b_cpk, b_temp, b_outoff;
+    DevBuf b_in_res, b_in_posts, b_in_counts, b_out;  // VPZ_MEM_HOST staging
+    int run_length_override = 0;
+};
+
+static int grow(Context *ctx, DevBuf &b, size_t need)
+{
+    return ensure_stage(ctx, &b.p, &b.bytes, need ? need : 1);
+}
+
+// Mode.cs:30-66
+struct PacketInfo {
+    int length, left_use_size1, left_start, left_end, right_start, right_end;
+};
+static PacketInfo get_packet_info(int size0, int size1, bool block_flag, bool prev_flag, bool next_flag)
+{
+    PacketInfo pi;
+    const int size = block_flag ? size1 : size0;
+    const bool prev = block_flag ? prev_flag : true;
+    const bool next = block_flag ? next_flag : true;
+    const int center = size / 2;
+    if (prev) {
+        pi.left_start = 0; pi.left_end = center; pi.length = size / 2; pi.left_use_size1 = block_flag ? 1 : 0;
+    } else {
+        pi.left_start = (size - size0) / 4; pi.left_end = (size + size0) / 4; pi.length = size0 / 2;
+        pi.left_use_size1 = 0;
+    }
+    if (next) { pi.right_start = center; pi.right_end = size; }
+    else { pi.right_start = (size * 3 - size0) / 4; pi.right_end = (size * 3 + size0) / 4; }
+    return pi;
+}
+
+// Floor1.cs:108-149: neighbours and sort order of the X list
+static int build_floor(const vpz_floor1_config &c, FloorDev *f)
+{
+    memset(f, 0, sizeof *f);
+    if (c.x_count < 2 || c.x_count > 64 || c.multiplier < 1 || c.multiplier > 4) return VPZ_E_INVALID_ARG;
+    static const int range_lookup[4] = {128, 64, 43, 32};  // Floor1.cs:36
+    f->x_count = c.x_count;
+    f->multiplier = c.multiplier;
+    f->range = range_lookup[c.multiplier - 1] * 2;
+    for (int i = 0; i < c.x_count; ++i) {
+        if (c.x_list[i] < 0 || c.x_list[i] > 32767) return VPZ_E_INVALID_ARG;
+        f->x_list[i] = (int16_t)c.x_list[i];
+    }
+    std::vector<int> order(c.x_count);
+    for (int i = 0; i < c.x_count; ++i) order[i] = i;
+    // sortIdx[0], [1] start as 0, 1 and take part in the exchange sort like every other entry
+    for (int i = 0; i < c.x_count - 1; ++i)
+        for (int j = i + 1; j < c.x_count; ++j) {
+            if (c.x_list[i] == c.x_list[j]) return VPZ_E_INVALID_ARG;  // InvalidDataException :141
+            if (c.x_list[order[i]] > c.x_list[order[j]]) std::swap(order[i], order[j]);
+        }
+    for (int i = 0; i < c.x_count; ++i) f->sort_idx[i] = (uint8_t)order[i];
+    for (int i = 2; i < c.x_count; ++i) {
+        int lo = 0, hi = 1;
+        for (int j = 2; j < i; ++j) {
+            const int t = c.x_list[j];
+            if (t < c.x_list[i]) { if (t > c.x_list[lo]) lo = j; }
+            else                 { if (t < c.x_list[hi]) hi = j; }
+        }
+        f->l_neigh[i] = (uint8_t)lo;
+        f->h_neigh[i] = (uint8_t)hi;
+    }
+    return VPZ_OK;
+}
+
+static bool supported_size(int n) { return n == 256 || n == 2048; }
+
+}  // namespace vpz
+
+struct vpz_decoder {
+    vpz::Decoder impl;
+};
+
+using namespace vpz;
+
+extern "C" {
+
+int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_streams, vpz_decoder **out)
+{
+    if (!c || !cfg || !out || n_streams <= 0) return VPZ_E_INVALID_ARG;
+    *out = nullptr;
+    Context *ctx = &c->impl;
+    if (cfg->channels < 1 || cfg->channels > VPZ_MAX_CHANNELS)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_create: channels out of range");
+    if (cfg->block_size0 > cfg->block_size1)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_create: block_size0 > block_size1");
+    if (!supported_size(cfg->block_size0) || !supported_size(cfg->block_size1))
+        return set_error(ctx, VPZ_E_UNSUPPORTED,
+                         "vpz_decoder_create: fused synthesis kernels exist for block sizes 256 and 2048 only");
+    if (cfg->floor_count < 0 || cfg->mapping_count < 0 || (cfg->floor_count && !cfg->floors) ||
+        (cfg->mapping_count && !cfg->mappings) || cfg->mapping_count > 256 || cfg->floor_count > 256)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_create: bad floor / mapping tables");
+    VPZ_HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    vpz_decoder *d = new (std::nothrow) vpz_decoder();
+    if (!d) return VPZ_E_NOMEM;
+    Decoder &D = d->impl;
+    D.ctx = ctx;
+    D.channels = cfg->channels;
+    D.size0 = cfg->block_size0;
+    D.size1 = cfg->block_size1;
+    D.clip = cfg->clip_samples ? 1 : 0;
+    D.n_streams = n_streams;
+    D.states.assign(n_streams, StreamState());
+    D.floors.assign(cfg->floors, cfg->floors + cfg->floor_count);
+    D.mappings.assign(cfg->mappings, cfg->mappings + cfg->mapping_count);
+    if (const char *e = getenv("VPZ_RUN_LENGTH")) D.run_length_override = atoi(e);
+
+    int rc = VPZ_OK;
+    std::vector<FloorDev> fdev(std::max<size_t>(1, D.floors.size()));
+    for (size_t i = 0; i < D.floors.size() && rc == VPZ_OK; ++i) rc = build_floor(D.floors[i], &fdev[i]);
+    std::vector<uint8_t> steps;
+    for (size_t m = 0; m < D.mappings.size() && rc == VPZ_OK; ++m) {
+        const vpz_mapping_config &mc = D.mappings[m];
+        if (mc.coupling_steps < 0 || mc.coupling_steps > VPZ_MAX_COUPLING) { rc = VPZ_E_INVALID_ARG; break; }
+        D.mapping_steps_off.push_back(mc.coupling_steps ? (int32_t)steps.size() : -1);
+        for (int i = 0; i < mc.coupling_steps; ++i) {
+            const int mag = mc.coupling_magnitude[i], ang = mc.coupling_angle[i];
+            if (mag == ang || mag >= D.channels || ang >= D.channels) { rc = VPZ_E_INVALID_ARG; break; }  // Mapping.cs:41
+            steps.push_back((uint8_t)mag);
+            steps.push_back((uint8_t)ang);
+        }
+        for (int ch = 0; ch < D.channels && rc == VPZ_OK; ++ch)
+            if (D.floors.size() && mc.channel_floor[ch] >= D.floors.size()) rc = VPZ_E_INVALID_ARG;
+    }
+    if (rc != VPZ_OK) {
+        delete d;
+        return set_error(ctx, rc, "vpz_decoder_create: invalid floor1 / mapping configuration");
+    }
+    if ((rc = get_tables(ctx, D.size0, &D.t0)) != VPZ_OK || (rc = get_tables(ctx, D.size1, &D.t1)) != VPZ_OK) {
+        delete d;
+        return rc;
+    }
+    hipError_t e = hipSuccess;
+    const size_t state_bytes = sizeof(float) * (size_t)n_streams * D.channels * (D.size1 / 2);
+    if (!ctx->d_inv_db) {
+        e = hipMalloc((void **)&ctx->d_inv_db, 256 * sizeof(float));
+        if (e == hipSuccess)
+            e = hipMemcpy(ctx->d_inv_db, k_inverse_db_bits, 256 * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&D.d_floors, sizeof(FloorDev) * fdev.size());
+    if (e == hipSuccess) e = hipMemcpy(D.d_floors, fdev.data(), sizeof(FloorDev) * fdev.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&D.d_state_h, state_bytes);
+    if (e == hipSuccess) e = hipMemset(D.d_state_h, 0, state_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&D.d_clipped, sizeof(int32_t) * (size_t)n_streams);
+    if (e == hipSuccess) e = hipMemset(D.d_clipped, 0, sizeof(int32_t) * (size_t)n_streams);
+    if (e == hipSuccess) e = hipMalloc((void **)&D.d_steps, steps.size() ? steps.size() : 1);
+    if (e == hipSuccess && !steps.empty()) e = hipMemcpy(D.d_steps, steps.data(), steps.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        vpz_decoder_destroy(d);
+        return set_error(ctx, VPZ_E_NOMEM, "vpz_decoder_create: device allocation", e);
+    }
+    *out = d;
+    return VPZ_OK;
+}
+
+void vpz_decoder_destroy(vpz_decoder *d)
+{
+    if (!d) return;
+    Decoder &D = d->impl;
+    if (D.ctx) {
+        (void)hipSetDevice(D.ctx->device);
+        (void)hipStreamSynchronize(D.ctx->stream);
+    }
+    DevBuf *bufs[] = {&D.b_frames, &D.b_runs, &D.b_recfloor, &D.b_finaly, &D.b_stepflags, &D.b_cpk, &D.b_temp,
+                      &D.b_outoff, &D.b_in_res, &D.b_in_posts, &D.b_in_counts, &D.b_out};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (D.d_floors) (void)hipFree(D.d_floors);
+    if (D.d_state_h) (void)hipFree(D.d_state_h);
+    if (D.d_clipped) (void)hipFree(D.d_clipped);
+    if (D.d_steps) (void)hipFree(D.d_steps);
+    delete d;
+}
+
+int vpz_decoder_reset(vpz_decoder *d, int32_t stream)
+{
+    if (!d) return VPZ_E_INVALID_ARG;
+    Decoder &D = d->impl;
+    if (stream >= D.n_streams) return set_error(D.ctx, VPZ_E_INVALID_ARG, "vpz_decoder_reset: bad stream");
+    VPZ_HIP_TRY(D.ctx, hipSetDevice(D.ctx->device));
+    const int lo = stream < 0 ? 0 : stream, hi = stream < 0 ? D.n_streams : stream + 1;
+    for (int s = lo; s < hi; ++s) D.states[s] = StreamState();  // StreamDecoder.cs:357-369
+    VPZ_HIP_TRY(D.ctx, hipMemsetAsync(D.d_clipped + lo, 0, sizeof(int32_t) * (size_t)(hi - lo), D.ctx->stream));
+    return VPZ_OK;
+}
+
+int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packets, const float *residue,
+                      const int16_t *posts, const uint8_t *post_counts, int mem_space, float *pcm_out,
+                      const int64_t *stream_out_offset, int64_t stream_out_capacity, int out_layout,
+                      int64_t channel_stride, int64_t *samples_written)
+{
+    if (!d) return VPZ_E_INVALID_ARG;
+    Decoder &D = d->impl;
+    Context *ctx = D.ctx;
+    if (n_packets < 0 || (n_packets > 0 && (!packets || !residue || !pcm_out)) || !samples_written)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: null argument");
+    if (mem_space != VPZ_MEM_HOST && mem_space != VPZ_MEM_DEVICE)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: bad mem_space");
+    if (out_layout != VPZ_OUT_INTERLEAVED && out_layout != VPZ_OUT_PLANAR)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: bad out_layout");
+    if (n_packets > (int64_t)0x7fffffff / std::max(1, D.channels))
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: batch too large");
+    VPZ_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int C = D.channels;
+    for (int s = 0; s < D.n_streams; ++s) samples_written[s] = 0;
+    if (n_packets == 0) return VPZ_OK;
+
+    // ---------------- pass 1: per-stream state machine -> frame descriptors
+    std::vector<StreamState> st = D.states;  // committed only when the whole batch is accepted
+    std::vector<std::vector<FrameDesc>> per_stream(D.n_streams);
+    std::vector<uint8_t> stream_started_with_prev(D.n_streams), stream_prev_long(D.n_streams);
+    for (int s = 0; s < D.n_streams; ++s) {
+        stream_started_with_prev[s] = st[s].has_prev;
+        stream_prev_long[s] = st[s].prev_long;
+    }
+    std::vector<int64_t> out_count(D.n_streams, 0);
+    std::vector<uint8_t> pkt_used((size_t)n_packets, 0);
+    bool any_floor = false, need_coupling = false;
+    int64_t temp_floats = 0;
+    std::vector<int64_t> temp_off((size_t)n_packets, -1);
+
+    for (int64_t p = 0; p < n_packets; ++p) {
+        const vpz_packet &pk = packets[p];
+        if (pk.stream < 0 || pk.stream >= D.n_streams)
+            return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: packet stream index out of range");
+        StreamState &S = st[pk.stream];
+        // Read(): once EOS was seen and the previous packet is drained nothing more is read (:441-447)
+        if (S.eos_found && S.prev_start == S.prev_end) continue;
+        const bool eos = pk.flags & VPZ_PKT_EOS;
+        if (eos) S.eos_found = true;  // _eosFound |= isEndOfStream (:647), before the null check
+        if (pk.flags & VPZ_PKT_NOT_DECODED) {
+            if (eos && S.has_prev && S.prev_stop > S.prev_end) {  // :451-455 drain, un-windowed
+                FrameDesc fd{};
+                fd.stream = pk.stream;
+                fd.flags = kFrameDrain;
+                fd.prev_end = S.prev_end;
+                fd.out_count = S.prev_stop - S.prev_end;
+                fd.out_off = out_count[pk.stream];
+                out_count[pk.stream] += fd.out_count;
+                S.current_position += fd.out_count;
+                S.prev_end = S.prev_stop;
+                S.prev_start = S.prev_stop;
+                per_stream[pk.stream].push_back(fd);
+            }
+            continue;
+        }
+        const bool no_floor = pk.flags & VPZ_PKT_NO_FLOOR;
+        if (!no_floor) {
+            if (pk.mapping >= D.mappings.size())
+                return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: packet mapping index out of range");
+            if (!posts || !post_counts || D.floors.empty())
+                return set_error(ctx, VPZ_E_INVALID_ARG,
+                                 "vpz_decoder_synth: posts and a floor table are required unless VPZ_PKT_NO_FLOOR");
+            any_floor = true;
+            if (D.mappings[pk.mapping].coupling_steps > 0) need_coupling = true;
+        }
+        if (pk.flags & VPZ_PKT_INTERLEAVED) need_coupling = true;
+        if (pk.residue_offset < 0)
+            return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: negative residue offset");
+
+        const bool bf = pk.flags & VPZ_PKT_BLOCK_FLAG;
+        const PacketInfo pi = get_packet_info(D.size0, D.size1, bf, pk.flags & VPZ_PKT_PREV_FLAG,
+                                              pk.flags & VPZ_PKT_NEXT_FLAG);
+        const int packet_len = S.prev_stop - S.prev_end;  // :654
+        int right_start = pi.right_start;
+        if (pk.granule != -1 && eos) {  // :658-666
+            const int64_t actual_end = S.current_position + packet_len;
+            const int diff = (int)(actual_end - pk.granule);
+            if (diff > 0) right_start = std::max(right_start - diff, 0);
+        }
+        FrameDesc fd{};
+        fd.stream = pk.stream;
+        fd.rec = (int32_t)(p * C);
+        fd.flags = (bf ? kFrameLong : 0u) | (pi.left_use_size1 ? kFrameSlope1 : 0u) | (no_floor ? kFrameNoFloor : 0u);
+        if (S.has_prev) {  // :670-675
+            const int slope_len = (pi.left_use_size1 ? D.size1 : D.size0) / 2;
+            if (packet_len > slope_len)  // windowSlope.AsSpan(0, packetLen) would throw (:778)
+                return set_error(ctx, VPZ_E_WINDOW_MISMATCH,
+                                 "vpz_decoder_synth: previous packet's tail is longer than this packet's window slope");
+            fd.packet_len = packet_len;
+            fd.prev_end = S.prev_end;
+            S.prev_start = pi.left_start;
+        } else {
+            fd.packet_len = 0;
+            S.prev_start = right_start;  // :679 first packet has no valid data before rightStart
+        }
+        fd.left_start = S.prev_start;  // emission starts at the new _prevPacketStart
+        S.prev_end = right_start;
+        S.prev_stop = pi.right_end;
+        S.has_prev = true;
+        S.prev_long = bf;
+        if (pk.granule != -1 && !S.has_position) {  // :459-463 (idx == 0 here)
+            S.has_position = true;
+            S.current_position = pk.granule - (S.prev_end - S.prev_start);
+        }
+        // a trim below LeftStart would make the reference spin (copyLen <= 0, :469-472): emit nothing
+        fd.out_count = std::max(0, S.prev_end - S.prev_start);
+        fd.out_off = out_count[pk.stream];
+        out_count[pk.stream] += fd.out_count;
+        S.current_position += fd.out_count;
+        S.prev_start = S.prev_end;  // everything readable is handed out by this call
+        pkt_used[(size_t)p] = 1;
+        temp_off[(size_t)p] = temp_floats;
+        temp_floats += (int64_t)C * ((bf ? D.size1 : D.size0) / 2);
+        fd.spec_off = pk.residue_offset;  // replaced by temp_off when the coupling pass runs
+        per_stream[pk.stream].push_back(fd);
+    }
+    for (int s = 0; s < D.n_streams; ++s)
+        if (out_count[s] > stream_out_capacity)
+            return set_error(ctx, VPZ_E_CAPACITY, "vpz_decoder_synth: stream_out_capacity too small");
+
+    // ---------------- pass 2: runs
+    int64_t total_frames = 0;
+    for (auto &v : per_stream) total_frames += (int64_t)v.size();
+    for (int s = 0; s < D.n_streams; ++s) samples_written[s] = out_count[s];
+    if (total_frames == 0) {
+        D.states = st;
+        return VPZ_OK;
+    }
+    int R = D.run_length_override;
+    if (R <= 0) {
+        const int64_t target_items = (int64_t)ctx->num_cu * 24;
+        R = (int)std::min<int64_t>(32, std::max<int64_t>(4, total_frames * C / std::max<int64_t>(1, target_items)));
+    }
+    std::vector<FrameDesc> frames;
+    frames.reserve((size_t)total_frames);
+    std::vector<RunDesc> runs;
+    for (int s = 0; s < D.n_streams; ++s) {
+        const auto &v = per_stream[s];
+        if (v.empty()) continue;
+        const int base = (int)frames.size();
+        frames.insert(frames.end(), v.begin(), v.end());
+        for (int f0 = 0; f0 < (int)v.size(); f0 += R) {
+            RunDesc r{};
+            r.first = base + f0;
+            r.count = std::min(R, (int)v.size() - f0);
+            r.stream = s;
+            if (f0 == 0) {
+                r.pre_kind = stream_started_with_prev[s] ? kPreState : kPreNone;
+                r.prev_long = stream_prev_long[s];
+            } else {
+                r.pre_kind = kPreRecompute;
+            }
+            if (f0 + R >= (int)v.size()) r.flags |= kRunSaveState;
+            runs.push_back(r);
+        }
+    }
+
+    // ---------------- device inputs
+    const float *d_res = residue;
+    const int16_t *d_posts = posts;
+    const uint8_t *d_counts = post_counts;
+    const int64_t n_rec = n_packets * C;
+    int rc;
+    if (mem_space == VPZ_MEM_HOST) {
+        int64_t res_floats = 0;
+        for (int64_t p = 0; p < n_packets; ++p) {
+            if (!pkt_used[(size_t)p]) continue;
+            const int half = ((packets[p].flags & VPZ_PKT_BLOCK_FLAG) ? D.size1 : D.size0) / 2;
+            res_floats = std::max(res_floats, packets[p].residue_offset + (int64_t)C * half);
+        }
+        if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)res_floats)) != VPZ_OK) return rc;
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res.p, residue, sizeof(float) * (size_t)res_floats,
+                                        hipMemcpyHostToDevice, ctx->stream));
+        d_res = static_cast<const float *>(D.b_in_res.p);
+        if (any_floor) {
+            if ((rc = grow(ctx, D.b_in_posts, sizeof(int16_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
+            if ((rc = grow(ctx, D.b_in_counts, (size_t)n_rec)) != VPZ_OK) return rc;
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_posts.p, posts, sizeof(int16_t) * 64 * (size_t)n_rec,
+                                            hipMemcpyHostToDevice, ctx->stream));
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_counts.p, post_counts, (size_t)n_rec, hipMemcpyHostToDevice,
+                                            ctx->stream));
+            d_posts = static_cast<const int16_t *>(D.b_in_posts.p);
+            d_counts = static_cast<const uint8_t *>(D.b_in_counts.p);
+        }
+    }
+
+    // ---------------- optional pass: de-interleave + inverse coupling into a planar temp
+    const float *d_spec = d_res;
+    if (need_coupling) {
+        if ((rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK) return rc;
+        const size_t cps = coupling_packet_size();
+        std::vector<uint8_t> cpk;
+        cpk.reserve((size_t)total_frames * cps);
+        // frames were appended stream by stream; rebuild the packet -> frame link through rec
+        int n_cpk = 0;
+        for (FrameDesc &fd : frames) {
+            if (fd.flags & kFrameDrain) continue;
+            const int64_t p = fd.rec / C;
+            const vpz_packet &pk = packets[p];
+            const int half = ((fd.flags & kFrameLong) ? D.size1 : D.size0) / 2;
+            const bool couple = !(fd.flags & kFrameNoFloor) && D.mappings[pk.mapping].coupling_steps > 0;
+            cpk.resize(cpk.size() + cps);
+            fill_coupling_packet(cpk.data() + (size_t)n_cpk * cps, pk.residue_offset, temp_off[(size_t)p], half,
+                                 couple ? D.mapping_steps_off[pk.mapping] : -1,
+                                 couple ? D.mappings[pk.mapping].coupling_steps : 0,
+                                 (pk.flags & VPZ_PKT_INTERLEAVED) ? 1 : 0);
+            fd.spec_off = temp_off[(size_t)p];
+            ++n_cpk;
+        }
+        if ((rc = grow(ctx, D.b_cpk, cpk.size())) != VPZ_OK) return rc;
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_cpk.p, cpk.data(), cpk.size(), hipMemcpyHostToDevice, ctx->stream));
+        VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // cpk is a local vector
+        hipError_t e = launch_coupling(D.b_cpk.p, n_cpk, D.d_steps, C, d_res, static_cast<float *>(D.b_temp.p),
+                                       D.size1 / 2, ctx->stream);
+        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "coupling kernel launch", e);
+        d_spec = static_cast<const float *>(D.b_temp.p);
+    }
+
+    // ---------------- optional pass: Floor1.UnwrapPosts
+    if (any_floor) {
+        std::vector<uint8_t> rec_floor((size_t)n_rec, 0);
+        for (int64_t p = 0; p < n_packets; ++p) {
+            if (!pkt_used[(size_t)p] || (packets[p].flags & VPZ_PKT_NO_FLOOR)) continue;
+            const vpz_mapping_config &mc = D.mappings[packets[p].mapping];
+            for (int ch = 0; ch < C; ++ch) rec_floor[(size_t)(p * C + ch)] = mc.channel_floor[ch];
+        }
+        if ((rc = grow(ctx, D.b_recfloor, (size_t)n_rec)) != VPZ_OK) return rc;
+        if ((rc = grow(ctx, D.b_finaly, sizeof(int16_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
+        if ((rc = grow(ctx, D.b_stepflags, 64 * (size_t)n_rec)) != VPZ_OK) return rc;
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_recfloor.p, rec_floor.data(), (size_t)n_rec, hipMemcpyHostToDevice,
+                                        ctx->stream));
+        VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // rec_floor is a local vector
+        hipError_t e = launch_floor1_unwrap((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(D.b_recfloor.p),
+                                            D.d_floors, static_cast<int16_t *>(D.b_finaly.p),
+                                            static_cast<uint8_t *>(D.b_stepflags.p), ctx->stream);
+        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor1 unwrap kernel launch", e);
+    }
+
+    // ---------------- output placement
+    float *d_out = pcm_out;
+    const int64_t *d_outoff = nullptr;
+    int64_t out_floats = 0;
+    std::vector<int64_t> offs(D.n_streams, 0);
+    if (stream_out_offset)
+        for (int s = 0; s < D.n_streams; ++s) offs[s] = stream_out_offset[s];
+    if (out_layout == VPZ_OUT_PLANAR && channel_stride < stream_out_capacity && C > 1)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: channel_stride smaller than stream_out_capacity");
+    if (stream_out_offset) {
+        if ((rc = grow(ctx, D.b_outoff, sizeof(int64_t) * (size_t)D.n_streams)) != VPZ_OK) return rc;
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_outoff.p, offs.data(), sizeof(int64_t) * (size_t)D.n_streams,
+                                        hipMemcpyHostToDevice, ctx->stream));
+        VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        d_outoff = static_cast<const int64_t *>(D.b_outoff.p);
+    }
+    if (mem_space == VPZ_MEM_HOST) {
+        for (int s = 0; s < D.n_streams; ++s) {
+            const int64_t ext = out_layout == VPZ_OUT_INTERLEAVED
+                                    ? offs[s] + out_count[s] * C
+                                    : offs[s] + (int64_t)(C - 1) * channel_stride + out_count[s];
+            if (out_count[s] > 0) out_floats = std::max(out_floats, ext);
+        }
+        if ((rc = grow(ctx, D.b_out, sizeof(float) * (size_t)out_floats)) != VPZ_OK) return rc;
+        d_out = static_cast<float *>(D.b_out.p);
+    }
+
+    // ---------------- descriptors + launch
+    if ((rc = grow(ctx, D.b_frames, sizeof(FrameDesc) * frames.size())) != VPZ_OK) return rc;
+    if ((rc = grow(ctx, D.b_runs, sizeof(RunDesc) * runs.size())) != VPZ_OK) return rc;
+    VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_frames.p, frames.data(), sizeof(FrameDesc) * frames.size(),
+                                    hipMemcpyHostToDevice, ctx->stream));
+    VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_runs.p, runs.data(), sizeof(RunDesc) * runs.size(), hipMemcpyHostToDevice,
+                                    ctx->stream));
+    VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // frames / runs are local vectors
+
+    SynthArgs a{};
+    a.frames = static_cast<const FrameDesc *>(D.b_frames.p);
+    a.runs = static_cast<const RunDesc *>(D.b_runs.p);
+    a.n_runs = (int32_t)runs.size();
+    a.channels = C;
+    a.size0 = D.size0;
+    a.size1 = D.size1;
+    a.spec = d_spec;
+    a.post_counts = any_floor ? d_counts : nullptr;
+    a.final_y = any_floor ? static_cast<const int16_t *>(D.b_finaly.p) : nullptr;
+    a.step_flags = any_floor ? static_cast<const uint8_t *>(D.b_stepflags.p) : nullptr;
+    a.rec_floor = any_floor ? static_cast<const uint8_t *>(D.b_recfloor.p) : nullptr;
+    a.floors = D.d_floors;
+    a.inv_db = ctx->d_inv_db;
+    a.state_h = D.d_state_h;
+    a.tw_long = D.t1->d_fast;
+    a.tw_short = D.t0->d_fast;
+    a.slope0 = D.t0->d_slope;
+    a.slope1 = D.t1->d_slope;
+    a.out = d_out;
+    a.stream_out_off = d_outoff;
+    a.channel_stride = channel_stride;
+    a.interleaved = out_layout == VPZ_OUT_INTERLEAVED;
+    a.clip = D.clip;
+    a.clipped = D.d_clipped;
+    hipError_t e = launch_synth(a, any_floor, ctx->stream);
+    if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "synth kernel launch", e);
+
+    if (mem_space == VPZ_MEM_HOST) {
+        for (int s = 0; s < D.n_streams; ++s) {
+            if (out_count[s] <= 0) continue;
+            if (out_layout == VPZ_OUT_INTERLEAVED) {
+                VPZ_HIP_TRY(ctx, hipMemcpyAsync(pcm_out + offs[s], d_out + offs[s],
+                                                sizeof(float) * (size_t)(out_count[s] * C), hipMemcpyDeviceToHost,
+                                                ctx->stream));
+            } else {
+                for (int ch = 0; ch < C; ++ch)
+                    VPZ_HIP_TRY(ctx, hipMemcpyAsync(pcm_out + offs[s] + (int64_t)ch * channel_stride,
+                                                    d_out + offs[s] + (int64_t)ch * channel_stride,
+                                                    sizeof(float) * (size_t)out_count[s], hipMemcpyDeviceToHost,
+                                                    ctx->stream));
+            }
+        }
+        VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    D.states = st;
+    return VPZ_OK;
+}
+
+int vpz_decoder_has_clipped(vpz_decoder *d, int32_t stream, int32_t *has_clipped)
+{
+    if (!d || !has_clipped) return VPZ_E_INVALID_ARG;
+    Decoder &D = d->impl;
+    if (stream < 0 || stream >= D.n_streams) return set_error(D.ctx, VPZ_E_INVALID_ARG, "bad stream index");
+    int32_t v = 0;
+    VPZ_HIP_TRY(D.ctx, hipMemcpyAsync(&v, D.d_clipped + stream, sizeof v, hipMemcpyDeviceToHost, D.ctx->stream));
+    VPZ_HIP_TRY(D.ctx, hipStreamSynchronize(D.ctx->stream));
+    *has_clipped = v != 0;
+    return VPZ_OK;
+}
+
+int vpz_decoder_position(vpz_decoder *d, int32_t stream, int64_t *sample_position)
+{
+    if (!d || !sample_position) return VPZ_E_INVALID_ARG;
+    Decoder &D = d->impl;
+    if (stream < 0 || stream >= D.n_streams) return set_error(D.ctx, VPZ_E_INVALID_ARG, "bad stream index");
+    *sample_position = D.states[stream].current_position;
+    return VPZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+// Internal declarations shared by the HIP translation units of libvorbispizza_synth.so.
+// gfx950 (MI355X) only -- no other back end exists or is dispatched to.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vorbispizza_synth.h"
+
+namespace vpz {
+
+// ---------------------------------------------------------------------------------------------
+// Device tables for one block size.
+//   fast path : unit twiddles of the N/4-point complex FFT factorisation (DESIGN.md "IMDCT kernel")
+//   exact path: the reference's A/B/C/bitrev tables (Mdct.cs:29-66), evaluated in the same f32 order
+//   window    : rising slope of the Vorbis window (BlocksizeDerivedCache.cs:25-36), f32 order
+// ---------------------------------------------------------------------------------------------
+struct BlockTables {
+    int n = 0;
+    // fast-path twiddles, float2 each: [tw n/4][twAB 512][twBC 64] (twAB only for n == 2048)
+    float2 *d_fast = nullptr;
+    // exact-path tables
+    float *d_A = nullptr, *d_B = nullptr, *d_C = nullptr;
+    uint16_t *d_bitrev = nullptr;
+    int ld = 0;
+    // window slope, n/2 floats
+    float *d_slope = nullptr;
+    std::vector<float> h_slope;
+};
+
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    int num_cu = 256;
+    std::string last_error;
+    std::map<int, BlockTables> tables;  // keyed by block size (Mdct._setupCache analogue)
+    float *d_inv_db = nullptr;          // 256-entry floor1 inverse dB table (Floor1.cs:407-473)
+    // staging buffers for VPZ_MEM_HOST calls (grown on demand, reused)
+    void *stage_in = nullptr;  size_t stage_in_bytes = 0;
+    void *stage_out = nullptr; size_t stage_out_bytes = 0;
+    void *stage_aux = nullptr; size_t stage_aux_bytes = 0;
+};
+
+int set_error(Context *ctx, int status, const char *what, hipError_t e = hipSuccess);
+int get_tables(Context *ctx, int n, BlockTables **out);
+int ensure_stage(Context *ctx, void **buf, size_t *have, size_t need);
+
+#define VPZ_HIP_TRY(ctx, expr)                                                   \
+    do {                                                                         \
+        hipError_t _e = (expr);                                                  \
+        if (_e != hipSuccess) return vpz::set_error((ctx), VPZ_E_HIP, #expr, _e); \
+    } while (0)
+
+// ---- kernel launchers (imdct_fast.hip / imdct_exact.hip / synth_kernels.hip) ----
+// spectra [count][n/2] -> out [count][n], device pointers, asynchronous on `stream`.
+hipError_t launch_imdct_fast_2048(const float *spectra, float *out, int64_t count,
+                                  const float2 *tw, int num_cu, hipStream_t stream);
+hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count,
+                                 const float2 *tw, int num_cu, hipStream_t stream);
+hipError_t launch_imdct_exact(int n, int ld, const float *spectra, float *out, int64_t count,
+                              const float *A, const float *B, const float *C,
+                              const uint16_t *bitrev, int num_cu, hipStream_t stream);
+
+// offsets (in float2 units) inside BlockTables::d_fast
+constexpr int kFastTwOffset = 0;       // tw[k] = exp(+2*pi*i*(k + 1/8)/n), k < n/4   (<= 512 entries)
+constexpr int kFastTwABOffset = 512;   // twAB[p*64 + l] = exp(+2*pi*i*l*p/512)
+constexpr int kFastTwBCOffset = 1024;  // twBC[l0*8 + q] = exp(+2*pi*i*l0*q/64)
+constexpr int kFastTableCount = 1024 + 64;
+
+}  // namespace vpz
+
+struct vpz_context {
+    vpz::Context impl;
+};
