@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded PCM Msamples/s of the MI355X Vorbis synthesis back end.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch of synthetic, HBM-resident input:
+BASELINE.json configs[1] -- batched long-block IMDCT (`Mdct.Reverse` semantics), N = 2048, 2 channels,
+65 536 frames = 131 072 channel-blocks per GPU (weak scaling: every rank owns its own batch; streams
+are independent, so there is no collective on the data path).  One sample = one float32 PCM value of
+one channel (N/2 per channel-block).
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  "roofline":     algorithmic bytes of the dominant kernel / its HIP-event duration vs 8 TB/s,
+  "cpu_baseline": the CPU oracle (restated reference, kind "port") timed on the host cores,
+  "extra_workloads": configs[2] (mixed 256/2048 window switching + overlap-add) and configs[3]
+                  (6 channels, Residue2-interleaved, coupled, Floor1 on the GPU), N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+FRAMES = 65536
+CHANNELS = 2
+N = 2048
+
+
+def cpu_baseline_imdct(seconds_target=12.0):
+    """Times the oracle's Mdct.Reverse restatement on the host: 1 thread, then all cores."""
+    import oracle
+    L = oracle.lib()
+    import ctypes as C
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(2048)
+    probe = (rng.standard_normal((512, N // 2)) * 2.0 ** -8).astype(np.float32)
+    out = np.empty((512, N), dtype=np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    t0 = time.perf_counter()
+    L.orc_mdct_reverse_batch(N, 512, fp(probe), fp(out))
+    per_block = (time.perf_counter() - t0) / 512
+    # single thread: ~1/4 of the budget
+    n1 = int(max(512, min(200000, seconds_target * 0.25 / per_block)))
+    x1 = np.tile(probe, (n1 // 512 + 1, 1))[:n1]
+    o1 = np.empty((n1, N), dtype=np.float32)
+    t0 = time.perf_counter()
+    L.orc_mdct_reverse_batch(N, n1, fp(x1), fp(o1))
+    t1 = time.perf_counter() - t0
+    rate1 = n1 * (N // 2) / t1 / 1e6
+    # all cores: one python thread per core, ctypes releases the GIL inside the C call
+    per_thread = int(max(512, min(200000, seconds_target * 0.75 / per_block)))
+    xs = [np.tile(probe, (per_thread // 512 + 1, 1))[:per_thread] for _ in range(cores)]
+    os_ = [np.empty((per_thread, N), dtype=np.float32) for _ in range(cores)]
+    ths = [threading.Thread(target=L.orc_mdct_reverse_batch, args=(N, per_thread, fp(xs[i]), fp(os_[i])))
+           for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    tall = time.perf_counter() - t0
+    rate_all = cores * per_thread * (N // 2) / tall / 1e6
+    return {
+        "value": round(rate_all, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "value_1thread": round(rate1, 2),
+        "sample": "oracle Mdct.Reverse restatement (gcc -O2 -ffp-contract=off), N=2048: %d channel-blocks on 1 "
+                  "thread (%.1f s), then %d per thread on %d threads (%.1f s)" % (n1, t1, per_thread, cores, tall),
+    }
+
+
+def build_synth_ola(torch, device):
+    """BASELINE configs[2]: one stereo stream, 65 536 frames, Markov block flags (seed 3)."""
+    import helpers
+    from vorbispizza_amd import capi, make_packets
+    flags = helpers.markov_block_flags(FRAMES, seed=3)
+    halves = np.where(flags & 1, 1024, 128).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(halves * CHANNELS)])
+    pk = make_packets(FRAMES)
+    pk["flags"] = flags | capi.PKT_NO_FLOOR
+    pk["granule"] = -1
+    pk["residue_offset"] = offs[:-1]
+    g = torch.Generator(device=device).manual_seed(3)
+    residue = torch.randn(int(offs[-1]), generator=g, device=device, dtype=torch.float32) * 2.0 ** -8
+    # samples per channel: every packet but the first emits RightStart - LeftStart
+    samples = 0
+    for f in range(1, FRAMES):
+        bf, pf, nf = flags[f] & 1, bool(flags[f] & 2), bool(flags[f] & 4)
+        if not bf:
+            samples += 128
+        else:
+            samples += (1024 if nf else 1472) - (0 if pf else 448)
+    return pk, residue, samples, int(offs[-1])
+
+
+def build_floor6(torch, device, frames=16384):
+    """BASELINE configs[3]: 6 channels, Residue2-interleaved residue zero above a cutoff, coupling
+    (0,1),(2,3), 29-post Floor1 rendered on the GPU, N = 2048."""
+    import helpers
+    from vorbispizza_amd import capi, make_packets
+    C6 = 6
+    rng = np.random.default_rng(6)
+    pk = make_packets(frames)
+    pk["flags"] = capi.PKT_BLOCK_FLAG | capi.PKT_PREV_FLAG | capi.PKT_NEXT_FLAG | capi.PKT_INTERLEAVED
+    pk["granule"] = -1
+    pk["residue_offset"] = np.arange(frames, dtype=np.int64) * (1024 * C6)
+    g = torch.Generator(device=device).manual_seed(6)
+    res = torch.round(torch.randn((frames, 1024, C6), generator=g, device=device) * 4.0)
+    res[:, 410:, :] = 0  # ~60 % zeros above the cutoff bin (end < N/2)
+    posts = np.zeros((frames * C6, 64), dtype=np.int16)
+    posts[:, 0] = rng.integers(20, 60, size=frames * C6)
+    posts[:, 1] = rng.integers(10, 40, size=frames * C6)
+    v = rng.integers(0, 10, size=(frames * C6, 27))
+    v[rng.random(v.shape) < 0.35] = 0
+    posts[:, 2:29] = v
+    counts = np.full(frames * C6, 29, dtype=np.uint8)
+    floors = [(helpers.LONG_XLIST, 2)]
+    mappings = [{"coupling": [(0, 1), (2, 3)], "channel_floor": [0] * C6}]
+    return pk, res.reshape(-1).contiguous(), torch.from_numpy(posts).to(device), torch.from_numpy(counts).to(device), \
+        floors, mappings, (frames - 1) * 1024
+
+
+def time_decoder(ctx, dec, torch, pk, residue, posts, counts, samples, channels, steps, warmup):
+    from vorbispizza_amd import capi
+    out = torch.empty(channels * (samples + 1024), device=residue.device, dtype=torch.float32)
+    cap = samples + 1024
+
+    def step():
+        dec.reset(-1)
+        w = dec.synth_raw(pk, residue, posts, counts, out, None, cap, capi.OUT_PLANAR, cap, capi.MEM_DEVICE)
+        assert int(w[0]) == samples, (int(w[0]), samples)
+
+    for _ in range(warmup):
+        step()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return dt, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[2]/[3] side measurements")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as ge
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if rank == 0:
+        ge.build()
+    if distributed:
+        dist.barrier()
+    from vorbispizza_amd import Context, Decoder, capi
+
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    ctx = Context(local_rank)
+
+    # ---------------- configs[1]: batched long-block IMDCT, device-resident
+    count = FRAMES * CHANNELS
+    g = torch.Generator(device=device).manual_seed(2048 + rank)
+    spectra = torch.randn((count, N // 2), generator=g, device=device, dtype=torch.float32) * 2.0 ** -8
+    out = torch.empty((count, N), device=device, dtype=torch.float32)
+    torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.imdct_batch(spectra, N, capi.IMDCT_FAST, out=out)
+    ctx.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.timer_start()  # HIP events on the stream the kernel is launched on
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.imdct_batch(spectra, N, capi.IMDCT_FAST, out=out)
+    kernel_ms = ctx.timer_stop() / args.steps  # also synchronises the stream
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        elapsed = float(t.item())
+
+    samples_per_step = world * count * (N // 2)
+    value = samples_per_step * args.steps / elapsed / 1e6
+    alg_bytes = count * (4 * (N // 2) + 4 * N)  # 12 288 B per channel-block
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "decoded PCM Msamples/s (batched stereo N=2048)",
+        "value": round(value, 1),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: batched long-block IMDCT (Mdct.Reverse semantics), N=2048, 2 ch, "
+                        "65536 frames = 131072 channel-blocks per GPU, spectra N(0, 2^-8) device-resident",
+            "channel_blocks_per_gpu": count, "block_size": N, "sharding": "independent batch per GPU, no collective",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "imdct2048_kernel", "kernel_ms": round(kernel_ms, 4),
+            "algorithmic_bytes_per_launch": alg_bytes,
+        },
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_imdct()
+        if not args.no_extras:
+            extras = {}
+            del out
+            torch.cuda.empty_cache()
+            # configs[2]
+            pk, residue, samples, res_floats = build_synth_ola(torch, device)
+            dec = Decoder(ctx, CHANNELS, 256, 2048)
+            dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 5, 2)
+            byt = 4 * res_floats + 4 * samples * CHANNELS
+            extras["configs[2] mixed 256/2048 + window + OLA, stereo, 65536 frames, planar out"] = {
+                "Msamples_per_s": round(samples * CHANNELS / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
+                "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "whole vpz_decoder_synth call incl. host state machine + descriptor upload"}
+            dec.close()
+            del residue
+            torch.cuda.empty_cache()
+            # configs[3]
+            pk, res6, posts, counts, floors, mappings, samples6 = build_floor6(torch, device)
+            dec = Decoder(ctx, 6, 256, 2048, floors=floors, mappings=mappings)
+            dt, _ = time_decoder(ctx, dec, torch, pk, res6, posts, counts, samples6, 6, 5, 2)
+            byt = 4 * res6.numel() + 4 * samples6 * 6 + posts.numel() * 2
+            extras["configs[3] 6ch Residue2-interleaved + coupling + Floor1 on GPU, N=2048, 16384 frames"] = {
+                "Msamples_per_s": round(samples6 * 6 / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
+                "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "3 kernels (unwrap, de-interleave+coupling, fused floor+IMDCT+OLA); whole call"}
+            dec.close()
+            result["extra_workloads"] = extras
+    ctx.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -93,6 +93,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libvorbispizza_synth.so is not built: run `python -c 'import __graft_entry__ as g; "
                               "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64,
+        # and a second copy initialised later finds no device.  Importing torch first makes the
+        # loader bind this library's NEEDED libamdhip64.so.7 to the copy torch already loaded.
+        if not os.environ.get("VPZ_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, restype, argtypes in _SIGNATURES:
             fn = getattr(L, name)
@@ -158,7 +166,7 @@ class Context:
     def imdct_batch(self, spectra, n, mode=IMDCT_FAST, out=None):
         """`Mdct.Reverse` (Mdct.cs:15-19) per row.  numpy in -> numpy out (host memory, synchronous);
         torch cuda tensor in -> torch cuda tensor out (device memory, asynchronous on the context stream)."""
-        half = n // 2
+        half = max(n // 2, 1)
         if _is_torch(spectra):
             import torch
             assert spectra.is_cuda and spectra.dtype == torch.float32 and spectra.is_contiguous()
