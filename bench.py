@@ -36,56 +36,70 @@ CHANNELS = 2
 N = 2048
 
 
-def cpu_baseline_imdct(seconds_target=12.0):
-    """Times the oracle's Mdct.Reverse restatement on the host: 1 thread, then all cores."""
+def host_threads(cap=16):
+    """Threads for the CPU baseline: the box's CPU share for one GPU, never more than `cap`."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(cap, n))
+
+
+def cpu_baseline_imdct(seconds_1thread=4.0, seconds_all=8.0):
+    """Times the oracle's Mdct.Reverse restatement on the host cores: 1 thread, then `host_threads()`
+    threads.  Every thread re-transforms its own 512-block buffer (6 MiB) until its deadline, so the
+    memory footprint is bounded regardless of the core count."""
+    import ctypes as C
+
     import oracle
     L = oracle.lib()
-    import ctypes as C
-    cores = os.cpu_count() or 1
+    threads = host_threads()
     rng = np.random.default_rng(2048)
-    probe = (rng.standard_normal((512, N // 2)) * 2.0 ** -8).astype(np.float32)
-    out = np.empty((512, N), dtype=np.float32)
+    chunk = 512
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
-    t0 = time.perf_counter()
-    L.orc_mdct_reverse_batch(N, 512, fp(probe), fp(out))
-    per_block = (time.perf_counter() - t0) / 512
-    # single thread: ~1/4 of the budget
-    n1 = int(max(512, min(200000, seconds_target * 0.25 / per_block)))
-    x1 = np.tile(probe, (n1 // 512 + 1, 1))[:n1]
-    o1 = np.empty((n1, N), dtype=np.float32)
-    t0 = time.perf_counter()
-    L.orc_mdct_reverse_batch(N, n1, fp(x1), fp(o1))
-    t1 = time.perf_counter() - t0
-    rate1 = n1 * (N // 2) / t1 / 1e6
-    # all cores: one python thread per core, ctypes releases the GIL inside the C call
-    per_thread = int(max(512, min(200000, seconds_target * 0.75 / per_block)))
-    xs = [np.tile(probe, (per_thread // 512 + 1, 1))[:per_thread] for _ in range(cores)]
-    os_ = [np.empty((per_thread, N), dtype=np.float32) for _ in range(cores)]
-    ths = [threading.Thread(target=L.orc_mdct_reverse_batch, args=(N, per_thread, fp(xs[i]), fp(os_[i])))
-           for i in range(cores)]
+
+    def worker(seconds, result, idx):
+        x = (rng.standard_normal((chunk, N // 2)) * 2.0 ** -8).astype(np.float32) if idx == 0 else xs[idx]
+        o = np.empty((chunk, N), dtype=np.float32)
+        done = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            L.orc_mdct_reverse_batch(N, chunk, fp(x), fp(o))
+            done += chunk
+        result[idx] = (done, time.perf_counter() - t0)
+
+    xs = [(np.random.default_rng(i).standard_normal((chunk, N // 2)) * 2.0 ** -8).astype(np.float32)
+          for i in range(threads)]
+    r1 = [None]
+    worker(seconds_1thread, r1, 0)
+    rate1 = r1[0][0] * (N // 2) / r1[0][1] / 1e6
+    res = [None] * threads
+    ths = [threading.Thread(target=worker, args=(seconds_all, res, i)) for i in range(threads)]
     t0 = time.perf_counter()
     for t in ths:
         t.start()
     for t in ths:
         t.join()
-    tall = time.perf_counter() - t0
-    rate_all = cores * per_thread * (N // 2) / tall / 1e6
+    wall = time.perf_counter() - t0
+    blocks = sum(r[0] for r in res)
+    rate_all = blocks * (N // 2) / wall / 1e6
     return {
-        "value": round(rate_all, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "value": round(rate_all, 2), "unit": "Msamples/s", "cores": threads, "kind": "port",
         "value_1thread": round(rate1, 2),
-        "sample": "oracle Mdct.Reverse restatement (gcc -O2 -ffp-contract=off), N=2048: %d channel-blocks on 1 "
-                  "thread (%.1f s), then %d per thread on %d threads (%.1f s)" % (n1, t1, per_thread, cores, tall),
+        "sample": "oracle Mdct.Reverse restatement (gcc -O2 -ffp-contract=off, scalar), N=2048: %d channel-blocks on "
+                  "1 thread in %.1f s, then %d channel-blocks on %d threads in %.1f s"
+                  % (r1[0][0], r1[0][1], blocks, threads, wall),
     }
 
 
-def build_synth_ola(torch, device):
+def build_synth_ola(torch, device, frames=FRAMES):
     """BASELINE configs[2]: one stereo stream, 65 536 frames, Markov block flags (seed 3)."""
     import helpers
     from vorbispizza_amd import capi, make_packets
-    flags = helpers.markov_block_flags(FRAMES, seed=3)
+    flags = helpers.markov_block_flags(frames, seed=3)
     halves = np.where(flags & 1, 1024, 128).astype(np.int64)
     offs = np.concatenate([[0], np.cumsum(halves * CHANNELS)])
-    pk = make_packets(FRAMES)
+    pk = make_packets(frames)
     pk["flags"] = flags | capi.PKT_NO_FLOOR
     pk["granule"] = -1
     pk["residue_offset"] = offs[:-1]
@@ -93,7 +107,7 @@ def build_synth_ola(torch, device):
     residue = torch.randn(int(offs[-1]), generator=g, device=device, dtype=torch.float32) * 2.0 ** -8
     # samples per channel: every packet but the first emits RightStart - LeftStart
     samples = 0
-    for f in range(1, FRAMES):
+    for f in range(1, frames):
         bf, pf, nf = flags[f] & 1, bool(flags[f] & 2), bool(flags[f] & 4)
         if not bf:
             samples += 128
@@ -157,6 +171,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[2]/[3] side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras-frames", type=int, default=FRAMES, help="frames of the configs[2] side measurement")
+    ap.add_argument("--extras-frames6", type=int, default=16384, help="frames of the configs[3] side measurement")
     args = ap.parse_args()
 
     import torch
@@ -247,11 +263,11 @@ def main():
             del out
             torch.cuda.empty_cache()
             # configs[2]
-            pk, residue, samples, res_floats = build_synth_ola(torch, device)
+            pk, residue, samples, res_floats = build_synth_ola(torch, device, args.extras_frames)
             dec = Decoder(ctx, CHANNELS, 256, 2048)
             dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 5, 2)
             byt = 4 * res_floats + 4 * samples * CHANNELS
-            extras["configs[2] mixed 256/2048 + window + OLA, stereo, 65536 frames, planar out"] = {
+            extras["configs[2] mixed 256/2048 + window + OLA, stereo, %d frames, planar out" % args.extras_frames] = {
                 "Msamples_per_s": round(samples * CHANNELS / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "whole vpz_decoder_synth call incl. host state machine + descriptor upload"}
@@ -259,11 +275,11 @@ def main():
             del residue
             torch.cuda.empty_cache()
             # configs[3]
-            pk, res6, posts, counts, floors, mappings, samples6 = build_floor6(torch, device)
+            pk, res6, posts, counts, floors, mappings, samples6 = build_floor6(torch, device, args.extras_frames6)
             dec = Decoder(ctx, 6, 256, 2048, floors=floors, mappings=mappings)
             dt, _ = time_decoder(ctx, dec, torch, pk, res6, posts, counts, samples6, 6, 5, 2)
             byt = 4 * res6.numel() + 4 * samples6 * 6 + posts.numel() * 2
-            extras["configs[3] 6ch Residue2-interleaved + coupling + Floor1 on GPU, N=2048, 16384 frames"] = {
+            extras["configs[3] 6ch Residue2-interleaved + coupling + Floor1 on GPU, N=2048, %d frames" % args.extras_frames6] = {
                 "Msamples_per_s": round(samples6 * 6 / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "3 kernels (unwrap, de-interleave+coupling, fused floor+IMDCT+OLA); whole call"}
