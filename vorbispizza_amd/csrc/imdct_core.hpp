@@ -41,6 +41,15 @@ __device__ __forceinline__ float lane_mirror8(float v, int lane)
     return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 7) << 2, __float_as_int(v)));
 }
 
+typedef float vpz_f4v __attribute__((ext_vector_type(4)));
+typedef float vpz_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_nt(float4 *p, float4 v)
+{
+    vpz_f4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<vpz_f4v *>(p));
+}
+__device__ __forceinline__ void store_nt(float *p, float v) { __builtin_nontemporal_store(v, p); }
+
 // In-register 8-point inverse DFT: v[p] <- sum_m v[m] * exp(+2*pi*i*p*m/8)
 __device__ __forceinline__ void radix8_inverse(float2 (&v)[8])
 {

@@ -6,6 +6,8 @@
 // workgroups of 4 wavefronts grid-stride over the batch with the next block's loads in flight
 // while the current one is transformed.  All global accesses are 8 or 16 bytes per lane and each
 // wave-instruction covers one contiguous 512 B / 1 KiB span.
+#include <cstdlib>
+
 #include "imdct_core.hpp"
 #include "vpz_internal.hpp"
 
@@ -27,12 +29,13 @@ __device__ __forceinline__ void store_full_block(const float *h, float *out, int
     for (int r = 0; r < H4 / LANES; ++r) {
         const int f = l + LANES * r;
         float4 v = h4[f];
-        o4[Q4 + f] = v;
+        // streaming (non-temporal) stores: the PCM is written once and never re-read here
+        store_nt(&o4[Q4 + f], v);
         float4 rv = make_float4(v.w, v.z, v.y, v.x);
         if (r < (H4 / LANES) / 2) {  // f < Q4: first quarter, negated mirror
-            o4[Q4 - 1 - f] = make_float4(-rv.x, -rv.y, -rv.z, -rv.w);
+            store_nt(&o4[Q4 - 1 - f], make_float4(-rv.x, -rv.y, -rv.z, -rv.w));
         } else {                     // last quarter, mirror
-            o4[3 * Q4 + (H4 - 1 - f)] = rv;
+            store_nt(&o4[3 * Q4 + (H4 - 1 - f)], rv);
         }
     }
 }
@@ -119,10 +122,30 @@ __global__ __launch_bounds__(kThreads) void imdct256_kernel(const float *__restr
     }
 }
 
-static int grid_for(int64_t work_groups, int num_cu, int groups_per_cu)
+// Persistent grid: exactly as many workgroups as the chip keeps resident (CUs x measured
+// occupancy), so that every workgroup gets the same share of the batch and there is no partial
+// last round of workgroups.
+template <typename K>
+static int resident_groups(K kernel, int num_cu)
 {
-    int64_t cap = (int64_t)num_cu * groups_per_cu;
-    int64_t g = work_groups < cap ? work_groups : cap;
+    int per_cu = 0;
+    if (const char *e = getenv("VPZ_IMDCT_GROUPS_PER_CU")) {  // tuning experiments only
+        per_cu = atoi(e);
+        if (per_cu > 0) return num_cu * per_cu;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 2;
+    }
+    // Measured on MI355X (profiles/r1_grid_sweep.txt): 2 workgroups (8 wavefronts) per CU stream
+    // HBM best for this 1:2 read:write shape; more resident waves only add DRAM page conflicts.
+    if (per_cu > 2) per_cu = 2;
+    return num_cu * per_cu;
+}
+
+static int grid_for(int64_t work_groups, int resident)
+{
+    int64_t g = work_groups < resident ? work_groups : resident;
     return (int)(g < 1 ? 1 : g);
 }
 
@@ -130,7 +153,9 @@ hipError_t launch_imdct_fast_2048(const float *spectra, float *out, int64_t coun
                                   const float2 *tw, int num_cu, hipStream_t stream)
 {
     if (count <= 0) return hipSuccess;
-    int grid = grid_for((count + kWavesPerGroup - 1) / kWavesPerGroup, num_cu, 4);
+    static int resident = 0;
+    if (!resident) resident = resident_groups(imdct2048_kernel, num_cu);
+    int grid = grid_for((count + kWavesPerGroup - 1) / kWavesPerGroup, resident);
     hipLaunchKernelGGL(imdct2048_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out,
                        (long)count, tw);
     return hipGetLastError();
@@ -140,8 +165,10 @@ hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count
                                  const float2 *tw, int num_cu, hipStream_t stream)
 {
     if (count <= 0) return hipSuccess;
+    static int resident = 0;
+    if (!resident) resident = resident_groups(imdct256_kernel, num_cu);
     int64_t per_group = kWavesPerGroup * 8;
-    int grid = grid_for((count + per_group - 1) / per_group, num_cu, 4);
+    int grid = grid_for((count + per_group - 1) / per_group, resident);
     hipLaunchKernelGGL(imdct256_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out,
                        (long)count, tw);
     return hipGetLastError();
