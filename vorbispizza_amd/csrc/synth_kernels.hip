@@ -257,63 +257,64 @@ __device__ __forceinline__ void render_floor_curve(float *curve, int *aux, int n
 // ---------------------------------------------------------------------------------------------
 // synth_kernel
 // ---------------------------------------------------------------------------------------------
-struct WaveCtx {
-    float *buf[2];   // ping-pong: buf[cur] receives h of the block being built, buf[cur^1] = previous h
-    int cur;
-    int prev_n4;     // n/4 of the previous block (0: none)
-};
-
-template <bool kHasFloor>
-__device__ __forceinline__ void build_block(const SynthArgs &a, const FrameDesc &fd, int ch, int lane,
-                                            const float2 (&xin)[8], float *hbuf, float *other,
-                                            const float2 *s_twL, const float2 *s_twAB,
-                                            const float2 *s_twBC, const float2 *s_twS,
-                                            const float *s_db, bool exec)
+// Utils.ClipValue (Utils.cs:44-58): strict comparisons, NaN passes through
+__device__ __forceinline__ bool clip1(float &v)
 {
-    const bool is_long = fd.flags & kFrameLong;
-    const int n = is_long ? a.size1 : a.size0;
-    const int half = n >> 1;
-    if (!exec) {  // Mapping.cs:190-194: the channel is silent, its whole block is zero
-        for (int i = lane; i < half; i += 64) hbuf[i] = 0.0f;
-        return;
+    if (v > 0.99999994f) { v = 0.99999994f; return true; }
+    if (v < -0.99999994f) { v = -0.99999994f; return true; }
+    return false;
+}
+
+// four consecutive outputs y[pos..pos+3], pos and n4 multiples of 4
+__device__ __forceinline__ float4 y4_from_h(const float *h, int pos, int n4)
+{
+    const float4 *h4 = reinterpret_cast<const float4 *>(h);
+    if (pos < n4) {
+        const float4 t = h4[(n4 - 4 - pos) >> 2];
+        return make_float4(-t.w, -t.z, -t.y, -t.x);
     }
-    float2 x[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) x[m] = xin[m];
-    if (kHasFloor && !(fd.flags & kFrameNoFloor)) {
-        // curve goes to the buffer that will receive h (free until the transposes start)
+    if (pos < 3 * n4) return h4[(pos - n4) >> 2];
+    const float4 t = h4[(5 * n4 - 4 - pos) >> 2];
+    return make_float4(t.w, t.z, t.y, t.x);
+}
+
+// Builds h of one channel-block into the wave-private LDS buffer `hbuf`:
+// (optional) Floor1 curve x spectrum, then the inverse MDCT.  kLong selects N = 2048 / 256.
+template <bool kHasFloor, bool kLong>
+__device__ __forceinline__ void build_block(const SynthArgs &a, uint32_t fd_flags, int rec, int lane,
+                                            float2 (&x)[8], float *hbuf, const float2 *s_twL,
+                                            const float2 *s_twAB, const float2 *s_twBC,
+                                            const float2 *s_twS, const float *s_db)
+{
+    constexpr int half = kLong ? 1024 : 128;
+    if (kHasFloor && !(fd_flags & kFrameNoFloor)) {
+        // the curve goes to the buffer that will receive h (free until the transposes start)
         int *aux = reinterpret_cast<int *>(hbuf + 1024);
-        render_floor_curve(hbuf, aux, half, fd.rec + ch, a, s_db, lane);
+        render_floor_curve(hbuf, aux, half, rec, a, s_db, lane);
         const float2 *c2 = reinterpret_cast<const float2 *>(hbuf);
-        if (n == 2048) {
+        const int k0 = kLong ? lane : (lane & 7);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) { float2 c = c2[lane + 64 * m]; x[m].x *= c.x; x[m].y *= c.y; }
-        } else {
-            const int l = lane & 7;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) { float2 c = c2[l + 8 * m]; x[m].x *= c.x; x[m].y *= c.y; }
+        for (int m = 0; m < 8; ++m) {
+            const float2 c = c2[k0 + (kLong ? 64 : 8) * m];
+            x[m].x *= c.x;
+            x[m].y *= c.y;
         }
     }
-    if (n == 2048) {
+    if (kLong) {
         imdct2048_wave(x, reinterpret_cast<float2 *>(hbuf), s_twL, s_twAB, s_twBC, lane);
     } else {
         // all eight lane groups transform the same short block; group 0's copy lands at hbuf[0..128)
         imdct256_wave8(x, reinterpret_cast<float2 *>(hbuf), s_twS, s_twBC, lane);
     }
-    (void)other;
 }
 
-__device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base, int n, int lane)
+__device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base, bool is_long, int lane)
 {
     const float2 *s = reinterpret_cast<const float2 *>(base);
-    if (n == 2048) {
+    const int k0 = is_long ? lane : (lane & 7);
+    const int st = is_long ? 64 : 8;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) x[m] = s[lane + 64 * m];
-    } else {
-        const int l = lane & 7;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) x[m] = s[l + 8 * m];
-    }
+    for (int m = 0; m < 8; ++m) x[m] = s[k0 + st * m];
 }
 
 template <bool kHasFloor>
@@ -349,95 +350,125 @@ __global__ __launch_bounds__(kSynthThreads) void synth_kernel(SynthArgs a)
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const long item = (long)blockIdx.x * kSynthWaves + wave;
-    if (item >= (long)a.n_runs * a.channels) return;
-    const int run_idx = (int)(item / a.channels);
-    const int ch = (int)(item - (long)run_idx * a.channels);
+    // wave-uniform values are forced into SGPRs so the descriptor reads become scalar loads
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x * kSynthWaves + wave;
+    if (item >= a.n_runs * a.channels) return;
+    const int run_idx = item / a.channels;
+    const int ch = item - run_idx * a.channels;
     const RunDesc run = a.runs[run_idx];
     const int half1 = a.size1 >> 1;
 
-    float *bufs[2] = {s_buf[wave][0], s_buf[wave][1]};
-    int cur = 0;
-    int prev_n4 = 0;
+    int cur = 0;      // s_buf[wave][cur] receives the block being built, [cur ^ 1] holds the previous h
+    int prev_n4 = 0;  // n/4 of the previous block (0: none yet)
 
-    auto exec_of = [&](const FrameDesc &fd) -> bool {
-        return a.post_counts == nullptr || (fd.flags & kFrameNoFloor) || a.post_counts[fd.rec + ch] != 0;
+    auto exec_of = [&](uint32_t flags, int rec) -> bool {
+        return a.post_counts == nullptr || (flags & kFrameNoFloor) || a.post_counts[rec + ch] != 0;
+    };
+    auto spectrum_of = [&](const FrameDesc &fd) -> const float * {
+        const int hh = (fd.flags & kFrameLong) ? (a.size1 >> 1) : (a.size0 >> 1);
+        return a.spec + fd.spec_off + (int64_t)ch * hh;
     };
 
-    // ---- block preceding the run
+    // ---- block preceding the run: from the saved state, or recomputed as "frame -1" of the loop
     if (run.pre_kind == kPreState) {
         const float *st = a.state_h + ((size_t)run.stream * a.channels + ch) * half1;
         const int ph = run.prev_long ? (a.size1 >> 1) : (a.size0 >> 1);
-        for (int i = lane; i < ph; i += 64) bufs[1][i] = st[i];
+        float *hp = s_buf[wave][1];
+        for (int i = lane; i < ph; i += 64) hp[i] = st[i];
         prev_n4 = ph >> 1;
-    } else if (run.pre_kind == kPreRecompute) {
-        const FrameDesc fd = a.frames[run.first - 1];
-        const int n = (fd.flags & kFrameLong) ? a.size1 : a.size0;
-        const bool ex = exec_of(fd);
-        float2 x[8];
-        if (ex) load_spectrum(x, a.spec + fd.spec_off + (size_t)ch * (n >> 1), n, lane);
-        build_block<kHasFloor>(a, fd, ch, lane, x, bufs[1], bufs[0], s_twL, s_twAB, s_twBC, s_twS, s_db, ex);
-        prev_n4 = n >> 2;
     }
+    const int fi0 = (run.pre_kind == kPreRecompute) ? -1 : 0;
+    if (fi0 < 0) cur = 1;  // the recomputed block lands in buffer 1, the first real block in buffer 0
 
     float *out_base = a.out + (a.stream_out_off ? a.stream_out_off[run.stream] : 0);
     bool clipped_any = false;
 
-    // ---- software pipeline: spectrum of frame i+1 is in flight while frame i is synthesised
+    // ---- software pipeline: the spectrum of frame i+1 is in flight while frame i is synthesised
     float2 xcur[8];
     {
-        const FrameDesc fd0 = a.frames[run.first];
-        if (!(fd0.flags & kFrameDrain) && exec_of(fd0)) {
-            const int n = (fd0.flags & kFrameLong) ? a.size1 : a.size0;
-            load_spectrum(xcur, a.spec + fd0.spec_off + (size_t)ch * (n >> 1), n, lane);
-        }
+        const FrameDesc fd0 = a.frames[run.first + fi0];
+        if (!(fd0.flags & kFrameDrain) && exec_of(fd0.flags, fd0.rec))
+            load_spectrum(xcur, spectrum_of(fd0), fd0.flags & kFrameLong, lane);
     }
-    int last_long = 0;
-    for (int fi = 0; fi < run.count; ++fi) {
+    for (int fi = fi0; fi < run.count; ++fi) {
         const FrameDesc fd = a.frames[run.first + fi];
         float2 xnext[8];
         if (fi + 1 < run.count) {
             const FrameDesc fn = a.frames[run.first + fi + 1];
-            if (!(fn.flags & kFrameDrain) && exec_of(fn)) {
-                const int nn = (fn.flags & kFrameLong) ? a.size1 : a.size0;
-                load_spectrum(xnext, a.spec + fn.spec_off + (size_t)ch * (nn >> 1), nn, lane);
-            }
+            if (!(fn.flags & kFrameDrain) && exec_of(fn.flags, fn.rec))
+                load_spectrum(xnext, spectrum_of(fn), fn.flags & kFrameLong, lane);
         }
         const bool drain = fd.flags & kFrameDrain;
-        const int n = (fd.flags & kFrameLong) ? a.size1 : a.size0;
-        const int n4 = n >> 2;
-        float *hcur = bufs[cur], *hprev = bufs[cur ^ 1];
-        if (!drain)
-            build_block<kHasFloor>(a, fd, ch, lane, xcur, hcur, hprev, s_twL, s_twAB, s_twBC, s_twS, s_db,
-                                   exec_of(fd));
-
-        // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 573-591)
-        const float *slope = (fd.flags & kFrameSlope1) ? s_slope1 : s_slope0;
-        const int plen = fd.packet_len;
-        for (int i = lane; i < fd.out_count; i += 64) {
-            float v;
-            if (drain) {
-                v = y_from_h(hprev, fd.prev_end + i, prev_n4);
+        const bool is_long = fd.flags & kFrameLong;
+        const int n4 = is_long ? (a.size1 >> 2) : (a.size0 >> 2);
+        float *hcur = s_buf[wave][cur];
+        const float *hprev = s_buf[wave][cur ^ 1];
+        if (!drain) {
+            if (!exec_of(fd.flags, fd.rec)) {
+                // Mapping.cs:190-194: the channel is silent, its whole block is zero
+                for (int i = lane; i < 2 * n4; i += 64) hcur[i] = 0.0f;
+            } else if (is_long) {
+                build_block<kHasFloor, true>(a, fd.flags, fd.rec + ch, lane, xcur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
             } else {
-                v = y_from_h(hcur, fd.left_start + i, n4);
-                if (i < plen) {
-                    const float t = y_from_h(hprev, fd.prev_end + i, prev_n4);
-                    v = (v * slope[i]) + (t * slope[plen - 1 - i]);
+                build_block<kHasFloor, false>(a, fd.flags, fd.rec + ch, lane, xcur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
+            }
+        }
+
+        if (fi >= 0 && fd.out_count > 0) {
+            // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 573-591)
+            const float *slope = (fd.flags & kFrameSlope1) ? s_slope1 : s_slope0;
+            const int plen = fd.packet_len;
+            float *dst = a.interleaved ? out_base + fd.out_off * a.channels + ch
+                                       : out_base + (int64_t)ch * a.channel_stride + fd.out_off;
+            // every window boundary of the 256/2048 geometries is a multiple of 64 samples, so unless
+            // an EOS trim cut the packet a float4 never straddles a mirror / overlap boundary
+            const bool vec = !drain && !a.interleaved &&
+                             ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0 &&
+                             (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+            if (vec) {
+                const float4 *s4 = reinterpret_cast<const float4 *>(slope);
+                for (int g = lane; g < (fd.out_count >> 2); g += 64) {
+                    const int i = g << 2;
+                    float4 v = y4_from_h(hcur, fd.left_start + i, n4);
+                    if (i < plen) {
+                        const float4 t = y4_from_h(hprev, fd.prev_end + i, prev_n4);
+                        const float4 wl = s4[g];
+                        const float4 wr = s4[((plen - 4 - i) >> 2)];  // reversed slope: wr.w pairs with sample i
+                        v.x = (v.x * wl.x) + (t.x * wr.w);
+                        v.y = (v.y * wl.y) + (t.y * wr.z);
+                        v.z = (v.z * wl.z) + (t.z * wr.y);
+                        v.w = (v.w * wl.w) + (t.w * wr.x);
+                    }
+                    if (a.clip) {
+                        clipped_any |= clip1(v.x);
+                        clipped_any |= clip1(v.y);
+                        clipped_any |= clip1(v.z);
+                        clipped_any |= clip1(v.w);
+                    }
+                    store_nt(reinterpret_cast<float4 *>(dst) + g, v);
+                }
+            } else {
+                const int64_t step = a.interleaved ? a.channels : 1;
+                for (int i = lane; i < fd.out_count; i += 64) {
+                    float v;
+                    if (drain) {
+                        v = y_from_h(hprev, fd.prev_end + i, prev_n4);
+                    } else {
+                        v = y_from_h(hcur, fd.left_start + i, n4);
+                        if (i < plen) {
+                            const float t = y_from_h(hprev, fd.prev_end + i, prev_n4);
+                            v = (v * slope[i]) + (t * slope[plen - 1 - i]);
+                        }
+                    }
+                    if (a.clip) clipped_any |= clip1(v);
+                    dst[i * step] = v;
                 }
             }
-            if (a.clip) {
-                if (v > 0.99999994f) { v = 0.99999994f; clipped_any = true; }
-                else if (v < -0.99999994f) { v = -0.99999994f; clipped_any = true; }
-            }
-            const int64_t t = fd.out_off + i;
-            if (a.interleaved) out_base[t * a.channels + ch] = v;
-            else out_base[(int64_t)ch * a.channel_stride + t] = v;
         }
         if (!drain) {
             cur ^= 1;
             prev_n4 = n4;
-            last_long = (fd.flags & kFrameLong) ? 1 : 0;
         }
 #pragma unroll
         for (int m = 0; m < 8; ++m) xcur[m] = xnext[m];
@@ -446,9 +477,8 @@ __global__ __launch_bounds__(kSynthThreads) void synth_kernel(SynthArgs a)
     // ---- keep the last block for the next batch (the reference keeps _prevPacketBuf)
     if ((run.flags & kRunSaveState) && prev_n4 > 0) {
         float *st = a.state_h + ((size_t)run.stream * a.channels + ch) * half1;
-        const float *hl = bufs[cur ^ 1];
+        const float *hl = s_buf[wave][cur ^ 1];
         for (int i = lane; i < 2 * prev_n4; i += 64) st[i] = hl[i];
-        (void)last_long;
     }
     if (a.clip && __any(clipped_any) && lane == 0) atomicOr(&a.clipped[run.stream], 1);
 }
@@ -492,6 +522,21 @@ hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t strea
     else
         hipLaunchKernelGGL(synth_kernel<false>, dim3(grid), dim3(kSynthThreads), 0, stream, args);
     return hipGetLastError();
+}
+
+// wavefronts of synth_kernel the chip keeps resident (for sizing runs so that the grid fills an
+// integral number of rounds)
+int synth_resident_waves(bool has_floor, int num_cu)
+{
+    int per_cu = 0;
+    hipError_t e = has_floor
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<true>, kSynthThreads, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<false>, kSynthThreads, 0);
+    if (e != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 2;
+    }
+    return num_cu * per_cu * kSynthWaves;
 }
 
 size_t coupling_packet_size() { return sizeof(CouplingPacket); }

@@ -19,6 +19,7 @@ hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *
 hipError_t launch_coupling(const void *pkts, int n_pkts, const uint8_t *steps, int channels,
                            const float *residue, float *temp, int max_half, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t stream);
+int synth_resident_waves(bool has_floor, int num_cu);
 size_t coupling_packet_size();
 void fill_coupling_packet(void *dst, int64_t src_off, int64_t dst_off, int32_t half, int32_t steps_off,
                           int32_t steps, int32_t interleaved);
@@ -378,10 +379,22 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         D.states = st;
         return VPZ_OK;
     }
+    // Run length: a wavefront synthesises R consecutive blocks of one channel (+1 recomputed block in
+    // front).  Pick the R (<= 32) for which the run count fills k whole rounds of the resident waves
+    // with the least total work k * (R + 1); short batches fall back to R = 4.
     int R = D.run_length_override;
     if (R <= 0) {
-        const int64_t target_items = (int64_t)ctx->num_cu * 24;
-        R = (int)std::min<int64_t>(32, std::max<int64_t>(4, total_frames * C / std::max<int64_t>(1, target_items)));
+        const int64_t slots = std::max(1, synth_resident_waves(any_floor, ctx->num_cu));
+        const int64_t work = total_frames * C;
+        R = 4;
+        int64_t best = -1;
+        for (int k = 1; k <= 64; ++k) {
+            int64_t r = (work + k * slots - 1) / (k * slots);
+            if (r > 32) continue;
+            if (r < 4) break;
+            const int64_t cost = (int64_t)k * (r + 1);
+            if (best < 0 || cost < best) { best = cost; R = (int)r; }
+        }
     }
     std::vector<FrameDesc> frames;
     frames.reserve((size_t)total_frames);
