@@ -19,9 +19,10 @@
 
 namespace vpz {
 
-constexpr int kSynthWaves = 4;
+constexpr int kSynthWaves = 8;
 constexpr int kSynthThreads = 64 * kSynthWaves;
 constexpr int kWaveBufFloats = 1160;  // h (<=1024 floats) | transposes (1152) | floor curve + 129 ints
+constexpr int kWaveTailFloats = 512;  // upper half of the previous block's h: all a later block can overlap with
 
 // ---------------------------------------------------------------------------------------------
 // Floor1.UnwrapPosts, one lane per record.  posts: raw [rec][64]; writes final_y = finalY *
@@ -258,24 +259,42 @@ __device__ __forceinline__ void render_floor_curve(float *curve, int *aux, int n
 // synth_kernel
 // ---------------------------------------------------------------------------------------------
 // Utils.ClipValue (Utils.cs:44-58): strict comparisons, NaN passes through
-__device__ __forceinline__ bool clip1(float &v)
+__device__ __forceinline__ float clip_value(float v)
 {
-    if (v > 0.99999994f) { v = 0.99999994f; return true; }
-    if (v < -0.99999994f) { v = -0.99999994f; return true; }
-    return false;
+    return v > 0.99999994f ? 0.99999994f : (v < -0.99999994f ? -0.99999994f : v);
 }
+__device__ __forceinline__ bool was_clipped(float v) { return v > 0.99999994f || v < -0.99999994f; }
 
-// four consecutive outputs y[pos..pos+3], pos and n4 multiples of 4
-__device__ __forceinline__ float4 y4_from_h(const float *h, int pos, int n4)
+// Branch-free addressing of the IMDCT output through its mirror symmetries (Mdct.cs:378-381).
+// y[pos..pos+3] (pos, n4 multiples of 4) = h4[idx] possibly reversed / negated.
+struct Y4Map {
+    int idx4;   // float4 index into h
+    bool rev, neg;
+};
+__device__ __forceinline__ Y4Map map_y4(int pos, int n4)
 {
-    const float4 *h4 = reinterpret_cast<const float4 *>(h);
-    if (pos < n4) {
-        const float4 t = h4[(n4 - 4 - pos) >> 2];
-        return make_float4(-t.w, -t.z, -t.y, -t.x);
-    }
-    if (pos < 3 * n4) return h4[(pos - n4) >> 2];
-    const float4 t = h4[(5 * n4 - 4 - pos) >> 2];
-    return make_float4(t.w, t.z, t.y, t.x);
+    const bool a = pos < n4, c = pos >= 3 * n4;
+    Y4Map m;
+    m.idx4 = (a ? (n4 - 4 - pos) : (c ? (5 * n4 - 4 - pos) : (pos - n4))) >> 2;
+    m.rev = a || c;
+    m.neg = a;
+    return m;
+}
+__device__ __forceinline__ float4 apply_y4(float4 t, bool rev, bool neg)
+{
+    float4 v = rev ? make_float4(t.w, t.z, t.y, t.x) : t;
+    const uint32_t sgn = neg ? 0x80000000u : 0u;
+    v.x = __uint_as_float(__float_as_uint(v.x) ^ sgn);
+    v.y = __uint_as_float(__float_as_uint(v.y) ^ sgn);
+    v.z = __uint_as_float(__float_as_uint(v.z) ^ sgn);
+    v.w = __uint_as_float(__float_as_uint(v.w) ^ sgn);
+    return v;
+}
+// previous block's output at position q (q in [N/2, N)) from the saved upper half of its h:
+// tail[j] = h[n4 + j]
+__device__ __forceinline__ float tail_at(const float *tail, int q, int pn4)
+{
+    return q < 3 * pn4 ? tail[q - 2 * pn4] : tail[4 * pn4 - 1 - q];
 }
 
 // Builds h of one channel-block into the wave-private LDS buffer `hbuf`:
@@ -318,7 +337,7 @@ __device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base,
 }
 
 template <bool kHasFloor>
-__global__ __launch_bounds__(kSynthThreads) void synth_kernel(SynthArgs a)
+__global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 {
     __shared__ float2 s_twL[512];
     __shared__ float2 s_twAB[512];
@@ -327,7 +346,8 @@ __global__ __launch_bounds__(kSynthThreads) void synth_kernel(SynthArgs a)
     __shared__ float s_slope1[1024];
     __shared__ float s_slope0[128];
     __shared__ float s_db[kHasFloor ? 256 : 1];
-    __shared__ float s_buf[kSynthWaves][2][kWaveBufFloats];
+    __shared__ float s_work[kSynthWaves][kWaveBufFloats];   // h of the block being built
+    __shared__ float s_tail[kSynthWaves][kWaveTailFloats];  // upper half of the previous block's h
 
     const bool has_long = a.size1 == 2048 || a.size0 == 2048;
     const bool has_short = a.size0 == 256 || a.size1 == 256;
@@ -346,7 +366,7 @@ __global__ __launch_bounds__(kSynthThreads) void synth_kernel(SynthArgs a)
     }
     for (int i = threadIdx.x; i < a.size1 / 2; i += kSynthThreads) s_slope1[i] = a.slope1[i];
     for (int i = threadIdx.x; i < a.size0 / 2 && i < 128; i += kSynthThreads) s_slope0[i] = a.slope0[i];
-    if (kHasFloor) s_db[threadIdx.x & 255] = a.inv_db[threadIdx.x & 255];
+    if (kHasFloor && threadIdx.x < 256) s_db[threadIdx.x] = a.inv_db[threadIdx.x];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -359,7 +379,8 @@ __global__ __launch_bounds__(kSynthThreads) void synth_kernel(SynthArgs a)
     const RunDesc run = a.runs[run_idx];
     const int half1 = a.size1 >> 1;
 
-    int cur = 0;      // s_buf[wave][cur] receives the block being built, [cur ^ 1] holds the previous h
+    float *hcur = s_work[wave];
+    float *tail = s_tail[wave];
     int prev_n4 = 0;  // n/4 of the previous block (0: none yet)
 
     auto exec_of = [&](uint32_t flags, int rec) -> bool {
@@ -373,13 +394,10 @@ __global__ __launch_bounds__(kSynthThreads) void synth_kernel(SynthArgs a)
     // ---- block preceding the run: from the saved state, or recomputed as "frame -1" of the loop
     if (run.pre_kind == kPreState) {
         const float *st = a.state_h + ((size_t)run.stream * a.channels + ch) * half1;
-        const int ph = run.prev_long ? (a.size1 >> 1) : (a.size0 >> 1);
-        float *hp = s_buf[wave][1];
-        for (int i = lane; i < ph; i += 64) hp[i] = st[i];
-        prev_n4 = ph >> 1;
+        prev_n4 = run.prev_long ? (a.size1 >> 2) : (a.size0 >> 2);
+        for (int i = lane; i < prev_n4; i += 64) tail[i] = st[i];
     }
     const int fi0 = (run.pre_kind == kPreRecompute) ? -1 : 0;
-    if (fi0 < 0) cur = 1;  // the recomputed block lands in buffer 1, the first real block in buffer 0
 
     float *out_base = a.out + (a.stream_out_off ? a.stream_out_off[run.stream] : 0);
     bool clipped_any = false;
@@ -396,18 +414,20 @@ __global__ __launch_bounds__(kSynthThreads) void synth_kernel(SynthArgs a)
         float2 xnext[8];
         if (fi + 1 < run.count) {
             const FrameDesc fn = a.frames[run.first + fi + 1];
-            if (!(fn.flags & kFrameDrain) && exec_of(fn.flags, fn.rec))
+            if (!(fn.flags & kFrameDrain) && exec_of(fn.flags, fn.rec) && !(a.ablate & 4))
                 load_spectrum(xnext, spectrum_of(fn), fn.flags & kFrameLong, lane);
         }
         const bool drain = fd.flags & kFrameDrain;
         const bool is_long = fd.flags & kFrameLong;
         const int n4 = is_long ? (a.size1 >> 2) : (a.size0 >> 2);
-        float *hcur = s_buf[wave][cur];
-        const float *hprev = s_buf[wave][cur ^ 1];
         if (!drain) {
             if (!exec_of(fd.flags, fd.rec)) {
                 // Mapping.cs:190-194: the channel is silent, its whole block is zero
                 for (int i = lane; i < 2 * n4; i += 64) hcur[i] = 0.0f;
+            } else if (a.ablate & 2) {
+                float2 *h2 = reinterpret_cast<float2 *>(hcur);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) h2[lane + 64 * m] = xcur[m];
             } else if (is_long) {
                 build_block<kHasFloor, true>(a, fd.flags, fd.rec + ch, lane, xcur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
             } else {
@@ -415,7 +435,13 @@ __global__ __launch_bounds__(kSynthThreads) void synth_kernel(SynthArgs a)
             }
         }
 
-        if (fi >= 0 && fd.out_count > 0) {
+        // gfx950's vmcnt counts stores as well as loads, in issue order, and the number of stores below
+        // is data dependent -- so the wait for the prefetched spectrum is forced HERE, before this
+        // frame's stores are issued; otherwise it would also wait for them (HBM write latency).
+#pragma unroll
+        for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(xnext[m].x), "v"(xnext[m].y));
+
+        if (fi >= 0 && fd.out_count > 0 && !(a.ablate & 1)) {
             // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 573-591)
             const float *slope = (fd.flags & kFrameSlope1) ? s_slope1 : s_slope0;
             const int plen = fd.packet_len;
@@ -427,58 +453,94 @@ __global__ __launch_bounds__(kSynthThreads) void synth_kernel(SynthArgs a)
                              ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0 &&
                              (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
             if (vec) {
+                // branch-free: lanes past the end clamp their reads and skip only the store; samples
+                // past the overlap take weights (1, 0)
+                const float4 *h4 = reinterpret_cast<const float4 *>(hcur);
+                const float4 *t4 = reinterpret_cast<const float4 *>(tail);
                 const float4 *s4 = reinterpret_cast<const float4 *>(slope);
-                for (int g = lane; g < (fd.out_count >> 2); g += 64) {
-                    const int i = g << 2;
-                    float4 v = y4_from_h(hcur, fd.left_start + i, n4);
-                    if (i < plen) {
-                        const float4 t = y4_from_h(hprev, fd.prev_end + i, prev_n4);
-                        const float4 wl = s4[g];
-                        const float4 wr = s4[((plen - 4 - i) >> 2)];  // reversed slope: wr.w pairs with sample i
-                        v.x = (v.x * wl.x) + (t.x * wr.w);
-                        v.y = (v.y * wl.y) + (t.y * wr.z);
-                        v.z = (v.z * wl.z) + (t.z * wr.y);
-                        v.w = (v.w * wl.w) + (t.w * wr.x);
-                    }
+                const int cnt4 = fd.out_count >> 2;
+                const int nr = (cnt4 + 63) >> 6;
+                const int pn4 = prev_n4;
+                for (int r = 0; r < nr; ++r) {
+                    const int g = lane + 64 * r;
+                    const bool live = g < cnt4;
+                    const int i = (live ? g : cnt4 - 1) << 2;
+                    const Y4Map mc = map_y4(fd.left_start + i, n4);
+                    const bool in = i < plen;
+                    const int ii = in ? i : 0;
+                    const int q = fd.prev_end + ii;          // in [2*pn4, 4*pn4) whenever `in`
+                    const bool pc = q >= 3 * pn4;
+                    int pidx = (pc ? (4 * pn4 - 4 - q) : (q - 2 * pn4)) >> 2;
+                    pidx = in ? pidx : 0;
+                    const int ridx = in ? ((plen - 4 - ii) >> 2) : 0;
+                    const float4 hv = h4[mc.idx4];
+                    const float4 pv = t4[pidx];
+                    const float4 wl = s4[ii >> 2];
+                    const float4 wr = s4[ridx];
+                    const float4 v = apply_y4(hv, mc.rev, mc.neg);
+                    const float4 t = apply_y4(pv, pc, false);
+                    // (v * v_lhs) + (v_prev * v_rhs), StreamDecoder.cs:788; wr is read reversed.
+                    // Scalars only from here on: a float4 that is selected / passed by reference ends
+                    // up in scratch memory.
+                    float o0 = (v.x * wl.x) + (t.x * wr.w);
+                    float o1 = (v.y * wl.y) + (t.y * wr.z);
+                    float o2 = (v.z * wl.z) + (t.z * wr.y);
+                    float o3 = (v.w * wl.w) + (t.w * wr.x);
+                    o0 = in ? o0 : v.x;
+                    o1 = in ? o1 : v.y;
+                    o2 = in ? o2 : v.z;
+                    o3 = in ? o3 : v.w;
                     if (a.clip) {
-                        clipped_any |= clip1(v.x);
-                        clipped_any |= clip1(v.y);
-                        clipped_any |= clip1(v.z);
-                        clipped_any |= clip1(v.w);
+                        clipped_any |= live && (was_clipped(o0) || was_clipped(o1) || was_clipped(o2) || was_clipped(o3));
+                        o0 = clip_value(o0);
+                        o1 = clip_value(o1);
+                        o2 = clip_value(o2);
+                        o3 = clip_value(o3);
                     }
-                    store_nt(reinterpret_cast<float4 *>(dst) + g, v);
+                    if (live) store_nt(reinterpret_cast<float4 *>(dst) + g, make_float4(o0, o1, o2, o3));
                 }
             } else {
                 const int64_t step = a.interleaved ? a.channels : 1;
                 for (int i = lane; i < fd.out_count; i += 64) {
                     float v;
                     if (drain) {
-                        v = y_from_h(hprev, fd.prev_end + i, prev_n4);
+                        v = tail_at(tail, fd.prev_end + i, prev_n4);
                     } else {
                         v = y_from_h(hcur, fd.left_start + i, n4);
                         if (i < plen) {
-                            const float t = y_from_h(hprev, fd.prev_end + i, prev_n4);
+                            const float t = tail_at(tail, fd.prev_end + i, prev_n4);
                             v = (v * slope[i]) + (t * slope[plen - 1 - i]);
                         }
                     }
-                    if (a.clip) clipped_any |= clip1(v);
+                    if (a.clip) {
+                        clipped_any |= was_clipped(v);
+                        v = clip_value(v);
+                    }
                     dst[i * step] = v;
                 }
             }
         }
         if (!drain) {
-            cur ^= 1;
+            // keep what a later block can overlap with: y[N/2 .. N) lives in the upper half of h
+            if (is_long) {
+                const float4 *src = reinterpret_cast<const float4 *>(hcur + 512);
+                float4 *dt = reinterpret_cast<float4 *>(tail);
+                const float4 t0 = src[lane], t1 = src[lane + 64];
+                dt[lane] = t0;
+                dt[lane + 64] = t1;
+            } else {
+                tail[lane] = hcur[64 + lane];
+            }
             prev_n4 = n4;
         }
 #pragma unroll
         for (int m = 0; m < 8; ++m) xcur[m] = xnext[m];
     }
 
-    // ---- keep the last block for the next batch (the reference keeps _prevPacketBuf)
+    // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
     if ((run.flags & kRunSaveState) && prev_n4 > 0) {
         float *st = a.state_h + ((size_t)run.stream * a.channels + ch) * half1;
-        const float *hl = s_buf[wave][cur ^ 1];
-        for (int i = lane; i < 2 * prev_n4; i += 64) st[i] = hl[i];
+        for (int i = lane; i < prev_n4; i += 64) st[i] = tail[i];
     }
     if (a.clip && __any(clipped_any) && lane == 0) atomicOr(&a.clipped[run.stream], 1);
 }

@@ -60,6 +60,7 @@ struct Decoder {
     DevBuf b_frames, b_runs, b_recfloor, b_finaly, b_stepflags, b_cpk, b_temp, b_outoff;
     DevBuf b_in_res, b_in_posts, b_in_counts, b_out;  // VPZ_MEM_HOST staging
     int run_length_override = 0;
+    int ablate = 0;  // VPZ_SYNTH_ABLATE, tuning experiments only
 };
 
 static int grow(Context *ctx, DevBuf &b, size_t need)
@@ -166,6 +167,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     D.floors.assign(cfg->floors, cfg->floors + cfg->floor_count);
     D.mappings.assign(cfg->mappings, cfg->mappings + cfg->mapping_count);
     if (const char *e = getenv("VPZ_RUN_LENGTH")) D.run_length_override = atoi(e);
+    if (const char *e = getenv("VPZ_SYNTH_ABLATE")) D.ablate = atoi(e);
 
     int rc = VPZ_OK;
     std::vector<FloorDev> fdev(std::max<size_t>(1, D.floors.size()));
@@ -562,6 +564,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     a.interleaved = out_layout == VPZ_OUT_INTERLEAVED;
     a.clip = D.clip;
     a.clipped = D.d_clipped;
+    a.ablate = D.ablate;
     hipError_t e = launch_synth(a, any_floor, ctx->stream);
     if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "synth kernel launch", e);
 
