@@ -178,19 +178,16 @@ def main():
     import torch
     import __graft_entry__ as ge
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from vorbispizza_amd import sharding
+    world, rank, local_rank = sharding.env_world()
     distributed = world > 1
     if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        sharding.init("nccl")  # RCCL; used only for the barrier and the max-over-ranks of the timing
     if rank == 0:
         ge.build()
     if distributed:
-        dist.barrier()
+        sharding.barrier()
     from vorbispizza_amd import Context, Decoder, capi
 
     device = torch.device("cuda", local_rank)
@@ -208,7 +205,7 @@ def main():
         ctx.imdct_batch(spectra, N, capi.IMDCT_FAST, out=out)
     ctx.synchronize()
     if distributed:
-        dist.barrier()
+        sharding.barrier()
     torch.cuda.synchronize()
     ctx.timer_start()  # HIP events on the stream the kernel is launched on
     t0 = time.perf_counter()
@@ -219,10 +216,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.barrier()
-        elapsed = float(t.item())
+        elapsed = sharding.max_over_ranks(elapsed, device)
+        kernel_ms = sharding.max_over_ranks(kernel_ms, device)
+        sharding.barrier()
 
     samples_per_step = world * count * (N // 2)
     value = samples_per_step * args.steps / elapsed / 1e6
@@ -287,8 +283,7 @@ def main():
             result["extra_workloads"] = extras
     ctx.close()
     if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+        sharding.finalize()
     if rank == 0:
         print(json.dumps(result))
 

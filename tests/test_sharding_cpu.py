@@ -1,0 +1,67 @@
+"""world_size-2 gloo test of the N > 1 path: stream partitioning (no data-path collective), the
+barrier and the max-over-ranks timing reduction bench.py uses."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys, time
+sys.path.insert(0, %(root)r)
+os.environ["VPZ_NO_TORCH"] = "1"
+from vorbispizza_amd import sharding
+world, rank, local_rank = sharding.init("gloo")
+assert world == 2
+n_streams = 1024 + 3
+lo, hi = sharding.shard_range(n_streams, world, rank)
+owned = list(range(lo, hi))
+assert all(sharding.owner_of(s, n_streams, world) == rank for s in owned)
+# every rank "processes" its own streams: the per-rank work is just a checksum here
+local_samples = sum(1000 + s for s in owned)
+sharding.barrier()
+t0 = time.perf_counter()
+time.sleep(0.05 * (rank + 1))          # rank 1 is the slow one
+elapsed = time.perf_counter() - t0
+slowest = sharding.max_over_ranks(elapsed)
+total = sharding.sum_over_ranks(local_samples)
+assert slowest >= 0.1 - 1e-3
+if rank == 0:
+    print(json.dumps({"lo": lo, "hi": hi, "slowest": slowest, "total": total}))
+sharding.finalize()
+'''
+
+
+def test_shard_range_partitions_exactly():
+    sys.path.insert(0, ROOT)
+    from vorbispizza_amd import sharding
+    for n in (0, 1, 7, 8, 1024, 1027):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = sharding.shard_range(n, world, r)
+                assert 0 <= lo <= hi <= n
+                seen += list(range(lo, hi))
+            assert seen == list(range(n))
+    assert sharding.shard_range(1024, 8, 3) == (384, 512)  # 128 streams per GPU (BASELINE configs[4])
+    with pytest.raises(ValueError):
+        sharding.shard_range(4, 2, 2)
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_run(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29511", str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=170)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert (res["lo"], res["hi"]) == (0, 514)
+    assert res["total"] == sum(1000 + s for s in range(1027))
+    assert res["slowest"] >= 0.099

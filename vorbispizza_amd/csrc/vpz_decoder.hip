@@ -44,8 +44,19 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+// Pinned host arena for the per-call descriptor uploads: copies out of it are truly asynchronous,
+// and the next call waits (on an event) only for the previous call's uploads before reusing it.
+struct PinnedArena {
+    char *base = nullptr;
+    size_t cap = 0, used = 0;
+    hipEvent_t uploaded = nullptr;
+    bool pending = false;
+};
+
 struct Decoder {
     Context *ctx = nullptr;
+    PinnedArena arena;
+    std::vector<std::vector<FrameDesc>> per_stream;  // reused across calls (capacity retained)
     int channels = 0, size0 = 0, size1 = 0, clip = 0;
     int n_streams = 0;
     std::vector<vpz_floor1_config> floors;
@@ -66,6 +77,35 @@ struct Decoder {
 static int grow(Context *ctx, DevBuf &b, size_t need)
 {
     return ensure_stage(ctx, &b.p, &b.bytes, need ? need : 1);
+}
+
+static int arena_begin(Context *ctx, PinnedArena &A, size_t need)
+{
+    if (A.pending) {
+        VPZ_HIP_TRY(ctx, hipEventSynchronize(A.uploaded));
+        A.pending = false;
+    }
+    if (!A.uploaded) VPZ_HIP_TRY(ctx, hipEventCreateWithFlags(&A.uploaded, hipEventDisableTiming));
+    if (A.cap < need) {
+        if (A.base) VPZ_HIP_TRY(ctx, hipHostFree(A.base));
+        A.base = nullptr;
+        A.cap = 0;
+        const size_t want = need + need / 2 + 4096;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&A.base), want, hipHostMallocDefault);
+        if (e != hipSuccess) return set_error(ctx, VPZ_E_NOMEM, "hipHostMalloc(descriptor arena)", e);
+        A.cap = want;
+    }
+    A.used = 0;
+    return VPZ_OK;
+}
+
+template <typename T>
+static T *arena_alloc(PinnedArena &A, size_t count)
+{
+    A.used = (A.used + 63) & ~(size_t)63;
+    T *p = reinterpret_cast<T *>(A.base + A.used);
+    A.used += sizeof(T) * count;
+    return p;
 }
 
 // Mode.cs:30-66
@@ -233,6 +273,8 @@ void vpz_decoder_destroy(vpz_decoder *d)
     if (D.d_state_h) (void)hipFree(D.d_state_h);
     if (D.d_clipped) (void)hipFree(D.d_clipped);
     if (D.d_steps) (void)hipFree(D.d_steps);
+    if (D.arena.base) (void)hipHostFree(D.arena.base);
+    if (D.arena.uploaded) (void)hipEventDestroy(D.arena.uploaded);
     delete d;
 }
 
@@ -271,7 +313,9 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
 
     // ---------------- pass 1: per-stream state machine -> frame descriptors
     std::vector<StreamState> st = D.states;  // committed only when the whole batch is accepted
-    std::vector<std::vector<FrameDesc>> per_stream(D.n_streams);
+    std::vector<std::vector<FrameDesc>> &per_stream = D.per_stream;
+    per_stream.resize(D.n_streams);
+    for (auto &v : per_stream) v.clear();
     std::vector<uint8_t> stream_started_with_prev(D.n_streams), stream_prev_long(D.n_streams);
     for (int s = 0; s < D.n_streams; ++s) {
         stream_started_with_prev[s] = st[s].has_prev;
@@ -373,6 +417,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         if (out_count[s] > stream_out_capacity)
             return set_error(ctx, VPZ_E_CAPACITY, "vpz_decoder_synth: stream_out_capacity too small");
 
+    int rc;
     // ---------------- pass 2: runs
     int64_t total_frames = 0;
     for (auto &v : per_stream) total_frames += (int64_t)v.size();
@@ -398,14 +443,21 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
             if (best < 0 || cost < best) { best = cost; R = (int)r; }
         }
     }
-    std::vector<FrameDesc> frames;
-    frames.reserve((size_t)total_frames);
-    std::vector<RunDesc> runs;
+    // all per-call descriptor tables live in one pinned arena
+    const size_t max_runs = (size_t)(total_frames / R) + (size_t)D.n_streams + 1;
+    const size_t arena_need = sizeof(FrameDesc) * (size_t)total_frames + sizeof(RunDesc) * max_runs +
+                              coupling_packet_size() * (size_t)total_frames + (size_t)(n_packets * C) +
+                              sizeof(int64_t) * (size_t)D.n_streams + 1024;
+    if ((rc = arena_begin(ctx, D.arena, arena_need)) != VPZ_OK) return rc;
+    FrameDesc *frames = arena_alloc<FrameDesc>(D.arena, (size_t)total_frames);
+    RunDesc *runs = arena_alloc<RunDesc>(D.arena, max_runs);
+    size_t n_frames = 0, n_runs = 0;
     for (int s = 0; s < D.n_streams; ++s) {
         const auto &v = per_stream[s];
         if (v.empty()) continue;
-        const int base = (int)frames.size();
-        frames.insert(frames.end(), v.begin(), v.end());
+        const int base = (int)n_frames;
+        memcpy(frames + n_frames, v.data(), sizeof(FrameDesc) * v.size());
+        n_frames += v.size();
         for (int f0 = 0; f0 < (int)v.size(); f0 += R) {
             RunDesc r{};
             r.first = base + f0;
@@ -418,7 +470,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
                 r.pre_kind = kPreRecompute;
             }
             if (f0 + R >= (int)v.size()) r.flags |= kRunSaveState;
-            runs.push_back(r);
+            runs[n_runs++] = r;
         }
     }
 
@@ -427,7 +479,6 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     const int16_t *d_posts = posts;
     const uint8_t *d_counts = post_counts;
     const int64_t n_rec = n_packets * C;
-    int rc;
     if (mem_space == VPZ_MEM_HOST) {
         int64_t res_floats = 0;
         for (int64_t p = 0; p < n_packets; ++p) {
@@ -456,27 +507,24 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     if (need_coupling) {
         if ((rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK) return rc;
         const size_t cps = coupling_packet_size();
-        std::vector<uint8_t> cpk;
-        cpk.reserve((size_t)total_frames * cps);
-        // frames were appended stream by stream; rebuild the packet -> frame link through rec
+        uint8_t *cpk = arena_alloc<uint8_t>(D.arena, cps * n_frames);
         int n_cpk = 0;
-        for (FrameDesc &fd : frames) {
+        for (size_t fi = 0; fi < n_frames; ++fi) {
+            FrameDesc &fd = frames[fi];
             if (fd.flags & kFrameDrain) continue;
             const int64_t p = fd.rec / C;
             const vpz_packet &pk = packets[p];
             const int half = ((fd.flags & kFrameLong) ? D.size1 : D.size0) / 2;
             const bool couple = !(fd.flags & kFrameNoFloor) && D.mappings[pk.mapping].coupling_steps > 0;
-            cpk.resize(cpk.size() + cps);
-            fill_coupling_packet(cpk.data() + (size_t)n_cpk * cps, pk.residue_offset, temp_off[(size_t)p], half,
+            fill_coupling_packet(cpk + (size_t)n_cpk * cps, pk.residue_offset, temp_off[(size_t)p], half,
                                  couple ? D.mapping_steps_off[pk.mapping] : -1,
                                  couple ? D.mappings[pk.mapping].coupling_steps : 0,
                                  (pk.flags & VPZ_PKT_INTERLEAVED) ? 1 : 0);
             fd.spec_off = temp_off[(size_t)p];
             ++n_cpk;
         }
-        if ((rc = grow(ctx, D.b_cpk, cpk.size())) != VPZ_OK) return rc;
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_cpk.p, cpk.data(), cpk.size(), hipMemcpyHostToDevice, ctx->stream));
-        VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // cpk is a local vector
+        if ((rc = grow(ctx, D.b_cpk, cps * (size_t)n_cpk)) != VPZ_OK) return rc;
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_cpk.p, cpk, cps * (size_t)n_cpk, hipMemcpyHostToDevice, ctx->stream));
         hipError_t e = launch_coupling(D.b_cpk.p, n_cpk, D.d_steps, C, d_res, static_cast<float *>(D.b_temp.p),
                                        D.size1 / 2, ctx->stream);
         if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "coupling kernel launch", e);
@@ -485,7 +533,8 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
 
     // ---------------- optional pass: Floor1.UnwrapPosts
     if (any_floor) {
-        std::vector<uint8_t> rec_floor((size_t)n_rec, 0);
+        uint8_t *rec_floor = arena_alloc<uint8_t>(D.arena, (size_t)n_rec);
+        memset(rec_floor, 0, (size_t)n_rec);
         for (int64_t p = 0; p < n_packets; ++p) {
             if (!pkt_used[(size_t)p] || (packets[p].flags & VPZ_PKT_NO_FLOOR)) continue;
             const vpz_mapping_config &mc = D.mappings[packets[p].mapping];
@@ -494,9 +543,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         if ((rc = grow(ctx, D.b_recfloor, (size_t)n_rec)) != VPZ_OK) return rc;
         if ((rc = grow(ctx, D.b_finaly, sizeof(int16_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
         if ((rc = grow(ctx, D.b_stepflags, 64 * (size_t)n_rec)) != VPZ_OK) return rc;
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_recfloor.p, rec_floor.data(), (size_t)n_rec, hipMemcpyHostToDevice,
-                                        ctx->stream));
-        VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // rec_floor is a local vector
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_recfloor.p, rec_floor, (size_t)n_rec, hipMemcpyHostToDevice, ctx->stream));
         hipError_t e = launch_floor1_unwrap((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(D.b_recfloor.p),
                                             D.d_floors, static_cast<int16_t *>(D.b_finaly.p),
                                             static_cast<uint8_t *>(D.b_stepflags.p), ctx->stream);
@@ -507,16 +554,14 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     float *d_out = pcm_out;
     const int64_t *d_outoff = nullptr;
     int64_t out_floats = 0;
-    std::vector<int64_t> offs(D.n_streams, 0);
-    if (stream_out_offset)
-        for (int s = 0; s < D.n_streams; ++s) offs[s] = stream_out_offset[s];
+    int64_t *offs = arena_alloc<int64_t>(D.arena, (size_t)D.n_streams);
+    for (int s = 0; s < D.n_streams; ++s) offs[s] = stream_out_offset ? stream_out_offset[s] : 0;
     if (out_layout == VPZ_OUT_PLANAR && channel_stride < stream_out_capacity && C > 1)
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: channel_stride smaller than stream_out_capacity");
     if (stream_out_offset) {
         if ((rc = grow(ctx, D.b_outoff, sizeof(int64_t) * (size_t)D.n_streams)) != VPZ_OK) return rc;
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_outoff.p, offs.data(), sizeof(int64_t) * (size_t)D.n_streams,
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_outoff.p, offs, sizeof(int64_t) * (size_t)D.n_streams,
                                         hipMemcpyHostToDevice, ctx->stream));
-        VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         d_outoff = static_cast<const int64_t *>(D.b_outoff.p);
     }
     if (mem_space == VPZ_MEM_HOST) {
@@ -531,18 +576,18 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     }
 
     // ---------------- descriptors + launch
-    if ((rc = grow(ctx, D.b_frames, sizeof(FrameDesc) * frames.size())) != VPZ_OK) return rc;
-    if ((rc = grow(ctx, D.b_runs, sizeof(RunDesc) * runs.size())) != VPZ_OK) return rc;
-    VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_frames.p, frames.data(), sizeof(FrameDesc) * frames.size(),
-                                    hipMemcpyHostToDevice, ctx->stream));
-    VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_runs.p, runs.data(), sizeof(RunDesc) * runs.size(), hipMemcpyHostToDevice,
+    if ((rc = grow(ctx, D.b_frames, sizeof(FrameDesc) * n_frames)) != VPZ_OK) return rc;
+    if ((rc = grow(ctx, D.b_runs, sizeof(RunDesc) * n_runs)) != VPZ_OK) return rc;
+    VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_frames.p, frames, sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice,
                                     ctx->stream));
-    VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // frames / runs are local vectors
+    VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_runs.p, runs, sizeof(RunDesc) * n_runs, hipMemcpyHostToDevice, ctx->stream));
+    VPZ_HIP_TRY(ctx, hipEventRecord(D.arena.uploaded, ctx->stream));
+    D.arena.pending = true;
 
     SynthArgs a{};
     a.frames = static_cast<const FrameDesc *>(D.b_frames.p);
     a.runs = static_cast<const RunDesc *>(D.b_runs.p);
-    a.n_runs = (int32_t)runs.size();
+    a.n_runs = (int32_t)n_runs;
     a.channels = C;
     a.size0 = D.size0;
     a.size1 = D.size1;

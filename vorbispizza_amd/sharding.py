@@ -1,0 +1,74 @@
+"""Multi-GPU sharding of independent streams / channel-block batches.
+
+Vorbis streams are independent, so the path shards embarrassingly: one process per GPU, a
+contiguous range of streams (or of a batch) per rank, NO collective on the data path.  The only
+communication is the barrier and the max-over-ranks of the elapsed time that bench.py needs; it goes
+through torch.distributed (backend "nccl" = RCCL on the GPUs, "gloo" in the CPU tests).
+"""
+import os
+
+
+def shard_range(n_items, world_size, rank):
+    """Contiguous partition: rank r owns [start, stop); item s belongs to rank s // ceil(n/world)."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad world_size / rank")
+    per = -(-n_items // world_size) if n_items > 0 else 0
+    start = min(n_items, rank * per)
+    return start, min(n_items, start + per)
+
+
+def owner_of(item, n_items, world_size):
+    per = -(-n_items // world_size) if n_items > 0 else 1
+    return min(world_size - 1, item // max(per, 1))
+
+
+def env_world():
+    """(world_size, rank, local_rank) from the torch.distributed.run environment."""
+    return (int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend):
+    """Initialise torch.distributed when launched with WORLD_SIZE > 1; returns (world, rank, local_rank)."""
+    world, rank, local_rank = env_world()
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if not dist.is_initialized():
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return world, rank, local_rank
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    """MAX-reduce a python float over all ranks (identity when not distributed)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device="cpu"):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def finalize():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
