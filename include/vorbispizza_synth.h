@@ -36,7 +36,10 @@ extern "C" {
 #define VPZ_E_HIP             (-3)  /* HIP runtime error; text via vpz_context_last_error */
 #define VPZ_E_NOMEM           (-4)
 #define VPZ_E_WINDOW_MISMATCH (-5)  /* previous tail longer than the window slope:
-                                       StreamDecoder.cs:777-778 would throw */
+                                       StreamDecoder.cs:777-778 would throw.  Like that exception the
+                                       condition costs only the offending packet: it is skipped, the
+                                       stream state is untouched, the rest of the batch is synthesised
+                                       and samples_written / PCM are valid on return */
 #define VPZ_E_NO_DEVICE       (-6)
 #define VPZ_E_CAPACITY        (-7)  /* output buffer too small for the samples produced */
 

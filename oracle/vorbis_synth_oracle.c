@@ -748,6 +748,9 @@ orc_stream *orc_stream_create(int channels, int size0, int size1)
     orc_window_slope(size1 / 2, s->slope1);
     s->buf[0] = (float *)calloc((size_t)size1 * (size_t)channels, sizeof(float));
     s->buf[1] = (float *)calloc((size_t)size1 * (size_t)channels, sizeof(float));
+    /* ProcessHeaderPackets :165-168: _currentPosition = 0; ResetDecoder(); _hasPosition = true */
+    s->current_position = 0;
+    s->has_position = 1;
     return s;
 }
 
@@ -875,7 +878,6 @@ long orc_synth_stream_planar(int channels, int size0, int size1, long frames, co
     float *buf2 = (float *)malloc(sizeof(float) * (size_t)size1);
     long f, total = 0;
     int half1 = size1 / 2, ch;
-    orc_stream_reset(s);
     for (f = 0; f < frames; ++f) {
         int bf = flags[f] & 1, pf = (flags[f] >> 1) & 1, nf = (flags[f] >> 2) & 1;
         int bs = bf ? size1 : size0;

@@ -94,6 +94,7 @@ void orc_mapping_synth(int channels, int block_size, float *buffer, int stride,
 /* ---- StreamDecoder.cs decode half: state (:45-49), ReadNextPacket (:640-694),
  * OverlapBuffers (:764-791), Read (:418-498), StoreInterleaved/StoreContiguous (:515-638). ---- */
 typedef struct orc_stream orc_stream;
+/* state as after ProcessHeaderPackets (StreamDecoder.cs:165-168): position 0, known */
 orc_stream *orc_stream_create(int channels, int size0, int size1);
 void orc_stream_destroy(orc_stream *s);
 void orc_stream_reset(orc_stream *s);                     /* ResetDecoder :357-369 */

@@ -39,9 +39,9 @@ def oracle_decode(orc, channels, size0, size1, packets, floors=(), mappings=(), 
     ABI), posts (np [channels, <=64]), post_count (np [channels]).  Returns PCM [channels, T] or [T, channels]."""
     L = orc.lib()
     st = L.orc_stream_create(channels, size0, size1)
-    L.orc_stream_reset(st)
     ofl = [orc.floor1_init(xl, mult) for (xl, mult) in floors]
     chunks = []
+    mismatches = []
     eos_seen = False
 
     def take():
@@ -90,8 +90,12 @@ def oracle_decode(orc, channels, size0, size1, packets, floors=(), mappings=(), 
         view[:, :n] = pcm
         rc = L.orc_stream_read_next_packet(st, 1, C.byref(info), int(pk.get("granule", -1)), eos)
         if rc < 0:
-            L.orc_stream_destroy(st)
-            raise RuntimeError("window mismatch")
+            # OverlapBuffers would throw (StreamDecoder.cs:777-778): that Read fails, the packet is
+            # consumed, the decoder state stays as it was
+            mismatches.append(len(chunks))
+            if eos:
+                eos_seen = True
+            continue
         if eos:
             eos_seen = True
         take()
@@ -99,6 +103,7 @@ def oracle_decode(orc, channels, size0, size1, packets, floors=(), mappings=(), 
     clipped = bool(L.orc_stream_has_clipped(st))
     L.orc_stream_destroy(st)
     pcm = np.concatenate(chunks, axis=1) if chunks else np.zeros((channels, 0), dtype=np.float32)
+    oracle_decode.last_mismatches = len(mismatches)
     return (pcm.T.copy() if interleave else pcm), pos, clipped
 
 
@@ -117,3 +122,21 @@ def random_posts(rng, xlist, multiplier, n_ch, silent_prob=0.0):
         vals[rng.random(len(vals)) < 0.35] = 0
         posts[c, 2:len(xlist)] = vals
     return posts, counts
+
+
+def packets_for_oracle(ogg, pk, residue, posts, counts):
+    """Converts the front end's batch arrays (vorbispizza_amd.front.OggVorbisFile.decode_packets) into
+    the per-packet dicts oracle_decode takes."""
+    C_ = ogg.channels
+    out = []
+    for i in range(len(pk)):
+        flags = int(pk["flags"][i])
+        d = {"flags": flags, "granule": int(pk["granule"][i]), "mapping": int(pk["mapping"][i])}
+        if not flags & PKT_NOT_DECODED:
+            half = (ogg.block_size1 if flags & PKT_BLOCK_FLAG else ogg.block_size0) // 2
+            off = int(pk["residue_offset"][i])
+            d["residue"] = residue[off: off + C_ * half]
+            d["posts"] = posts[i * C_:(i + 1) * C_]
+            d["post_count"] = counts[i * C_:(i + 1) * C_]
+        out.append(d)
+    return out

@@ -1,0 +1,84 @@
+"""The C++ CPU front end (Ogg demux + Vorbis setup + entropy decode) on the reference's
+own fixtures (tests/golden/*.ogg are copies of /root/reference/TestFiles/*.ogg -- data, not code).
+Known answers: channels, rates, block sizes, packet counts, floor / residue /
+coupling layout, and the decoded sample count, which must equal the stream's granule span."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# file -> (sha256[:16], channels, audio packets, short, long, samples, floor posts, residue types, coupling)
+FACTS = {
+    "1test.ogg": ("9e11f3008b507327", 1, 25, 8, 17, 17318, [(19, 2), (29, 2)], [1, 1], []),
+    "2test.ogg": ("ec0b573cb2f09dfa", 1, 310, 1, 309, 315790, [(6, 4), (29, 2)], [1, 1], []),
+    "3test.ogg": ("9da311d45f63d0b1", 2, 366, 95, 271, 288094, [(19, 2), (29, 2)], [2, 2], [(0, 1)]),
+    # last granule 548223, first audio page starts 63 samples in; the trailing empty packet (page 17) is
+    # the 606th packet and hits the reference's OverlapBuffers exception (StreamDecoder.cs:777-778)
+    "issue6test.ogg": ("3b863d0503d22b6e", 2, 606, 80, 526, 548160, [(13, 2), (29, 2)], [2, 2], [(0, 1)]),
+}
+
+
+@pytest.fixture(scope="module")
+def front():
+    from vorbispizza_amd import _build
+    _build.build_host()
+    from vorbispizza_amd import front as f
+    return f
+
+
+@pytest.mark.parametrize("name", sorted(FACTS))
+def test_fixture_header_facts(front, name):
+    sha, ch, n_pk, n_short, n_long, samples, floors, res_types, coupling = FACTS[name]
+    path = os.path.join(GOLDEN, name)
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest()[:16] == sha
+    f = front.OggVorbisFile(path)
+    assert (f.channels, f.sample_rate, f.block_size0, f.block_size1) == (ch, 44100, 256, 2048)
+    assert f.audio_packets == n_pk
+    assert [(len(x), m) for x, m in f.floors] == floors
+    assert f.residue_types == res_types
+    assert all(m["coupling"] == coupling for m in f.mappings) and len(f.mappings) == 2
+    assert f.info.bad_crc_pages == 0
+    pk, res, posts, counts = f.decode_packets()
+    longs = int((pk["flags"] & 1).sum())
+    assert (n_pk - longs, longs) == (n_short, n_long)
+    assert not (pk["flags"] & helpers.PKT_NOT_DECODED).any()
+    assert int((pk["flags"] & helpers.PKT_EOS != 0).sum()) == 1 and pk["flags"][-1] & helpers.PKT_EOS
+    # Residue2 streams hand the interleaved vector over, residue 1 streams planar
+    assert bool((pk["flags"] & helpers.PKT_INTERLEAVED).any()) == (res_types[0] == 2)
+    # floor posts stay inside their ranges
+    assert posts.min() >= 0 and counts.max() <= 29
+
+
+@pytest.mark.parametrize("name", sorted(FACTS))
+def test_decoded_sample_count_equals_granule_span(front, oracle, name):
+    samples = FACTS[name][5]
+    f = front.OggVorbisFile(os.path.join(GOLDEN, name))
+    pk, res, posts, counts = f.decode_packets()
+    opk = helpers.packets_for_oracle(f, pk, res, posts, counts)
+    pcm, pos, _ = helpers.oracle_decode(oracle, f.channels, f.block_size0, f.block_size1, opk,
+                                        floors=f.floors, mappings=f.mappings)
+    assert pcm.shape == (f.channels, samples)
+    assert pos == samples
+    assert helpers.oracle_decode.last_mismatches == (1 if name == "issue6test.ogg" else 0)
+    assert np.isfinite(pcm).all()
+    assert 0.05 < np.abs(pcm).max() < 1.5          # real audio, not garbage from a bad Huffman decode
+    # decoded audio is smooth: a wrong codeword anywhere shows up as broadband noise
+    d = np.diff(pcm, axis=1)
+    assert np.sqrt((d ** 2).mean()) < 0.6 * np.sqrt((pcm ** 2).mean()) + 1e-3
+
+
+def test_truncated_and_corrupt_input(front):
+    data = open(os.path.join(GOLDEN, "1test.ogg"), "rb").read()
+    with pytest.raises(front.FrontError):
+        front.OggVorbisFile(data[:40])                       # no complete header packets
+    bad = bytearray(data)
+    bad[-100] ^= 0x55                                        # CRC failure on the audio page -> page dropped
+    f = front.OggVorbisFile(bytes(bad))
+    assert f.info.bad_crc_pages >= 1 and f.audio_packets < 25
+    with pytest.raises(front.FrontError):
+        front.OggVorbisFile(b"not an ogg file at all" * 10)

@@ -187,21 +187,24 @@ def test_failed_eos_packet_drains_tail_unwindowed(ctx, oracle):
     dec.close()
 
 
-def test_window_mismatch_is_an_error_not_a_crash(ctx):
-    """Quirk q11: a long tail (1024) followed by a short block would throw in OverlapBuffers."""
+def test_window_mismatch_is_reported_and_costs_only_that_packet(ctx, oracle):
+    """Quirk q11: a long tail (1024) followed by a short block throws in OverlapBuffers
+    (StreamDecoder.cs:777-778).  That Read fails, the packet is consumed, the state is untouched."""
     from vorbispizza_amd import Decoder, SynthError, capi
-    flags = np.array([PKT_BLOCK_FLAG | PKT_PREV_FLAG | PKT_NEXT_FLAG, 0], dtype=np.uint8)
-    spec = helpers.gaussian_spectra((2, 1, 1024), seed=14)
-    pk, res, _ = build_batch([flags], [spec], 1, extra_flags=PKT_NO_FLOOR)
+    L3 = PKT_BLOCK_FLAG | PKT_PREV_FLAG | PKT_NEXT_FLAG
+    flags = np.array([L3, L3, 0, L3, L3], dtype=np.uint8)  # the short block in the middle does not fit
+    spec = helpers.gaussian_spectra((5, 1, 1024), seed=14)
+    pk, res, opk = build_batch([flags], [spec], 1, extra_flags=PKT_NO_FLOOR)
     dec = Decoder(ctx, 1, 256, 2048)
+    cap = 8192
+    out = np.zeros(cap, dtype=np.float32)
     with pytest.raises(SynthError) as e:
-        dec.synth(pk, res)
+        dec.synth_raw(pk, res, None, None, out, None, cap, capi.OUT_PLANAR, cap, capi.MEM_HOST)
     assert e.value.status == capi.E_WINDOW_MISMATCH
-    # the failed batch left no state behind: a consistent batch still decodes from scratch
-    flags2 = helpers.markov_block_flags(10, seed=1)
-    pk2, res2, _ = build_batch([flags2], [helpers.gaussian_spectra((10, 1, 1024), seed=2)], 1,
-                               extra_flags=PKT_NO_FLOOR)
-    assert dec.synth(pk2, res2)[0].shape[1] > 0
+    ref, pos, _ = helpers.oracle_decode(oracle, 1, 256, 2048, opk[0])
+    assert helpers.oracle_decode.last_mismatches == 1 and ref.shape == (1, 3072)
+    assert dec.position(0) == pos == 3072
+    assert np.abs(out[:3072] - ref[0]).max() <= TOL
     dec.close()
 
 

@@ -42,8 +42,29 @@ def _deps(src):
     return deps
 
 
+HOST_DIR = os.path.join(_HERE, "host")
+HOST_LIB_PATH = os.path.join(LIB_DIR, "libvorbispizza_host.so")
+
+
+def build_host(force=False, verbose=False):
+    """Compile the C++ CPU front end (Ogg + Vorbis setup + entropy decode) with g++."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = [os.path.join(HOST_DIR, "vorbis_front.cpp")]
+    deps = srcs + [os.path.join(HOST_DIR, "vorbis_front.h"), os.path.join(_HERE, "..", "include", "vorbispizza_synth.h")]
+    stale = force or not os.path.exists(HOST_LIB_PATH) or any(
+        os.path.getmtime(d) > os.path.getmtime(HOST_LIB_PATH) for d in deps)
+    if stale:
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+               "-o", HOST_LIB_PATH] + srcs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return HOST_LIB_PATH
+
+
 def build(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link the C-ABI shared library."""
+    build_host(force, verbose)
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
     objs, relink = [], force or not os.path.exists(LIB_PATH)

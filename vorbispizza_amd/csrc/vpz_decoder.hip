@@ -34,7 +34,7 @@ struct StreamState {
     bool prev_long = false;     // block flag of the packet held in _prevPacketBuf
     int prev_start = 0, prev_end = 0, prev_stop = 0;
     int64_t current_position = 0;
-    bool has_position = false;
+    bool has_position = true;   // ProcessHeaderPackets: _currentPosition = 0; _hasPosition = true (:165-168)
     bool eos_found = false;
     bool has_clipped = false;
 };
@@ -285,7 +285,12 @@ int vpz_decoder_reset(vpz_decoder *d, int32_t stream)
     if (stream >= D.n_streams) return set_error(D.ctx, VPZ_E_INVALID_ARG, "vpz_decoder_reset: bad stream");
     VPZ_HIP_TRY(D.ctx, hipSetDevice(D.ctx->device));
     const int lo = stream < 0 ? 0 : stream, hi = stream < 0 ? D.n_streams : stream + 1;
-    for (int s = lo; s < hi; ++s) D.states[s] = StreamState();  // StreamDecoder.cs:357-369
+    for (int s = lo; s < hi; ++s) {  // StreamDecoder.cs:357-369: the position value itself is kept
+        const int64_t pos = D.states[s].current_position;
+        D.states[s] = StreamState();
+        D.states[s].current_position = pos;
+        D.states[s].has_position = false;
+    }
     VPZ_HIP_TRY(D.ctx, hipMemsetAsync(D.d_clipped + lo, 0, sizeof(int32_t) * (size_t)(hi - lo), D.ctx->stream));
     return VPZ_OK;
 }
@@ -324,6 +329,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     std::vector<int64_t> out_count(D.n_streams, 0);
     std::vector<uint8_t> pkt_used((size_t)n_packets, 0);
     bool any_floor = false, need_coupling = false;
+    int64_t mismatches = 0;
     int64_t temp_floats = 0;
     std::vector<int64_t> temp_off((size_t)n_packets, -1);
 
@@ -382,9 +388,13 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         fd.flags = (bf ? kFrameLong : 0u) | (pi.left_use_size1 ? kFrameSlope1 : 0u) | (no_floor ? kFrameNoFloor : 0u);
         if (S.has_prev) {  // :670-675
             const int slope_len = (pi.left_use_size1 ? D.size1 : D.size0) / 2;
-            if (packet_len > slope_len)  // windowSlope.AsSpan(0, packetLen) would throw (:778)
-                return set_error(ctx, VPZ_E_WINDOW_MISMATCH,
-                                 "vpz_decoder_synth: previous packet's tail is longer than this packet's window slope");
+            if (packet_len > slope_len) {
+                // windowSlope.AsSpan(0, packetLen) would throw (:778): that Read fails, the packet is
+                // consumed and the decoder state stays as it was.  The rest of the batch is still
+                // synthesised; the call reports the condition at the end.
+                ++mismatches;
+                continue;
+            }
             fd.packet_len = packet_len;
             fd.prev_end = S.prev_end;
             S.prev_start = pi.left_start;
@@ -424,7 +434,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     for (int s = 0; s < D.n_streams; ++s) samples_written[s] = out_count[s];
     if (total_frames == 0) {
         D.states = st;
-        return VPZ_OK;
+        return mismatches ? set_error(ctx, VPZ_E_WINDOW_MISMATCH, "vpz_decoder_synth: window mismatch, packet skipped") : VPZ_OK;
     }
     // Run length: a wavefront synthesises R consecutive blocks of one channel (+1 recomputed block in
     // front).  Pick the R (<= 32) for which the run count fills k whole rounds of the resident waves
@@ -631,6 +641,10 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     D.states = st;
+    if (mismatches)
+        return set_error(ctx, VPZ_E_WINDOW_MISMATCH,
+                         "vpz_decoder_synth: a packet's previous tail is longer than its window slope "
+                         "(StreamDecoder.cs:777-778 throws); the packet was skipped, everything else was synthesised");
     return VPZ_OK;
 }
 

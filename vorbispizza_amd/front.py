@@ -1,0 +1,115 @@
+"""ctypes view of the C++ CPU front end (vorbispizza_amd/host): Ogg demux, Vorbis setup headers and the
+per-packet entropy decode -- the stage the reference host keeps on the CPU.  It yields exactly the arrays
+vpz_decoder_synth consumes."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvorbispizza_host.so")
+_lib = None
+
+
+class Info(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("sample_rate", C.c_int32), ("block_size0", C.c_int32),
+                ("block_size1", C.c_int32), ("floor_count", C.c_int32), ("residue_count", C.c_int32),
+                ("mapping_count", C.c_int32), ("mode_count", C.c_int32), ("codebook_count", C.c_int32),
+                ("audio_packets", C.c_int64), ("last_granule", C.c_int64), ("residue_floats", C.c_int64),
+                ("pages", C.c_int32), ("bad_crc_pages", C.c_int32)]
+
+
+class FrontError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            from . import _build
+            _build.build_host()
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.vpzh_open_memory.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+        L.vpzh_open_memory.restype = C.c_int
+        L.vpzh_close.argtypes = [vp]
+        L.vpzh_close.restype = None
+        L.vpzh_last_error.argtypes = [vp]
+        L.vpzh_last_error.restype = C.c_char_p
+        L.vpzh_get_info.argtypes = [vp, C.POINTER(Info)]
+        L.vpzh_get_info.restype = C.c_int
+        L.vpzh_get_floor1.argtypes = [vp, C.c_int, C.POINTER(capi.Floor1Config)]
+        L.vpzh_get_floor1.restype = C.c_int
+        L.vpzh_get_mapping.argtypes = [vp, C.c_int, C.POINTER(capi.MappingConfig)]
+        L.vpzh_get_mapping.restype = C.c_int
+        L.vpzh_get_residue_type.argtypes = [vp, C.c_int]
+        L.vpzh_get_residue_type.restype = C.c_int
+        L.vpzh_decode_all.argtypes = [vp, C.c_int32, C.c_int64, vp, vp, vp, vp]
+        L.vpzh_decode_all.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+class OggVorbisFile:
+    """One logical Vorbis stream of an .ogg file, entropy-decoded on the CPU.
+
+    Attributes mirror what StreamDecoder holds after LoadStreamHeader / LoadBooks
+    (StreamDecoder.cs:213-321): channels, sample_rate, block sizes, floors [(x_list, multiplier)],
+    mappings [{"coupling": [(mag, ang)], "channel_floor": [...]}]."""
+
+    def __init__(self, path_or_bytes):
+        data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+        self._data = np.frombuffer(bytes(data), dtype=np.uint8)
+        self._h = C.c_void_p()
+        rc = lib().vpzh_open_memory(self._data.ctypes.data, self._data.size, C.byref(self._h))
+        if rc != 0:
+            msg = lib().vpzh_last_error(self._h).decode() if self._h else "open failed"
+            self.close()
+            raise FrontError("%s (status %d)" % (msg, rc))
+        info = Info()
+        lib().vpzh_get_info(self._h, C.byref(info))
+        self.info = info
+        self.channels, self.sample_rate = info.channels, info.sample_rate
+        self.block_size0, self.block_size1 = info.block_size0, info.block_size1
+        self.audio_packets, self.last_granule = info.audio_packets, info.last_granule
+        self.floors, self.mappings = [], []
+        for i in range(info.floor_count):
+            f = capi.Floor1Config()
+            if lib().vpzh_get_floor1(self._h, i, C.byref(f)) != 0:
+                raise FrontError("floor %d cannot be represented" % i)
+            self.floors.append((list(f.x_list[: f.x_count]), f.multiplier))
+        for i in range(info.mapping_count):
+            m = capi.MappingConfig()
+            lib().vpzh_get_mapping(self._h, i, C.byref(m))
+            self.mappings.append({
+                "coupling": [(m.coupling_magnitude[j], m.coupling_angle[j]) for j in range(m.coupling_steps)],
+                "channel_floor": list(m.channel_floor[: self.channels])})
+        self.residue_types = [lib().vpzh_get_residue_type(self._h, i) for i in range(info.residue_count)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vpzh_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode_packets(self, stream_id=0, residue_base=0):
+        """Entropy-decode every audio packet.  Returns (packets, residue, posts, post_counts) in the
+        layout of vpz_decoder_synth."""
+        n, C_ = self.audio_packets, self.channels
+        packets = capi.make_packets(n)
+        residue = np.zeros(max(1, self.info.residue_floats), dtype=np.float32)
+        posts = np.zeros((n * C_, 64), dtype=np.int16)
+        counts = np.zeros(n * C_, dtype=np.uint8)
+        rc = lib().vpzh_decode_all(self._h, stream_id, residue_base, packets.ctypes.data, residue.ctypes.data,
+                                   posts.ctypes.data, counts.ctypes.data)
+        if rc != 0:
+            raise FrontError(lib().vpzh_last_error(self._h).decode())
+        return packets, residue[: self.info.residue_floats], posts, counts

@@ -1,0 +1,945 @@
+// C++ CPU front end: Ogg demux + Vorbis setup + per-packet entropy decode.
+// Mirrors the reference's CPU stage so real .ogg files can be pushed through vpz_decoder_synth; every
+// function cites the C# it follows.  Bit-serial / integer work only.
+#include "vorbis_front.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct InvalidData : std::runtime_error {
+    explicit InvalidData(const char *w) : std::runtime_error(w) {}
+};
+struct Unsupported : std::runtime_error {
+    explicit Unsupported(const char *w) : std::runtime_error(w) {}
+};
+
+int ilog(int x)  // Utils.cs:19-28
+{
+    int cnt = 0;
+    while (x > 0) { ++cnt; x >>= 1; }
+    return cnt;
+}
+
+uint32_t bit_reverse32(uint32_t n)  // Utils.cs:30-42
+{
+    n = ((n & 0xAAAAAAAAu) >> 1) | ((n & 0x55555555u) << 1);
+    n = ((n & 0xCCCCCCCCu) >> 2) | ((n & 0x33333333u) << 2);
+    n = ((n & 0xF0F0F0F0u) >> 4) | ((n & 0x0F0F0F0Fu) << 4);
+    n = ((n & 0xFF00FF00u) >> 8) | ((n & 0x00FF00FFu) << 8);
+    return (n >> 16) | (n << 16);
+}
+
+float vorbis_float32(uint32_t bits)  // Utils.cs:92-105
+{
+    int sign = (int32_t)bits >> 31;
+    int exponent = (int)((bits & 0x7fe00000u) >> 21) - 788;
+    float mantissa = (float)((((int)(bits & 0x1fffffu)) ^ sign) + (sign & 1));
+    return std::scalbn(mantissa, exponent);  // MathF.ScaleB
+}
+
+// ---------------------------------------------------------------------------------------------
+// VorbisPacket bit reader (VorbisPacket.cs:157-292): LSB-first; reads past the end return the
+// truncated value; only SkipBits past the end raises IsShort.
+// ---------------------------------------------------------------------------------------------
+struct BitReader {
+    const uint8_t *data = nullptr;
+    int64_t total_bits = 0, pos = 0;
+    bool is_short = false;
+
+    void init(const uint8_t *d, size_t bytes) { data = d; total_bits = (int64_t)bytes * 8; pos = 0; is_short = false; }
+    int64_t remaining() const { return total_bits - pos; }
+
+    uint64_t try_peek(int count, int *bits_read) const
+    {
+        int64_t rem = remaining();
+        int n = (int)(rem < count ? rem : count);
+        *bits_read = n;
+        if (n <= 0) { *bits_read = 0; return 0; }
+        uint64_t v = 0;
+        int64_t byte = pos >> 3;
+        int shift = (int)(pos & 7);
+        int got = 0;
+        // gather up to 9 bytes
+        int need_bytes = (shift + n + 7) >> 3;
+        unsigned __int128 acc = 0;
+        for (int i = 0; i < need_bytes; ++i) acc |= (unsigned __int128)data[byte + i] << (8 * i);
+        acc >>= shift;
+        v = (uint64_t)acc;
+        if (n < 64) v &= ((uint64_t)1 << n) - 1;
+        (void)got;
+        return v;
+    }
+    int skip(int count)  // SkipBits / SkipExtraBits
+    {
+        if (count <= 0) return 0;
+        int64_t rem = remaining();
+        if (rem >= count) { pos += count; return count; }
+        pos = total_bits;
+        is_short = true;
+        return (int)rem;
+    }
+    uint64_t read_bits(int count)
+    {
+        int n;
+        uint64_t v = try_peek(count, &n);
+        pos += n;
+        return v;
+    }
+    bool read_bit() { return read_bits(1) != 0; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Codebook.cs + Huffman.cs
+// ---------------------------------------------------------------------------------------------
+struct HuffNode {
+    int value = 0, length = 0, bits = 0, mask = 0;
+};
+
+struct Codebook {
+    int dimensions = 0, entries = 0, map_type = 0, max_bits = 0, prefix_bits = 0;
+    std::vector<int> lengths;
+    std::vector<float> lookup;
+    std::vector<HuffNode> prefix, overflow;
+
+    void read(BitReader &p)
+    {
+        if (p.read_bits(24) != 0x564342u) throw InvalidData("Book header had invalid signature!");
+        dimensions = (int)p.read_bits(16);
+        entries = (int)p.read_bits(24);
+        lengths.assign(entries, 0);
+        init_tree(p);
+        map_type = (int)p.read_bits(4);
+        init_lookup(p);
+    }
+
+    void init_tree(BitReader &p)  // Codebook.cs:44-145
+    {
+        bool sparse;
+        int total = 0, max_len;
+        if (p.read_bit()) {
+            int len = (int)p.read_bits(5) + 1;
+            for (int i = 0; i < entries;) {
+                int cnt = (int)p.read_bits(ilog(entries - i));
+                while (--cnt >= 0) {
+                    if (i >= entries) throw InvalidData("ordered codebook overruns its entry count");
+                    lengths[i++] = len;
+                }
+                ++len;
+            }
+            sparse = false;
+            max_len = len;
+        } else {
+            max_len = -1;
+            sparse = p.read_bit();
+            for (int i = 0; i < entries; i++) {
+                if (!sparse || p.read_bit()) {
+                    lengths[i] = (int)p.read_bits(5) + 1;
+                    ++total;
+                } else {
+                    lengths[i] = -1;
+                }
+                if (lengths[i] > max_len) max_len = lengths[i];
+            }
+        }
+        if (max_len <= -1) { max_bits = 0; return; }  // Huffman.Empty
+        max_bits = max_len;
+
+        // ComputeCodewords (Codebook.cs:147-218), always in the non-sparse arrangement: the sparse
+        // one only changes how the same (symbol, length, code) triples are stored
+        std::vector<int> codes(entries, 0);
+        if (!compute_codewords(codes)) throw InvalidData("over-specified Huffman tree");
+        generate_table(codes);
+        (void)sparse;
+        (void)total;
+    }
+
+    bool compute_codewords(std::vector<int> &codes)
+    {
+        uint32_t available[33];
+        memset(available, 0, sizeof available);
+        int k;
+        for (k = 0; k < entries; ++k)
+            if (lengths[k] > 0) break;
+        if (k == entries) return true;
+        codes[k] = 0;
+        for (int i = 1; i <= lengths[k]; ++i) available[i] = 1u << (32 - i);
+        for (int i = k + 1; i < entries; ++i) {
+            int z = lengths[i];
+            if (z <= 0) continue;
+            while (z > 0 && available[z] == 0) --z;
+            if (z == 0) return false;
+            uint32_t res = available[z];
+            available[z] = 0;
+            codes[i] = (int)bit_reverse32(res);
+            if (z != lengths[i])
+                for (int y = lengths[i]; y > z; --y) available[y] = res + (1u << (32 - y));
+        }
+        return true;
+    }
+
+    void generate_table(const std::vector<int> &codes)  // Huffman.cs:24-105
+    {
+        int count = 0, last_valid = -1, max_len = 0;
+        std::vector<HuffNode> list;
+        list.reserve(entries);
+        for (int i = 0; i < entries; ++i) {
+            int len = lengths[i];
+            if (len != 0) { ++count; last_valid = i; }
+            if (len > 0) {
+                HuffNode n;
+                n.value = i;
+                n.length = len;
+                n.bits = codes[i];
+                n.mask = (int)((1u << (len & 31)) - 1u);
+                list.push_back(n);
+                if (len > max_len) max_len = len;
+            }
+        }
+        if (count == 1 && lengths[last_valid] != 1) throw InvalidData("Invalid single entry.");
+        int table_bits = max_len > 10 ? 10 : max_len;
+        prefix_bits = table_bits;
+        prefix.assign((size_t)1 << table_bits, HuffNode());
+        for (const HuffNode &n : list) {
+            if (n.length > table_bits) {
+                overflow.push_back(n);
+            } else {
+                int max_val = 1 << (table_bits - n.length);
+                for (int j = 0; j < max_val; ++j) prefix[(size_t)((j << n.length) | n.bits)] = n;
+            }
+        }
+    }
+
+    static int lookup1_values(int entries, int dimensions)  // Codebook.cs:290-298
+    {
+        int r = (int)std::floor(std::exp(std::log((double)entries) / dimensions));
+        if (std::floor(std::pow((double)r + 1, dimensions)) <= entries) ++r;
+        return r;
+    }
+
+    void init_lookup(BitReader &p)  // Codebook.cs:220-288
+    {
+        if (map_type == 0) return;
+        if (map_type > 2) throw InvalidData("invalid codebook lookup type");
+        float min_value = vorbis_float32((uint32_t)p.read_bits(32));
+        float delta_value = vorbis_float32((uint32_t)p.read_bits(32));
+        int value_bits = (int)p.read_bits(4) + 1;
+        bool sequence_p = p.read_bit();
+        size_t count = (size_t)entries * dimensions;
+        lookup.assign(count, 0.f);
+        size_t mcount = map_type == 1 ? (size_t)lookup1_values(entries, dimensions) : count;
+        std::vector<uint16_t> mult(mcount);
+        for (size_t i = 0; i < mcount; ++i) mult[i] = (uint16_t)p.read_bits(value_bits);
+        for (int idx = 0; idx < entries; ++idx) {
+            float last = 0.f;
+            uint32_t idx_div = 1;
+            for (int i = 0; i < dimensions; ++i) {
+                size_t moff = map_type == 1 ? (size_t)(((uint32_t)idx / idx_div) % (uint32_t)mcount)
+                                            : (size_t)idx * dimensions + i;
+                volatile float prod = (float)mult[moff] * delta_value;  // separately rounded mul, add, add
+                volatile float sum = prod + min_value;
+                float value = sum + last;
+                lookup[(size_t)idx * dimensions + i] = value;
+                if (sequence_p) last = value;
+                if (map_type == 1) idx_div *= (uint32_t)mcount;
+            }
+        }
+    }
+
+    int decode_scalar(BitReader &p) const  // Codebook.cs:301-335
+    {
+        int n;
+        uint64_t data = p.try_peek(prefix_bits, &n);
+        if (n != 0 && !prefix.empty()) {
+            const HuffNode &node = prefix[(size_t)data];
+            if (node.length != 0) {
+                p.skip(node.length);
+                return node.value;
+            }
+        }
+        int d = (int)p.try_peek(max_bits, &n);
+        if (n != 0) {
+            for (const HuffNode &node : overflow)
+                if (node.bits == (d & node.mask)) {
+                    p.skip(node.length);
+                    return node.value;
+                }
+        }
+        return -1;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Floor1.cs:39-219
+// ---------------------------------------------------------------------------------------------
+struct Floor1 {
+    std::vector<uint8_t> partition_class, class_dimensions, class_subclasses, class_masterbooks;
+    std::vector<std::vector<int>> subclass_books;
+    std::vector<int> x_list;
+    int multiplier = 0, range = 0, y_bits = 0;
+
+    void read(BitReader &p, int n_books)
+    {
+        static const int range_lookup[4] = {128, 64, 43, 32};
+        static const int ybits_lookup[4] = {8, 7, 7, 6};
+        int maximum_class = -1;
+        partition_class.resize((size_t)p.read_bits(5));
+        for (auto &pc : partition_class) {
+            pc = (uint8_t)p.read_bits(4);
+            if (pc > maximum_class) maximum_class = pc;
+        }
+        maximum_class += 1;
+        class_dimensions.assign(maximum_class, 0);
+        class_subclasses.assign(maximum_class, 0);
+        class_masterbooks.assign(maximum_class, 0);
+        subclass_books.assign(maximum_class, {});
+        for (int i = 0; i < maximum_class; ++i) {
+            class_dimensions[i] = (uint8_t)(p.read_bits(3) + 1);
+            class_subclasses[i] = (uint8_t)p.read_bits(2);
+            if (class_subclasses[i] > 0) class_masterbooks[i] = (uint8_t)p.read_bits(8);
+            subclass_books[i].resize((size_t)1 << class_subclasses[i]);
+            for (auto &b : subclass_books[i]) {
+                int book = (int)p.read_bits(8) - 1;
+                if (book >= n_books) throw InvalidData("floor1 subclass book out of range");
+                b = book;
+            }
+        }
+        int mult = (int)p.read_bits(2);
+        range = range_lookup[mult] * 2;
+        y_bits = ybits_lookup[mult];
+        multiplier = mult + 1;
+        int range_bits = (int)p.read_bits(4);
+        x_list.clear();
+        x_list.push_back(0);
+        x_list.push_back(1 << range_bits);
+        for (uint8_t cls : partition_class)
+            for (int j = 0; j < class_dimensions[cls]; ++j) x_list.push_back((int)p.read_bits(range_bits));
+        for (size_t i = 0; i < x_list.size(); ++i)
+            for (size_t j = i + 1; j < x_list.size(); ++j)
+                if (x_list[i] == x_list[j]) throw InvalidData("duplicate floor1 X value");  // Floor1.cs:140-141
+    }
+
+    // Floor1.Unpack :162-219 -> posts[64], returns PostCount
+    int unpack(BitReader &p, const std::vector<Codebook> &books, int *posts) const
+    {
+        if (!p.read_bit()) return 0;
+        int post_count = 2;
+        posts[0] = (int)p.read_bits(y_bits);
+        posts[1] = (int)p.read_bits(y_bits);
+        for (size_t i = 0; i < partition_class.size(); ++i) {
+            int cls = partition_class[i];
+            int cdim = class_dimensions[cls];
+            int cbits = class_subclasses[cls];
+            int csub = (1 << cbits) - 1;
+            uint32_t cval = 0;
+            if (cbits > 0) {
+                int v = books[class_masterbooks[cls]].decode_scalar(p);
+                if (v == -1) return 0;  // bad value: bail, PostCount = 0
+                cval = (uint32_t)v;
+            }
+            for (int j = 0; j < cdim; ++j) {
+                int book_idx = subclass_books[cls][cval & (uint32_t)csub];
+                cval >>= cbits;
+                int post = 0;
+                if (book_idx >= 0) {
+                    post = books[book_idx].decode_scalar(p);
+                    if (post == -1) return 0;
+                }
+                if (post_count < 64) posts[post_count] = post;  // Posts is int[64] (Floor1.cs:17)
+                ++post_count;
+            }
+        }
+        return post_count;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Residue0.cs / Residue1.cs / Residue2.cs
+// ---------------------------------------------------------------------------------------------
+struct Residue {
+    int type = 0, begin = 0, end = 0, partition_size = 0, classifications = 0, class_book = 0, max_stages = 0;
+    std::vector<uint8_t> cascade;
+    std::vector<std::vector<uint8_t>> books;  // per class: book per stage (empty: null)
+    std::vector<int> decode_map;
+    std::vector<int> part_word_cache;
+
+    void read(BitReader &p, int type_, const std::vector<Codebook> &cbs)
+    {
+        type = type_;
+        begin = (int)p.read_bits(24);
+        end = (int)p.read_bits(24);
+        partition_size = (int)p.read_bits(24) + 1;
+        classifications = (int)p.read_bits(6) + 1;
+        class_book = (int)p.read_bits(8);
+        cascade.assign(classifications, 0);
+        int acc = 0;
+        for (auto &c : cascade) {
+            uint32_t low = (uint32_t)p.read_bits(4);
+            uint32_t bits = low & 7u;
+            if (low & 8u) bits |= (uint32_t)p.read_bits(5) << 3;
+            c = (uint8_t)bits;
+            acc += __builtin_popcount(bits);
+        }
+        std::vector<uint8_t> book_nums(acc);
+        for (auto &b : book_nums) {
+            b = (uint8_t)p.read_bits(8);
+            if (b >= cbs.size() || cbs[b].map_type == 0) throw InvalidData("residue book without value mapping");
+        }
+        if (class_book >= (int)cbs.size()) throw InvalidData("residue class book out of range");
+        const Codebook &cb = cbs[class_book];
+        int partvals = 1;
+        for (int i = 0; i < cb.dimensions; ++i) {
+            partvals *= classifications;
+            if (partvals > cb.entries) throw InvalidData("residue classbook too small");
+        }
+        books.assign(classifications, {});
+        acc = 0;
+        int maxstage = 0;
+        for (int j = 0; j < classifications; ++j) {
+            int stages = ilog(cascade[j]);
+            if (stages <= 0) continue;
+            books[j].assign(stages, 0);
+            if (stages > maxstage) maxstage = stages;
+            for (int k = 0; k < stages; ++k)
+                if (cascade[j] & (1 << k)) books[j][k] = book_nums[acc++];
+        }
+        max_stages = maxstage;
+        decode_map.assign((size_t)partvals * cb.dimensions, 0);
+        for (int j = 0; j < partvals; ++j) {
+            int val = j, mult = partvals / classifications;
+            for (int k = 0; k < cb.dimensions; ++k) {
+                int deco = val / mult;
+                val -= deco * mult;
+                mult /= classifications;
+                decode_map[(size_t)j * cb.dimensions + k] = deco;
+            }
+        }
+    }
+
+    // WriteVectors: Residue0.cs:208-231 (type 0, sums the entry into ONE bin: quirk q9) and
+    // Residue1.cs:12-34 (types 1 and 2)
+    bool write_vectors(const Codebook &cb, BitReader &p, float *chan, int chan_len, int offset) const
+    {
+        if (type == 0) {
+            int steps = partition_size / cb.dimensions;
+            for (int step = 0; step < steps; ++step) {
+                int entry = cb.decode_scalar(p);
+                if (entry == -1) return true;
+                float r = 0;
+                const float *lk = &cb.lookup[(size_t)entry * cb.dimensions];
+                for (int d = 0; d < cb.dimensions; ++d) { volatile float t = r + lk[d]; r = t; }
+                if (offset + step < chan_len) { volatile float t = chan[offset + step] + r; chan[offset + step] = t; }
+            }
+            return false;
+        }
+        for (int i = 0; i < partition_size;) {
+            int entry = cb.decode_scalar(p);
+            if (entry == -1) return true;
+            const float *lk = &cb.lookup[(size_t)entry * cb.dimensions];
+            if (offset + i + cb.dimensions > chan_len) throw InvalidData("residue vector overruns the block");
+            for (int j = 0; j < cb.dimensions; ++j) chan[offset + i + j] += lk[j];
+            i += cb.dimensions;
+        }
+        return false;
+    }
+
+    // Residue0.Decode :117-206.  buffer: `count` channels at stride `stride`.
+    void decode(BitReader &p, const std::vector<uint8_t> &do_not_decode, int block_size, float *buffer, int stride,
+                const std::vector<Codebook> &cbs)
+    {
+        int half = block_size / 2;
+        int b = begin < half ? begin : half;
+        int e = end < half ? end : half;
+        int n = e - b;
+        if (n <= 0) return;
+        const int count = (int)do_not_decode.size();
+        int partition_count = n / partition_size;
+        const Codebook &cb = cbs[class_book];
+        int dim = cb.dimensions;
+        int partition_words = (partition_count + dim - 1) / dim;
+        part_word_cache.assign((size_t)count * partition_words, 0);
+        for (int stage = 0; stage < max_stages; ++stage) {
+            for (int partition_idx = 0, entry_idx = 0; partition_idx < partition_count; ++entry_idx) {
+                if (stage == 0) {
+                    for (int ch = 0; ch < count; ++ch) {
+                        if (do_not_decode[ch]) continue;
+                        int idx = cb.decode_scalar(p);
+                        if (idx >= 0 && idx < (int)decode_map.size() / dim) {
+                            part_word_cache[(size_t)ch * partition_words + entry_idx] = idx;
+                        } else {
+                            partition_idx = partition_count;
+                            stage = max_stages;
+                            break;
+                        }
+                    }
+                }
+                for (int dim_idx = 0; partition_idx < partition_count && dim_idx < dim; ++dim_idx, ++partition_idx) {
+                    int offset = b + partition_idx * partition_size;
+                    for (int ch = 0; ch < count; ++ch) {
+                        if (do_not_decode[ch]) continue;
+                        int map_index = part_word_cache[(size_t)ch * partition_words + entry_idx] * dim;
+                        int idx = decode_map[(size_t)map_index + dim_idx];
+                        if ((cascade[idx] & (1 << stage)) == 0) continue;
+                        if (books[idx].empty()) continue;
+                        const Codebook &book = cbs[books[idx][stage]];
+                        if (write_vectors(book, p, buffer + (size_t)ch * stride, stride, offset)) {
+                            partition_idx = partition_count;
+                            stage = max_stages;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+    }
+};
+
+struct Mapping {  // Mapping.cs:19-95
+    std::vector<uint8_t> coupling_angle, coupling_magnitude, mux, submap_floor, submap_residue;
+    void read(BitReader &p, int channels, int n_floors, int n_residues)
+    {
+        int submaps = 1;
+        if (p.read_bit()) submaps += (int)p.read_bits(4);
+        int steps = 0;
+        if (p.read_bit()) steps = (int)p.read_bits(8) + 1;
+        int cbits = ilog(channels - 1);
+        for (int j = 0; j < steps; ++j) {
+            int mag = (int)p.read_bits(cbits), ang = (int)p.read_bits(cbits);
+            if (mag == ang || mag > channels - 1 || ang > channels - 1)
+                throw InvalidData("Invalid magnitude or angle in mapping header!");
+            coupling_angle.push_back((uint8_t)ang);
+            coupling_magnitude.push_back((uint8_t)mag);
+        }
+        if (p.read_bits(2) != 0) throw InvalidData("Reserved bits not 0 in mapping header.");
+        mux.assign(channels, 0);
+        if (submaps > 1)
+            for (int c = 0; c < channels; ++c) {
+                mux[c] = (uint8_t)p.read_bits(4);
+                if (mux[c] > submaps) throw InvalidData("Invalid channel mux submap index in mapping header!");
+            }
+        for (int j = 0; j < submaps; ++j) {
+            p.skip(8);
+            int fl = (int)p.read_bits(8);
+            if (fl >= n_floors) throw InvalidData("Invalid floor number in mapping header!");
+            int rs = (int)p.read_bits(8);
+            if (rs >= n_residues) throw InvalidData("Invalid residue number in mapping header!");
+            submap_floor.push_back((uint8_t)fl);
+            submap_residue.push_back((uint8_t)rs);
+        }
+    }
+};
+
+struct Mode {  // Mode.cs:12-28
+    bool block_flag = false;
+    int mapping = 0;
+};
+
+struct OggPacket {
+    std::vector<uint8_t> data;
+    int64_t granule = -1;
+    bool eos = false;
+};
+
+// Ogg CRC (polynomial 0x04c11db7, no reflection), Ogg/Crc.cs
+uint32_t g_crc_table[256];
+bool g_crc_ready = false;
+void crc_init()
+{
+    if (g_crc_ready) return;
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t r = i << 24;
+        for (int j = 0; j < 8; ++j) r = (r << 1) ^ ((r & 0x80000000u) ? 0x04c11db7u : 0u);
+        g_crc_table[i] = r;
+    }
+    g_crc_ready = true;
+}
+uint32_t crc_update(uint32_t crc, const uint8_t *d, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) crc = (crc << 8) ^ g_crc_table[((crc >> 24) & 0xff) ^ d[i]];
+    return crc;
+}
+
+}  // namespace
+
+struct vpzh_stream {
+    std::string error;
+    int channels = 0, sample_rate = 0, size0 = 0, size1 = 0;
+    std::vector<Codebook> books;
+    std::vector<Floor1> floors;
+    std::vector<Residue> residues;
+    std::vector<Mapping> mappings;
+    std::vector<Mode> modes;
+    int mode_field_bits = 0;
+    std::vector<OggPacket> audio;
+    int64_t last_granule = -1;
+    int pages = 0, bad_crc = 0;
+    int64_t residue_floats = 0;
+
+    // ---- container: Ogg/PageReaderBase.cs:286-361 (sync, CRC), Ogg/PacketProvider.cs:427-560 (packets)
+    void demux(const uint8_t *d, size_t size, std::vector<OggPacket> &packets)
+    {
+        crc_init();
+        size_t pos = 0;
+        bool have_serial = false;
+        uint32_t serial = 0;
+        std::vector<uint8_t> pending;  // packet continued from earlier pages
+        bool pending_valid = false;
+        OggPacket *last_granule_candidate = nullptr;
+        (void)last_granule_candidate;
+        while (pos + 27 <= size) {
+            if (memcmp(d + pos, "OggS", 4) != 0) { ++pos; continue; }
+            const uint8_t *h = d + pos;
+            int nseg = h[26];
+            if (pos + 27 + nseg > size) break;
+            size_t body = 0;
+            for (int i = 0; i < nseg; ++i) body += h[27 + i];
+            if (pos + 27 + nseg + body > size) break;
+            uint32_t stored = (uint32_t)h[22] | ((uint32_t)h[23] << 8) | ((uint32_t)h[24] << 16) | ((uint32_t)h[25] << 24);
+            uint32_t crc = crc_update(0, h, 22);
+            static const uint8_t zero4[4] = {0, 0, 0, 0};
+            crc = crc_update(crc, zero4, 4);
+            crc = crc_update(crc, h + 26, 1 + nseg + body);
+            if (crc != stored) { ++bad_crc; ++pos; continue; }  // resync byte-wise
+            ++pages;
+            uint32_t ser = (uint32_t)h[14] | ((uint32_t)h[15] << 8) | ((uint32_t)h[16] << 16) | ((uint32_t)h[17] << 24);
+            uint8_t flags = h[5];
+            int64_t granule = 0;
+            for (int i = 7; i >= 0; --i) granule = (granule << 8) | h[6 + i];
+            const size_t page_len = 27 + nseg + body;
+            if (!have_serial) {
+                if (!(flags & 2)) { pos += page_len; continue; }  // wait for a beginning-of-stream page
+                serial = ser;
+                have_serial = true;
+            }
+            if (ser != serial) { pos += page_len; continue; }  // other logical streams are ignored
+            const uint8_t *seg = h + 27;
+            const uint8_t *data = h + 27 + nseg;
+            const bool continuation = flags & 1;
+            // packet count as PageHeader.GetPacketCount: terminated packets + 1 if the page ends open
+            int packet_count = 0;
+            for (int i = 0; i < nseg; ++i) if (seg[i] < 255) ++packet_count;
+            const bool page_continued = nseg > 0 && seg[nseg - 1] == 255;
+            if (page_continued) ++packet_count;
+            if (!continuation && pending_valid) {  // broken continuation: drop what we had
+                pending.clear();
+                pending_valid = false;
+            }
+            int packet_idx = 0;
+            size_t off = 0, cur = 0;
+            bool first_is_continuation = continuation;
+            for (int i = 0; i < nseg; ++i) {
+                cur += seg[i];
+                if (seg[i] < 255) {
+                    OggPacket pk;
+                    if (packet_idx == 0 && first_is_continuation) {
+                        if (pending_valid) {
+                            pk.data = pending;
+                            pk.data.insert(pk.data.end(), data + off, data + off + cur);
+                        } else {
+                            // continuation of a packet we never saw: the reference drops it
+                            off += cur; cur = 0; ++packet_idx;
+                            continue;
+                        }
+                        pending.clear();
+                        pending_valid = false;
+                    } else {
+                        pk.data.assign(data + off, data + off + cur);
+                    }
+                    // GranulePosition only on the last packet of the page (PacketProvider.cs:515-530)
+                    pk.granule = (packet_idx == packet_count - 1) ? granule : -1;
+                    packets.push_back(std::move(pk));
+                    off += cur; cur = 0; ++packet_idx;
+                }
+            }
+            if (page_continued) {
+                if (packet_idx == 0 && first_is_continuation && pending_valid) {
+                    pending.insert(pending.end(), data + off, data + off + cur);
+                } else {
+                    pending.assign(data + off, data + off + cur);
+                    pending_valid = true;
+                }
+            }
+            last_granule = granule;
+            pos += page_len;
+        }
+        // IsEndOfStream: last packet completed in the last page (PacketProvider.cs:522-525)
+        if (!packets.empty() && packets.back().granule != -1) packets.back().eos = true;
+    }
+
+    void load_headers(std::vector<OggPacket> &pk)
+    {
+        if (pk.size() < 3) throw InvalidData("missing header packets");
+        // identification, StreamDecoder.cs:213-240
+        {
+            BitReader p;
+            p.init(pk[0].data.data(), pk[0].data.size());
+            static const uint8_t sig[11] = {0x01, 'v', 'o', 'r', 'b', 'i', 's', 0, 0, 0, 0};
+            for (uint8_t c : sig) if (p.read_bits(8) != c) throw InvalidData("not a Vorbis identification header");
+            channels = (int)p.read_bits(8);
+            sample_rate = (int)p.read_bits(32);
+            p.read_bits(32); p.read_bits(32); p.read_bits(32);
+            int b0 = (int)p.read_bits(4), b1 = (int)p.read_bits(4);
+            size0 = 1 << b0;
+            size1 = 1 << b1;
+            if (channels < 1) throw InvalidData("no channels");
+        }
+        {   // comments: only the signature is checked (StreamDecoder.cs:242-260)
+            BitReader p;
+            p.init(pk[1].data.data(), pk[1].data.size());
+            static const uint8_t sig[7] = {0x03, 'v', 'o', 'r', 'b', 'i', 's'};
+            for (uint8_t c : sig) if (p.read_bits(8) != c) throw InvalidData("not a Vorbis comment header");
+        }
+        // setup, StreamDecoder.cs:262-321
+        BitReader p;
+        p.init(pk[2].data.data(), pk[2].data.size());
+        static const uint8_t sig[7] = {0x05, 'v', 'o', 'r', 'b', 'i', 's'};
+        for (uint8_t c : sig) if (p.read_bits(8) != c) throw InvalidData("not a Vorbis setup header");
+        books.resize((size_t)p.read_bits(8) + 1);
+        for (auto &b : books) b.read(p);
+        int times = (int)p.read_bits(6) + 1;
+        p.skip(16 * times);
+        int n_floors = (int)p.read_bits(6) + 1;
+        floors.resize(n_floors);
+        for (auto &f : floors) {
+            int type = (int)p.read_bits(16);
+            if (type == 0) throw Unsupported("floor type 0 is not implemented (SURVEY.md f-3)");
+            if (type != 1) throw InvalidData("Invalid floor type!");
+            f.read(p, (int)books.size());
+        }
+        int n_res = (int)p.read_bits(6) + 1;
+        residues.resize(n_res);
+        for (auto &r : residues) {
+            int type = (int)p.read_bits(16);
+            if (type > 2) throw InvalidData("Invalid residue type!");
+            r.read(p, type, books);
+        }
+        int n_map = (int)p.read_bits(6) + 1;
+        mappings.resize(n_map);
+        for (auto &m : mappings) {
+            if (p.read_bits(16) != 0) throw InvalidData("Invalid mapping type!");
+            m.read(p, channels, n_floors, n_res);
+        }
+        int n_modes = (int)p.read_bits(6) + 1;
+        modes.resize(n_modes);
+        for (auto &m : modes) {
+            m.block_flag = p.read_bit();
+            if (p.read_bits(32) != 0) throw InvalidData("Mode header had invalid window or transform type!");
+            m.mapping = (int)p.read_bits(8);
+            if (m.mapping >= n_map) throw InvalidData("Mode header had invalid mapping index!");
+        }
+        if (!p.read_bit()) throw InvalidData("Book packet did not end on correct bit!");
+        mode_field_bits = ilog(n_modes - 1);
+    }
+
+    // residue floats one packet contributes to the batch
+    int64_t packet_floats(const OggPacket &pk) const
+    {
+        BitReader p;
+        p.init(pk.data.data(), pk.data.size());
+        if (p.read_bits(1) != 0) return 0;
+        int mode_idx = (int)p.read_bits(mode_field_bits);
+        if (mode_idx >= (int)modes.size()) return 0;
+        return (int64_t)channels * ((modes[mode_idx].block_flag ? size1 : size0) / 2);
+    }
+
+    // StreamDecoder.DecodeNextPacket :696-762 -> Mode.Decode -> Mapping.DecodePacket :98-163
+    void decode_packet(const OggPacket &pk, int32_t stream_id, int64_t residue_off, vpz_packet *out, float *residue,
+                       int16_t *posts, uint8_t *post_counts)
+    {
+        memset(out, 0, sizeof *out);
+        out->stream = stream_id;
+        out->granule = -1;
+        out->residue_offset = residue_off;
+        if (pk.eos) out->flags |= VPZ_PKT_EOS;
+        for (int c = 0; c < channels; ++c) post_counts[c] = 0;
+        memset(posts, 0, sizeof(int16_t) * 64 * (size_t)channels);
+        BitReader p;
+        p.init(pk.data.data(), pk.data.size());
+        if (p.read_bits(1) != 0) { out->flags |= VPZ_PKT_NOT_DECODED; return; }
+        int mode_idx = (int)p.read_bits(mode_field_bits);
+        if ((unsigned)mode_idx >= modes.size()) throw InvalidData("Unused mode index.");
+        const Mode &mode = modes[mode_idx];
+        if (p.is_short) { out->flags |= VPZ_PKT_NOT_DECODED; return; }  // Mode.cs:32-36
+        const int block_size = mode.block_flag ? size1 : size0;
+        const int half = block_size / 2;
+        if (mode.block_flag) {
+            out->flags |= VPZ_PKT_BLOCK_FLAG;
+            if (p.read_bit()) out->flags |= VPZ_PKT_PREV_FLAG;
+            if (p.read_bit()) out->flags |= VPZ_PKT_NEXT_FLAG;
+        }
+        out->mapping = (uint8_t)mode.mapping;
+        out->granule = pk.granule;
+        const Mapping &map = mappings[mode.mapping];
+
+        // floors, Mapping.cs:109-118
+        std::vector<uint8_t> no_execute(channels);
+        for (int ch = 0; ch < channels; ++ch) {
+            int raw[64];
+            memset(raw, 0, sizeof raw);
+            int pc = floors[map.submap_floor[map.mux[ch]]].unpack(p, books, raw);
+            if (pc > 64) pc = 64;
+            post_counts[ch] = (uint8_t)pc;
+            for (int i = 0; i < 64; ++i) {
+                int v = raw[i];
+                posts[ch * 64 + i] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+            }
+            no_execute[ch] = pc == 0;
+        }
+        // coupling fix-up, Mapping.cs:121-130
+        for (size_t i = 0; i < map.coupling_angle.size(); ++i) {
+            int mag = map.coupling_magnitude[i], ang = map.coupling_angle[i];
+            if (!(no_execute[mag] && no_execute[ang])) { no_execute[mag] = 0; no_execute[ang] = 0; }
+        }
+        // residues, Mapping.cs:132-163.  decodeBuffer is allocated once per packet and reused by every
+        // submap without clearing (reference behaviour, matters only for multi-submap residue 0/1).
+        float *dst = residue;  // planar [ch][half] unless the interleaved shortcut below is taken
+        memset(dst, 0, sizeof(float) * (size_t)channels * half);
+        std::vector<float> decode_buffer((size_t)channels * block_size, 0.f);
+        const int submaps = (int)map.submap_residue.size();
+        for (int i = 0; i < submaps; ++i) {
+            std::vector<uint8_t> dnd;
+            std::vector<int> members;
+            for (int j = 0; j < channels; ++j)
+                if (map.mux[j] == i) { dnd.push_back(no_execute[j]); members.push_back(j); }
+            Residue &res = residues[map.submap_residue[i]];
+            const int count = (int)dnd.size();
+            if (res.type == 2) {  // Residue2.cs:12-52
+                bool any = false;
+                for (uint8_t f : dnd) if (!f) any = true;
+                if (!any) {
+                    for (int k = 0; k < count; ++k) memset(&decode_buffer[(size_t)k * block_size], 0, sizeof(float) * half);
+                } else {
+                    std::vector<float> tmp((size_t)half * count, 0.f);
+                    std::vector<uint8_t> one(1, 0);
+                    res.decode(p, one, block_size * count, tmp.data(), half * count, books);
+                    if (submaps == 1 && count == channels && channels > 1) {
+                        // hand the Residue2 vector over as it is: the GPU de-interleaves (Residue2.cs:42-51)
+                        memcpy(dst, tmp.data(), sizeof(float) * (size_t)half * channels);
+                        out->flags |= VPZ_PKT_INTERLEAVED;
+                        return;
+                    }
+                    if (count == 1) {
+                        memcpy(&decode_buffer[0], tmp.data(), sizeof(float) * half);
+                    } else {
+                        for (int k = 0; k < count; ++k)
+                            for (int b = 0; b < half; ++b) decode_buffer[(size_t)k * block_size + b] = tmp[(size_t)b * count + k];
+                    }
+                }
+            } else {
+                res.decode(p, dnd, block_size, decode_buffer.data(), block_size, books);
+            }
+            for (int k = 0; k < count; ++k)
+                memcpy(dst + (size_t)members[k] * half, &decode_buffer[(size_t)k * block_size], sizeof(float) * half);
+        }
+    }
+};
+
+extern "C" {
+
+int vpzh_open_memory(const uint8_t *data, uint64_t size, vpzh_stream **out)
+{
+    if (!data || !out) return VPZH_E_ARG;
+    *out = nullptr;
+    std::unique_ptr<vpzh_stream> s(new vpzh_stream());
+    int rc = VPZH_OK;
+    try {
+        std::vector<OggPacket> packets;
+        s->demux(data, (size_t)size, packets);
+        s->load_headers(packets);
+        s->audio.assign(std::make_move_iterator(packets.begin() + 3), std::make_move_iterator(packets.end()));
+        s->residue_floats = 0;
+        for (const OggPacket &pk : s->audio) s->residue_floats += s->packet_floats(pk);
+    } catch (const Unsupported &e) {
+        s->error = e.what();
+        rc = VPZH_E_UNSUPPORTED;
+    } catch (const std::exception &e) {
+        s->error = e.what();
+        rc = VPZH_E_INVALID_DATA;
+    }
+    *out = s.release();
+    return rc;
+}
+
+void vpzh_close(vpzh_stream *s) { delete s; }
+
+const char *vpzh_last_error(vpzh_stream *s) { return s ? s->error.c_str() : ""; }
+
+int vpzh_get_info(vpzh_stream *s, vpzh_info *info)
+{
+    if (!s || !info) return VPZH_E_ARG;
+    memset(info, 0, sizeof *info);
+    info->channels = s->channels;
+    info->sample_rate = s->sample_rate;
+    info->block_size0 = s->size0;
+    info->block_size1 = s->size1;
+    info->floor_count = (int32_t)s->floors.size();
+    info->residue_count = (int32_t)s->residues.size();
+    info->mapping_count = (int32_t)s->mappings.size();
+    info->mode_count = (int32_t)s->modes.size();
+    info->codebook_count = (int32_t)s->books.size();
+    info->audio_packets = (int64_t)s->audio.size();
+    info->last_granule = s->last_granule;
+    info->residue_floats = s->residue_floats;
+    info->pages = s->pages;
+    info->bad_crc_pages = s->bad_crc;
+    return VPZH_OK;
+}
+
+int vpzh_get_floor1(vpzh_stream *s, int index, vpz_floor1_config *out)
+{
+    if (!s || !out || index < 0 || index >= (int)s->floors.size()) return VPZH_E_ARG;
+    const Floor1 &f = s->floors[index];
+    memset(out, 0, sizeof *out);
+    if (f.x_list.size() > VPZ_MAX_FLOOR1_POSTS) return VPZH_E_INVALID_DATA;
+    out->x_count = (int32_t)f.x_list.size();
+    out->multiplier = f.multiplier;
+    for (size_t i = 0; i < f.x_list.size(); ++i) out->x_list[i] = f.x_list[i];
+    return VPZH_OK;
+}
+
+int vpzh_get_mapping(vpzh_stream *s, int index, vpz_mapping_config *out)
+{
+    if (!s || !out || index < 0 || index >= (int)s->mappings.size()) return VPZH_E_ARG;
+    const Mapping &m = s->mappings[index];
+    memset(out, 0, sizeof *out);
+    out->coupling_steps = (int32_t)m.coupling_angle.size();
+    for (size_t i = 0; i < m.coupling_angle.size(); ++i) {
+        out->coupling_magnitude[i] = m.coupling_magnitude[i];
+        out->coupling_angle[i] = m.coupling_angle[i];
+    }
+    for (int c = 0; c < s->channels && c <= VPZ_MAX_CHANNELS; ++c) out->channel_floor[c] = m.submap_floor[m.mux[c]];
+    return VPZH_OK;
+}
+
+int vpzh_get_residue_type(vpzh_stream *s, int index)
+{
+    if (!s || index < 0 || index >= (int)s->residues.size()) return VPZH_E_ARG;
+    return s->residues[index].type;
+}
+
+int vpzh_decode_all(vpzh_stream *s, int32_t stream_id, int64_t residue_base, vpz_packet *packets, float *residue,
+                    int16_t *posts, uint8_t *post_counts)
+{
+    if (!s || !packets || !residue || !posts || !post_counts) return VPZH_E_ARG;
+    try {
+        int64_t off = 0;
+        for (size_t i = 0; i < s->audio.size(); ++i) {
+            const int64_t n = s->packet_floats(s->audio[i]);
+            s->decode_packet(s->audio[i], stream_id, residue_base + off, &packets[i], residue + off,
+                             posts + i * 64 * (size_t)s->channels, post_counts + i * (size_t)s->channels);
+            off += n;
+        }
+    } catch (const std::exception &e) {
+        s->error = e.what();
+        return VPZH_E_INVALID_DATA;
+    }
+    return VPZH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+/*
+ * vorbis_front.h -- C entry points of the C++ CPU front end.
+ *
+ * This is the part the real host (the C# VorbisReader / StreamDecoder) keeps on the CPU: Ogg page sync +
+ * CRC + lacing -> packets (Ogg/PageReaderBase.cs, Ogg/PacketProvider.cs:427-560), the three Vorbis
+ * headers (StreamDecoder.cs:213-353: codebooks, floors, residues, mappings, modes) and, per audio
+ * packet, the bit-serial entropy decode up to Mapping.cs:163 (mode bits, Floor1.Unpack, Residue0/1/2
+ * decode).  It produces exactly the arrays vpz_decoder_synth takes, so that real .ogg files can be pushed
+ * through the GPU back end without a .NET host.  Integer / Huffman stage only: bit-exact by construction,
+ * no sample arithmetic beyond the codebook vector accumulation the reference does in Residue*.cs.
+ */
+#ifndef VORBISPIZZA_FRONT_H
+#define VORBISPIZZA_FRONT_H
+
+#include <stdint.h>
+
+#include "../../include/vorbispizza_synth.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPZH_OK             0
+#define VPZH_E_INVALID_DATA (-1)  /* InvalidDataException in the reference */
+#define VPZH_E_UNSUPPORTED  (-2)  /* floor type 0 */
+#define VPZH_E_ARG          (-3)
+
+typedef struct vpzh_stream vpzh_stream;
+
+/* Parses the container and the three header packets of the first logical stream in `data`. */
+int  vpzh_open_memory(const uint8_t *data, uint64_t size, vpzh_stream **out);
+void vpzh_close(vpzh_stream *s);
+const char *vpzh_last_error(vpzh_stream *s);
+
+typedef struct vpzh_info {
+    int32_t channels, sample_rate, block_size0, block_size1;
+    int32_t floor_count, residue_count, mapping_count, mode_count, codebook_count;
+    int64_t audio_packets;      /* packets after the three headers */
+    int64_t last_granule;       /* granule position of the last page == total samples per channel */
+    int64_t residue_floats;     /* floats vpzh_decode_all writes to `residue` */
+    int32_t pages, bad_crc_pages;
+} vpzh_info;
+int vpzh_get_info(vpzh_stream *s, vpzh_info *info);
+
+/* setup products the synthesis back end needs (vpz_stream_config) */
+int vpzh_get_floor1(vpzh_stream *s, int index, vpz_floor1_config *out);
+int vpzh_get_mapping(vpzh_stream *s, int index, vpz_mapping_config *out);
+int vpzh_get_residue_type(vpzh_stream *s, int index);
+
+/* Entropy-decodes every audio packet.  packets[audio_packets], residue[residue_floats],
+ * posts[audio_packets*channels*64], post_counts[audio_packets*channels].  `stream_id` is written to
+ * vpz_packet.stream, `residue_base` is added to every residue_offset.  Packets whose first bit is set
+ * or that fail GetPacketInfo get VPZ_PKT_NOT_DECODED (StreamDecoder.cs:728, 750-761). */
+int vpzh_decode_all(vpzh_stream *s, int32_t stream_id, int64_t residue_base, vpz_packet *packets,
+                    float *residue, int16_t *posts, uint8_t *post_counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
