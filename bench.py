@@ -143,6 +143,83 @@ def build_floor6(torch, device, frames=16384):
         floors, mappings, (frames - 1) * 1024
 
 
+def build_real_streams(torch, device, name, copies):
+    """`copies` independent streams of one fixture: CPU entropy decode once (C++ front end), batch
+    arrays replicated with their own stream ids (BASELINE configs[4]: per-GPU share of 1024 streams)."""
+    from vorbispizza_amd.front import OggVorbisFile
+    t0 = time.perf_counter()
+    f = OggVorbisFile(os.path.join(ROOT, "tests", "golden", name))
+    pk, res, posts, counts = f.decode_packets()
+    t_front = time.perf_counter() - t0
+    n = len(pk)
+    pk_all = np.tile(pk, copies)
+    pk_all["stream"] = np.repeat(np.arange(copies, dtype=np.int32), n)
+    pk_all["residue_offset"] += np.repeat(np.arange(copies, dtype=np.int64) * res.size, n)
+    d_res = torch.from_numpy(res).to(device).repeat(copies)
+    d_posts = torch.from_numpy(posts).to(device).repeat(copies, 1)
+    d_counts = torch.from_numpy(counts).to(device).repeat(copies)
+    return f, pk_all, d_res, d_posts, d_counts, t_front
+
+
+def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2):
+    """GPU-stage rate over `copies` x 3test.ogg + `copies` x issue6test.ogg, interleaved output."""
+    from vorbispizza_amd import Decoder, SynthError, capi
+    groups = []
+    total_samples = 0
+    t_front_total = 0.0
+    for name, samples in (("3test.ogg", 288094), ("issue6test.ogg", 548160)):
+        f, pk, res, posts, counts, t_front = build_real_streams(torch, device, name, copies)
+        dec = Decoder(ctx, f.channels, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings,
+                      n_streams=copies)
+        cap = samples + 2048
+        out = torch.empty(copies * cap * f.channels, device=device, dtype=torch.float32)
+        offs = np.arange(copies, dtype=np.int64) * cap * f.channels
+        groups.append((dec, pk, res, posts, counts, out, offs, cap, samples, f.channels))
+        total_samples += copies * samples * f.channels
+        t_front_total += t_front * copies  # a real host decodes every stream; we decoded one copy
+
+    def step():
+        for dec, pk, res, posts, counts, out, offs, cap, samples, ch in groups:
+            dec.reset(-1)
+            try:
+                w = dec.synth_raw(pk, res, posts, counts, out, offs, cap, capi.OUT_INTERLEAVED, 0, capi.MEM_DEVICE)
+            except SynthError as e:  # issue6test.ogg's trailing empty packet (skipped, like the reference's throw)
+                assert e.status == capi.E_WINDOW_MISMATCH
+                continue
+            assert int(w[0]) == samples, (int(w[0]), samples)
+
+    for _ in range(warmup):
+        step()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    for g in groups:
+        g[0].close()
+    return dt, total_samples, t_front_total
+
+
+def cpu_plumbing_2test():
+    """BASELINE configs[0]: TestFiles/2test.ogg decoded on the CPU only (front end + oracle)."""
+    import helpers
+    import oracle
+    from vorbispizza_amd.front import OggVorbisFile
+    t0 = time.perf_counter()
+    f = OggVorbisFile(os.path.join(ROOT, "tests", "golden", "2test.ogg"))
+    pk, res, posts, counts = f.decode_packets()
+    t1 = time.perf_counter()
+    pcm, pos, _ = helpers.oracle_decode(oracle, f.channels, f.block_size0, f.block_size1,
+                                        helpers.packets_for_oracle(f, pk, res, posts, counts),
+                                        floors=f.floors, mappings=f.mappings)
+    t2 = time.perf_counter()
+    return {"file": "tests/golden/2test.ogg (mono 44.1 kHz, 310 packets)", "samples": int(pcm.shape[1]),
+            "expected_samples": 315790, "front_end_ms": round((t1 - t0) * 1e3, 2),
+            "oracle_synthesis_ms": round((t2 - t1) * 1e3, 2),
+            "note": "CPU only: C++ front end + C oracle driven packet by packet from Python"}
+
+
 def time_decoder(ctx, dec, torch, pk, residue, posts, counts, samples, channels, steps, warmup):
     from vorbispizza_amd import capi
     out = torch.empty(channels * (samples + 1024), device=residue.device, dtype=torch.float32)
@@ -280,6 +357,17 @@ def main():
                 "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "3 kernels (unwrap, de-interleave+coupling, fused floor+IMDCT+OLA); whole call"}
             dec.close()
+            del res6, posts, counts
+            torch.cuda.empty_cache()
+            # configs[4], one GPU's share: 128 stereo streams (64 x 3test.ogg + 64 x issue6test.ogg)
+            dt, tot, t_front = time_real_streams(ctx, torch, device, 64)
+            extras["configs[4] share of one GPU: 128 real stereo streams (64x 3test.ogg + 64x issue6test.ogg), "
+                   "interleaved out, decoded spectra device-resident"] = {
+                "Msamples_per_s": round(tot / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
+                "cpu_entropy_decode_s_for_128_streams_1thread": round(t_front, 3),
+                "end_to_end_Msamples_per_s_incl_cpu_entropy_decode_1thread": round(tot / (dt + t_front) / 1e6, 2),
+                "note": "2 decoder groups (one per setup header); GPU stage = unwrap + de-interleave/coupling + fused synth"}
+            extras["configs[0] plumbing"] = cpu_plumbing_2test()
             result["extra_workloads"] = extras
     ctx.close()
     if distributed:
