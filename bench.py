@@ -36,6 +36,20 @@ CHANNELS = 2
 N = 2048
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 FETCH_SIZE x2 correction): counters cannot be
+    collected inside this process, so the figure is read from profiles/ and null if absent."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.txt")
+    try:
+        for line in open(path):
+            if line.startswith("corrected HBM traffic per launch:"):
+                return int(float(line.split(":")[1].split("MB")[0]) * 1e6)
+    except OSError:
+        pass
+    return None
+
+
 def host_threads(cap=16):
     """Threads for the CPU baseline: the box's CPU share for one GPU, never more than `cap`."""
     try:
@@ -322,7 +336,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_bytes(),
             "kernel": "imdct2048_kernel", "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": alg_bytes,
         },
