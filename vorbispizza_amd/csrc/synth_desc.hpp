@@ -16,18 +16,18 @@ constexpr uint32_t kFrameNoFloor = 8u;     // spectrum is already floored (VPZ_P
 constexpr uint32_t kFrameDrain = 4u;       // no new block: emit the previous tail un-windowed
                                            // (StreamDecoder.cs:451-455, quirk q4)
 
-struct FrameDesc {
-    int64_t spec_off;    // float offset of channel 0's spectrum; channel c at + c*(blocksize/2)
-    int64_t out_off;     // first output sample (per channel) of this frame inside its stream
-    int32_t stream;
-    int32_t rec;         // first channel record (packet_index * channels) for exec / floor data
-    int32_t left_start;  // PacketInfo.LeftStart
-    int32_t packet_len;  // overlap length = prevStop - prevEnd (0 when there is no previous block)
-    int32_t prev_end;    // position of the previous block's tail in ITS output (prevEnd)
-    int32_t out_count;   // samples emitted per channel: rightStart' - LeftStart
+struct FrameDesc {        // 32 bytes: staged per run into LDS by the wavefront that owns the run
+    int64_t spec_off;     // float offset of channel 0's spectrum; channel c at + c*(blocksize/2)
+    int64_t out_off;      // first output sample (per channel) of this frame inside its stream
+    int32_t rec;          // first channel record (packet_index * channels) for exec / floor data
+    uint16_t left_start;  // PacketInfo.LeftStart (emission start inside this block's output)
+    uint16_t packet_len;  // overlap length = prevStop - prevEnd (0 when there is no previous block)
+    uint16_t prev_end;    // position of the previous block's tail in ITS output (prevEnd)
+    uint16_t out_count;   // samples emitted per channel: rightStart' - LeftStart
     uint32_t flags;
-    int32_t reserved;
 };
+static_assert(sizeof(FrameDesc) == 32, "FrameDesc is staged as two 16-byte words");
+constexpr int kMaxRunLength = 32;
 
 // how a run obtains the block that precedes its first frame
 constexpr int32_t kPreNone = 0;     // the stream has no previous block (first packet / after reset)

@@ -348,6 +348,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     __shared__ float s_db[kHasFloor ? 256 : 1];
     __shared__ float s_work[kSynthWaves][kWaveBufFloats];   // h of the block being built
     __shared__ float s_tail[kSynthWaves][kWaveTailFloats];  // upper half of the previous block's h
+    __shared__ uint4 s_desc[kSynthWaves][(kMaxRunLength + 1) * 2];  // the run's frame descriptors
 
     const bool has_long = a.size1 == 2048 || a.size0 == 2048;
     const bool has_short = a.size0 == 256 || a.size1 == 256;
@@ -390,6 +391,31 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         const int hh = (fd.flags & kFrameLong) ? (a.size1 >> 1) : (a.size0 >> 1);
         return a.spec + fd.spec_off + (int64_t)ch * hh;
     };
+    const int fi0 = (run.pre_kind == kPreRecompute) ? -1 : 0;
+    // Stage the run's descriptors in LDS with one coalesced read: per-frame scalar loads from
+    // global memory put an L2 round trip on every frame's critical path.
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.frames + (run.first + fi0));
+        const int n16 = (run.count - fi0) * 2;
+        for (int i = lane; i < n16; i += 64) s_desc[wave][i] = src[i];
+    }
+    auto frame_at = [&](int fi) -> FrameDesc {  // broadcast LDS read, then into SGPRs
+        const uint4 lo = s_desc[wave][(fi - fi0) * 2], hi = s_desc[wave][(fi - fi0) * 2 + 1];
+        FrameDesc fd;
+        const uint32_t w0 = __builtin_amdgcn_readfirstlane(lo.x), w1 = __builtin_amdgcn_readfirstlane(lo.y);
+        const uint32_t w2 = __builtin_amdgcn_readfirstlane(lo.z), w3 = __builtin_amdgcn_readfirstlane(lo.w);
+        const uint32_t w4 = __builtin_amdgcn_readfirstlane(hi.x), w5 = __builtin_amdgcn_readfirstlane(hi.y);
+        const uint32_t w6 = __builtin_amdgcn_readfirstlane(hi.z), w7 = __builtin_amdgcn_readfirstlane(hi.w);
+        fd.spec_off = (int64_t)(((uint64_t)w1 << 32) | w0);
+        fd.out_off = (int64_t)(((uint64_t)w3 << 32) | w2);
+        fd.rec = (int32_t)w4;
+        fd.left_start = (uint16_t)(w5 & 0xFFFF);
+        fd.packet_len = (uint16_t)(w5 >> 16);
+        fd.prev_end = (uint16_t)(w6 & 0xFFFF);
+        fd.out_count = (uint16_t)(w6 >> 16);
+        fd.flags = w7;
+        return fd;
+    };
 
     // ---- block preceding the run: from the saved state, or recomputed as "frame -1" of the loop
     if (run.pre_kind == kPreState) {
@@ -397,25 +423,21 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         prev_n4 = run.prev_long ? (a.size1 >> 2) : (a.size0 >> 2);
         for (int i = lane; i < prev_n4; i += 64) tail[i] = st[i];
     }
-    const int fi0 = (run.pre_kind == kPreRecompute) ? -1 : 0;
-
     float *out_base = a.out + (a.stream_out_off ? a.stream_out_off[run.stream] : 0);
     bool clipped_any = false;
 
     // ---- software pipeline: the spectrum of frame i+1 is in flight while frame i is synthesised
     float2 xcur[8];
-    {
-        const FrameDesc fd0 = a.frames[run.first + fi0];
-        if (!(fd0.flags & kFrameDrain) && exec_of(fd0.flags, fd0.rec))
-            load_spectrum(xcur, spectrum_of(fd0), fd0.flags & kFrameLong, lane);
-    }
+    FrameDesc fd_next = frame_at(fi0);
+    if (!(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec))
+        load_spectrum(xcur, spectrum_of(fd_next), fd_next.flags & kFrameLong, lane);
     for (int fi = fi0; fi < run.count; ++fi) {
-        const FrameDesc fd = a.frames[run.first + fi];
+        const FrameDesc fd = fd_next;
         float2 xnext[8];
         if (fi + 1 < run.count) {
-            const FrameDesc fn = a.frames[run.first + fi + 1];
-            if (!(fn.flags & kFrameDrain) && exec_of(fn.flags, fn.rec) && !(a.ablate & 4))
-                load_spectrum(xnext, spectrum_of(fn), fn.flags & kFrameLong, lane);
+            fd_next = frame_at(fi + 1);
+            if (!(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec) && !(a.ablate & 4))
+                load_spectrum(xnext, spectrum_of(fd_next), fd_next.flags & kFrameLong, lane);
         }
         const bool drain = fd.flags & kFrameDrain;
         const bool is_long = fd.flags & kFrameLong;
@@ -452,7 +474,48 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             const bool vec = !drain && !a.interleaved &&
                              ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0 &&
                              (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
-            if (vec) {
+            if (vec && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 &&
+                fd.prev_end == 1024 && fd.out_count == 1024 && prev_n4 == 512 && a.size1 == 2048) {
+                // long block after a long block with long windows on both sides (the steady state of
+                // every stream): the geometry is a compile-time constant -- first half of the output
+                // is the negated mirror of h[0:512) over the straight previous tail, second half is
+                // h[0:512) straight over the mirrored tail; both window halves come from one table.
+                const float4 *h4 = reinterpret_cast<const float4 *>(hcur);
+                const float4 *t4 = reinterpret_cast<const float4 *>(tail);
+                const float4 *s4 = reinterpret_cast<const float4 *>(s_slope1);
+                float4 *d4 = reinterpret_cast<float4 *>(dst);
+                float o[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = lane + 64 * r;
+                    const float4 wl = s4[g], wr = s4[255 - g];
+                    if (r < 2) {
+                        const float4 hv = h4[127 - g], pv = t4[g];
+                        o[r][0] = (-hv.w * wl.x) + (pv.x * wr.w);
+                        o[r][1] = (-hv.z * wl.y) + (pv.y * wr.z);
+                        o[r][2] = (-hv.y * wl.z) + (pv.z * wr.y);
+                        o[r][3] = (-hv.x * wl.w) + (pv.w * wr.x);
+                    } else {
+                        const float4 hv = h4[g - 128], pv = t4[255 - g];
+                        o[r][0] = (hv.x * wl.x) + (pv.w * wr.w);
+                        o[r][1] = (hv.y * wl.y) + (pv.z * wr.z);
+                        o[r][2] = (hv.z * wl.z) + (pv.y * wr.y);
+                        o[r][3] = (hv.w * wl.w) + (pv.x * wr.x);
+                    }
+                }
+                if (a.clip) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            clipped_any |= was_clipped(o[r][c]);
+                            o[r][c] = clip_value(o[r][c]);
+                        }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    store_nt(d4 + lane + 64 * r, make_float4(o[r][0], o[r][1], o[r][2], o[r][3]));
+            } else if (vec) {
                 // branch-free: lanes past the end clamp their reads and skip only the store; samples
                 // past the overlap take weights (1, 0)
                 const float4 *h4 = reinterpret_cast<const float4 *>(hcur);

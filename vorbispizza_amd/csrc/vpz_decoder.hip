@@ -345,10 +345,9 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         if (pk.flags & VPZ_PKT_NOT_DECODED) {
             if (eos && S.has_prev && S.prev_stop > S.prev_end) {  // :451-455 drain, un-windowed
                 FrameDesc fd{};
-                fd.stream = pk.stream;
                 fd.flags = kFrameDrain;
-                fd.prev_end = S.prev_end;
-                fd.out_count = S.prev_stop - S.prev_end;
+                fd.prev_end = (uint16_t)S.prev_end;
+                fd.out_count = (uint16_t)(S.prev_stop - S.prev_end);
                 fd.out_off = out_count[pk.stream];
                 out_count[pk.stream] += fd.out_count;
                 S.current_position += fd.out_count;
@@ -383,7 +382,6 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
             if (diff > 0) right_start = std::max(right_start - diff, 0);
         }
         FrameDesc fd{};
-        fd.stream = pk.stream;
         fd.rec = (int32_t)(p * C);
         fd.flags = (bf ? kFrameLong : 0u) | (pi.left_use_size1 ? kFrameSlope1 : 0u) | (no_floor ? kFrameNoFloor : 0u);
         if (S.has_prev) {  // :670-675
@@ -395,14 +393,14 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
                 ++mismatches;
                 continue;
             }
-            fd.packet_len = packet_len;
-            fd.prev_end = S.prev_end;
+            fd.packet_len = (uint16_t)packet_len;
+            fd.prev_end = (uint16_t)S.prev_end;
             S.prev_start = pi.left_start;
         } else {
             fd.packet_len = 0;
             S.prev_start = right_start;  // :679 first packet has no valid data before rightStart
         }
-        fd.left_start = S.prev_start;  // emission starts at the new _prevPacketStart
+        fd.left_start = (uint16_t)S.prev_start;  // emission starts at the new _prevPacketStart
         S.prev_end = right_start;
         S.prev_stop = pi.right_end;
         S.has_prev = true;
@@ -412,7 +410,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
             S.current_position = pk.granule - (S.prev_end - S.prev_start);
         }
         // a trim below LeftStart would make the reference spin (copyLen <= 0, :469-472): emit nothing
-        fd.out_count = std::max(0, S.prev_end - S.prev_start);
+        fd.out_count = (uint16_t)std::max(0, S.prev_end - S.prev_start);
         fd.out_off = out_count[pk.stream];
         out_count[pk.stream] += fd.out_count;
         S.current_position += fd.out_count;
@@ -439,7 +437,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     // Run length: a wavefront synthesises R consecutive blocks of one channel (+1 recomputed block in
     // front).  Pick the R (<= 32) for which the run count fills k whole rounds of the resident waves
     // with the least total work k * (R + 1); short batches fall back to R = 4.
-    int R = D.run_length_override;
+    int R = std::min(D.run_length_override, kMaxRunLength);
     if (R <= 0) {
         const int64_t slots = std::max(1, synth_resident_waves(any_floor, ctx->num_cu));
         const int64_t work = total_frames * C;
@@ -447,7 +445,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         int64_t best = -1;
         for (int k = 1; k <= 64; ++k) {
             int64_t r = (work + k * slots - 1) / (k * slots);
-            if (r > 32) continue;
+            if (r > kMaxRunLength) continue;
             if (r < 4) break;
             const int64_t cost = (int64_t)k * (r + 1);
             if (best < 0 || cost < best) { best = cost; R = (int)r; }
