@@ -157,11 +157,12 @@ __device__ __forceinline__ void imdct256_wave8(const float2 (&xa)[8], float2 *sc
     radix8_inverse(z);  // over m (stride 8), output digit p
 #pragma unroll
     for (int p = 1; p < 8; ++p) z[p] = cmul(z[p], s_twBC[l * 8 + p]);
-    // transpose inside the group: (lane l, reg p) -> (lane p, reg l)
+    // transpose inside the group: (lane l, reg p) -> (lane p, reg l).  Row stride 9 (not 8) keeps both
+    // the ds_write_b64 (16-lane groups) and the ds_read_b64 (32-lane groups) free of bank conflicts.
 #pragma unroll
-    for (int p = 0; p < 8; ++p) scratch[72 * g + 8 * p + l] = z[p];
+    for (int p = 0; p < 8; ++p) scratch[72 * g + 9 * p + l] = z[p];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) z[r] = scratch[72 * g + 8 * l + r];
+    for (int r = 0; r < 8; ++r) z[r] = scratch[72 * g + 9 * l + r];
     radix8_inverse(z);  // over l, output digit q;  lane holds Z[j], j = l + 8*q
     float wim[8];
 #pragma unroll
