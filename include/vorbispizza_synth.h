@@ -178,6 +178,11 @@ int vpz_decoder_synth(vpz_decoder *dec, int64_t n_packets, const vpz_packet *pac
                       int out_layout, int64_t channel_stride,
                       int64_t *samples_written);
 
+/* Samples per channel each packet of the LAST vpz_decoder_synth call contributed, in packet order
+ * (what one `Read` of the reference returns for that packet: it hands out at most one packet's worth per
+ * call, StreamDecoder.cs:436).  0 for skipped / ignored packets.  Copies min(n_packets, capacity). */
+int vpz_decoder_last_packet_samples(vpz_decoder *dec, int32_t *out, int64_t capacity);
+
 /* `StreamDecoder.HasClipped` (StreamDecoder.cs:1001); synchronises the context. */
 int vpz_decoder_has_clipped(vpz_decoder *dec, int32_t stream, int32_t *has_clipped);
 /* `_currentPosition` after the last synth call (StreamDecoder.cs:493) */

@@ -25,8 +25,8 @@ FACTS = {
 
 @pytest.fixture(scope="module")
 def front():
-    from vorbispizza_amd import _build
-    _build.build_host()
+    import __graft_entry__ as ge
+    ge.build()
     from vorbispizza_amd import front as f
     return f
 

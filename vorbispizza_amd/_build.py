@@ -47,15 +47,17 @@ HOST_LIB_PATH = os.path.join(LIB_DIR, "libvorbispizza_host.so")
 
 
 def build_host(force=False, verbose=False):
-    """Compile the C++ CPU front end (Ogg + Vorbis setup + entropy decode) with g++."""
+    """Compile the C++ host side with g++: the CPU front end (Ogg + Vorbis setup + entropy decode) and
+    the VorbisReader / StreamDecoder.Read mirror, which calls the C ABI of libvorbispizza_synth.so."""
     os.makedirs(LIB_DIR, exist_ok=True)
-    srcs = [os.path.join(HOST_DIR, "vorbis_front.cpp")]
-    deps = srcs + [os.path.join(HOST_DIR, "vorbis_front.h"), os.path.join(_HERE, "..", "include", "vorbispizza_synth.h")]
+    srcs = [os.path.join(HOST_DIR, "vorbis_front.cpp"), os.path.join(HOST_DIR, "vorbis_reader.cpp")]
+    deps = srcs + [os.path.join(HOST_DIR, "vorbis_front.h"), os.path.join(HOST_DIR, "vorbis_reader.h"),
+                   os.path.join(_HERE, "..", "include", "vorbispizza_synth.h"), LIB_PATH]
     stale = force or not os.path.exists(HOST_LIB_PATH) or any(
-        os.path.getmtime(d) > os.path.getmtime(HOST_LIB_PATH) for d in deps)
+        os.path.exists(d) and os.path.getmtime(d) > os.path.getmtime(HOST_LIB_PATH) for d in deps)
     if stale:
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall",
-               "-o", HOST_LIB_PATH] + srcs
+               "-o", HOST_LIB_PATH] + srcs + ["-L" + LIB_DIR, "-lvorbispizza_synth", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -63,8 +65,8 @@ def build_host(force=False, verbose=False):
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP translation unit for gfx950 and link the C-ABI shared library."""
-    build_host(force, verbose)
+    """Compile every HIP translation unit for gfx950 and link the C-ABI shared library, then the
+    C++ host library that sits above it."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
     objs, relink = [], force or not os.path.exists(LIB_PATH)
@@ -87,6 +89,7 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    build_host(force, verbose)
     return LIB_PATH
 
 

@@ -71,6 +71,7 @@ _SIGNATURES = [
     ("vpz_decoder_reset", C.c_int, [_vp, C.c_int32]),
     ("vpz_decoder_synth", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int64,
                                     C.c_int, C.c_int64, _vp]),
+    ("vpz_decoder_last_packet_samples", C.c_int, [_vp, _vp, C.c_int64]),
     ("vpz_decoder_has_clipped", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int32)]),
     ("vpz_decoder_position", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64)]),
 ]
@@ -272,6 +273,11 @@ class Decoder:
             else:
                 res.append(blk[: written[s] * C_].reshape(written[s], C_).copy())
         return res
+
+    def last_packet_samples(self, n_packets):
+        out = np.zeros(n_packets, dtype=np.int32)
+        self.ctx._check(lib().vpz_decoder_last_packet_samples(self._h, _ptr(out), n_packets))
+        return out
 
     def has_clipped(self, stream=0):
         v = C.c_int32()

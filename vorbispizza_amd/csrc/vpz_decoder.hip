@@ -72,6 +72,7 @@ struct Decoder {
     DevBuf b_in_res, b_in_posts, b_in_counts, b_out;  // VPZ_MEM_HOST staging
     int run_length_override = 0;
     int ablate = 0;  // VPZ_SYNTH_ABLATE, tuning experiments only
+    std::vector<int32_t> packet_samples;  // per packet of the last synth call
 };
 
 static int grow(Context *ctx, DevBuf &b, size_t need)
@@ -314,6 +315,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     VPZ_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int C = D.channels;
     for (int s = 0; s < D.n_streams; ++s) samples_written[s] = 0;
+    D.packet_samples.assign((size_t)n_packets, 0);
     if (n_packets == 0) return VPZ_OK;
 
     // ---------------- pass 1: per-stream state machine -> frame descriptors
@@ -350,6 +352,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
                 fd.out_count = (uint16_t)(S.prev_stop - S.prev_end);
                 fd.out_off = out_count[pk.stream];
                 out_count[pk.stream] += fd.out_count;
+                D.packet_samples[(size_t)p] = fd.out_count;
                 S.current_position += fd.out_count;
                 S.prev_end = S.prev_stop;
                 S.prev_start = S.prev_stop;
@@ -413,6 +416,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         fd.out_count = (uint16_t)std::max(0, S.prev_end - S.prev_start);
         fd.out_off = out_count[pk.stream];
         out_count[pk.stream] += fd.out_count;
+        D.packet_samples[(size_t)p] = fd.out_count;
         S.current_position += fd.out_count;
         S.prev_start = S.prev_end;  // everything readable is handed out by this call
         pkt_used[(size_t)p] = 1;
@@ -643,6 +647,15 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         return set_error(ctx, VPZ_E_WINDOW_MISMATCH,
                          "vpz_decoder_synth: a packet's previous tail is longer than its window slope "
                          "(StreamDecoder.cs:777-778 throws); the packet was skipped, everything else was synthesised");
+    return VPZ_OK;
+}
+
+int vpz_decoder_last_packet_samples(vpz_decoder *d, int32_t *out, int64_t capacity)
+{
+    if (!d || (!out && capacity > 0) || capacity < 0) return VPZ_E_INVALID_ARG;
+    const Decoder &D = d->impl;
+    const int64_t n = std::min<int64_t>(capacity, (int64_t)D.packet_samples.size());
+    if (n > 0) memcpy(out, D.packet_samples.data(), sizeof(int32_t) * (size_t)n);
     return VPZ_OK;
 }
 

@@ -30,7 +30,8 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             from . import _build
-            _build.build_host()
+            _build.build()
+        capi.lib()  # the host library links against libvorbispizza_synth.so (and needs torch's HIP first)
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.vpzh_open_memory.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
@@ -49,6 +50,29 @@ def lib():
         L.vpzh_get_residue_type.restype = C.c_int
         L.vpzh_decode_all.argtypes = [vp, C.c_int32, C.c_int64, vp, vp, vp, vp]
         L.vpzh_decode_all.restype = C.c_int
+        L.vpzh_decode_range.argtypes = [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int64, vp, vp, vp, vp,
+                                        C.POINTER(C.c_int64)]
+        L.vpzh_decode_range.restype = C.c_int
+        # VorbisReader mirror (vorbis_reader.h)
+        L.vpzr_open_memory.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp)]
+        L.vpzr_open_memory.restype = C.c_int
+        L.vpzr_close.argtypes = [vp]
+        L.vpzr_close.restype = None
+        L.vpzr_last_error.argtypes = [vp]
+        L.vpzr_last_error.restype = C.c_char_p
+        for name in ("vpzr_channels", "vpzr_sample_rate", "vpzr_is_end_of_stream", "vpzr_has_clipped"):
+            getattr(L, name).argtypes = [vp]
+            getattr(L, name).restype = C.c_int
+        L.vpzr_sample_position.argtypes = [vp]
+        L.vpzr_sample_position.restype = C.c_int64
+        L.vpzr_set_clip_samples.argtypes = [vp, C.c_int]
+        L.vpzr_set_clip_samples.restype = C.c_int
+        L.vpzr_set_batch_packets.argtypes = [vp, C.c_int]
+        L.vpzr_set_batch_packets.restype = C.c_int
+        L.vpzr_read_samples.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int)]
+        L.vpzr_read_samples.restype = C.c_int64
+        L.vpzr_read_samples_planar.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int)]
+        L.vpzr_read_samples_planar.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -113,3 +137,51 @@ class OggVorbisFile:
         if rc != 0:
             raise FrontError(lib().vpzh_last_error(self._h).decode())
         return packets, residue[: self.info.residue_floats], posts, counts
+
+
+class VorbisReader:
+    """Mirror of NVorbis.VorbisReader's read surface (VorbisReader.cs:232-253) on top of the GPU back
+    end: ReadSamples(buffer) interleaved / ReadSamples(buffer, samplesToRead, channelStride) planar,
+    at most one packet's worth per call, 0 at the end."""
+
+    def __init__(self, ctx, path_or_bytes, clip_samples=True, batch_packets=128):
+        data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+        self._data = np.frombuffer(bytes(data), dtype=np.uint8)
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        rc = lib().vpzr_open_memory(ctx._h, self._data.ctypes.data, self._data.size, C.byref(self._h))
+        if rc != 0:
+            msg = lib().vpzr_last_error(self._h).decode() if self._h else ""
+            self.Dispose()
+            raise FrontError("Could not load the specified container. %s" % msg)
+        lib().vpzr_set_clip_samples(self._h, int(clip_samples))
+        lib().vpzr_set_batch_packets(self._h, batch_packets)
+
+    Channels = property(lambda self: lib().vpzr_channels(self._h))
+    SampleRate = property(lambda self: lib().vpzr_sample_rate(self._h))
+    SamplePosition = property(lambda self: lib().vpzr_sample_position(self._h))
+    IsEndOfStream = property(lambda self: bool(lib().vpzr_is_end_of_stream(self._h)))
+    HasClipped = property(lambda self: bool(lib().vpzr_has_clipped(self._h)))
+
+    def ReadSamples(self, buffer, samplesToRead=None, channelStride=None):
+        st = C.c_int(0)
+        buf = buffer.reshape(-1)
+        if samplesToRead is None:
+            n = lib().vpzr_read_samples(self._h, buf.ctypes.data, buf.size, C.byref(st))
+        else:
+            n = lib().vpzr_read_samples_planar(self._h, buf.ctypes.data, buf.size, samplesToRead, channelStride,
+                                               C.byref(st))
+        if st.value != 0:
+            raise capi.SynthError(st.value, lib().vpzr_last_error(self._h).decode())
+        return int(n)
+
+    def Dispose(self):
+        if getattr(self, "_h", None):
+            lib().vpzr_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.Dispose()
+        except Exception:
+            pass

@@ -923,23 +923,36 @@ int vpzh_get_residue_type(vpzh_stream *s, int index)
     return s->residues[index].type;
 }
 
-int vpzh_decode_all(vpzh_stream *s, int32_t stream_id, int64_t residue_base, vpz_packet *packets, float *residue,
-                    int16_t *posts, uint8_t *post_counts)
+int vpzh_decode_range(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
+                      vpz_packet *packets, float *residue, int16_t *posts, uint8_t *post_counts,
+                      int64_t *residue_floats_used)
 {
-    if (!s || !packets || !residue || !posts || !post_counts) return VPZH_E_ARG;
+    if (!s || !packets || !residue || !posts || !post_counts || first < 0 || count < 0 ||
+        first + count > (int64_t)s->audio.size())
+        return VPZH_E_ARG;
     try {
         int64_t off = 0;
-        for (size_t i = 0; i < s->audio.size(); ++i) {
-            const int64_t n = s->packet_floats(s->audio[i]);
-            s->decode_packet(s->audio[i], stream_id, residue_base + off, &packets[i], residue + off,
-                             posts + i * 64 * (size_t)s->channels, post_counts + i * (size_t)s->channels);
+        for (int64_t k = 0; k < count; ++k) {
+            const OggPacket &pk = s->audio[(size_t)(first + k)];
+            const int64_t n = s->packet_floats(pk);
+            s->decode_packet(pk, stream_id, residue_base + off, &packets[k], residue + off,
+                             posts + (size_t)k * 64 * (size_t)s->channels, post_counts + (size_t)k * (size_t)s->channels);
             off += n;
         }
+        if (residue_floats_used) *residue_floats_used = off;
     } catch (const std::exception &e) {
         s->error = e.what();
         return VPZH_E_INVALID_DATA;
     }
     return VPZH_OK;
+}
+
+int vpzh_decode_all(vpzh_stream *s, int32_t stream_id, int64_t residue_base, vpz_packet *packets, float *residue,
+                    int16_t *posts, uint8_t *post_counts)
+{
+    if (!s) return VPZH_E_ARG;
+    return vpzh_decode_range(s, 0, (int64_t)s->audio.size(), stream_id, residue_base, packets, residue, posts,
+                             post_counts, nullptr);
 }
 
 }  // extern "C"

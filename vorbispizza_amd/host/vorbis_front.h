@@ -54,6 +54,12 @@ int vpzh_get_residue_type(vpzh_stream *s, int index);
 int vpzh_decode_all(vpzh_stream *s, int32_t stream_id, int64_t residue_base, vpz_packet *packets,
                     float *residue, int16_t *posts, uint8_t *post_counts);
 
+/* Same for the packet range [first, first+count); *residue_floats_used receives the floats written.
+ * `residue` must hold channels * block_size1/2 * count floats in the worst case. */
+int vpzh_decode_range(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
+                      vpz_packet *packets, float *residue, int16_t *posts, uint8_t *post_counts,
+                      int64_t *residue_floats_used);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,230 @@
+// Host-side mirror of the reference's public read path -- `VorbisReader.ReadSamples` ->
+// `StreamDecoder.Read` (VorbisReader.cs:232-253, StreamDecoder.cs:407-498) -- written in C++ above the
+// C ABI, because no .NET toolchain exists in this pipeline.  It keeps exactly what the C# host keeps
+// (container + entropy decode, vorbis_front.cpp) and hands every batch of packets to
+// vpz_decoder_synth; the PCM a call returns obeys the reference's contract:
+//   * interleaved `L R L R` for Read(buffer), planar with `channelStride` for Read(buffer, n, stride);
+//   * the return value is samples per channel;
+//   * at most ONE packet's worth of samples per call (`while (idx == 0)`, StreamDecoder.cs:436);
+//   * ClipSamples defaults to true as VorbisReader.ProcessNewStream sets it (VorbisReader.cs:71).
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "vorbis_front.h"
+#include "vorbis_reader.h"
+
+struct vpzr_reader {
+    vpz_context *ctx = nullptr;
+    vpzh_stream *front = nullptr;
+    vpz_decoder *dec = nullptr;
+    vpzh_info info{};
+    std::string error;
+    bool clip = true;
+    int batch = 128;
+    int64_t next_packet = 0;          // first packet not yet synthesised
+    // PCM of the current batch, interleaved [sample][channel], and how it splits into packets
+    std::vector<float> pcm;
+    std::vector<int32_t> packet_samples;
+    size_t cur_packet = 0;            // index into packet_samples
+    int64_t cur_offset = 0;           // samples of the batch already handed out (start of cur_packet + consumed)
+    int32_t cur_remaining = 0;        // samples left in the current packet
+    int64_t position = 0;
+    bool ended = false;
+    // scratch for the front end
+    std::vector<vpz_packet> packets;
+    std::vector<float> residue;
+    std::vector<int16_t> posts;
+    std::vector<uint8_t> counts;
+
+    int fail(int status, const char *what)
+    {
+        error = what;
+        if (ctx && status == VPZ_E_HIP) error += std::string(": ") + vpz_context_last_error(ctx);
+        return status;
+    }
+
+    int ensure_decoder()
+    {
+        if (dec) return VPZ_OK;
+        std::vector<vpz_floor1_config> floors(info.floor_count);
+        std::vector<vpz_mapping_config> mappings(info.mapping_count);
+        for (int i = 0; i < info.floor_count; ++i)
+            if (vpzh_get_floor1(front, i, &floors[i]) != VPZH_OK) return fail(VPZ_E_UNSUPPORTED, "floor cannot be represented");
+        for (int i = 0; i < info.mapping_count; ++i) vpzh_get_mapping(front, i, &mappings[i]);
+        vpz_stream_config cfg{};
+        cfg.channels = info.channels;
+        cfg.block_size0 = info.block_size0;
+        cfg.block_size1 = info.block_size1;
+        cfg.floor_count = info.floor_count;
+        cfg.floors = floors.data();
+        cfg.mapping_count = info.mapping_count;
+        cfg.mappings = mappings.data();
+        cfg.clip_samples = clip ? 1 : 0;
+        int rc = vpz_decoder_create(ctx, &cfg, 1, &dec);
+        if (rc != VPZ_OK) return fail(rc, vpz_context_last_error(ctx));
+        return VPZ_OK;
+    }
+
+    // decode + synthesise the next batch of packets; returns VPZ_OK, sets `ended` when none are left
+    int refill()
+    {
+        pcm.clear();
+        packet_samples.clear();
+        cur_packet = 0;
+        cur_offset = 0;
+        cur_remaining = 0;
+        if (next_packet >= info.audio_packets) { ended = true; return VPZ_OK; }
+        int rc = ensure_decoder();
+        if (rc != VPZ_OK) return rc;
+        const int64_t n = std::min<int64_t>(batch, info.audio_packets - next_packet);
+        const int C = info.channels;
+        const int half1 = info.block_size1 / 2;
+        packets.resize((size_t)n);
+        residue.assign((size_t)n * C * half1, 0.f);
+        posts.assign((size_t)n * C * 64, 0);
+        counts.assign((size_t)n * C, 0);
+        int64_t used = 0;
+        if (vpzh_decode_range(front, next_packet, n, 0, 0, packets.data(), residue.data(), posts.data(), counts.data(),
+                              &used) != VPZH_OK)
+            return fail(VPZ_E_INVALID_ARG, vpzh_last_error(front));
+        next_packet += n;
+        const int64_t cap = n * half1 + info.block_size1;
+        pcm.assign((size_t)cap * C, 0.f);
+        int64_t written = 0;
+        rc = vpz_decoder_synth(dec, n, packets.data(), residue.data(), posts.data(), counts.data(), VPZ_MEM_HOST,
+                               pcm.data(), nullptr, cap, VPZ_OUT_INTERLEAVED, 0, &written);
+        // a window mismatch (the reference's OverlapBuffers exception) costs only that packet; the
+        // reference test harness never reads that far (AssetTest.cs:107-118), so keep going
+        if (rc != VPZ_OK && rc != VPZ_E_WINDOW_MISMATCH) return fail(rc, vpz_context_last_error(ctx));
+        packet_samples.resize((size_t)n);
+        vpz_decoder_last_packet_samples(dec, packet_samples.data(), n);
+        pcm.resize((size_t)written * C);
+        return VPZ_OK;
+    }
+
+    // StreamDecoder.Read core (:418-498)
+    int64_t read(float *buffer, int64_t buffer_len, int64_t samples_to_read, int64_t channel_stride, bool interleave,
+                 int *status)
+    {
+        const int C = info.channels;
+        *status = VPZ_OK;
+        if (buffer_len % C != 0) { *status = fail(VPZ_E_INVALID_ARG, "Length must be a multiple of Channels."); return 0; }
+        if (buffer_len < samples_to_read * C) { *status = fail(VPZ_E_INVALID_ARG, "The buffer is too small for the requested amount."); return 0; }
+        int64_t idx = 0;
+        while (idx == 0) {
+            if (cur_remaining == 0) {
+                // next packet that exists; packets that emit nothing simply loop on, like ReadNextPacket
+                bool have = false;
+                while (!have) {
+                    if (cur_packet < packet_samples.size()) {
+                        cur_remaining = packet_samples[cur_packet++];
+                        have = true;
+                    } else {
+                        if (ended) return idx;
+                        int rc = refill();
+                        if (rc != VPZ_OK) { *status = rc; return idx; }
+                        if (ended) return idx;
+                    }
+                }
+                if (cur_remaining == 0) continue;
+            }
+            const int64_t copy_len = std::min<int64_t>(samples_to_read - idx, cur_remaining);
+            if (copy_len <= 0) break;
+            const float *src = pcm.data() + (size_t)cur_offset * C;
+            if (interleave) {
+                memcpy(buffer + idx * C, src, sizeof(float) * (size_t)(copy_len * C));
+            } else {
+                for (int ch = 0; ch < C; ++ch)
+                    for (int64_t i = 0; i < copy_len; ++i) buffer[ch * channel_stride + idx + i] = src[i * C + ch];
+            }
+            idx += copy_len;
+            cur_offset += copy_len;
+            cur_remaining -= (int32_t)copy_len;
+            position += copy_len;
+        }
+        return idx;
+    }
+};
+
+extern "C" {
+
+int vpzr_open_memory(vpz_context *ctx, const uint8_t *data, uint64_t size, vpzr_reader **out)
+{
+    if (!ctx || !data || !out) return VPZ_E_INVALID_ARG;
+    *out = nullptr;
+    std::unique_ptr<vpzr_reader> r(new vpzr_reader());
+    r->ctx = ctx;
+    int rc = vpzh_open_memory(data, size, &r->front);
+    if (rc != VPZH_OK) {
+        r->error = r->front ? vpzh_last_error(r->front) : "could not load the specified container";
+        *out = r.release();
+        return rc == VPZH_E_UNSUPPORTED ? VPZ_E_UNSUPPORTED : VPZ_E_INVALID_ARG;
+    }
+    vpzh_get_info(r->front, &r->info);
+    *out = r.release();
+    return VPZ_OK;
+}
+
+void vpzr_close(vpzr_reader *r)
+{
+    if (!r) return;
+    if (r->dec) vpz_decoder_destroy(r->dec);
+    if (r->front) vpzh_close(r->front);
+    delete r;
+}
+
+const char *vpzr_last_error(vpzr_reader *r) { return r ? r->error.c_str() : ""; }
+int vpzr_channels(vpzr_reader *r) { return r ? r->info.channels : 0; }
+int vpzr_sample_rate(vpzr_reader *r) { return r ? r->info.sample_rate : 0; }
+int64_t vpzr_sample_position(vpzr_reader *r) { return r ? r->position : 0; }
+int vpzr_is_end_of_stream(vpzr_reader *r) { return r ? (r->ended && r->cur_remaining == 0 && r->cur_packet >= r->packet_samples.size()) : 1; }
+
+int vpzr_set_clip_samples(vpzr_reader *r, int clip)
+{
+    if (!r) return VPZ_E_INVALID_ARG;
+    if (r->dec) return VPZ_E_INVALID_ARG;  // fixed once decoding has started
+    r->clip = clip != 0;
+    return VPZ_OK;
+}
+
+int vpzr_set_batch_packets(vpzr_reader *r, int packets)
+{
+    if (!r || packets < 1) return VPZ_E_INVALID_ARG;
+    r->batch = packets;
+    return VPZ_OK;
+}
+
+int vpzr_has_clipped(vpzr_reader *r)
+{
+    int32_t v = 0;
+    if (r && r->dec) vpz_decoder_has_clipped(r->dec, 0, &v);
+    return v;
+}
+
+int64_t vpzr_read_samples(vpzr_reader *r, float *buffer, int64_t buffer_len, int *status)
+{
+    int st = VPZ_OK;
+    if (!r || (!buffer && buffer_len)) { if (status) *status = VPZ_E_INVALID_ARG; return 0; }
+    const int C = r->info.channels;
+    const int64_t count = buffer_len - buffer_len % C;  // VorbisReader.cs:235
+    int64_t n = count == 0 ? 0 : r->read(buffer, count, count / C, 0, true, &st);
+    if (status) *status = st;
+    return n;
+}
+
+int64_t vpzr_read_samples_planar(vpzr_reader *r, float *buffer, int64_t buffer_len, int64_t samples_to_read,
+                                 int64_t channel_stride, int *status)
+{
+    int st = VPZ_OK;
+    if (!r || (!buffer && buffer_len)) { if (status) *status = VPZ_E_INVALID_ARG; return 0; }
+    const int C = r->info.channels;
+    const int64_t count = buffer_len - buffer_len % C;  // VorbisReader.cs:246
+    int64_t n = count == 0 ? 0 : r->read(buffer, count, samples_to_read, channel_stride, false, &st);
+    if (status) *status = st;
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+/*
+ * vorbis_reader.h -- C entry points of the host-side mirror of VorbisReader / StreamDecoder.Read
+ * (VorbisReader.cs:232-253, StreamDecoder.cs:407-498) built above the C ABI.  See vorbis_reader.cpp.
+ */
+#ifndef VORBISPIZZA_READER_H
+#define VORBISPIZZA_READER_H
+
+#include <stdint.h>
+
+#include "../../include/vorbispizza_synth.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vpzr_reader vpzr_reader;
+
+/* `new VorbisReader(stream); Initialize()` on an in-memory .ogg; decoding runs on `ctx`'s GPU. */
+int  vpzr_open_memory(vpz_context *ctx, const uint8_t *data, uint64_t size, vpzr_reader **out);
+void vpzr_close(vpzr_reader *r);
+const char *vpzr_last_error(vpzr_reader *r);
+
+int     vpzr_channels(vpzr_reader *r);             /* IVorbisReader.Channels */
+int     vpzr_sample_rate(vpzr_reader *r);          /* IVorbisReader.SampleRate */
+int64_t vpzr_sample_position(vpzr_reader *r);      /* samples per channel handed out so far */
+int     vpzr_is_end_of_stream(vpzr_reader *r);
+int     vpzr_has_clipped(vpzr_reader *r);          /* IStreamDecoder.HasClipped */
+int     vpzr_set_clip_samples(vpzr_reader *r, int clip);      /* ClipSamples; default true (VorbisReader.cs:71) */
+int     vpzr_set_batch_packets(vpzr_reader *r, int packets);  /* packets synthesised per GPU call (default 128) */
+
+/* `ReadSamples(Span<float> buffer)`: interleaved, returns samples per channel, at most one packet's
+ * worth per call, 0 at the end of the stream.  *status receives a VPZ_* code. */
+int64_t vpzr_read_samples(vpzr_reader *r, float *buffer, int64_t buffer_len, int *status);
+/* `ReadSamples(Span<float> buffer, int samplesToRead, int channelStride)`: planar. */
+int64_t vpzr_read_samples_planar(vpzr_reader *r, float *buffer, int64_t buffer_len, int64_t samples_to_read,
+                                 int64_t channel_stride, int *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
