@@ -282,3 +282,63 @@ def test_floor_curve_is_bit_exact(ctx, oracle):
     # one wrong floor bin (a y off by one = 11.5 % amplitude step on one bin) would show as >= 1e-4 here
     assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
     dec.close()
+
+
+def random_xlist(rng, half, posts):
+    inner = rng.choice(np.arange(1, half), size=posts - 2, replace=False)
+    return [0, half] + [int(v) for v in inner]
+
+
+@pytest.mark.parametrize("size0,size1", [(64, 64), (64, 512), (128, 1024), (256, 256), (512, 4096), (1024, 8192),
+                                         (2048, 8192), (256, 4096)])
+def test_any_block_size_pair_decodes(ctx, oracle, size0, size1):
+    """Block sizes other than 256/2048 take the three-pass path (floor, exact IMDCT, OLA).  Its IMDCT is
+    the reference's own schedule, so for N = 64/128 it reproduces the reference's literal output (q1)."""
+    from vorbispizza_amd import Decoder, make_packets
+    rng = np.random.default_rng(size0 * 7 + size1)
+    channels, frames = 2, 30
+    bf = (rng.random(frames) < 0.6).astype(np.uint8) if size0 != size1 else np.zeros(frames, dtype=np.uint8)
+    prev = np.concatenate([[1], bf[:-1]])
+    nxt = np.concatenate([bf[1:], [1]])
+    flags = (bf * PKT_BLOCK_FLAG | prev * PKT_PREV_FLAG * bf | nxt * PKT_NEXT_FLAG * bf).astype(np.uint8)
+    h0, h1 = size0 // 2, size1 // 2
+    floors = [(random_xlist(rng, h0, min(19, h0 // 2)), 2), (random_xlist(rng, h1, min(29, h1 // 2)), 1)]
+    mappings = [{"coupling": [(0, 1)], "channel_floor": [0, 0]}, {"coupling": [(1, 0)], "channel_floor": [1, 1]}]
+    opk = []
+    for f in range(frames):
+        half = h1 if bf[f] else h0
+        xl, mult = floors[int(bf[f])]
+        res = (rng.standard_normal((channels, half)) * 3).round().astype(np.float32)
+        res[:, int(half * 0.8):] = 0
+        posts, counts = helpers.random_posts(rng, xl, mult, channels, silent_prob=0.15)
+        interleaved = bool(f % 2)
+        layout = res.T.reshape(-1) if interleaved else res.reshape(-1)
+        opk.append({"flags": int(flags[f]) | (PKT_INTERLEAVED if interleaved else 0), "mapping": int(bf[f]),
+                    "residue": layout.copy(), "posts": posts, "post_count": counts, "granule": -1})
+    pk = make_packets(frames)
+    off = 0
+    for f, p in enumerate(opk):
+        pk[f]["flags"], pk[f]["mapping"], pk[f]["granule"], pk[f]["residue_offset"] = p["flags"], p["mapping"], -1, off
+        off += p["residue"].size
+    res = np.concatenate([p["residue"] for p in opk])
+    posts = np.concatenate([p["posts"] for p in opk]).astype(np.int16)
+    counts = np.concatenate([p["post_count"] for p in opk]).astype(np.uint8)
+    ref, pos, _ = helpers.oracle_decode(oracle, channels, size0, size1, opk, floors=floors, mappings=mappings)
+    # one batch, then the same stream in three batches (state carried in HBM between calls)
+    for splits in ([frames], [7, 1, frames - 8]):
+        dec = Decoder(ctx, channels, size0, size1, floors=floors, mappings=mappings)
+        outs, a = [], 0
+        for n in splits:
+            sub = pk[a:a + n].copy()
+            base = int(sub["residue_offset"][0])
+            sub["residue_offset"] -= base
+            end = int(pk["residue_offset"][a + n]) if a + n < frames else res.size
+            outs.append(dec.synth(sub, res[base:end], posts[a * channels:(a + n) * channels],
+                                  counts[a * channels:(a + n) * channels])[0])
+            a += n
+        got = np.concatenate(outs, axis=1)
+        assert got.shape == ref.shape
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() <= TOL * scale
+        assert dec.position(0) == pos
+        dec.close()

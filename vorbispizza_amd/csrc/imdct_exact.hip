@@ -66,7 +66,7 @@ __device__ __forceinline__ void iter_54(float *z)
 __global__ __launch_bounds__(kExactThreads) void imdct_exact_kernel(
     int n, int ld, const float *__restrict__ spectra, float *__restrict__ out, long count,
     const float *__restrict__ A, const float *__restrict__ B, const float *__restrict__ C,
-    const uint16_t *__restrict__ bitrev)
+    const uint16_t *__restrict__ bitrev, const int64_t *__restrict__ src_off, const int64_t *__restrict__ dst_off)
 {
     extern __shared__ float s_mem[];
     float *buffer = s_mem;       // n floats  (the reference's `buffer`, alias u)
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kExactThreads) void imdct_exact_kernel(
     const int n2 = n >> 1, n4 = n >> 2, n8 = n >> 3;
 
     for (long blk = blockIdx.x; blk < count; blk += gridDim.x) {
-        const float *src = spectra + blk * n2;
+        const float *src = src_off ? spectra + src_off[blk] : spectra + blk * n2;
         for (int i = tid; i < n2; i += kExactThreads) buffer[i] = src[i];
         __syncthreads();
 
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kExactThreads) void imdct_exact_kernel(
         __syncthreads();
 
         // Step8 (Mdct.cs:360-414): v -> global output, mirrored stores
-        float *dst = out + blk * n;
+        float *dst = dst_off ? out + dst_off[blk] : out + blk * n;
         for (int it = tid; it < (n2 >> 3); it += kExactThreads) {
             const float *Bb = B + n2 - 8 - 8 * it;
             const float *e = buf2 + n2 - 8 - 8 * it;
@@ -236,14 +236,15 @@ __global__ __launch_bounds__(kExactThreads) void imdct_exact_kernel(
 
 hipError_t launch_imdct_exact(int n, int ld, const float *spectra, float *out, int64_t count,
                               const float *A, const float *B, const float *C,
-                              const uint16_t *bitrev, int num_cu, hipStream_t stream)
+                              const uint16_t *bitrev, int num_cu, hipStream_t stream,
+                              const int64_t *src_off, const int64_t *dst_off)
 {
     if (count <= 0) return hipSuccess;
     const size_t lds = sizeof(float) * (size_t)(n + n / 2);
     int64_t cap = (int64_t)num_cu * 4;
     int grid = (int)(count < cap ? count : cap);
     hipLaunchKernelGGL(imdct_exact_kernel, dim3(grid), dim3(kExactThreads), lds, stream, n, ld,
-                       spectra, out, (long)count, A, B, C, bitrev);
+                       spectra, out, (long)count, A, B, C, bitrev, src_off, dst_off);
     return hipGetLastError();
 }
 

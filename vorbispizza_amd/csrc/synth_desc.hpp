@@ -29,6 +29,19 @@ struct FrameDesc {        // 32 bytes: staged per run into LDS by the wavefront 
 static_assert(sizeof(FrameDesc) == 32, "FrameDesc is staged as two 16-byte words");
 constexpr int kMaxRunLength = 32;
 
+// any-block-size path (generic_*_kernel): one record per packet, full IMDCT outputs live in HBM
+constexpr uint32_t kFrameSaveState = 16u;  // last block of its stream in this batch
+struct GenericFrame {
+    int64_t spec_off;    // planar spectrum in the temp, channel c at + c*(n/2)
+    int64_t y_off;       // full IMDCT output of channel 0 in ybuf, channel c at + c*n
+    int64_t prev_y_off;  // previous block's output (channel 0); -1: saved state, -2: none
+    int64_t out_off;
+    int32_t rec, stream, n, prev_n;
+    int32_t left_start, packet_len, prev_end, out_count;
+    uint32_t flags;
+    int32_t reserved;
+};
+
 // how a run obtains the block that precedes its first frame
 constexpr int32_t kPreNone = 0;     // the stream has no previous block (first packet / after reset)
 constexpr int32_t kPreState = 1;    // previous block's h is in the decoder's device state

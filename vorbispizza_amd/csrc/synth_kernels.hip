@@ -188,21 +188,27 @@ __device__ __forceinline__ Seg load_segment(const int *cxy, int j, int m, int n)
     return s;
 }
 
-__device__ __forceinline__ void render_floor_curve(float *curve, int *aux, int n, int rec,
-                                                   const SynthArgs &a, const float *s_db, int lane)
+// kWords = bitmap words (32 bins each) the block size needs: 32 for n <= 1024, 128 for n <= 4096.
+// aux layout (ints): [0..kWords) bitmap, [kWords..2*kWords) exclusive prefix popcounts, then 65
+// compacted active posts (x in the low 16 bits, signed y in the high 16).
+template <int kWords>
+__device__ __forceinline__ void render_floor_curve_t(float *curve, int *aux, int n, int rec,
+                                                     const FloorDev *floors, const uint8_t *rec_floor,
+                                                     const uint8_t *step_flags, const int16_t *final_y,
+                                                     const float *s_db, int lane)
 {
-    const FloorDev &f = a.floors[a.rec_floor[rec]];
+    const FloorDev &f = floors[rec_floor[rec]];
     const int pc = f.x_count;
-    int *bitmap = aux, *prefix = aux + 32, *cxy = aux + 64;
-    if (lane < 32) bitmap[lane] = 0;
+    int *bitmap = aux, *prefix = aux + kWords, *cxy = aux + 2 * kWords;
+    for (int w = lane; w < kWords; w += 64) bitmap[w] = 0;
     // compact the active posts in X order (Floor1.cs:238-252)
     bool active = false;
     int x = 0, y = 0;
     if (lane < pc) {
         const int idx = f.sort_idx[lane];
-        active = (lane == 0) || a.step_flags[(size_t)rec * 64 + idx] != 0;
+        active = (lane == 0) || step_flags[(size_t)rec * 64 + idx] != 0;
         x = f.x_list[idx];
-        y = a.final_y[(size_t)rec * 64 + idx];
+        y = final_y[(size_t)rec * 64 + idx];
     }
     const unsigned long long mask = __ballot(active);
     const int m = __popcll(mask);
@@ -211,16 +217,31 @@ __device__ __forceinline__ void render_floor_curve(float *curve, int *aux, int n
         cxy[pos] = (x & 0xFFFF) | (y << 16);
         if (x < n) atomicOr(reinterpret_cast<unsigned int *>(&bitmap[x >> 5]), 1u << (x & 31));
     }
-    // exclusive prefix popcount over the 32 bitmap words
-    {
-        int c = (lane < 32) ? __popc((unsigned)bitmap[lane]) : 0;
+    // exclusive prefix popcount over the bitmap words
+    if (kWords <= 32) {
+        int c = (lane < kWords) ? __popc((unsigned)bitmap[lane]) : 0;
         int incl = c;
 #pragma unroll
         for (int d = 1; d < 32; d <<= 1) {
             int t = __shfl_up(incl, d);
             if ((lane & 31) >= d) incl += t;
         }
-        if (lane < 32) prefix[lane] = incl - c;
+        if (lane < kWords) prefix[lane] = incl - c;
+    } else {
+        constexpr int per = kWords / 64;  // words per lane
+        int c[per > 0 ? per : 1];
+        int sum = 0;
+#pragma unroll
+        for (int i = 0; i < per; ++i) { c[i] = __popc((unsigned)bitmap[lane * per + i]); sum += c[i]; }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        int run = incl - sum;
+#pragma unroll
+        for (int i = 0; i < per; ++i) { prefix[lane * per + i] = run; run += c[i]; }
     }
     const int groups = n >> 2;  // runs of 4 bins
     for (int g = lane; g < groups; g += 64) {
@@ -253,6 +274,12 @@ __device__ __forceinline__ void render_floor_curve(float *curve, int *aux, int n
         }
         reinterpret_cast<float4 *>(curve)[g] = make_float4(v[0], v[1], v[2], v[3]);
     }
+}
+
+__device__ __forceinline__ void render_floor_curve(float *curve, int *aux, int n, int rec,
+                                                   const SynthArgs &a, const float *s_db, int lane)
+{
+    render_floor_curve_t<32>(curve, aux, n, rec, a.floors, a.rec_floor, a.step_flags, a.final_y, s_db, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -609,6 +636,108 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Any-block-size path (64 .. 8192): three plain passes over HBM instead of the fused kernel --
+//   generic_floor_kernel : Floor1 curve x spectrum in place (or zeros for a silent channel)
+//   imdct_exact_kernel   : the reference's own IMDCT schedule (imdct_exact.hip), gathered by offset
+//   generic_ola_kernel   : window + overlap-add + clip + store from the full IMDCT outputs
+// It exists so that every Vorbis block-size pair decodes; the 256/2048 pair takes the fused kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void generic_floor_kernel(const GenericFrame *__restrict__ frames, int channels,
+                                                          float *__restrict__ spec,
+                                                          const uint8_t *__restrict__ post_counts,
+                                                          const int16_t *__restrict__ final_y,
+                                                          const uint8_t *__restrict__ step_flags,
+                                                          const uint8_t *__restrict__ rec_floor,
+                                                          const FloorDev *__restrict__ floors,
+                                                          const float *__restrict__ inv_db)
+{
+    __shared__ float s_curve[4096];
+    __shared__ int s_aux[2 * 128 + 65];
+    __shared__ float s_db[256];
+    const int lane = threadIdx.x;
+    const GenericFrame fr = frames[blockIdx.x / channels];
+    const int ch = blockIdx.x % channels;
+    if (fr.flags & (kFrameDrain | kFrameNoFloor)) return;
+    const int half = fr.n >> 1;
+    float *x = spec + fr.spec_off + (int64_t)ch * half;
+    if (post_counts[fr.rec + ch] == 0) {  // Mapping.cs:190-194
+        for (int i = lane; i < half; i += 64) x[i] = 0.0f;
+        return;
+    }
+    for (int i = lane; i < 256; i += 64) s_db[i] = inv_db[i];
+    if (half <= 1024)
+        render_floor_curve_t<32>(s_curve, s_aux, half, fr.rec + ch, floors, rec_floor, step_flags, final_y, s_db, lane);
+    else
+        render_floor_curve_t<128>(s_curve, s_aux, half, fr.rec + ch, floors, rec_floor, step_flags, final_y, s_db, lane);
+    for (int i = lane; i < half; i += 64) x[i] *= s_curve[i];
+}
+
+// y[pos] of a block whose full IMDCT output sits in memory
+__global__ __launch_bounds__(256) void generic_ola_kernel(const GenericFrame *__restrict__ frames, int channels,
+                                                         int size0, int size1, const float *__restrict__ ybuf,
+                                                         float *__restrict__ state_y,
+                                                         const float *__restrict__ slope0,
+                                                         const float *__restrict__ slope1, float *__restrict__ out,
+                                                         const int64_t *__restrict__ stream_out_off,
+                                                         int64_t channel_stride, int interleaved, int clip,
+                                                         int32_t *__restrict__ clipped)
+{
+    const GenericFrame fr = frames[blockIdx.x / channels];
+    const int ch = blockIdx.x % channels;
+    const int half1 = size1 >> 1;
+    const bool drain = fr.flags & kFrameDrain;
+    const float *ycur = drain ? nullptr : ybuf + fr.y_off + (int64_t)ch * fr.n;
+    // previous block: its full output in ybuf, or the saved upper half (positions prev_n/2 .. prev_n)
+    const float *yprev = nullptr;
+    int prev_base = 0;
+    if (fr.prev_y_off >= 0) {
+        yprev = ybuf + fr.prev_y_off + (int64_t)ch * fr.prev_n;
+    } else if (fr.prev_y_off == -1) {
+        yprev = state_y + ((int64_t)fr.stream * channels + ch) * half1;
+        prev_base = fr.prev_n >> 1;
+    }
+    const float *slope = (fr.flags & kFrameSlope1) ? slope1 : slope0;
+    float *base = out + (stream_out_off ? stream_out_off[fr.stream] : 0);
+    float *dst = interleaved ? base + fr.out_off * channels + ch : base + (int64_t)ch * channel_stride + fr.out_off;
+    const int64_t step = interleaved ? channels : 1;
+    bool clipped_any = false;
+    for (int i = threadIdx.x; i < fr.out_count; i += 256) {
+        float v;
+        if (drain) {
+            v = yprev[fr.prev_end + i - prev_base];
+        } else {
+            v = ycur[fr.left_start + i];
+            if (i < fr.packet_len) {
+                const float t = yprev[fr.prev_end + i - prev_base];
+                v = (v * slope[i]) + (t * slope[fr.packet_len - 1 - i]);
+            }
+        }
+        if (clip) {
+            clipped_any |= was_clipped(v);
+            v = clip_value(v);
+        }
+        dst[i * step] = v;
+    }
+    if (clip && clipped_any) atomicOr(&clipped[fr.stream], 1);
+}
+
+// Runs after generic_ola_kernel (same stream): the last block of each stream keeps y[n/2 .. n) for
+// the next call.  A separate launch because the block that reads a stream's old state and the block
+// that would overwrite it are different workgroups of the OLA launch.
+__global__ __launch_bounds__(256) void generic_save_state_kernel(const GenericFrame *__restrict__ frames,
+                                                                const int32_t *__restrict__ save_list, int channels,
+                                                                int size1, const float *__restrict__ ybuf,
+                                                                float *__restrict__ state_y)
+{
+    const GenericFrame fr = frames[save_list[blockIdx.x / channels]];
+    const int ch = blockIdx.x % channels;
+    const int h = fr.n >> 1;
+    const float *ycur = ybuf + fr.y_off + (int64_t)ch * fr.n;
+    float *st = state_y + ((int64_t)fr.stream * channels + ch) * (size1 >> 1);
+    for (int i = threadIdx.x; i < h; i += 256) st[i] = ycur[h + i];
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *post_counts,
@@ -662,6 +791,37 @@ int synth_resident_waves(bool has_floor, int num_cu)
         per_cu = 2;
     }
     return num_cu * per_cu * kSynthWaves;
+}
+
+hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, float *spec,
+                                const uint8_t *post_counts, const int16_t *final_y, const uint8_t *step_flags,
+                                const uint8_t *rec_floor, const FloorDev *floors, const float *inv_db, hipStream_t stream)
+{
+    if (n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(generic_floor_kernel, dim3(n_frames * channels), dim3(64), 0, stream, frames, channels, spec,
+                       post_counts, final_y, step_flags, rec_floor, floors, inv_db);
+    return hipGetLastError();
+}
+
+hipError_t launch_generic_ola(const GenericFrame *frames, int n_frames, int channels, int size0, int size1,
+                              const float *ybuf, float *state_y, const float *slope0, const float *slope1, float *out,
+                              const int64_t *stream_out_off, int64_t channel_stride, int interleaved, int clip,
+                              int32_t *clipped, hipStream_t stream)
+{
+    if (n_frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(generic_ola_kernel, dim3(n_frames * channels), dim3(256), 0, stream, frames, channels, size0,
+                       size1, ybuf, state_y, slope0, slope1, out, stream_out_off, channel_stride, interleaved, clip,
+                       clipped);
+    return hipGetLastError();
+}
+
+hipError_t launch_generic_save_state(const GenericFrame *frames, const int32_t *save_list, int n_save, int channels,
+                                     int size1, const float *ybuf, float *state_y, hipStream_t stream)
+{
+    if (n_save <= 0) return hipSuccess;
+    hipLaunchKernelGGL(generic_save_state_kernel, dim3(n_save * channels), dim3(256), 0, stream, frames, save_list,
+                       channels, size1, ybuf, state_y);
+    return hipGetLastError();
 }
 
 size_t coupling_packet_size() { return sizeof(CouplingPacket); }

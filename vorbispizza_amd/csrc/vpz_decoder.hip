@@ -20,6 +20,15 @@ hipError_t launch_coupling(const void *pkts, int n_pkts, const uint8_t *steps, i
                            const float *residue, float *temp, int max_half, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t stream);
 int synth_resident_waves(bool has_floor, int num_cu);
+hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, float *spec,
+                                const uint8_t *post_counts, const int16_t *final_y, const uint8_t *step_flags,
+                                const uint8_t *rec_floor, const FloorDev *floors, const float *inv_db, hipStream_t stream);
+hipError_t launch_generic_ola(const GenericFrame *frames, int n_frames, int channels, int size0, int size1,
+                              const float *ybuf, float *state_y, const float *slope0, const float *slope1, float *out,
+                              const int64_t *stream_out_off, int64_t channel_stride, int interleaved, int clip,
+                              int32_t *clipped, hipStream_t stream);
+hipError_t launch_generic_save_state(const GenericFrame *frames, const int32_t *save_list, int n_save, int channels,
+                                     int size1, const float *ybuf, float *state_y, hipStream_t stream);
 size_t coupling_packet_size();
 void fill_coupling_packet(void *dst, int64_t src_off, int64_t dst_off, int32_t half, int32_t steps_off,
                           int32_t steps, int32_t interleaved);
@@ -70,6 +79,8 @@ struct Decoder {
     std::vector<int32_t> mapping_steps_off;  // per mapping: offset into d_steps (pairs*2), -1 none
     DevBuf b_frames, b_runs, b_recfloor, b_finaly, b_stepflags, b_cpk, b_temp, b_outoff;
     DevBuf b_in_res, b_in_posts, b_in_counts, b_out;  // VPZ_MEM_HOST staging
+    DevBuf b_gframes, b_glists, b_ybuf;               // any-block-size path
+    bool generic = false;  // block sizes other than 256 / 2048: three-pass path (synth_kernels.hip)
     int run_length_override = 0;
     int ablate = 0;  // VPZ_SYNTH_ABLATE, tuning experiments only
     std::vector<int32_t> packet_samples;  // per packet of the last synth call
@@ -187,9 +198,9 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_create: channels out of range");
     if (cfg->block_size0 > cfg->block_size1)
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_create: block_size0 > block_size1");
-    if (!supported_size(cfg->block_size0) || !supported_size(cfg->block_size1))
-        return set_error(ctx, VPZ_E_UNSUPPORTED,
-                         "vpz_decoder_create: fused synthesis kernels exist for block sizes 256 and 2048 only");
+    for (int bs : {cfg->block_size0, cfg->block_size1})
+        if (bs < 64 || bs > 8192 || (bs & (bs - 1)) != 0)
+            return set_error(ctx, VPZ_E_UNSUPPORTED, "vpz_decoder_create: block sizes must be powers of two in [64, 8192]");
     if (cfg->floor_count < 0 || cfg->mapping_count < 0 || (cfg->floor_count && !cfg->floors) ||
         (cfg->mapping_count && !cfg->mappings) || cfg->mapping_count > 256 || cfg->floor_count > 256)
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_create: bad floor / mapping tables");
@@ -204,6 +215,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     D.size1 = cfg->block_size1;
     D.clip = cfg->clip_samples ? 1 : 0;
     D.n_streams = n_streams;
+    D.generic = !(supported_size(cfg->block_size0) && supported_size(cfg->block_size1));
     D.states.assign(n_streams, StreamState());
     D.floors.assign(cfg->floors, cfg->floors + cfg->floor_count);
     D.mappings.assign(cfg->mappings, cfg->mappings + cfg->mapping_count);
@@ -266,7 +278,7 @@ void vpz_decoder_destroy(vpz_decoder *d)
         (void)hipSetDevice(D.ctx->device);
         (void)hipStreamSynchronize(D.ctx->stream);
     }
-    DevBuf *bufs[] = {&D.b_frames, &D.b_runs, &D.b_recfloor, &D.b_finaly, &D.b_stepflags, &D.b_cpk, &D.b_temp,
+    DevBuf *bufs[] = {&D.b_gframes, &D.b_glists, &D.b_ybuf, &D.b_frames, &D.b_runs, &D.b_recfloor, &D.b_finaly, &D.b_stepflags, &D.b_cpk, &D.b_temp,
                       &D.b_outoff, &D.b_in_res, &D.b_in_posts, &D.b_in_counts, &D.b_out};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -330,7 +342,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     }
     std::vector<int64_t> out_count(D.n_streams, 0);
     std::vector<uint8_t> pkt_used((size_t)n_packets, 0);
-    bool any_floor = false, need_coupling = false;
+    bool any_floor = false, need_coupling = D.generic;  // the generic path always works on its own planar copy
     int64_t mismatches = 0;
     int64_t temp_floats = 0;
     std::vector<int64_t> temp_off((size_t)n_packets, -1);
@@ -459,7 +471,8 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     const size_t max_runs = (size_t)(total_frames / R) + (size_t)D.n_streams + 1;
     const size_t arena_need = sizeof(FrameDesc) * (size_t)total_frames + sizeof(RunDesc) * max_runs +
                               coupling_packet_size() * (size_t)total_frames + (size_t)(n_packets * C) +
-                              sizeof(int64_t) * (size_t)D.n_streams + 1024;
+                              sizeof(int64_t) * (size_t)D.n_streams + 1024 +
+                              (D.generic ? (sizeof(GenericFrame) + 20 * (size_t)C) * (size_t)total_frames + 4096 : 0);
     if ((rc = arena_begin(ctx, D.arena, arena_need)) != VPZ_OK) return rc;
     FrameDesc *frames = arena_alloc<FrameDesc>(D.arena, (size_t)total_frames);
     RunDesc *runs = arena_alloc<RunDesc>(D.arena, max_runs);
@@ -587,6 +600,90 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         d_out = static_cast<float *>(D.b_out.p);
     }
 
+    if (D.generic) {
+        // ---------------- any-block-size path: floor pass, exact IMDCT per size, OLA pass, state save
+        GenericFrame *gf = arena_alloc<GenericFrame>(D.arena, n_frames);
+        int64_t *src0 = arena_alloc<int64_t>(D.arena, n_frames * (size_t)C), *dst0 = arena_alloc<int64_t>(D.arena, n_frames * (size_t)C);
+        int64_t *src1 = arena_alloc<int64_t>(D.arena, n_frames * (size_t)C), *dst1 = arena_alloc<int64_t>(D.arena, n_frames * (size_t)C);
+        int32_t *save_list = arena_alloc<int32_t>(D.arena, (size_t)D.n_streams + 1);
+        size_t n0 = 0, n1 = 0, n_save = 0, fi = 0;
+        int64_t y_floats = 0;
+        for (int s = 0; s < D.n_streams; ++s) {
+            const size_t cnt = per_stream[s].size();
+            int64_t prev_y = stream_started_with_prev[s] ? -1 : -2;
+            int prev_n = stream_prev_long[s] ? D.size1 : D.size0;
+            long last_block = -1;
+            for (size_t k = 0; k < cnt; ++k, ++fi) {
+                const FrameDesc &fd = frames[fi];
+                GenericFrame g{};
+                g.spec_off = fd.spec_off;
+                g.out_off = fd.out_off;
+                g.rec = fd.rec;
+                g.stream = s;
+                g.left_start = fd.left_start;
+                g.packet_len = fd.packet_len;
+                g.prev_end = fd.prev_end;
+                g.out_count = fd.out_count;
+                g.flags = fd.flags;
+                g.prev_y_off = prev_y;
+                g.prev_n = prev_n;
+                if (!(fd.flags & kFrameDrain)) {
+                    g.n = (fd.flags & kFrameLong) ? D.size1 : D.size0;
+                    g.y_off = y_floats;
+                    for (int ch = 0; ch < C; ++ch) {
+                        const int64_t so = fd.spec_off + (int64_t)ch * (g.n / 2), dofs = y_floats + (int64_t)ch * g.n;
+                        if (fd.flags & kFrameLong) { src1[n1] = so; dst1[n1++] = dofs; }
+                        else { src0[n0] = so; dst0[n0++] = dofs; }
+                    }
+                    y_floats += (int64_t)C * g.n;
+                    prev_y = g.y_off;
+                    prev_n = g.n;
+                    last_block = (long)fi;
+                }
+                gf[fi] = g;
+            }
+            if (last_block >= 0) {
+                gf[last_block].flags |= kFrameSaveState;
+                save_list[n_save++] = (int32_t)last_block;
+            }
+        }
+        if ((rc = grow(ctx, D.b_gframes, sizeof(GenericFrame) * n_frames)) != VPZ_OK) return rc;
+        if ((rc = grow(ctx, D.b_glists, sizeof(int64_t) * 4 * n_frames * (size_t)C + sizeof(int32_t) * (n_save + 1))) != VPZ_OK) return rc;
+        if ((rc = grow(ctx, D.b_ybuf, sizeof(float) * (size_t)std::max<int64_t>(y_floats, 1))) != VPZ_OK) return rc;
+        int64_t *d_lists = static_cast<int64_t *>(D.b_glists.p);
+        int64_t *d_src0 = d_lists, *d_dst0 = d_lists + n_frames * C, *d_src1 = d_lists + 2 * n_frames * C,
+                *d_dst1 = d_lists + 3 * n_frames * C;
+        int32_t *d_save = reinterpret_cast<int32_t *>(d_lists + 4 * n_frames * C);
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_gframes.p, gf, sizeof(GenericFrame) * n_frames, hipMemcpyHostToDevice, ctx->stream));
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_src0, src0, sizeof(int64_t) * n0, hipMemcpyHostToDevice, ctx->stream));
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_dst0, dst0, sizeof(int64_t) * n0, hipMemcpyHostToDevice, ctx->stream));
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_src1, src1, sizeof(int64_t) * n1, hipMemcpyHostToDevice, ctx->stream));
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_dst1, dst1, sizeof(int64_t) * n1, hipMemcpyHostToDevice, ctx->stream));
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_save, save_list, sizeof(int32_t) * n_save, hipMemcpyHostToDevice, ctx->stream));
+        VPZ_HIP_TRY(ctx, hipEventRecord(D.arena.uploaded, ctx->stream));
+        D.arena.pending = true;
+        const GenericFrame *d_gf = static_cast<const GenericFrame *>(D.b_gframes.p);
+        float *d_temp = static_cast<float *>(D.b_temp.p);
+        float *d_y = static_cast<float *>(D.b_ybuf.p);
+        hipError_t e = hipSuccess;
+        if (any_floor)
+            e = launch_generic_floor(d_gf, (int)n_frames, C, d_temp, d_counts, static_cast<const int16_t *>(D.b_finaly.p),
+                                     static_cast<const uint8_t *>(D.b_stepflags.p),
+                                     static_cast<const uint8_t *>(D.b_recfloor.p), D.d_floors, ctx->d_inv_db, ctx->stream);
+        if (e == hipSuccess && n0)
+            e = launch_imdct_exact(D.size0, D.t0->ld, d_temp, d_y, (int64_t)n0, D.t0->d_A, D.t0->d_B, D.t0->d_C,
+                                   D.t0->d_bitrev, ctx->num_cu, ctx->stream, d_src0, d_dst0);
+        if (e == hipSuccess && n1)
+            e = launch_imdct_exact(D.size1, D.t1->ld, d_temp, d_y, (int64_t)n1, D.t1->d_A, D.t1->d_B, D.t1->d_C,
+                                   D.t1->d_bitrev, ctx->num_cu, ctx->stream, d_src1, d_dst1);
+        if (e == hipSuccess)
+            e = launch_generic_ola(d_gf, (int)n_frames, C, D.size0, D.size1, d_y, D.d_state_h, D.t0->d_slope,
+                                   D.t1->d_slope, d_out, d_outoff, channel_stride, out_layout == VPZ_OUT_INTERLEAVED,
+                                   D.clip, D.d_clipped, ctx->stream);
+        if (e == hipSuccess)
+            e = launch_generic_save_state(d_gf, d_save, (int)n_save, C, D.size1, d_y, D.d_state_h, ctx->stream);
+        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "generic synthesis kernel launch", e);
+    } else {
     // ---------------- descriptors + launch
     if ((rc = grow(ctx, D.b_frames, sizeof(FrameDesc) * n_frames)) != VPZ_OK) return rc;
     if ((rc = grow(ctx, D.b_runs, sizeof(RunDesc) * n_runs)) != VPZ_OK) return rc;
@@ -624,6 +721,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     a.ablate = D.ablate;
     hipError_t e = launch_synth(a, any_floor, ctx->stream);
     if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "synth kernel launch", e);
+    }
 
     if (mem_space == VPZ_MEM_HOST) {
         for (int s = 0; s < D.n_streams; ++s) {

@@ -64,7 +64,8 @@ hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count
                                  const float2 *tw, int num_cu, hipStream_t stream);
 hipError_t launch_imdct_exact(int n, int ld, const float *spectra, float *out, int64_t count,
                               const float *A, const float *B, const float *C,
-                              const uint16_t *bitrev, int num_cu, hipStream_t stream);
+                              const uint16_t *bitrev, int num_cu, hipStream_t stream,
+                              const int64_t *src_off = nullptr, const int64_t *dst_off = nullptr);
 
 // offsets (in float2 units) inside BlockTables::d_fast
 constexpr int kFastTwOffset = 0;       // tw[k] = exp(+2*pi*i*(k + 1/8)/n), k < n/4   (<= 512 entries)
