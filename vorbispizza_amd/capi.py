@@ -115,6 +115,16 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+def _sync_producer(*tensors):
+    """The C ABI orders work only on the context's own HIP stream.  Tensors produced on torch's
+    current stream must be complete before the library reads them, so wait for that stream here."""
+    for t in tensors:
+        if t is not None and _is_torch(t) and t.is_cuda:
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
+            return
+
+
 def _ptr(x):
     if x is None:
         return None
@@ -174,6 +184,7 @@ class Context:
             count = spectra.numel() // half
             if out is None:
                 out = torch.empty((count, n), dtype=torch.float32, device=spectra.device)
+            _sync_producer(spectra)
             self._check(lib().vpz_imdct_batch(self._h, n, count, _ptr(spectra), _ptr(out), MEM_DEVICE, mode))
             return out
         spectra = np.ascontiguousarray(spectra, dtype=np.float32).reshape(-1, half)
@@ -241,6 +252,8 @@ class Decoder:
         written = np.zeros(self.n_streams, dtype=np.int64)
         packets = np.ascontiguousarray(packets, dtype=PACKET_DTYPE)
         offs = None if stream_out_offset is None else np.ascontiguousarray(stream_out_offset, dtype=np.int64)
+        if mem_space == MEM_DEVICE:
+            _sync_producer(residue, posts, post_counts, pcm_out)
         rc = lib().vpz_decoder_synth(self._h, len(packets), _ptr(packets), _ptr(residue), _ptr(posts),
                                      _ptr(post_counts), mem_space, _ptr(pcm_out), _ptr(offs), capacity,
                                      out_layout, channel_stride, _ptr(written))

@@ -78,10 +78,7 @@ struct SynthArgs {
     int32_t size0, size1;
     const float *spec;          // planar spectra (caller residue or the coupling temp)
     const uint8_t *post_counts; // [rec] PostCount; nullptr => every channel executes, no floor
-    const int16_t *final_y;     // [rec][64] unwrapped posts * multiplier (from the unwrap kernel)
-    const uint8_t *step_flags;  // [rec][64]
-    const uint8_t *rec_floor;   // [rec] floor index of the record
-    const FloorDev *floors;
+    const uint8_t *curve_y;     // [rec][size1/2] inverse-dB table index per bin (floor1_prepare_kernel)
     const float *inv_db;        // 256 floats
     float *state_h;             // [stream][channel][size1/2]
     const float2 *tw_long;      // fast tables of size1 (BlockTables::d_fast)

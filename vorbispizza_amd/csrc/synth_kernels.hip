@@ -1,11 +1,12 @@
 // Fused PCM-synthesis kernels behind vpz_decoder_synth:
 //
-//   floor1_unwrap_kernel   Floor1.UnwrapPosts (Floor1.cs:270-353), one LANE per channel-record,
+//   floor1_prepare_kernel  Floor1.UnwrapPosts (Floor1.cs:270-353, one LANE per channel-record) and the
+//                          curve render (Floor1.cs:236-262, 372-397) as one table index per bin;
 //                          integer only, bit-exact.
 //   coupling_kernel        Residue2 de-interleave (Residue2.cs:42-51) + inverse square-polar
 //                          coupling (Mapping.cs:166-172, 198-269), element-wise, bit-exact.
-//   synth_kernel           per channel-block: Floor1 curve render x residue (Floor1.cs:236-262,
-//                          372-397) -> inverse MDCT (Mdct.cs) -> window + overlap-add with the
+//   synth_kernel           per channel-block: inverse dB table lookup x residue (Floor1.cs:383,395)
+//                          -> inverse MDCT (Mdct.cs) -> window + overlap-add with the
 //                          previous block (StreamDecoder.cs:764-791) -> clip (Utils.cs:44-58) ->
 //                          interleaved / planar store (StreamDecoder.cs:515-638).
 //
@@ -40,61 +41,7 @@ __device__ __forceinline__ int render_point(int x0, int y0, int x1, int y1, int 
     return dy < 0 ? y0 - off : y0 + off;
 }
 
-__global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int16_t *__restrict__ posts,
-                                                          const uint8_t *__restrict__ post_counts,
-                                                          const uint8_t *__restrict__ rec_floor,
-                                                          const FloorDev *__restrict__ floors,
-                                                          int16_t *__restrict__ final_y,
-                                                          uint8_t *__restrict__ step_flags)
-{
-    __shared__ int s_y[64][64];       // [post][lane]
-    __shared__ uint8_t s_f[64][64];
-    const int lane = threadIdx.x;
-    const int rec = blockIdx.x * 64 + lane;
-    if (rec >= n_rec) return;
-    const int pc_raw = post_counts[rec];
-    if (pc_raw == 0) return;  // ExecuteChannel false: nothing to unwrap
-    const FloorDev &f = floors[rec_floor[rec]];
-    const int pc = f.x_count;  // Unpack leaves PostCount == xList.Length or 0 (Floor1.cs:173-218)
-    const int16_t *p = posts + (size_t)rec * 64;
-    for (int i = 0; i < 64; ++i) s_f[i][lane] = 0;
-    s_f[0][lane] = 1;
-    s_f[1][lane] = 1;
-    s_y[0][lane] = p[0];
-    s_y[1][lane] = p[1];
-    for (int i = 2; i < pc; ++i) {
-        const int lo = f.l_neigh[i], hi = f.h_neigh[i];
-        const int predicted = render_point(f.x_list[lo], s_y[lo][lane], f.x_list[hi], s_y[hi][lane],
-                                           f.x_list[i]);
-        const int val = p[i];
-        const int highroom = f.range - predicted;
-        const int lowroom = predicted;
-        const int room = (highroom < lowroom ? highroom : lowroom) * 2;
-        int result;
-        if (val != 0) {
-            s_f[lo][lane] = 1;
-            s_f[hi][lane] = 1;
-            s_f[i][lane] = 1;
-            if (val >= room) {
-                result = (highroom > lowroom) ? val - lowroom + predicted : predicted - val + highroom - 1;
-            } else {
-                result = ((val % 2) == 1) ? predicted - ((val + 1) / 2) : predicted + (val / 2);
-            }
-        } else {
-            s_f[i][lane] = 0;
-            result = predicted;
-        }
-        s_y[i][lane] = result;
-    }
-    int16_t *fy = final_y + (size_t)rec * 64;
-    uint8_t *sf = step_flags + (size_t)rec * 64;
-    for (int i = 0; i < pc; ++i) {
-        int v = s_y[i][lane] * f.multiplier;
-        v = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
-        fy[i] = (int16_t)v;
-        sf[i] = s_f[i][lane];
-    }
-}
+// (the kernel itself, floor1_prepare_kernel, follows the render helpers below)
 
 // ---------------------------------------------------------------------------------------------
 // De-interleave + inverse coupling into a planar temp.  One thread per (packet, bin).
@@ -164,51 +111,50 @@ __device__ __forceinline__ int div_floor_small(int a, int b)
     return q;
 }
 
+// One rendered segment between two active posts, packed for LDS:
+//   A = x0 | x1 << 16          (x1 already clipped to n: quirk q2, Floor1.cs:248)
+//   B = (y0 & 0xFFFF) | base << 16   (base = dy / adx, C# truncating division, signed)
+//   C = adx | rseg << 13 | (dy < 0) << 31,  rseg = |dy| - |base| * adx
 struct Seg {
     int x0, y0, x1, adx, sy, base, rseg;
 };
 
-__device__ __forceinline__ Seg load_segment(const int *cxy, int j, int m, int n)
+__device__ __forceinline__ Seg unpack_segment(int A, int B, int C)
 {
     Seg s;
-    const int p0 = cxy[j];
-    s.x0 = p0 & 0xFFFF;
-    s.y0 = p0 >> 16;
-    int x1raw, y1;
-    if (j + 1 < m) { const int p1 = cxy[j + 1]; x1raw = p1 & 0xFFFF; y1 = p1 >> 16; }
-    else { x1raw = n; y1 = s.y0; }  // flat tail, Floor1.cs:259-262
-    s.x1 = x1raw < n ? x1raw : n;
-    s.adx = s.x1 - s.x0;
-    const int dy = y1 - s.y0;
-    const int ady = iabs(dy);
-    s.sy = dy < 0 ? -1 : 1;
-    const int ab = div_floor_small(ady, s.adx);  // |dy / adx| (C# truncating division)
-    s.base = s.sy * ab;
-    s.rseg = ady - ab * s.adx;
+    s.x0 = A & 0xFFFF;
+    s.x1 = (A >> 16) & 0xFFFF;
+    s.y0 = (int)(int16_t)(B & 0xFFFF);
+    s.base = B >> 16;
+    s.adx = C & 0x1FFF;
+    s.rseg = (C >> 13) & 0x1FFF;
+    s.sy = (C < 0) ? -1 : 1;
     return s;
 }
 
 // kWords = bitmap words (32 bins each) the block size needs: 32 for n <= 1024, 128 for n <= 4096.
-// aux layout (ints): [0..kWords) bitmap, [kWords..2*kWords) exclusive prefix popcounts, then 65
-// compacted active posts (x in the low 16 bits, signed y in the high 16).
+// aux layout (ints): [0..kWords) bitmap, [kWords..2*kWords) exclusive prefix popcounts, then four
+// arrays of 65: compacted active posts (x | y << 16) and the packed segments A, B, C.
+// sy / sf: this record's unwrapped posts (finalY * multiplier) and step flags, element i at [i * stride].
+// Output: one byte per bin = index into the inverse dB table.  Every lane renders a contiguous run of
+// bins: one exact division for its first bin (closed form of the DDA: y = y0 + trunc(dy*k/adx), error
+// term (|dy|*k mod adx) - adx), then the reference's DDA (Floor1.cs:386-396) step by step.
 template <int kWords>
-__device__ __forceinline__ void render_floor_curve_t(float *curve, int *aux, int n, int rec,
-                                                     const FloorDev *floors, const uint8_t *rec_floor,
-                                                     const uint8_t *step_flags, const int16_t *final_y,
-                                                     const float *s_db, int lane)
+__device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int n, const FloorDev &f,
+                                                     const int *sy, const uint8_t *sf, int stride, int lane)
 {
-    const FloorDev &f = floors[rec_floor[rec]];
     const int pc = f.x_count;
     int *bitmap = aux, *prefix = aux + kWords, *cxy = aux + 2 * kWords;
+    int *segA = cxy + 65, *segB = segA + 65, *segC = segB + 65;
     for (int w = lane; w < kWords; w += 64) bitmap[w] = 0;
     // compact the active posts in X order (Floor1.cs:238-252)
     bool active = false;
     int x = 0, y = 0;
     if (lane < pc) {
         const int idx = f.sort_idx[lane];
-        active = (lane == 0) || step_flags[(size_t)rec * 64 + idx] != 0;
+        active = (lane == 0) || sf[idx * stride] != 0;
         x = f.x_list[idx];
-        y = final_y[(size_t)rec * 64 + idx];
+        y = sy[idx * stride];
     }
     const unsigned long long mask = __ballot(active);
     const int m = __popcll(mask);
@@ -216,6 +162,23 @@ __device__ __forceinline__ void render_floor_curve_t(float *curve, int *aux, int
         const int pos = __popcll(mask & ((1ull << lane) - 1ull));
         cxy[pos] = (x & 0xFFFF) | (y << 16);
         if (x < n) atomicOr(reinterpret_cast<unsigned int *>(&bitmap[x >> 5]), 1u << (x & 31));
+    }
+    // one lane per segment: slope parameters, with the only division a segment needs
+    if (lane < m) {
+        const int p0 = cxy[lane];
+        const int x0 = p0 & 0xFFFF, y0 = p0 >> 16;
+        int x1raw = n, y1 = y0;  // flat tail after the last active post (Floor1.cs:259-262)
+        if (lane + 1 < m) { const int p1 = cxy[lane + 1]; x1raw = p1 & 0xFFFF; y1 = p1 >> 16; }
+        const int x1 = x1raw < n ? x1raw : n;
+        const int adx = x1 - x0;
+        const int dy = y1 - y0;
+        const int ady = iabs(dy);
+        const int ab = adx > 0 ? div_floor_small(ady, adx) : 0;
+        const int base = dy < 0 ? -ab : ab;
+        const int rseg = adx > 0 ? ady - ab * adx : 0;
+        segA[lane] = x0 | (x1 << 16);
+        segB[lane] = (y0 & 0xFFFF) | (base << 16);
+        segC[lane] = (adx > 0 ? adx : 0) | (rseg << 13) | (dy < 0 ? (int)0x80000000 : 0);
     }
     // exclusive prefix popcount over the bitmap words
     if (kWords <= 32) {
@@ -243,27 +206,32 @@ __device__ __forceinline__ void render_floor_curve_t(float *curve, int *aux, int
 #pragma unroll
         for (int i = 0; i < per; ++i) { prefix[lane * per + i] = run; run += c[i]; }
     }
-    const int groups = n >> 2;  // runs of 4 bins
-    for (int g = lane; g < groups; g += 64) {
-        int xx = 4 * g;
-        const unsigned w = (unsigned)bitmap[xx >> 5];
-        int j = prefix[xx >> 5] + __popc(w & ((2u << (xx & 31)) - 1u)) - 1;
-        Seg s = load_segment(cxy, j, m, n);
+    const int per_lane = n >= 256 ? (n >> 6) : 4;  // bins per lane, a multiple of 4
+    int xx = lane * per_lane;
+    if (xx >= n) return;
+    const unsigned w = (unsigned)bitmap[xx >> 5];
+    int j = prefix[xx >> 5] + __popc(w & ((2u << (xx & 31)) - 1u)) - 1;
+    Seg s = unpack_segment(segA[j], segB[j], segC[j]);
+    int yy, err;
+    {
         const int k = xx - s.x0;
         const int ady = iabs(s.base) * s.adx + s.rseg;
         const int aa = ady * k;
         const int q = div_floor_small(aa, s.adx);
-        int yy = s.y0 + s.sy * q;
-        int err = (aa - q * s.adx) - s.adx;
-        float v[4];
+        yy = s.y0 + s.sy * q;
+        err = (aa - q * s.adx) - s.adx;
+    }
+    uint32_t *out4 = reinterpret_cast<uint32_t *>(out + xx);
+    for (int t4 = 0; t4 < per_lane; t4 += 4) {
+        uint32_t packed = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            int yi = yy < 0 ? 0 : (yy > 255 ? 255 : yy);  // the reference would throw outside 0..255
-            v[t] = s_db[yi];
+            const int yi = yy < 0 ? 0 : (yy > 255 ? 255 : yy);  // the reference would throw outside 0..255
+            packed |= (uint32_t)yi << (8 * t);
             ++xx;
-            if (xx == s.x1 && xx < n) {  // next segment starts exactly on its post
+            if (xx == s.x1 && xx < n) {  // the next segment starts exactly on its post
                 ++j;
-                s = load_segment(cxy, j, m, n);
+                s = unpack_segment(segA[j], segB[j], segC[j]);
                 yy = s.y0;
                 err = -s.adx;
             } else {
@@ -272,14 +240,108 @@ __device__ __forceinline__ void render_floor_curve_t(float *curve, int *aux, int
                 if (err >= 0) { err -= s.adx; yy += s.sy; }
             }
         }
-        reinterpret_cast<float4 *>(curve)[g] = make_float4(v[0], v[1], v[2], v[3]);
+        out4[t4 >> 2] = packed;
     }
 }
 
-__device__ __forceinline__ void render_floor_curve(float *curve, int *aux, int n, int rec,
-                                                   const SynthArgs &a, const float *s_db, int lane)
+// ---------------------------------------------------------------------------------------------
+// floor1_prepare_kernel: everything integer about Floor1 for 64 channel-records per wavefront.
+//   phase 1: Floor1.UnwrapPosts (Floor1.cs:270-353), one LANE per record, results in LDS;
+//   phase 2: for each of the 64 records the whole wavefront renders the curve (Floor1.cs:236-262,
+//            372-397) as one table index per bin -> curve_y[rec][bin] (uint8).
+// The synthesis kernels then only look the indices up in the inverse dB table and multiply.
+// rec_info[rec]: floor index in bits 0..6, bit 7 = long block.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPrepWaves = 8;
+constexpr int kPrepFloorsInLds = 8;
+
+__global__ __launch_bounds__(64 * kPrepWaves) void floor1_prepare_kernel(int n_rec, const int16_t *__restrict__ posts,
+                                                                        const uint8_t *__restrict__ post_counts,
+                                                                        const uint8_t *__restrict__ rec_info,
+                                                                        const FloorDev *__restrict__ g_floors,
+                                                                        int n_floors, int half0, int half1,
+                                                                        uint8_t *__restrict__ curve_y, int ablate)
 {
-    render_floor_curve_t<32>(curve, aux, n, rec, a.floors, a.rec_floor, a.step_flags, a.final_y, s_db, lane);
+    __shared__ int s_y[64][65];       // [post][record], padded
+    __shared__ uint8_t s_f[64][65];
+    __shared__ int s_aux[kPrepWaves][2 * 128 + 4 * 65];
+    __shared__ uint8_t s_have[64];
+    __shared__ int16_t s_posts[64][66];          // raw posts of the 64 records, staged with coalesced loads
+    __shared__ FloorDev s_floors[kPrepFloorsInLds];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // stage the inputs: a per-lane walk over global memory would put one DRAM round trip on every post
+    {
+        const int first = blockIdx.x * 64;
+        for (int i = threadIdx.x; i < 64 * 32; i += 64 * kPrepWaves) {  // 32 dwords (64 posts) per record
+            const int r = i >> 5, w = i & 31;
+            uint32_t v = 0;
+            if (first + r < n_rec) v = reinterpret_cast<const uint32_t *>(posts + (size_t)(first + r) * 64)[w];
+            s_posts[r][2 * w] = (int16_t)(v & 0xFFFF);
+            s_posts[r][2 * w + 1] = (int16_t)(v >> 16);
+        }
+        const int nf = n_floors < kPrepFloorsInLds ? n_floors : kPrepFloorsInLds;
+        const int words = nf * (int)(sizeof(FloorDev) / 4);
+        for (int i = threadIdx.x; i < words; i += 64 * kPrepWaves)
+            reinterpret_cast<uint32_t *>(s_floors)[i] = reinterpret_cast<const uint32_t *>(g_floors)[i];
+    }
+    __syncthreads();
+    const FloorDev *floors = (n_floors <= kPrepFloorsInLds) ? s_floors : g_floors;
+    if (wave == 0 && !(ablate & 16)) {  // phase 1: one lane per record
+        const int rec = blockIdx.x * 64 + lane;
+        bool have = false;
+        if (rec < n_rec && post_counts[rec] != 0) {
+            have = true;
+            const FloorDev &f = floors[rec_info[rec] & 0x7F];
+            const int pc = f.x_count;  // Unpack leaves PostCount == xList.Length or 0 (Floor1.cs:173-218)
+            const int16_t *p = s_posts[lane];
+            for (int i = 0; i < 64; ++i) s_f[i][lane] = 0;
+            s_f[0][lane] = 1;
+            s_f[1][lane] = 1;
+            s_y[0][lane] = p[0];
+            s_y[1][lane] = p[1];
+            for (int i = 2; i < pc; ++i) {
+                const int lo = f.l_neigh[i], hi = f.h_neigh[i];
+                const int predicted = render_point(f.x_list[lo], s_y[lo][lane], f.x_list[hi], s_y[hi][lane], f.x_list[i]);
+                const int val = p[i];
+                const int highroom = f.range - predicted;
+                const int lowroom = predicted;
+                const int room = (highroom < lowroom ? highroom : lowroom) * 2;
+                int result;
+                if (val != 0) {
+                    s_f[lo][lane] = 1;
+                    s_f[hi][lane] = 1;
+                    s_f[i][lane] = 1;
+                    if (val >= room) {
+                        result = (highroom > lowroom) ? val - lowroom + predicted : predicted - val + highroom - 1;
+                    } else {
+                        result = ((val % 2) == 1) ? predicted - ((val + 1) / 2) : predicted + (val / 2);
+                    }
+                } else {
+                    s_f[i][lane] = 0;
+                    result = predicted;
+                }
+                s_y[i][lane] = result;
+            }
+            for (int i = 0; i < pc; ++i) {  // Apply multiplies by _multiplier (Floor1.cs:237,245)
+                int v = s_y[i][lane] * f.multiplier;
+                s_y[i][lane] = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+            }
+        }
+        s_have[lane] = have ? 1 : 0;
+    }
+    __syncthreads();
+    // phase 2: every wavefront renders its share of the 64 records
+    for (int r = wave; r < 64; r += kPrepWaves) {
+        if (!s_have[r] || (ablate & 32)) continue;
+        const int rr = blockIdx.x * 64 + r;
+        const uint8_t info = rec_info[rr];
+        const FloorDev &f = floors[info & 0x7F];
+        const int n = (info & 0x80) ? half1 : half0;
+        uint8_t *row = curve_y + (size_t)rr * half1;
+        if (n <= 1024) render_floor_indices<32>(row, s_aux[wave], n, f, &s_y[0][r], &s_f[0][r], 65, lane);
+        else render_floor_indices<128>(row, s_aux[wave], n, f, &s_y[0][r], &s_f[0][r], 65, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -327,23 +389,16 @@ __device__ __forceinline__ float tail_at(const float *tail, int q, int pn4)
 // Builds h of one channel-block into the wave-private LDS buffer `hbuf`:
 // (optional) Floor1 curve x spectrum, then the inverse MDCT.  kLong selects N = 2048 / 256.
 template <bool kHasFloor, bool kLong>
-__device__ __forceinline__ void build_block(const SynthArgs &a, uint32_t fd_flags, int rec, int lane,
-                                            float2 (&x)[8], float *hbuf, const float2 *s_twL,
-                                            const float2 *s_twAB, const float2 *s_twBC,
-                                            const float2 *s_twS, const float *s_db)
+__device__ __forceinline__ void build_block(uint32_t fd_flags, int lane, float2 (&x)[8], const uint32_t (&fy)[8],
+                                            float *hbuf, const float2 *s_twL, const float2 *s_twAB,
+                                            const float2 *s_twBC, const float2 *s_twS, const float *s_db)
 {
-    constexpr int half = kLong ? 1024 : 128;
     if (kHasFloor && !(fd_flags & kFrameNoFloor)) {
-        // the curve goes to the buffer that will receive h (free until the transposes start)
-        int *aux = reinterpret_cast<int *>(hbuf + 1024);
-        render_floor_curve(hbuf, aux, half, rec, a, s_db, lane);
-        const float2 *c2 = reinterpret_cast<const float2 *>(hbuf);
-        const int k0 = kLong ? lane : (lane & 7);
+        // Floor1.Apply's multiply (Floor1.cs:383,395): fy[m] holds the two table indices of bins 2k, 2k+1
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            const float2 c = c2[k0 + (kLong ? 64 : 8) * m];
-            x[m].x *= c.x;
-            x[m].y *= c.y;
+            x[m].x *= s_db[fy[m] & 0xFFu];
+            x[m].y *= s_db[(fy[m] >> 8) & 0xFFu];
         }
     }
     if (kLong) {
@@ -352,6 +407,16 @@ __device__ __forceinline__ void build_block(const SynthArgs &a, uint32_t fd_flag
         // all eight lane groups transform the same short block; group 0's copy lands at hbuf[0..128)
         imdct256_wave8(x, reinterpret_cast<float2 *>(hbuf), s_twS, s_twBC, lane);
     }
+}
+
+// the two floor-table indices (bytes) of bins 2k, 2k+1 for each of the lane's 8 points
+__device__ __forceinline__ void load_floor_indices(uint32_t (&fy)[8], const uint8_t *row, bool is_long, int lane)
+{
+    const uint16_t *s = reinterpret_cast<const uint16_t *>(row);
+    const int k0 = is_long ? lane : (lane & 7);
+    const int st = is_long ? 64 : 8;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) fy[m] = s[k0 + st * m];
 }
 
 __device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base, bool is_long, int lane)
@@ -455,16 +520,25 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 
     // ---- software pipeline: the spectrum of frame i+1 is in flight while frame i is synthesised
     float2 xcur[8];
+    uint32_t fycur[8];
     FrameDesc fd_next = frame_at(fi0);
-    if (!(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec))
+    if (!(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec)) {
         load_spectrum(xcur, spectrum_of(fd_next), fd_next.flags & kFrameLong, lane);
+        if (kHasFloor && !(fd_next.flags & kFrameNoFloor))
+            load_floor_indices(fycur, a.curve_y + (size_t)(fd_next.rec + ch) * half1, fd_next.flags & kFrameLong, lane);
+    }
     for (int fi = fi0; fi < run.count; ++fi) {
         const FrameDesc fd = fd_next;
         float2 xnext[8];
+        uint32_t fynext[8];
         if (fi + 1 < run.count) {
             fd_next = frame_at(fi + 1);
-            if (!(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec) && !(a.ablate & 4))
+            if (!(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec) && !(a.ablate & 4)) {
                 load_spectrum(xnext, spectrum_of(fd_next), fd_next.flags & kFrameLong, lane);
+                if (kHasFloor && !(fd_next.flags & kFrameNoFloor))
+                    load_floor_indices(fynext, a.curve_y + (size_t)(fd_next.rec + ch) * half1,
+                                       fd_next.flags & kFrameLong, lane);
+            }
         }
         const bool drain = fd.flags & kFrameDrain;
         const bool is_long = fd.flags & kFrameLong;
@@ -478,9 +552,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 #pragma unroll
                 for (int m = 0; m < 8; ++m) h2[lane + 64 * m] = xcur[m];
             } else if (is_long) {
-                build_block<kHasFloor, true>(a, fd.flags, fd.rec + ch, lane, xcur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
+                build_block<kHasFloor, true>(fd.flags, lane, xcur, fycur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
             } else {
-                build_block<kHasFloor, false>(a, fd.flags, fd.rec + ch, lane, xcur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
+                build_block<kHasFloor, false>(fd.flags, lane, xcur, fycur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
             }
         }
 
@@ -488,7 +562,10 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         // is data dependent -- so the wait for the prefetched spectrum is forced HERE, before this
         // frame's stores are issued; otherwise it would also wait for them (HBM write latency).
 #pragma unroll
-        for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(xnext[m].x), "v"(xnext[m].y));
+        for (int m = 0; m < 8; ++m) {
+            asm volatile("" ::"v"(xnext[m].x), "v"(xnext[m].y));
+            if (kHasFloor) asm volatile("" ::"v"(fynext[m]));
+        }
 
         if (fi >= 0 && fd.out_count > 0 && !(a.ablate & 1)) {
             // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 573-591)
@@ -624,7 +701,10 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             prev_n4 = n4;
         }
 #pragma unroll
-        for (int m = 0; m < 8; ++m) xcur[m] = xnext[m];
+        for (int m = 0; m < 8; ++m) {
+            xcur[m] = xnext[m];
+            if (kHasFloor) fycur[m] = fynext[m];
+        }
     }
 
     // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
@@ -642,34 +722,23 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 //   generic_ola_kernel   : window + overlap-add + clip + store from the full IMDCT outputs
 // It exists so that every Vorbis block-size pair decodes; the 256/2048 pair takes the fused kernel.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void generic_floor_kernel(const GenericFrame *__restrict__ frames, int channels,
-                                                          float *__restrict__ spec,
-                                                          const uint8_t *__restrict__ post_counts,
-                                                          const int16_t *__restrict__ final_y,
-                                                          const uint8_t *__restrict__ step_flags,
-                                                          const uint8_t *__restrict__ rec_floor,
-                                                          const FloorDev *__restrict__ floors,
-                                                          const float *__restrict__ inv_db)
+__global__ __launch_bounds__(256) void generic_floor_kernel(const GenericFrame *__restrict__ frames, int channels,
+                                                           int half1, float *__restrict__ spec,
+                                                           const uint8_t *__restrict__ post_counts,
+                                                           const uint8_t *__restrict__ curve_y,
+                                                           const float *__restrict__ inv_db)
 {
-    __shared__ float s_curve[4096];
-    __shared__ int s_aux[2 * 128 + 65];
-    __shared__ float s_db[256];
-    const int lane = threadIdx.x;
     const GenericFrame fr = frames[blockIdx.x / channels];
     const int ch = blockIdx.x % channels;
     if (fr.flags & (kFrameDrain | kFrameNoFloor)) return;
     const int half = fr.n >> 1;
     float *x = spec + fr.spec_off + (int64_t)ch * half;
     if (post_counts[fr.rec + ch] == 0) {  // Mapping.cs:190-194
-        for (int i = lane; i < half; i += 64) x[i] = 0.0f;
+        for (int i = threadIdx.x; i < half; i += 256) x[i] = 0.0f;
         return;
     }
-    for (int i = lane; i < 256; i += 64) s_db[i] = inv_db[i];
-    if (half <= 1024)
-        render_floor_curve_t<32>(s_curve, s_aux, half, fr.rec + ch, floors, rec_floor, step_flags, final_y, s_db, lane);
-    else
-        render_floor_curve_t<128>(s_curve, s_aux, half, fr.rec + ch, floors, rec_floor, step_flags, final_y, s_db, lane);
-    for (int i = lane; i < half; i += 64) x[i] *= s_curve[i];
+    const uint8_t *row = curve_y + (size_t)(fr.rec + ch) * half1;
+    for (int i = threadIdx.x; i < half; i += 256) x[i] *= inv_db[row[i]];
 }
 
 // y[pos] of a block whose full IMDCT output sits in memory
@@ -740,13 +809,13 @@ __global__ __launch_bounds__(256) void generic_save_state_kernel(const GenericFr
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *post_counts,
-                                const uint8_t *rec_floor, const FloorDev *floors, int16_t *final_y,
-                                uint8_t *step_flags, hipStream_t stream)
+hipError_t launch_floor1_prepare(int n_rec, const int16_t *posts, const uint8_t *post_counts,
+                                 const uint8_t *rec_info, const FloorDev *floors, int n_floors, int half0, int half1,
+                                 uint8_t *curve_y, int ablate, hipStream_t stream)
 {
     if (n_rec <= 0) return hipSuccess;
-    hipLaunchKernelGGL(floor1_unwrap_kernel, dim3((n_rec + 63) / 64), dim3(64), 0, stream, n_rec, posts,
-                       post_counts, rec_floor, floors, final_y, step_flags);
+    hipLaunchKernelGGL(floor1_prepare_kernel, dim3((n_rec + 63) / 64), dim3(64 * kPrepWaves), 0, stream, n_rec, posts,
+                       post_counts, rec_info, floors, n_floors, half0, half1, curve_y, ablate);
     return hipGetLastError();
 }
 
@@ -793,13 +862,13 @@ int synth_resident_waves(bool has_floor, int num_cu)
     return num_cu * per_cu * kSynthWaves;
 }
 
-hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, float *spec,
-                                const uint8_t *post_counts, const int16_t *final_y, const uint8_t *step_flags,
-                                const uint8_t *rec_floor, const FloorDev *floors, const float *inv_db, hipStream_t stream)
+hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, int half1, float *spec,
+                                const uint8_t *post_counts, const uint8_t *curve_y, const float *inv_db,
+                                hipStream_t stream)
 {
     if (n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(generic_floor_kernel, dim3(n_frames * channels), dim3(64), 0, stream, frames, channels, spec,
-                       post_counts, final_y, step_flags, rec_floor, floors, inv_db);
+    hipLaunchKernelGGL(generic_floor_kernel, dim3(n_frames * channels), dim3(256), 0, stream, frames, channels, half1,
+                       spec, post_counts, curve_y, inv_db);
     return hipGetLastError();
 }
 

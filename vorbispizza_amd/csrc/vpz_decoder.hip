@@ -13,16 +13,16 @@
 
 namespace vpz {
 
-hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *post_counts,
-                                const uint8_t *rec_floor, const FloorDev *floors, int16_t *final_y,
-                                uint8_t *step_flags, hipStream_t stream);
+hipError_t launch_floor1_prepare(int n_rec, const int16_t *posts, const uint8_t *post_counts,
+                                 const uint8_t *rec_info, const FloorDev *floors, int n_floors, int half0, int half1,
+                                 uint8_t *curve_y, int ablate, hipStream_t stream);
 hipError_t launch_coupling(const void *pkts, int n_pkts, const uint8_t *steps, int channels,
                            const float *residue, float *temp, int max_half, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t stream);
 int synth_resident_waves(bool has_floor, int num_cu);
-hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, float *spec,
-                                const uint8_t *post_counts, const int16_t *final_y, const uint8_t *step_flags,
-                                const uint8_t *rec_floor, const FloorDev *floors, const float *inv_db, hipStream_t stream);
+hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, int half1, float *spec,
+                                const uint8_t *post_counts, const uint8_t *curve_y, const float *inv_db,
+                                hipStream_t stream);
 hipError_t launch_generic_ola(const GenericFrame *frames, int n_frames, int channels, int size0, int size1,
                               const float *ybuf, float *state_y, const float *slope0, const float *slope1, float *out,
                               const int64_t *stream_out_off, int64_t channel_stride, int interleaved, int clip,
@@ -77,7 +77,7 @@ struct Decoder {
     int32_t *d_clipped = nullptr;
     uint8_t *d_steps = nullptr;              // coupling steps of all mappings, pairs (mag, ang)
     std::vector<int32_t> mapping_steps_off;  // per mapping: offset into d_steps (pairs*2), -1 none
-    DevBuf b_frames, b_runs, b_recfloor, b_finaly, b_stepflags, b_cpk, b_temp, b_outoff;
+    DevBuf b_frames, b_runs, b_recfloor, b_curve, b_cpk, b_temp, b_outoff;
     DevBuf b_in_res, b_in_posts, b_in_counts, b_out;  // VPZ_MEM_HOST staging
     DevBuf b_gframes, b_glists, b_ybuf;               // any-block-size path
     bool generic = false;  // block sizes other than 256 / 2048: three-pass path (synth_kernels.hip)
@@ -278,7 +278,7 @@ void vpz_decoder_destroy(vpz_decoder *d)
         (void)hipSetDevice(D.ctx->device);
         (void)hipStreamSynchronize(D.ctx->stream);
     }
-    DevBuf *bufs[] = {&D.b_gframes, &D.b_glists, &D.b_ybuf, &D.b_frames, &D.b_runs, &D.b_recfloor, &D.b_finaly, &D.b_stepflags, &D.b_cpk, &D.b_temp,
+    DevBuf *bufs[] = {&D.b_gframes, &D.b_glists, &D.b_ybuf, &D.b_frames, &D.b_runs, &D.b_recfloor, &D.b_curve, &D.b_cpk, &D.b_temp,
                       &D.b_outoff, &D.b_in_res, &D.b_in_posts, &D.b_in_counts, &D.b_out};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -563,16 +563,16 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         for (int64_t p = 0; p < n_packets; ++p) {
             if (!pkt_used[(size_t)p] || (packets[p].flags & VPZ_PKT_NO_FLOOR)) continue;
             const vpz_mapping_config &mc = D.mappings[packets[p].mapping];
-            for (int ch = 0; ch < C; ++ch) rec_floor[(size_t)(p * C + ch)] = mc.channel_floor[ch];
+            const uint8_t long_bit = (packets[p].flags & VPZ_PKT_BLOCK_FLAG) ? 0x80 : 0;
+            for (int ch = 0; ch < C; ++ch) rec_floor[(size_t)(p * C + ch)] = (uint8_t)(mc.channel_floor[ch] | long_bit);
         }
         if ((rc = grow(ctx, D.b_recfloor, (size_t)n_rec)) != VPZ_OK) return rc;
-        if ((rc = grow(ctx, D.b_finaly, sizeof(int16_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
-        if ((rc = grow(ctx, D.b_stepflags, 64 * (size_t)n_rec)) != VPZ_OK) return rc;
+        if ((rc = grow(ctx, D.b_curve, (size_t)n_rec * (size_t)(D.size1 / 2))) != VPZ_OK) return rc;
         VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_recfloor.p, rec_floor, (size_t)n_rec, hipMemcpyHostToDevice, ctx->stream));
-        hipError_t e = launch_floor1_unwrap((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(D.b_recfloor.p),
-                                            D.d_floors, static_cast<int16_t *>(D.b_finaly.p),
-                                            static_cast<uint8_t *>(D.b_stepflags.p), ctx->stream);
-        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor1 unwrap kernel launch", e);
+        hipError_t e = launch_floor1_prepare((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(D.b_recfloor.p),
+                                             D.d_floors, (int)D.floors.size(), D.size0 / 2, D.size1 / 2,
+                                             static_cast<uint8_t *>(D.b_curve.p), D.ablate, ctx->stream);
+        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor1 prepare kernel launch", e);
     }
 
     // ---------------- output placement
@@ -667,9 +667,8 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         float *d_y = static_cast<float *>(D.b_ybuf.p);
         hipError_t e = hipSuccess;
         if (any_floor)
-            e = launch_generic_floor(d_gf, (int)n_frames, C, d_temp, d_counts, static_cast<const int16_t *>(D.b_finaly.p),
-                                     static_cast<const uint8_t *>(D.b_stepflags.p),
-                                     static_cast<const uint8_t *>(D.b_recfloor.p), D.d_floors, ctx->d_inv_db, ctx->stream);
+            e = launch_generic_floor(d_gf, (int)n_frames, C, D.size1 / 2, d_temp, d_counts,
+                                     static_cast<const uint8_t *>(D.b_curve.p), ctx->d_inv_db, ctx->stream);
         if (e == hipSuccess && n0)
             e = launch_imdct_exact(D.size0, D.t0->ld, d_temp, d_y, (int64_t)n0, D.t0->d_A, D.t0->d_B, D.t0->d_C,
                                    D.t0->d_bitrev, ctx->num_cu, ctx->stream, d_src0, d_dst0);
@@ -702,10 +701,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     a.size1 = D.size1;
     a.spec = d_spec;
     a.post_counts = any_floor ? d_counts : nullptr;
-    a.final_y = any_floor ? static_cast<const int16_t *>(D.b_finaly.p) : nullptr;
-    a.step_flags = any_floor ? static_cast<const uint8_t *>(D.b_stepflags.p) : nullptr;
-    a.rec_floor = any_floor ? static_cast<const uint8_t *>(D.b_recfloor.p) : nullptr;
-    a.floors = D.d_floors;
+    a.curve_y = any_floor ? static_cast<const uint8_t *>(D.b_curve.p) : nullptr;
     a.inv_db = ctx->d_inv_db;
     a.state_h = D.d_state_h;
     a.tw_long = D.t1->d_fast;
