@@ -106,6 +106,13 @@ typedef struct vpz_floor1_config {        /* Floor1.cs:30-31 (`_xList`, `_multip
                                              _lNeigh/_hNeigh/_sortIdx as Floor1.cs:108-149 does */
 } vpz_floor1_config;
 
+typedef struct vpz_floor0_config {        /* Floor0.cs:29-35 (LSP floor, "virtually unused") */
+    int32_t order;                        /* _order, 1..255 */
+    int32_t rate;                         /* _rate */
+    int32_t bark_map_size;                /* _bark_map_size */
+    int32_t amp_bits, amp_ofs;            /* _ampBits, _ampOfs */
+} vpz_floor0_config;
+
 typedef struct vpz_mapping_config {       /* Mapping.cs:11-15 */
     int32_t coupling_steps;
     uint8_t coupling_magnitude[VPZ_MAX_COUPLING];
@@ -121,6 +128,10 @@ typedef struct vpz_stream_config {
     int32_t mapping_count;
     const vpz_mapping_config *mappings;
     int32_t clip_samples;                 /* StreamDecoder.ClipSamples (StreamDecoder.cs:993) */
+    /* floor types: NULL = every floor is type 1.  Otherwise floor_types[i] in {0, 1} for each of the
+     * floor_count floors; floors[i] is read for type 1 and floors0[i] for type 0 (same index). */
+    const uint8_t *floor_types;
+    const vpz_floor0_config *floors0;
 } vpz_stream_config;
 
 /* One audio packet as the CPU stage leaves it at Mapping.cs:163. */
@@ -177,6 +188,14 @@ int vpz_decoder_synth(vpz_decoder *dec, int64_t n_packets, const vpz_packet *pac
                       float *pcm_out, const int64_t *stream_out_offset, int64_t stream_out_capacity,
                       int out_layout, int64_t channel_stride,
                       int64_t *samples_written);
+
+/* Floor 0 data of the NEXT vpz_decoder_synth call (Floor0.Data after Unpack, Floor0.cs:113-162), for the
+ * channel records whose floor is type 0: amp[rec] = Data.Amp (0 => ExecuteChannel false; the caller also
+ * sets post_counts[rec] = Amp != 0), coeff[rec*coeff_stride + j] = Data.Coeff[j], j < order.  Pointers
+ * live in `mem_space` like the other inputs of that call and are consumed by it.  Where the reference
+ * indexes its w map out of range (bark_map_size > blocksize/2, Floor0.cs:99-109,185-190 -- it throws) the
+ * value 2*cos(pi*k/bark_map_size) is computed instead. */
+int vpz_decoder_set_floor0_data(vpz_decoder *dec, const float *amp, const float *coeff, int32_t coeff_stride);
 
 /* Samples per channel each packet of the LAST vpz_decoder_synth call contributed, in packet order
  * (what one `Read` of the reference returns for that packet: it hands out at most one packet's worth per

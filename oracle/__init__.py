@@ -34,6 +34,11 @@ class PacketInfo(C.Structure):
         return self.RightStart - self.LeftStart
 
 
+class Floor0(C.Structure):
+    _fields_ = [("order", C.c_int), ("rate", C.c_int), ("bark_map_size", C.c_int), ("amp_bits", C.c_int),
+                ("amp_ofs", C.c_int)]
+
+
 class Floor1(C.Structure):
     _fields_ = [("count", C.c_int), ("multiplier", C.c_int), ("range", C.c_int),
                 ("xlist", C.c_int * 65), ("lneigh", C.c_int * 65), ("hneigh", C.c_int * 65),
@@ -70,6 +75,10 @@ def lib():
         L.orc_floor1_render.restype = None
         L.orc_floor1_inverse_db_table.argtypes = []
         L.orc_floor1_inverse_db_table.restype = f32p
+        L.orc_floor0_apply.argtypes = [C.POINTER(Floor0), f32p, C.c_float, C.c_int, f32p]
+        L.orc_floor0_apply.restype = C.c_int
+        L.orc_floor0_bark_map.argtypes = [C.POINTER(Floor0), C.c_int, i32p]
+        L.orc_floor0_bark_map.restype = None
         L.orc_clip_value.argtypes = [C.c_float, i32p]
         L.orc_clip_value.restype = C.c_float
         L.orc_mapping_synth.argtypes = [C.c_int, C.c_int, f32p, C.c_int, C.POINTER(Floor1), i32p,
@@ -129,6 +138,24 @@ def apply_coupling(mag, ang, vector_form=True):
     ang = np.array(ang, dtype=np.float32)
     lib().orc_apply_coupling(_fp(mag), _fp(ang), mag.size, int(vector_form))
     return mag, ang
+
+
+def floor0_apply(order, rate, bark_map_size, amp_bits, amp_ofs, coeff, amp, block_size, residue):
+    """Floor0.Apply (Floor0.cs:164-225); returns the multiplied residue, raises where the reference throws."""
+    f = Floor0(order, rate, bark_map_size, amp_bits, amp_ofs)
+    c = np.array(coeff, dtype=np.float32)
+    r = np.array(residue, dtype=np.float32)
+    rc = lib().orc_floor0_apply(C.byref(f), _fp(c), float(amp), block_size, _fp(r))
+    if rc != 0:
+        raise IndexError("Floor0.Apply indexes its w map out of range (bark_map_size > blockSize/2)")
+    return r
+
+
+def floor0_bark_map(order, rate, bark_map_size, n):
+    f = Floor0(order, rate, bark_map_size, 0, 0)
+    m = np.zeros(n + 1, dtype=np.int32)
+    lib().orc_floor0_bark_map(C.byref(f), n, m.ctypes.data_as(C.POINTER(C.c_int)))
+    return m
 
 
 def inverse_db_table():

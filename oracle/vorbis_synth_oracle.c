@@ -685,6 +685,64 @@ void orc_floor1_apply(const orc_floor1 *f, int *posts, int post_count, int block
     }
 }
 
+/* ------------------------------------------------------------------ Floor0.cs */
+static float to_bark(double lsp) /* :97-100 */
+{
+    return (float)(13.1 * atan(0.00074 * lsp) + 2.24 * atan(0.0000000185 * lsp * lsp) + .0001 * lsp);
+}
+
+void orc_floor0_bark_map(const orc_floor0 *f, int n, int *map) /* :82-95 */
+{
+    float scale = (float)f->bark_map_size / to_bark(f->rate / 2.0);
+    int i;
+    for (i = 0; i < n + 1; ++i) map[i] = 0;
+    for (i = 0; i < n + 1 - 2; ++i) {
+        int v = (int)floor((double)(to_bark((f->rate / 2.0) / n * i) * scale));
+        map[i] = v < f->bark_map_size - 1 ? v : f->bark_map_size - 1;
+    }
+    map[n] = -1;
+}
+
+int orc_floor0_apply(const orc_floor0 *f, float *coeff, float amp, int block_size, float *residue) /* :164-225 */
+{
+    int n = block_size / 2;
+    int *bark = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    float wdel = (float)(3.14159265358979323846 / f->bark_map_size); /* (float)(Math.PI / _bark_map_size) */
+    float amp_ofs = (float)f->amp_ofs;
+    int i = 0, j, rc = 0;
+    if (amp <= 0.0f) {
+        memset(residue, 0, sizeof(float) * (size_t)n);
+        free(bark);
+        return 0;
+    }
+    orc_floor0_bark_map(f, n, bark);
+    for (j = 0; j < f->order; ++j) coeff[j] = 2.0f * cosf(coeff[j]);
+    while (i < n) {
+        int k = bark[i];
+        float p = .5f, q = .5f, w;
+        if (k < 0 || k >= n) { rc = -1; break; } /* wMap has n entries (:102) */
+        w = 2.0f * cosf(wdel * (float)k);     /* wMap[k], :106 */
+        for (j = 1; j < f->order; j += 2) {
+            q *= w - coeff[j - 1];
+            p *= w - coeff[j];
+        }
+        if (j == f->order) {
+            q *= w - coeff[j - 1];
+            p *= p * (4.0f - w * w);
+            q *= q;
+        } else {
+            p *= p * (2.0f - w);
+            q *= q * (2.0f + w);
+        }
+        q = amp / sqrtf(p + q) - amp_ofs;
+        q = expf(q * 0.11512925f);
+        residue[i] *= q;
+        while (bark[++i] == k) residue[i] *= q;
+    }
+    free(bark);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ Utils.cs:9-10,44-58 */
 float orc_clip_value(float value, int *clipped)
 {

@@ -77,6 +77,20 @@ void orc_floor1_render(const orc_floor1 *f, const int *final_y, const uint8_t *s
                        int post_count, int n, float *residue);
 const float *orc_floor1_inverse_db_table(void);
 
+/* ---- Floor0.cs (LSP floor; "virtually unused", no fixture) ----
+ * ctor tables :82-111 (bark map per block size, w map) and Apply :164-225.  coeff[order] and amp are
+ * what Unpack (:113-162) leaves in Floor0.Data.  Two reference quirks are kept: the bark map leaves bin
+ * n-1 at 0 (:88-93 loop bound), and the w map is indexed by the BARK value but sized by the block
+ * (:99-109), so the reference throws when bark_map_size > n/2 -- the oracle then returns -1. */
+typedef struct orc_floor0 {
+    int order, rate, bark_map_size, amp_bits, amp_ofs;
+} orc_floor0;
+/* residue[0..block_size/2) *= curve; mutates coeff (coeff[j] = 2 cos(coeff[j]), :181-184).
+ * returns 0, or -1 where the reference would throw IndexOutOfRangeException */
+int orc_floor0_apply(const orc_floor0 *f, float *coeff, float amp, int block_size, float *residue);
+/* the bark map of :82-95 for n = block_size/2 (n+1 entries) */
+void orc_floor0_bark_map(const orc_floor0 *f, int n, int *map);
+
 /* ---- Utils.cs:44-58 ---- */
 float orc_clip_value(float v, int *clipped);
 

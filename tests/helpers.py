@@ -39,7 +39,7 @@ def oracle_decode(orc, channels, size0, size1, packets, floors=(), mappings=(), 
     ABI), posts (np [channels, <=64]), post_count (np [channels]).  Returns PCM [channels, T] or [T, channels]."""
     L = orc.lib()
     st = L.orc_stream_create(channels, size0, size1)
-    ofl = [orc.floor1_init(xl, mult) for (xl, mult) in floors]
+    ofl = [orc.floor1_init(*f) if not isinstance(f, dict) else None for f in floors]
     chunks = []
     mismatches = []
     eos_seen = False
@@ -80,6 +80,26 @@ def oracle_decode(orc, channels, size0, size1, packets, floors=(), mappings=(), 
             res = res.reshape(channels, half)
         if flags & PKT_NO_FLOOR:
             pcm = np.stack([orc.mdct_reverse(res[c][None, :], n)[0] for c in range(channels)])
+        elif any(isinstance(f, dict) for f in floors):
+            # mixed floor types: Mapping.cs:166-195 step by step (type-0 floors: Floor0.cs:164-225)
+            m = mappings[pk.get("mapping", 0)]
+            res = res.copy()
+            for mag, ang in reversed(m.get("coupling", [])):
+                res[mag], res[ang] = orc.apply_coupling(res[mag], res[ang])
+            pcm = np.zeros((channels, n), dtype=np.float32)
+            for c in range(channels):
+                fl = floors[m.get("channel_floor", [0] * channels)[c]]
+                if isinstance(fl, dict):
+                    amp = float(pk["f0_amp"][c])
+                    if amp == 0:
+                        continue  # ExecuteChannel false (Floor0.cs:22)
+                    spec = orc.floor0_apply(fl["order"], fl["rate"], fl["bark_map_size"], fl["amp_bits"], fl["amp_ofs"],
+                                            pk["f0_coeff"][c][:fl["order"]], amp, n, res[c])
+                else:
+                    if pk["post_count"][c] == 0:
+                        continue
+                    spec = orc.floor1_apply(orc.floor1_init(*fl), pk["posts"][c], int(pk["post_count"][c]), n, res[c])
+                pcm[c] = orc.mdct_reverse(spec[None, :], n)[0]
         else:
             m = mappings[pk.get("mapping", 0)]
             pcm = orc.mapping_synth(channels, n, res, ofl, m.get("channel_floor", [0] * channels),

@@ -289,7 +289,7 @@ def random_xlist(rng, half, posts):
     return [0, half] + [int(v) for v in inner]
 
 
-@pytest.mark.parametrize("size0,size1", [(64, 64), (64, 512), (128, 1024), (256, 256), (512, 4096), (1024, 8192),
+@pytest.mark.parametrize("size0,size1", [(2048, 2048), (64, 64), (64, 512), (128, 1024), (256, 256), (512, 4096), (1024, 8192),
                                          (2048, 8192), (256, 4096)])
 def test_any_block_size_pair_decodes(ctx, oracle, size0, size1):
     """Block sizes other than 256/2048 take the three-pass path (floor, exact IMDCT, OLA).  Its IMDCT is
@@ -342,3 +342,74 @@ def test_any_block_size_pair_decodes(ctx, oracle, size0, size1):
         assert np.abs(got - ref).max() <= TOL * scale
         assert dec.position(0) == pos
         dec.close()
+
+
+def floor0_safe_amp(coeff, bark_map_size, amp_ofs):
+    """Largest amp for which Floor0's curve stays <= 0 dB: amp_ofs * min_k sqrt(p(k) + q(k))."""
+    c = 2.0 * np.cos(coeff.astype(np.float64))
+    w = 2.0 * np.cos(np.pi / bark_map_size * np.arange(bark_map_size))
+    p = np.full_like(w, 0.5)
+    q = np.full_like(w, 0.5)
+    order = len(c)
+    j = 1
+    while j < order:
+        q *= w - c[j - 1]
+        p *= w - c[j]
+        j += 2
+    if j == order:
+        q *= w - c[j - 1]
+        p *= p * (4.0 - w * w)
+        q *= q
+    else:
+        p *= p * (2.0 - w)
+        q *= q * (2.0 + w)
+    return float(amp_ofs * np.sqrt(np.maximum(p + q, 1e-30)).min())
+
+
+@pytest.mark.parametrize("size0,size1,order,bark", [(2048, 2048, 8, 256), (256, 2048, 9, 64), (512, 1024, 16, 128)])
+def test_floor0_matches_oracle(ctx, oracle, size0, size1, order, bark):
+    """Type-0 (LSP) floor, Floor0.cs:164-225: channel 0 uses a floor 0, channel 1 a floor 1, coupled.
+    cosf / sqrtf / expf are the device library's, so the bar is relative (1e-5 of the signal)."""
+    from vorbispizza_amd import Decoder, make_packets
+    rng = np.random.default_rng(order)
+    channels, frames = 2, 12
+    bf = (rng.random(frames) < 0.6).astype(np.uint8) if size0 != size1 else np.zeros(frames, dtype=np.uint8)
+    prev = np.concatenate([[1], bf[:-1]])
+    nxt = np.concatenate([bf[1:], [1]])
+    flags = (bf * PKT_BLOCK_FLAG | prev * PKT_PREV_FLAG * bf | nxt * PKT_NEXT_FLAG * bf).astype(np.uint8)
+    h0, h1 = size0 // 2, size1 // 2
+    f0 = {"order": order, "rate": 44100, "bark_map_size": bark, "amp_bits": 6, "amp_ofs": 100}
+    floors = [f0, (random_xlist(rng, h0, 11), 2), (random_xlist(rng, h1, 19), 2)]
+    mappings = [{"coupling": [(0, 1)], "channel_floor": [0, 1]}, {"coupling": [(0, 1)], "channel_floor": [0, 2]}]
+    opk, amps, coeffs = [], [], []
+    for f in range(frames):
+        half = h1 if bf[f] else h0
+        xl, mult = floors[2 if bf[f] else 1]
+        res = (rng.standard_normal((channels, half)) * 3).round().astype(np.float32)
+        posts, counts = helpers.random_posts(rng, xl, mult, channels)
+        # LSP frequencies in (0, pi), increasing; amplitude like Unpack computes it: amp * ampOfs / (2^bits - 1)
+        coeff = np.zeros((channels, 32), dtype=np.float32)
+        coeff[0, :order] = np.sort(rng.uniform(0.05, 3.0, order))
+        # an amplitude that keeps the curve in a sane dB range: amp / sqrt(p+q) - ampOfs <= 0 everywhere
+        amp0 = floor0_safe_amp(coeff[0, :order], bark, 100.0) * rng.uniform(0.3, 1.0) if f != 3 else 0.0  # frame 3 silent
+        amp = np.array([np.float32(amp0), 0], dtype=np.float32)
+        counts[0] = 1 if amp[0] != 0 else 0                            # ExecuteChannel of the floor-0 channel
+        opk.append({"flags": int(flags[f]), "mapping": int(bf[f]), "residue": res.reshape(-1).copy(), "posts": posts,
+                    "post_count": counts, "granule": -1, "f0_amp": amp, "f0_coeff": coeff})
+        amps.append(amp)
+        coeffs.append(coeff)
+    pk = make_packets(frames)
+    off = 0
+    for f, p in enumerate(opk):
+        pk[f]["flags"], pk[f]["mapping"], pk[f]["granule"], pk[f]["residue_offset"] = p["flags"], p["mapping"], -1, off
+        off += p["residue"].size
+    res = np.concatenate([p["residue"] for p in opk])
+    posts = np.concatenate([p["posts"] for p in opk]).astype(np.int16)
+    counts = np.concatenate([p["post_count"] for p in opk]).astype(np.uint8)
+    ref, pos, _ = helpers.oracle_decode(oracle, channels, size0, size1, opk, floors=floors, mappings=mappings)
+    dec = Decoder(ctx, channels, size0, size1, floors=floors, mappings=mappings)
+    dec.set_floor0_data(np.concatenate(amps), np.concatenate(coeffs))
+    got = dec.synth(pk, res, posts, counts)[0]
+    assert got.shape == ref.shape and np.isfinite(ref).all()
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+    dec.close()

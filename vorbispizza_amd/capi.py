@@ -25,6 +25,11 @@ class Floor1Config(C.Structure):
     _fields_ = [("x_count", C.c_int32), ("multiplier", C.c_int32), ("x_list", C.c_int32 * MAX_FLOOR1_POSTS)]
 
 
+class Floor0Config(C.Structure):
+    _fields_ = [("order", C.c_int32), ("rate", C.c_int32), ("bark_map_size", C.c_int32), ("amp_bits", C.c_int32),
+                ("amp_ofs", C.c_int32)]
+
+
 class MappingConfig(C.Structure):
     _fields_ = [("coupling_steps", C.c_int32),
                 ("coupling_magnitude", C.c_uint8 * MAX_COUPLING),
@@ -36,7 +41,8 @@ class StreamConfig(C.Structure):
     _fields_ = [("channels", C.c_int32), ("block_size0", C.c_int32), ("block_size1", C.c_int32),
                 ("floor_count", C.c_int32), ("floors", C.POINTER(Floor1Config)),
                 ("mapping_count", C.c_int32), ("mappings", C.POINTER(MappingConfig)),
-                ("clip_samples", C.c_int32)]
+                ("clip_samples", C.c_int32),
+                ("floor_types", C.POINTER(C.c_uint8)), ("floors0", C.POINTER(Floor0Config))]
 
 
 class Packet(C.Structure):
@@ -71,6 +77,7 @@ _SIGNATURES = [
     ("vpz_decoder_reset", C.c_int, [_vp, C.c_int32]),
     ("vpz_decoder_synth", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int64,
                                     C.c_int, C.c_int64, _vp]),
+    ("vpz_decoder_set_floor0_data", C.c_int, [_vp, _vp, _vp, C.c_int32]),
     ("vpz_decoder_last_packet_samples", C.c_int, [_vp, _vp, C.c_int64]),
     ("vpz_decoder_has_clipped", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int32)]),
     ("vpz_decoder_position", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64)]),
@@ -143,6 +150,7 @@ class Context:
             self._h = None
             raise SynthError(rc, "vpz_context_create(device=%d)" % device)
         self.device = device
+        self._children = []  # weak references to decoders: they must be destroyed before the context
 
     def _check(self, rc):
         if rc != OK:
@@ -150,6 +158,11 @@ class Context:
 
     def close(self):
         if self._h:
+            for ref in self._children:
+                child = ref()
+                if child is not None:
+                    child.close()
+            self._children = []
             lib().vpz_context_destroy(self._h)
             self._h = None
 
@@ -204,11 +217,20 @@ class Decoder:
 
     def __init__(self, ctx, channels, block_size0, block_size1, floors=(), mappings=(), n_streams=1,
                  clip_samples=False):
-        """floors: [(x_list, multiplier)], mappings: [{"coupling": [(mag, ang)], "channel_floor": [..]}]"""
+        """floors: [(x_list, multiplier)] for a type-1 floor or {"order":, "rate":, "bark_map_size":, "amp_bits":,
+        "amp_ofs":} for a type-0 floor; mappings: [{"coupling": [(mag, ang)], "channel_floor": [..]}]"""
         self.ctx = ctx
         self.channels, self.size0, self.size1, self.n_streams = channels, block_size0, block_size1, n_streams
         fl = (Floor1Config * max(1, len(floors)))()
-        for i, (xl, mult) in enumerate(floors):
+        ftypes = (C.c_uint8 * max(1, len(floors)))()
+        fl0 = (Floor0Config * max(1, len(floors)))()
+        for i, f in enumerate(floors):
+            if isinstance(f, dict):
+                ftypes[i] = 0
+                fl0[i] = Floor0Config(f["order"], f["rate"], f["bark_map_size"], f["amp_bits"], f["amp_ofs"])
+                continue
+            ftypes[i] = 1
+            xl, mult = f
             if len(xl) > MAX_FLOOR1_POSTS:
                 raise SynthError(E_INVALID_ARG, "floor1 X list too long")
             fl[i].x_count = len(xl)
@@ -225,17 +247,19 @@ class Decoder:
             for c, f in enumerate(m.get("channel_floor", [0] * channels)):
                 mp[i].channel_floor[c] = f
         cfg = StreamConfig(channels, block_size0, block_size1, len(floors), fl, len(mappings), mp,
-                           1 if clip_samples else 0)
+                           1 if clip_samples else 0, ftypes, fl0)
         self._h = _vp()
         rc = lib().vpz_decoder_create(ctx._h, C.byref(cfg), n_streams, C.byref(self._h))
         if rc != OK:
             self._h = None
             raise SynthError(rc, lib().vpz_context_last_error(ctx._h).decode())
+        import weakref
+        ctx._children.append(weakref.ref(self))
 
     def close(self):
-        if self._h:
+        if self._h and self.ctx._h:
             lib().vpz_decoder_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
@@ -286,6 +310,12 @@ class Decoder:
             else:
                 res.append(blk[: written[s] * C_].reshape(written[s], C_).copy())
         return res
+
+    def set_floor0_data(self, amp, coeff):
+        """amp [records], coeff [records, stride] (numpy, host memory) for the next synth call."""
+        self._f0 = (np.ascontiguousarray(amp, dtype=np.float32), np.ascontiguousarray(coeff, dtype=np.float32))
+        self.ctx._check(lib().vpz_decoder_set_floor0_data(self._h, _ptr(self._f0[0]), _ptr(self._f0[1]),
+                                                          self._f0[1].shape[1]))
 
     def last_packet_samples(self, n_packets):
         out = np.zeros(n_packets, dtype=np.int32)

@@ -250,7 +250,7 @@ __device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int
 //   phase 2: for each of the 64 records the whole wavefront renders the curve (Floor1.cs:236-262,
 //            372-397) as one table index per bin -> curve_y[rec][bin] (uint8).
 // The synthesis kernels then only look the indices up in the inverse dB table and multiply.
-// rec_info[rec]: floor index in bits 0..6, bit 7 = long block.
+// rec_info[rec]: floor index in bits 0..5, bit 6 = type-0 floor (handled by floor0.hip), bit 7 = long block.
 // ---------------------------------------------------------------------------------------------
 constexpr int kPrepWaves = 8;
 constexpr int kPrepFloorsInLds = 8;
@@ -290,9 +290,9 @@ __global__ __launch_bounds__(64 * kPrepWaves) void floor1_prepare_kernel(int n_r
     if (wave == 0 && !(ablate & 16)) {  // phase 1: one lane per record
         const int rec = blockIdx.x * 64 + lane;
         bool have = false;
-        if (rec < n_rec && post_counts[rec] != 0) {
+        if (rec < n_rec && post_counts[rec] != 0 && !(rec_info[rec] & 0x40)) {  // bit 6: type-0 floor, not ours
             have = true;
-            const FloorDev &f = floors[rec_info[rec] & 0x7F];
+            const FloorDev &f = floors[rec_info[rec] & 0x3F];
             const int pc = f.x_count;  // Unpack leaves PostCount == xList.Length or 0 (Floor1.cs:173-218)
             const int16_t *p = s_posts[lane];
             for (int i = 0; i < 64; ++i) s_f[i][lane] = 0;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * kPrepWaves) void floor1_prepare_kernel(int n_r
         if (!s_have[r] || (ablate & 32)) continue;
         const int rr = blockIdx.x * 64 + r;
         const uint8_t info = rec_info[rr];
-        const FloorDev &f = floors[info & 0x7F];
+        const FloorDev &f = floors[info & 0x3F];
         const int n = (info & 0x80) ? half1 : half0;
         uint8_t *row = curve_y + (size_t)rr * half1;
         if (n <= 1024) render_floor_indices<32>(row, s_aux[wave], n, f, &s_y[0][r], &s_f[0][r], 65, lane);
@@ -479,6 +479,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     auto exec_of = [&](uint32_t flags, int rec) -> bool {
         return a.post_counts == nullptr || (flags & kFrameNoFloor) || a.post_counts[rec + ch] != 0;
     };
+    // which transform a frame takes depends on its block SIZE, not on its flag (size0 may be 2048 too)
+    auto is_2048 = [&](uint32_t flags) -> bool { return ((flags & kFrameLong) ? a.size1 : a.size0) == 2048; };
     auto spectrum_of = [&](const FrameDesc &fd) -> const float * {
         const int hh = (fd.flags & kFrameLong) ? (a.size1 >> 1) : (a.size0 >> 1);
         return a.spec + fd.spec_off + (int64_t)ch * hh;
@@ -523,9 +525,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     uint32_t fycur[8];
     FrameDesc fd_next = frame_at(fi0);
     if (!(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec)) {
-        load_spectrum(xcur, spectrum_of(fd_next), fd_next.flags & kFrameLong, lane);
+        load_spectrum(xcur, spectrum_of(fd_next), is_2048(fd_next.flags), lane);
         if (kHasFloor && !(fd_next.flags & kFrameNoFloor))
-            load_floor_indices(fycur, a.curve_y + (size_t)(fd_next.rec + ch) * half1, fd_next.flags & kFrameLong, lane);
+            load_floor_indices(fycur, a.curve_y + (size_t)(fd_next.rec + ch) * half1, is_2048(fd_next.flags), lane);
     }
     for (int fi = fi0; fi < run.count; ++fi) {
         const FrameDesc fd = fd_next;
@@ -534,15 +536,15 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         if (fi + 1 < run.count) {
             fd_next = frame_at(fi + 1);
             if (!(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec) && !(a.ablate & 4)) {
-                load_spectrum(xnext, spectrum_of(fd_next), fd_next.flags & kFrameLong, lane);
+                load_spectrum(xnext, spectrum_of(fd_next), is_2048(fd_next.flags), lane);
                 if (kHasFloor && !(fd_next.flags & kFrameNoFloor))
                     load_floor_indices(fynext, a.curve_y + (size_t)(fd_next.rec + ch) * half1,
-                                       fd_next.flags & kFrameLong, lane);
+                                       is_2048(fd_next.flags), lane);
             }
         }
         const bool drain = fd.flags & kFrameDrain;
-        const bool is_long = fd.flags & kFrameLong;
-        const int n4 = is_long ? (a.size1 >> 2) : (a.size0 >> 2);
+        const bool is_long = is_2048(fd.flags);  // "long" below means: the 2048-point transform
+        const int n4 = is_long ? 512 : 64;
         if (!drain) {
             if (!exec_of(fd.flags, fd.rec)) {
                 // Mapping.cs:190-194: the channel is silent, its whole block is zero
@@ -569,7 +571,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 
         if (fi >= 0 && fd.out_count > 0 && !(a.ablate & 1)) {
             // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 573-591)
-            const float *slope = (fd.flags & kFrameSlope1) ? s_slope1 : s_slope0;
+            // equal block sizes share one slope table (s_slope0 only holds a 128-entry short slope)
+            const float *slope = ((fd.flags & kFrameSlope1) || a.size0 == a.size1) ? s_slope1 : s_slope0;
             const int plen = fd.packet_len;
             float *dst = a.interleaved ? out_base + fd.out_off * a.channels + ch
                                        : out_base + (int64_t)ch * a.channel_stride + fd.out_off;

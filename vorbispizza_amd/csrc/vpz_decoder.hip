@@ -29,6 +29,13 @@ hipError_t launch_generic_ola(const GenericFrame *frames, int n_frames, int chan
                               int32_t *clipped, hipStream_t stream);
 hipError_t launch_generic_save_state(const GenericFrame *frames, const int32_t *save_list, int n_save, int channels,
                                      int size1, const float *ybuf, float *state_y, hipStream_t stream);
+hipError_t launch_floor0_apply(const void *recs, int n_recs, const void *floors, const int32_t *bark_maps,
+                               const float *amp, const float *coeff, int coeff_stride, float *spec,
+                               uint8_t *curve_y, int half1, hipStream_t stream);
+size_t floor0_dev_size();
+size_t floor0_rec_size();
+void fill_floor0_dev(void *dst, int order, int bark_map_size, int amp_ofs, int64_t off_short, int64_t off_long);
+void fill_floor0_rec(void *dst, int64_t spec_off, int rec, int floor, int half, int is_long);
 size_t coupling_packet_size();
 void fill_coupling_packet(void *dst, int64_t src_off, int64_t dst_off, int32_t half, int32_t steps_off,
                           int32_t steps, int32_t interleaved);
@@ -81,6 +88,14 @@ struct Decoder {
     DevBuf b_in_res, b_in_posts, b_in_counts, b_out;  // VPZ_MEM_HOST staging
     DevBuf b_gframes, b_glists, b_ybuf;               // any-block-size path
     bool generic = false;  // block sizes other than 256 / 2048: three-pass path (synth_kernels.hip)
+    // type-0 floors (Floor0.cs)
+    std::vector<uint8_t> floor_types;
+    std::vector<vpz_floor0_config> floors0;
+    void *d_floors0 = nullptr;
+    int32_t *d_bark_maps = nullptr;
+    DevBuf b_f0recs, b_in_amp, b_in_coeff;
+    const float *f0_amp = nullptr, *f0_coeff = nullptr;
+    int32_t f0_stride = 0;
     int run_length_override = 0;
     int ablate = 0;  // VPZ_SYNTH_ABLATE, tuning experiments only
     std::vector<int32_t> packet_samples;  // per packet of the last synth call
@@ -201,8 +216,8 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     for (int bs : {cfg->block_size0, cfg->block_size1})
         if (bs < 64 || bs > 8192 || (bs & (bs - 1)) != 0)
             return set_error(ctx, VPZ_E_UNSUPPORTED, "vpz_decoder_create: block sizes must be powers of two in [64, 8192]");
-    if (cfg->floor_count < 0 || cfg->mapping_count < 0 || (cfg->floor_count && !cfg->floors) ||
-        (cfg->mapping_count && !cfg->mappings) || cfg->mapping_count > 256 || cfg->floor_count > 256)
+    if (cfg->floor_count < 0 || cfg->mapping_count < 0 || (cfg->floor_count && !cfg->floors && !cfg->floor_types) ||
+        (cfg->mapping_count && !cfg->mappings) || cfg->mapping_count > 256 || cfg->floor_count > 64)
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_create: bad floor / mapping tables");
     VPZ_HIP_TRY(ctx, hipSetDevice(ctx->device));
 
@@ -217,14 +232,31 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     D.n_streams = n_streams;
     D.generic = !(supported_size(cfg->block_size0) && supported_size(cfg->block_size1));
     D.states.assign(n_streams, StreamState());
-    D.floors.assign(cfg->floors, cfg->floors + cfg->floor_count);
+    D.floors.assign((size_t)cfg->floor_count, vpz_floor1_config{});
+    D.floor_types.assign((size_t)cfg->floor_count, 1);
+    D.floors0.assign((size_t)cfg->floor_count, vpz_floor0_config{});
+    for (int i = 0; i < cfg->floor_count; ++i) {
+        if (cfg->floor_types) D.floor_types[i] = cfg->floor_types[i];
+        if (D.floor_types[i] == 1 && cfg->floors) D.floors[i] = cfg->floors[i];
+        if (D.floor_types[i] == 0 && cfg->floors0) D.floors0[i] = cfg->floors0[i];
+    }
     D.mappings.assign(cfg->mappings, cfg->mappings + cfg->mapping_count);
     if (const char *e = getenv("VPZ_RUN_LENGTH")) D.run_length_override = atoi(e);
     if (const char *e = getenv("VPZ_SYNTH_ABLATE")) D.ablate = atoi(e);
 
     int rc = VPZ_OK;
     std::vector<FloorDev> fdev(std::max<size_t>(1, D.floors.size()));
-    for (size_t i = 0; i < D.floors.size() && rc == VPZ_OK; ++i) rc = build_floor(D.floors[i], &fdev[i]);
+    for (size_t i = 0; i < D.floors.size() && rc == VPZ_OK; ++i) {
+        if (D.floor_types[i] == 1) {
+            rc = build_floor(D.floors[i], &fdev[i]);
+        } else if (D.floor_types[i] == 0) {  // Floor0.cs:50-51
+            const vpz_floor0_config &f0 = D.floors0[i];
+            if (f0.order < 1 || f0.order > 255 || f0.rate < 1 || f0.bark_map_size < 1 || f0.amp_bits < 0 || f0.amp_bits > 63)
+                rc = VPZ_E_INVALID_ARG;
+        } else {
+            rc = VPZ_E_INVALID_ARG;
+        }
+    }
     std::vector<uint8_t> steps;
     for (size_t m = 0; m < D.mappings.size() && rc == VPZ_OK; ++m) {
         const vpz_mapping_config &mc = D.mappings[m];
@@ -262,6 +294,41 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     if (e == hipSuccess) e = hipMemset(D.d_clipped, 0, sizeof(int32_t) * (size_t)n_streams);
     if (e == hipSuccess) e = hipMalloc((void **)&D.d_steps, steps.size() ? steps.size() : 1);
     if (e == hipSuccess && !steps.empty()) e = hipMemcpy(D.d_steps, steps.data(), steps.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        // Floor0 ctor tables (Floor0.cs:82-95): one bark map per block size, n+1 ints, last bin left at 0
+        std::vector<int32_t> maps;
+        std::vector<char> devs(floor0_dev_size() * std::max<size_t>(1, D.floors0.size()), 0);
+        bool any0 = false;
+        for (size_t i = 0; i < D.floors0.size(); ++i) {
+            if (D.floor_types[i] != 0) continue;
+            any0 = true;
+            const vpz_floor0_config &f0 = D.floors0[i];
+            int64_t off[2];
+            const int halves[2] = {D.size0 / 2, D.size1 / 2};
+            for (int b = 0; b < 2; ++b) {
+                const int n = halves[b];
+                off[b] = (int64_t)maps.size();
+                auto to_bark = [](double lsp) -> float {
+                    return (float)(13.1 * atan(0.00074 * lsp) + 2.24 * atan(0.0000000185 * lsp * lsp) + .0001 * lsp);
+                };
+                const float scale = (float)f0.bark_map_size / to_bark(f0.rate / 2.0);
+                std::vector<int32_t> m((size_t)n + 1, 0);
+                for (int k = 0; k < n + 1 - 2; ++k) {
+                    const int v = (int)floor((double)(to_bark((f0.rate / 2.0) / n * k) * scale));
+                    m[k] = std::min(f0.bark_map_size - 1, v);
+                }
+                m[n] = -1;
+                maps.insert(maps.end(), m.begin(), m.end());
+            }
+            fill_floor0_dev(devs.data() + i * floor0_dev_size(), f0.order, f0.bark_map_size, f0.amp_ofs, off[0], off[1]);
+        }
+        if (any0) {
+            e = hipMalloc(&D.d_floors0, devs.size());
+            if (e == hipSuccess) e = hipMemcpy(D.d_floors0, devs.data(), devs.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void **)&D.d_bark_maps, sizeof(int32_t) * maps.size());
+            if (e == hipSuccess) e = hipMemcpy(D.d_bark_maps, maps.data(), sizeof(int32_t) * maps.size(), hipMemcpyHostToDevice);
+        }
+    }
     if (e != hipSuccess) {
         vpz_decoder_destroy(d);
         return set_error(ctx, VPZ_E_NOMEM, "vpz_decoder_create: device allocation", e);
@@ -278,7 +345,7 @@ void vpz_decoder_destroy(vpz_decoder *d)
         (void)hipSetDevice(D.ctx->device);
         (void)hipStreamSynchronize(D.ctx->stream);
     }
-    DevBuf *bufs[] = {&D.b_gframes, &D.b_glists, &D.b_ybuf, &D.b_frames, &D.b_runs, &D.b_recfloor, &D.b_curve, &D.b_cpk, &D.b_temp,
+    DevBuf *bufs[] = {&D.b_f0recs, &D.b_in_amp, &D.b_in_coeff, &D.b_gframes, &D.b_glists, &D.b_ybuf, &D.b_frames, &D.b_runs, &D.b_recfloor, &D.b_curve, &D.b_cpk, &D.b_temp,
                       &D.b_outoff, &D.b_in_res, &D.b_in_posts, &D.b_in_counts, &D.b_out};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -286,6 +353,8 @@ void vpz_decoder_destroy(vpz_decoder *d)
     if (D.d_state_h) (void)hipFree(D.d_state_h);
     if (D.d_clipped) (void)hipFree(D.d_clipped);
     if (D.d_steps) (void)hipFree(D.d_steps);
+    if (D.d_floors0) (void)hipFree(D.d_floors0);
+    if (D.d_bark_maps) (void)hipFree(D.d_bark_maps);
     if (D.arena.base) (void)hipHostFree(D.arena.base);
     if (D.arena.uploaded) (void)hipEventDestroy(D.arena.uploaded);
     delete d;
@@ -344,6 +413,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     std::vector<uint8_t> pkt_used((size_t)n_packets, 0);
     bool any_floor = false, need_coupling = D.generic;  // the generic path always works on its own planar copy
     int64_t mismatches = 0;
+    bool any_floor0 = false;
     int64_t temp_floats = 0;
     std::vector<int64_t> temp_off((size_t)n_packets, -1);
 
@@ -381,6 +451,8 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
                                  "vpz_decoder_synth: posts and a floor table are required unless VPZ_PKT_NO_FLOOR");
             any_floor = true;
             if (D.mappings[pk.mapping].coupling_steps > 0) need_coupling = true;
+            for (int ch = 0; ch < C && !any_floor0; ++ch)
+                if (D.floor_types[D.mappings[pk.mapping].channel_floor[ch]] == 0) any_floor0 = true;
         }
         if (pk.flags & VPZ_PKT_INTERLEAVED) need_coupling = true;
         if (pk.residue_offset < 0)
@@ -529,6 +601,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
 
     // ---------------- optional pass: de-interleave + inverse coupling into a planar temp
     const float *d_spec = d_res;
+    if (any_floor0) need_coupling = true;  // type-0 floors are applied in place on the planar temp
     if (need_coupling) {
         if ((rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK) return rc;
         const size_t cps = coupling_packet_size();
@@ -564,7 +637,9 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
             if (!pkt_used[(size_t)p] || (packets[p].flags & VPZ_PKT_NO_FLOOR)) continue;
             const vpz_mapping_config &mc = D.mappings[packets[p].mapping];
             const uint8_t long_bit = (packets[p].flags & VPZ_PKT_BLOCK_FLAG) ? 0x80 : 0;
-            for (int ch = 0; ch < C; ++ch) rec_floor[(size_t)(p * C + ch)] = (uint8_t)(mc.channel_floor[ch] | long_bit);
+            for (int ch = 0; ch < C; ++ch)
+                rec_floor[(size_t)(p * C + ch)] = (uint8_t)(mc.channel_floor[ch] | long_bit |
+                                                            (D.floor_types[mc.channel_floor[ch]] == 0 ? 0x40 : 0));
         }
         if ((rc = grow(ctx, D.b_recfloor, (size_t)n_rec)) != VPZ_OK) return rc;
         if ((rc = grow(ctx, D.b_curve, (size_t)n_rec * (size_t)(D.size1 / 2))) != VPZ_OK) return rc;
@@ -573,6 +648,49 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
                                              D.d_floors, (int)D.floors.size(), D.size0 / 2, D.size1 / 2,
                                              static_cast<uint8_t *>(D.b_curve.p), D.ablate, ctx->stream);
         if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor1 prepare kernel launch", e);
+    }
+
+    // ---------------- optional pass: Floor0.Apply in place on the temp (rare; Floor0.cs:164-225)
+    if (any_floor0) {
+        if (!D.f0_amp || !D.f0_coeff || D.f0_stride < 1)
+            return set_error(ctx, VPZ_E_INVALID_ARG,
+                             "vpz_decoder_synth: type-0 floors need vpz_decoder_set_floor0_data before the call");
+        const float *d_amp = D.f0_amp, *d_coeff = D.f0_coeff;
+        if (mem_space == VPZ_MEM_HOST) {
+            if ((rc = grow(ctx, D.b_in_amp, sizeof(float) * (size_t)n_rec)) != VPZ_OK) return rc;
+            if ((rc = grow(ctx, D.b_in_coeff, sizeof(float) * (size_t)n_rec * D.f0_stride)) != VPZ_OK) return rc;
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_amp.p, D.f0_amp, sizeof(float) * (size_t)n_rec, hipMemcpyHostToDevice, ctx->stream));
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_coeff.p, D.f0_coeff, sizeof(float) * (size_t)n_rec * D.f0_stride,
+                                            hipMemcpyHostToDevice, ctx->stream));
+            d_amp = static_cast<const float *>(D.b_in_amp.p);
+            d_coeff = static_cast<const float *>(D.b_in_coeff.p);
+        }
+        const size_t rs = floor0_rec_size();
+        std::vector<char> recs;
+        int n_f0 = 0;
+        for (size_t fi = 0; fi < n_frames; ++fi) {
+            const FrameDesc &fd = frames[fi];
+            if (fd.flags & (kFrameDrain | kFrameNoFloor)) continue;
+            const vpz_packet &pk = packets[fd.rec / C];
+            const vpz_mapping_config &mc = D.mappings[pk.mapping];
+            const int half = ((fd.flags & kFrameLong) ? D.size1 : D.size0) / 2;
+            for (int ch = 0; ch < C; ++ch) {
+                const int fl = mc.channel_floor[ch];
+                if (D.floor_types[fl] != 0) continue;
+                recs.resize(recs.size() + rs);
+                fill_floor0_rec(recs.data() + (size_t)n_f0 * rs, fd.spec_off + (int64_t)ch * half, fd.rec + ch, fl, half,
+                                (fd.flags & kFrameLong) ? 1 : 0);
+                ++n_f0;
+            }
+        }
+        if ((rc = grow(ctx, D.b_f0recs, recs.size())) != VPZ_OK) return rc;
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_f0recs.p, recs.data(), recs.size(), hipMemcpyHostToDevice, ctx->stream));
+        VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // recs is a local vector
+        hipError_t e = launch_floor0_apply(D.b_f0recs.p, n_f0, D.d_floors0, D.d_bark_maps, d_amp, d_coeff, D.f0_stride,
+                                           static_cast<float *>(D.b_temp.p), static_cast<uint8_t *>(D.b_curve.p),
+                                           D.size1 / 2, ctx->stream);
+        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor0 kernel launch", e);
+        D.f0_amp = D.f0_coeff = nullptr;  // consumed
     }
 
     // ---------------- output placement
@@ -741,6 +859,18 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         return set_error(ctx, VPZ_E_WINDOW_MISMATCH,
                          "vpz_decoder_synth: a packet's previous tail is longer than its window slope "
                          "(StreamDecoder.cs:777-778 throws); the packet was skipped, everything else was synthesised");
+    return VPZ_OK;
+}
+
+int vpz_decoder_set_floor0_data(vpz_decoder *d, const float *amp, const float *coeff, int32_t coeff_stride)
+{
+    if (!d) return VPZ_E_INVALID_ARG;
+    Decoder &D = d->impl;
+    if ((amp == nullptr) != (coeff == nullptr) || (amp && coeff_stride < 1))
+        return set_error(D.ctx, VPZ_E_INVALID_ARG, "vpz_decoder_set_floor0_data: bad arguments");
+    D.f0_amp = amp;
+    D.f0_coeff = coeff;
+    D.f0_stride = coeff_stride;
     return VPZ_OK;
 }
 
