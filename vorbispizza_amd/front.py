@@ -44,6 +44,15 @@ def lib():
         L.vpzh_get_info.restype = C.c_int
         L.vpzh_get_floor1.argtypes = [vp, C.c_int, C.POINTER(capi.Floor1Config)]
         L.vpzh_get_floor1.restype = C.c_int
+        L.vpzh_get_floor_type.argtypes = [vp, C.c_int]
+        L.vpzh_get_floor_type.restype = C.c_int
+        L.vpzh_get_floor0.argtypes = [vp, C.c_int, C.POINTER(capi.Floor0Config)]
+        L.vpzh_get_floor0.restype = C.c_int
+        L.vpzh_max_floor0_order.argtypes = [vp]
+        L.vpzh_max_floor0_order.restype = C.c_int
+        L.vpzh_decode_range_ex.argtypes = [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int64, vp, vp, vp, vp,
+                                           C.POINTER(C.c_int64), vp, vp, C.c_int32]
+        L.vpzh_decode_range_ex.restype = C.c_int
         L.vpzh_get_mapping.argtypes = [vp, C.c_int, C.POINTER(capi.MappingConfig)]
         L.vpzh_get_mapping.restype = C.c_int
         L.vpzh_get_residue_type.argtypes = [vp, C.c_int]
@@ -101,10 +110,18 @@ class OggVorbisFile:
         self.audio_packets, self.last_granule = info.audio_packets, info.last_granule
         self.floors, self.mappings = [], []
         for i in range(info.floor_count):
+            if lib().vpzh_get_floor_type(self._h, i) == 0:
+                f0 = capi.Floor0Config()
+                lib().vpzh_get_floor0(self._h, i, C.byref(f0))
+                self.floors.append({"order": f0.order, "rate": f0.rate, "bark_map_size": f0.bark_map_size,
+                                    "amp_bits": f0.amp_bits, "amp_ofs": f0.amp_ofs})
+                continue
             f = capi.Floor1Config()
             if lib().vpzh_get_floor1(self._h, i, C.byref(f)) != 0:
                 raise FrontError("floor %d cannot be represented" % i)
             self.floors.append((list(f.x_list[: f.x_count]), f.multiplier))
+        self.floor0_stride = lib().vpzh_max_floor0_order(self._h)
+        self.floor0_data = None  # (amp [records], coeff [records, stride]) of the last decode_packets call
         for i in range(info.mapping_count):
             m = capi.MappingConfig()
             lib().vpzh_get_mapping(self._h, i, C.byref(m))
@@ -132,8 +149,15 @@ class OggVorbisFile:
         residue = np.zeros(max(1, self.info.residue_floats), dtype=np.float32)
         posts = np.zeros((n * C_, 64), dtype=np.int16)
         counts = np.zeros(n * C_, dtype=np.uint8)
-        rc = lib().vpzh_decode_all(self._h, stream_id, residue_base, packets.ctypes.data, residue.ctypes.data,
-                                   posts.ctypes.data, counts.ctypes.data)
+        amp = coeff = None
+        if self.floor0_stride > 0:
+            amp = np.zeros(n * C_, dtype=np.float32)
+            coeff = np.zeros((n * C_, self.floor0_stride), dtype=np.float32)
+        rc = lib().vpzh_decode_range_ex(self._h, 0, n, stream_id, residue_base, packets.ctypes.data, residue.ctypes.data,
+                                        posts.ctypes.data, counts.ctypes.data, None,
+                                        None if amp is None else amp.ctypes.data,
+                                        None if coeff is None else coeff.ctypes.data, self.floor0_stride)
+        self.floor0_data = None if amp is None else (amp, coeff)
         if rc != 0:
             raise FrontError(lib().vpzh_last_error(self._h).decode())
         return packets, residue[: self.info.residue_floats], posts, counts

@@ -360,6 +360,54 @@ struct Floor1 {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Floor0.cs:37-80 (header) and :113-162 (Unpack)
+// ---------------------------------------------------------------------------------------------
+struct Floor0 {
+    int order = 0, rate = 0, bark_map_size = 0, amp_bits = 0, amp_ofs = 0;
+    std::vector<uint8_t> book_list;
+
+    void read(BitReader &p, const std::vector<Codebook> &cbs)
+    {
+        order = (int)p.read_bits(8);
+        rate = (int)p.read_bits(16);
+        bark_map_size = (int)p.read_bits(16);
+        amp_bits = (int)p.read_bits(6);
+        amp_ofs = (int)p.read_bits(8);
+        book_list.resize((size_t)p.read_bits(4) + 1);
+        if (order < 1 || rate < 1 || bark_map_size < 1) throw InvalidData("invalid floor0 header");
+        for (auto &b : book_list) {
+            b = (uint8_t)p.read_bits(8);
+            if (b >= cbs.size() || cbs[b].map_type == 0 || cbs[b].dimensions < 1) throw InvalidData("invalid floor0 book");
+        }
+    }
+
+    // returns Data.Amp; coeff[order] = Data.Coeff
+    float unpack(BitReader &p, const std::vector<Codebook> &cbs, float *coeff) const
+    {
+        for (int i = 0; i < order; ++i) coeff[i] = 0.f;
+        const uint64_t amp_raw = p.read_bits(amp_bits);
+        const double amp_div = (double)((1 << amp_bits) - 1);
+        float amp = (float)((double)(amp_raw * (uint64_t)amp_ofs) / amp_div);  // (float)(amp * _ampOfs / ampDiv)
+        const uint32_t book_num = (uint32_t)p.read_bits(ilog((int)book_list.size()));
+        if (book_num >= book_list.size()) return 0.f;
+        const Codebook &book = cbs[book_list[book_num]];
+        for (int i = 0; i < order;) {
+            const int entry = book.decode_scalar(p);
+            if (entry == -1) return 0.f;
+            const float *lk = &book.lookup[(size_t)entry * book.dimensions];
+            for (int j = 0; i < order && j < book.dimensions; ++j, ++i) coeff[i] = lk[j];
+        }
+        const int dim = book.dimensions;
+        float last = 0.f;
+        for (int j = 0; j < order;) {
+            for (int k = 0; j < order && k < dim; ++j, ++k) coeff[j] += last;
+            last = coeff[j - 1];
+        }
+        return amp;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Residue0.cs / Residue1.cs / Residue2.cs
 // ---------------------------------------------------------------------------------------------
 struct Residue {
@@ -571,7 +619,10 @@ struct vpzh_stream {
     std::string error;
     int channels = 0, sample_rate = 0, size0 = 0, size1 = 0;
     std::vector<Codebook> books;
-    std::vector<Floor1> floors;
+    std::vector<Floor1> floors;          // indexed by floor number; unused entries for type-0 floors
+    std::vector<Floor0> floors0;         // same indexing; unused entries for type-1 floors
+    std::vector<uint8_t> floor_types;
+    int max_floor0_order = 0;
     std::vector<Residue> residues;
     std::vector<Mapping> mappings;
     std::vector<Mode> modes;
@@ -706,11 +757,19 @@ struct vpzh_stream {
         p.skip(16 * times);
         int n_floors = (int)p.read_bits(6) + 1;
         floors.resize(n_floors);
-        for (auto &f : floors) {
+        floors0.resize(n_floors);
+        floor_types.assign(n_floors, 1);
+        for (int i = 0; i < n_floors; ++i) {
             int type = (int)p.read_bits(16);
-            if (type == 0) throw Unsupported("floor type 0 is not implemented (SURVEY.md f-3)");
-            if (type != 1) throw InvalidData("Invalid floor type!");
-            f.read(p, (int)books.size());
+            if (type == 0) {
+                floor_types[i] = 0;
+                floors0[i].read(p, books);
+                if (floors0[i].order > max_floor0_order) max_floor0_order = floors0[i].order;
+            } else if (type == 1) {
+                floors[i].read(p, (int)books.size());
+            } else {
+                throw InvalidData("Invalid floor type!");
+            }
         }
         int n_res = (int)p.read_bits(6) + 1;
         residues.resize(n_res);
@@ -750,7 +809,8 @@ struct vpzh_stream {
 
     // StreamDecoder.DecodeNextPacket :696-762 -> Mode.Decode -> Mapping.DecodePacket :98-163
     void decode_packet(const OggPacket &pk, int32_t stream_id, int64_t residue_off, vpz_packet *out, float *residue,
-                       int16_t *posts, uint8_t *post_counts)
+                       int16_t *posts, uint8_t *post_counts, float *f0_amp = nullptr, float *f0_coeff = nullptr,
+                       int f0_stride = 0)
     {
         memset(out, 0, sizeof *out);
         out->stream = stream_id;
@@ -780,9 +840,21 @@ struct vpzh_stream {
         // floors, Mapping.cs:109-118
         std::vector<uint8_t> no_execute(channels);
         for (int ch = 0; ch < channels; ++ch) {
+            const int fl = map.submap_floor[map.mux[ch]];
+            if (floor_types[fl] == 0) {  // Floor0.Unpack; ExecuteChannel = Amp != 0
+                float tmp[256];
+                const float amp = floors0[fl].unpack(p, books, tmp);
+                if (f0_amp) {
+                    f0_amp[ch] = amp;
+                    for (int i = 0; i < f0_stride; ++i) f0_coeff[(size_t)ch * f0_stride + i] = i < floors0[fl].order ? tmp[i] : 0.f;
+                }
+                post_counts[ch] = amp != 0.f ? 1 : 0;
+                no_execute[ch] = amp == 0.f;
+                continue;
+            }
             int raw[64];
             memset(raw, 0, sizeof raw);
-            int pc = floors[map.submap_floor[map.mux[ch]]].unpack(p, books, raw);
+            int pc = floors[fl].unpack(p, books, raw);
             if (pc > 64) pc = 64;
             post_counts[ch] = (uint8_t)pc;
             for (int i = 0; i < 64; ++i) {
@@ -891,9 +963,29 @@ int vpzh_get_info(vpzh_stream *s, vpzh_info *info)
     return VPZH_OK;
 }
 
+int vpzh_get_floor_type(vpzh_stream *s, int index)
+{
+    if (!s || index < 0 || index >= (int)s->floor_types.size()) return VPZH_E_ARG;
+    return s->floor_types[index];
+}
+
+int vpzh_get_floor0(vpzh_stream *s, int index, vpz_floor0_config *out)
+{
+    if (!s || !out || index < 0 || index >= (int)s->floors0.size() || s->floor_types[index] != 0) return VPZH_E_ARG;
+    const Floor0 &f = s->floors0[index];
+    out->order = f.order;
+    out->rate = f.rate;
+    out->bark_map_size = f.bark_map_size;
+    out->amp_bits = f.amp_bits;
+    out->amp_ofs = f.amp_ofs;
+    return VPZH_OK;
+}
+
+int vpzh_max_floor0_order(vpzh_stream *s) { return s ? s->max_floor0_order : 0; }
+
 int vpzh_get_floor1(vpzh_stream *s, int index, vpz_floor1_config *out)
 {
-    if (!s || !out || index < 0 || index >= (int)s->floors.size()) return VPZH_E_ARG;
+    if (!s || !out || index < 0 || index >= (int)s->floors.size() || s->floor_types[index] != 1) return VPZH_E_ARG;
     const Floor1 &f = s->floors[index];
     memset(out, 0, sizeof *out);
     if (f.x_list.size() > VPZ_MAX_FLOOR1_POSTS) return VPZH_E_INVALID_DATA;
@@ -923,20 +1015,24 @@ int vpzh_get_residue_type(vpzh_stream *s, int index)
     return s->residues[index].type;
 }
 
-int vpzh_decode_range(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
-                      vpz_packet *packets, float *residue, int16_t *posts, uint8_t *post_counts,
-                      int64_t *residue_floats_used)
+int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
+                         vpz_packet *packets, float *residue, int16_t *posts, uint8_t *post_counts,
+                         int64_t *residue_floats_used, float *f0_amp, float *f0_coeff, int32_t f0_stride)
 {
     if (!s || !packets || !residue || !posts || !post_counts || first < 0 || count < 0 ||
         first + count > (int64_t)s->audio.size())
         return VPZH_E_ARG;
+    if (f0_amp && (!f0_coeff || f0_stride < s->max_floor0_order)) return VPZH_E_ARG;
     try {
         int64_t off = 0;
+        const size_t C = (size_t)s->channels;
         for (int64_t k = 0; k < count; ++k) {
             const OggPacket &pk = s->audio[(size_t)(first + k)];
             const int64_t n = s->packet_floats(pk);
             s->decode_packet(pk, stream_id, residue_base + off, &packets[k], residue + off,
-                             posts + (size_t)k * 64 * (size_t)s->channels, post_counts + (size_t)k * (size_t)s->channels);
+                             posts + (size_t)k * 64 * C, post_counts + (size_t)k * C,
+                             f0_amp ? f0_amp + (size_t)k * C : nullptr,
+                             f0_coeff ? f0_coeff + (size_t)k * C * (size_t)f0_stride : nullptr, f0_stride);
             off += n;
         }
         if (residue_floats_used) *residue_floats_used = off;
@@ -945,6 +1041,14 @@ int vpzh_decode_range(vpzh_stream *s, int64_t first, int64_t count, int32_t stre
         return VPZH_E_INVALID_DATA;
     }
     return VPZH_OK;
+}
+
+int vpzh_decode_range(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
+                      vpz_packet *packets, float *residue, int16_t *posts, uint8_t *post_counts,
+                      int64_t *residue_floats_used)
+{
+    return vpzh_decode_range_ex(s, first, count, stream_id, residue_base, packets, residue, posts, post_counts,
+                                residue_floats_used, nullptr, nullptr, 0);
 }
 
 int vpzh_decode_all(vpzh_stream *s, int32_t stream_id, int64_t residue_base, vpz_packet *packets, float *residue,

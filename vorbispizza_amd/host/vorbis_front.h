@@ -22,7 +22,7 @@ extern "C" {
 
 #define VPZH_OK             0
 #define VPZH_E_INVALID_DATA (-1)  /* InvalidDataException in the reference */
-#define VPZH_E_UNSUPPORTED  (-2)  /* floor type 0 */
+#define VPZH_E_UNSUPPORTED  (-2)
 #define VPZH_E_ARG          (-3)
 
 typedef struct vpzh_stream vpzh_stream;
@@ -43,7 +43,10 @@ typedef struct vpzh_info {
 int vpzh_get_info(vpzh_stream *s, vpzh_info *info);
 
 /* setup products the synthesis back end needs (vpz_stream_config) */
+int vpzh_get_floor_type(vpzh_stream *s, int index);   /* 0 or 1 */
 int vpzh_get_floor1(vpzh_stream *s, int index, vpz_floor1_config *out);
+int vpzh_get_floor0(vpzh_stream *s, int index, vpz_floor0_config *out);
+int vpzh_max_floor0_order(vpzh_stream *s);            /* 0 when the stream has no type-0 floor */
 int vpzh_get_mapping(vpzh_stream *s, int index, vpz_mapping_config *out);
 int vpzh_get_residue_type(vpzh_stream *s, int index);
 
@@ -59,6 +62,12 @@ int vpzh_decode_all(vpzh_stream *s, int32_t stream_id, int64_t residue_base, vpz
 int vpzh_decode_range(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
                       vpz_packet *packets, float *residue, int16_t *posts, uint8_t *post_counts,
                       int64_t *residue_floats_used);
+
+/* With the Floor0.Data of type-0 floor channels: f0_amp[count*channels], f0_coeff[count*channels*f0_stride]
+ * (f0_stride >= vpzh_max_floor0_order); pass NULL when the stream has no type-0 floor. */
+int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
+                         vpz_packet *packets, float *residue, int16_t *posts, uint8_t *post_counts,
+                         int64_t *residue_floats_used, float *f0_amp, float *f0_coeff, int32_t f0_stride);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,7 @@ struct vpzr_reader {
     std::vector<float> residue;
     std::vector<int16_t> posts;
     std::vector<uint8_t> counts;
+    std::vector<float> f0_amp, f0_coeff;
 
     int fail(int status, const char *what)
     {
@@ -50,9 +51,14 @@ struct vpzr_reader {
     {
         if (dec) return VPZ_OK;
         std::vector<vpz_floor1_config> floors(info.floor_count);
+        std::vector<vpz_floor0_config> floors0(info.floor_count);
+        std::vector<uint8_t> floor_types(info.floor_count, 1);
         std::vector<vpz_mapping_config> mappings(info.mapping_count);
-        for (int i = 0; i < info.floor_count; ++i)
-            if (vpzh_get_floor1(front, i, &floors[i]) != VPZH_OK) return fail(VPZ_E_UNSUPPORTED, "floor cannot be represented");
+        for (int i = 0; i < info.floor_count; ++i) {
+            floor_types[i] = (uint8_t)vpzh_get_floor_type(front, i);
+            const int rc0 = floor_types[i] == 0 ? vpzh_get_floor0(front, i, &floors0[i]) : vpzh_get_floor1(front, i, &floors[i]);
+            if (rc0 != VPZH_OK) return fail(VPZ_E_UNSUPPORTED, "floor cannot be represented");
+        }
         for (int i = 0; i < info.mapping_count; ++i) vpzh_get_mapping(front, i, &mappings[i]);
         vpz_stream_config cfg{};
         cfg.channels = info.channels;
@@ -63,6 +69,8 @@ struct vpzr_reader {
         cfg.mapping_count = info.mapping_count;
         cfg.mappings = mappings.data();
         cfg.clip_samples = clip ? 1 : 0;
+        cfg.floor_types = floor_types.data();
+        cfg.floors0 = floors0.data();
         int rc = vpz_decoder_create(ctx, &cfg, 1, &dec);
         if (rc != VPZ_OK) return fail(rc, vpz_context_last_error(ctx));
         return VPZ_OK;
@@ -87,9 +95,16 @@ struct vpzr_reader {
         posts.assign((size_t)n * C * 64, 0);
         counts.assign((size_t)n * C, 0);
         int64_t used = 0;
-        if (vpzh_decode_range(front, next_packet, n, 0, 0, packets.data(), residue.data(), posts.data(), counts.data(),
-                              &used) != VPZH_OK)
+        const int f0_stride = vpzh_max_floor0_order(front);
+        if (f0_stride > 0) {
+            f0_amp.assign((size_t)n * C, 0.f);
+            f0_coeff.assign((size_t)n * C * f0_stride, 0.f);
+        }
+        if (vpzh_decode_range_ex(front, next_packet, n, 0, 0, packets.data(), residue.data(), posts.data(), counts.data(),
+                                 &used, f0_stride ? f0_amp.data() : nullptr, f0_stride ? f0_coeff.data() : nullptr,
+                                 f0_stride) != VPZH_OK)
             return fail(VPZ_E_INVALID_ARG, vpzh_last_error(front));
+        if (f0_stride > 0) vpz_decoder_set_floor0_data(dec, f0_amp.data(), f0_coeff.data(), f0_stride);
         next_packet += n;
         const int64_t cap = n * half1 + info.block_size1;
         pcm.assign((size_t)cap * C, 0.f);
