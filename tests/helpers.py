@@ -158,5 +158,8 @@ def packets_for_oracle(ogg, pk, residue, posts, counts):
             d["residue"] = residue[off: off + C_ * half]
             d["posts"] = posts[i * C_:(i + 1) * C_]
             d["post_count"] = counts[i * C_:(i + 1) * C_]
+            if getattr(ogg, "floor0_data", None) is not None:
+                d["f0_amp"] = ogg.floor0_data[0][i * C_:(i + 1) * C_]
+                d["f0_coeff"] = ogg.floor0_data[1][i * C_:(i + 1) * C_]
         out.append(d)
     return out

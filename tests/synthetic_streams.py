@@ -1,0 +1,116 @@
+"""Synthetic Ogg/Vorbis streams (tests/vorbis_writer.py) that exercise what the reference's four fixtures
+do not: Floor0, residue type 0, several submaps, ordered / sparse codebooks, lookup type 2, block sizes
+other than 256/2048, three modes, and packets continued over page boundaries."""
+import numpy as np
+
+import vorbis_writer as vw
+
+
+def _scalar_book(rng, entries, **kw):
+    return vw.random_codebook(rng, 1, entries, 0, **kw)
+
+
+def _floor1(rng, books, half, partitions, multiplier):
+    """Appends its books to `books`; two classes: class 0 without subclasses, class 1 with 2 subclass bits."""
+    base = len(books)
+    books.append(_scalar_book(rng, 4))                    # masterbook of class 1
+    books.append(_scalar_book(rng, 8))                    # subclass books
+    books.append(_scalar_book(rng, 12, sparse=True))
+    books.append(_scalar_book(rng, 6, ordered=True))
+    class_dims = [2, 3]
+    class_sub = [0, 2]
+    class_master = [0, base]
+    sub_books = [[base + 1], [base + 2, -1, base + 3, base + 1]]
+    part_class = [int(rng.integers(2)) for _ in range(partitions)]
+    n_x = sum(class_dims[c] for c in part_class)
+    rangebits = vw.ilog(half - 1)
+    xs = [int(v) for v in rng.choice(np.arange(1, half), size=n_x, replace=False)]
+    return vw.Floor1(part_class, class_dims, class_sub, class_master, sub_books, multiplier, rangebits, xs)
+
+
+def _residue(rng, books, rtype, half, partition_size, classifications, class_dims, vq):
+    """vq: list of (dims, lookup_type, entries) books shared by the classes."""
+    base = len(books)
+    for dims, lt, entries in vq:
+        books.append(vw.random_codebook(rng, dims, entries, lt, sparse=bool(rng.integers(2))))
+    books.append(_scalar_book(rng, classifications ** class_dims))
+    classbook = len(books) - 1
+    cascade, rbooks = [], []
+    for c in range(classifications):
+        casc = int(rng.integers(0, 8)) if c else 0      # class 0: nothing coded
+        if c == classifications - 1:
+            casc |= 0x21                                # a high stage too: cascade needs the 5 high bits
+        cascade.append(casc)
+        rbooks.append([base + int(rng.integers(len(vq))) if casc & (1 << st) else None for st in range(8)])
+    begin = int(rng.integers(0, 3)) * partition_size
+    end = half - int(rng.integers(0, 2)) * partition_size
+    return vw.Residue(rtype, begin, end, partition_size, classbook, cascade, rbooks)
+
+
+def mono_floor1_res1(seed=1):
+    """mono, block sizes 64/512, residue 1, three modes."""
+    rng = np.random.default_rng(seed)
+    books = []
+    f_short = _floor1(rng, books, 32, 3, 2)
+    f_long = _floor1(rng, books, 256, 6, 1)
+    r_short = _residue(rng, books, 1, 32, 8, 3, 2, [(2, 1, 9), (4, 1, 16), (2, 2, 7)])
+    r_long = _residue(rng, books, 1, 256, 16, 4, 2, [(2, 1, 25), (4, 2, 10), (8, 1, 256)])
+    maps = [vw.Mapping(1, [], [0], [0], [0]), vw.Mapping(1, [], [0], [1], [1])]
+    modes = [(0, 0), (1, 1), (1, 1)]
+    return vw.Stream(1, 8000, 6, 9, books, [f_short, f_long], [r_short, r_long], maps, modes), rng
+
+
+def stereo_coupled_res2(seed=2):
+    """stereo, one coupling step, residue 2, 256/2048 (the fast GPU path)."""
+    rng = np.random.default_rng(seed)
+    books = []
+    f_short = _floor1(rng, books, 128, 4, 2)
+    f_long = _floor1(rng, books, 1024, 8, 4)
+    r_short = _residue(rng, books, 2, 256, 16, 3, 2, [(2, 1, 9), (4, 1, 81)])
+    r_long = _residue(rng, books, 2, 2048, 32, 4, 3, [(2, 1, 49), (4, 2, 12), (8, 1, 300)])
+    maps = [vw.Mapping(2, [(0, 1)], [0, 0], [0], [0]), vw.Mapping(2, [(0, 1)], [0, 0], [1], [1])]
+    return vw.Stream(2, 44100, 8, 11, books, [f_short, f_long], [r_short, r_long], maps, [(0, 0), (1, 1)]), rng
+
+
+def three_channels_two_submaps(seed=3):
+    """3 channels in 2 submaps (mux 0,0,1): residue 0 on the pair, residue 1 on the third; coupling (0,1)
+    and (2,0); block sizes 128/1024."""
+    rng = np.random.default_rng(seed)
+    books = []
+    f_a = _floor1(rng, books, 64, 3, 3)
+    f_b = _floor1(rng, books, 512, 7, 2)
+    f_c = _floor1(rng, books, 512, 5, 1)
+    r0_short = _residue(rng, books, 0, 64, 8, 3, 2, [(2, 1, 9), (4, 1, 16)])
+    r1_short = _residue(rng, books, 1, 64, 8, 2, 1, [(2, 2, 6)])
+    r0_long = _residue(rng, books, 0, 512, 16, 3, 2, [(4, 1, 81), (8, 1, 256)])
+    r1_long = _residue(rng, books, 1, 512, 32, 3, 2, [(2, 1, 25), (4, 2, 9)])
+    coupling = [(0, 1), (2, 0)]
+    maps = [vw.Mapping(3, coupling, [0, 0, 1], [0, 0], [0, 1]), vw.Mapping(3, coupling, [0, 0, 1], [1, 2], [2, 3])]
+    return (vw.Stream(3, 22050, 7, 10, books, [f_a, f_b, f_c], [r0_short, r1_short, r0_long, r1_long], maps,
+                      [(0, 0), (1, 1)]), rng)
+
+
+def stereo_floor0(seed=4):
+    """stereo, Floor0 on both block sizes (two LSP books to choose from), residue 1, equal 512/512 blocks."""
+    rng = np.random.default_rng(seed)
+    books = []
+
+    def lsp_book(dims):
+        # ascending-ish LSP coefficients in (0, pi): min > 0, small positive steps, sequence_p
+        entries = 16
+        b = vw.Codebook(dims, [4] * entries, 1,
+                        minv=vw.float32_pack(5, 788 - 5), delta=vw.float32_pack(1, 788 - 5), value_bits=2,
+                        seq_p=True, mults=[int(v) for v in rng.integers(0, 4, size=vw.lookup1_values(entries, dims))])
+        return b
+
+    books.append(lsp_book(2))
+    books.append(lsp_book(4))
+    f0 = vw.Floor0(8, 16000, 128, 6, 40, [0, 1], max_amp_raw=3)
+    f1 = vw.Floor0(12, 16000, 200, 5, 30, [1, 0], max_amp_raw=2)
+    r = _residue(rng, books, 1, 256, 16, 3, 2, [(2, 1, 25), (4, 1, 81)])
+    maps = [vw.Mapping(2, [], [0, 0], [0], [0]), vw.Mapping(2, [(0, 1)], [0, 0], [1], [0])]
+    return vw.Stream(2, 16000, 9, 9, books, [f0, f1], [r], maps, [(0, 0), (1, 1)]), rng
+
+
+ALL = {"mono_floor1_res1": mono_floor1_res1, "stereo_coupled_res2": stereo_coupled_res2,
+       "three_channels_two_submaps": three_channels_two_submaps, "stereo_floor0": stereo_floor0}

@@ -79,3 +79,52 @@ def test_many_streams_of_real_files_in_one_batch(ctx, oracle):
     ref, _, _ = helpers.oracle_decode(oracle, 2, 256, 2048, opk, floors=f.floors, mappings=f.mappings, interleave=True)
     assert np.abs(outs[0] - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
     dec.close()
+
+
+@pytest.mark.parametrize("name", ["mono_floor1_res1", "stereo_coupled_res2", "three_channels_two_submaps", "stereo_floor0"])
+def test_synthetic_stream_decodes_like_the_oracle(ctx, oracle, name):
+    """Streams from the spec-based writer (tests/vorbis_writer.py): Floor0, residue 0, two submaps, block
+    sizes outside 256/2048 -- container to PCM through the front end and the GPU, against the oracle."""
+    import synthetic_streams as ss
+    from vorbispizza_amd import Decoder, capi
+    from vorbispizza_amd.front import OggVorbisFile
+    stream, rng = ss.ALL[name]()
+    ogg, _ = stream.build(rng, 40)
+    f = OggVorbisFile(ogg)
+    pk, res, posts, counts = f.decode_packets()
+    dec = Decoder(ctx, f.channels, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings)
+    if f.floor0_data is not None:
+        dec.set_floor0_data(*f.floor0_data)
+    outs = dec.synth(pk, res, posts, counts, out_layout=capi.OUT_PLANAR)
+    opk = helpers.packets_for_oracle(f, pk, res, posts, counts)
+    ref, pos, _ = helpers.oracle_decode(oracle, f.channels, f.block_size0, f.block_size1, opk,
+                                        floors=f.floors, mappings=f.mappings)
+    assert outs[0].shape == ref.shape and ref.shape[1] == f.last_granule
+    assert np.isfinite(ref).all()
+    assert np.abs(outs[0] - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+    assert dec.position(0) == pos
+    dec.close()
+
+
+def test_synthetic_stream_through_the_reader_mirror(ctx, oracle):
+    import synthetic_streams as ss
+    from vorbispizza_amd.front import OggVorbisFile, VorbisReader
+    stream, rng = ss.three_channels_two_submaps(seed=21)
+    ogg, _ = stream.build(rng, 30)
+    f = OggVorbisFile(ogg)
+    pk, res, posts, counts = f.decode_packets()
+    ref, _, _ = helpers.oracle_decode(oracle, 3, f.block_size0, f.block_size1,
+                                      helpers.packets_for_oracle(f, pk, res, posts, counts),
+                                      floors=f.floors, mappings=f.mappings, interleave=True, clip=True)
+    r = VorbisReader(ctx, ogg, batch_packets=7)
+    got = []
+    buf = np.zeros(3 * 700, dtype=np.float32)
+    while True:
+        n = r.ReadSamples(buf)
+        if n == 0:
+            break
+        got.append(buf[: n * 3].reshape(n, 3).copy())
+    got = np.concatenate(got)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-5
+    r.Dispose()
