@@ -82,3 +82,35 @@ def test_truncated_and_corrupt_input(front):
     assert f.info.bad_crc_pages >= 1 and f.audio_packets < 25
     with pytest.raises(front.FrontError):
         front.OggVorbisFile(b"not an ogg file at all" * 10)
+
+
+def test_decode_into_shared_batch_buffers_from_threads(front):
+    """Several handles decoded from several threads straight into slices of one batch buffer give what
+    decode_packets gives for each stream alone (stream ids and residue offsets rebased)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from vorbispizza_amd import capi
+    data = open(os.path.join(GOLDEN, "3test.ogg"), "rb").read()
+    ref_f = front.OggVorbisFile(data)
+    pk0, res0, posts0, counts0 = ref_f.decode_packets()
+    n, C_, rf, copies = ref_f.audio_packets, ref_f.channels, ref_f.info.residue_floats, 6
+    pk = capi.make_packets(n * copies)
+    res = np.zeros(rf * copies, dtype=np.float32)
+    posts = np.zeros((n * copies * C_, 64), dtype=np.int16)
+    counts = np.zeros(n * copies * C_, dtype=np.uint8)
+
+    def job(k):
+        f = front.OggVorbisFile(data)
+        f.decode_into(pk[k * n:(k + 1) * n], res[k * rf:(k + 1) * rf], posts[k * n * C_:(k + 1) * n * C_],
+                      counts[k * n * C_:(k + 1) * n * C_], stream_id=k, residue_base=k * rf)
+        f.close()
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        list(pool.map(job, range(copies)))
+    for k in range(copies):
+        sl = pk[k * n:(k + 1) * n]
+        assert (sl["stream"] == k).all()
+        assert np.array_equal(sl["residue_offset"], pk0["residue_offset"] + k * rf)
+        assert np.array_equal(sl["flags"], pk0["flags"]) and np.array_equal(sl["granule"], pk0["granule"])
+        assert np.array_equal(res[k * rf:(k + 1) * rf], res0)
+        assert np.array_equal(posts[k * n * C_:(k + 1) * n * C_], posts0)
+        assert np.array_equal(counts[k * n * C_:(k + 1) * n * C_], counts0)

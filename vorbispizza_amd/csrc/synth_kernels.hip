@@ -578,9 +578,22 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                                        : out_base + (int64_t)ch * a.channel_stride + fd.out_off;
             // every window boundary of the 256/2048 geometries is a multiple of 64 samples, so unless
             // an EOS trim cut the packet a float4 never straddles a mirror / overlap boundary
-            const bool vec = !drain && !a.interleaved &&
-                             ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0 &&
-                             (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+            // (interleaved output keeps the float4 arithmetic and scatters the four samples with the
+            // channel stride; the other channels' waves fill the gaps of the same cache lines)
+            const bool vec = !drain && ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0 &&
+                             (a.interleaved || (reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+            const int64_t ostep = a.interleaved ? a.channels : 1;
+            auto store4 = [&](int g, float o0, float o1, float o2, float o3) {
+                if (a.interleaved) {
+                    float *d = dst + (int64_t)(4 * g) * ostep;
+                    d[0] = o0;
+                    d[ostep] = o1;
+                    d[2 * ostep] = o2;
+                    d[3 * ostep] = o3;
+                } else {
+                    store_nt(reinterpret_cast<float4 *>(dst) + g, make_float4(o0, o1, o2, o3));
+                }
+            };
             if (vec && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 &&
                 fd.prev_end == 1024 && fd.out_count == 1024 && prev_n4 == 512 && a.size1 == 2048) {
                 // long block after a long block with long windows on both sides (the steady state of
@@ -590,7 +603,6 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 const float4 *h4 = reinterpret_cast<const float4 *>(hcur);
                 const float4 *t4 = reinterpret_cast<const float4 *>(tail);
                 const float4 *s4 = reinterpret_cast<const float4 *>(s_slope1);
-                float4 *d4 = reinterpret_cast<float4 *>(dst);
                 float o[4][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -620,8 +632,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    store_nt(d4 + lane + 64 * r, make_float4(o[r][0], o[r][1], o[r][2], o[r][3]));
+                for (int r = 0; r < 4; ++r) store4(lane + 64 * r, o[r][0], o[r][1], o[r][2], o[r][3]);
             } else if (vec) {
                 // branch-free: lanes past the end clamp their reads and skip only the store; samples
                 // past the overlap take weights (1, 0)
@@ -667,10 +678,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         o2 = clip_value(o2);
                         o3 = clip_value(o3);
                     }
-                    if (live) store_nt(reinterpret_cast<float4 *>(dst) + g, make_float4(o0, o1, o2, o3));
+                    if (live) store4(g, o0, o1, o2, o3);
                 }
             } else {
-                const int64_t step = a.interleaved ? a.channels : 1;
                 for (int i = lane; i < fd.out_count; i += 64) {
                     float v;
                     if (drain) {
@@ -686,7 +696,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         clipped_any |= was_clipped(v);
                         v = clip_value(v);
                     }
-                    dst[i * step] = v;
+                    dst[i * ostep] = v;
                 }
             }
         }

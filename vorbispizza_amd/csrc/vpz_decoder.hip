@@ -3,6 +3,8 @@
 // (StreamDecoder.cs:418-498, 640-694; Mode.cs:30-66) and turns a batch of packets into frame /
 // run descriptors for the kernels in synth_kernels.hip.  No sample arithmetic happens here.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -67,12 +69,18 @@ struct PinnedArena {
     size_t cap = 0, used = 0;
     hipEvent_t uploaded = nullptr;
     bool pending = false;
+    DevBuf dev;  // device mirror, same layout: one hipMemcpyAsync per call
 };
 
+// Mode.cs:30-66
+struct PacketInfo {
+    int length, left_use_size1, left_start, left_end, right_start, right_end;
+};
 struct Decoder {
     Context *ctx = nullptr;
-    PinnedArena arena;
-    std::vector<std::vector<FrameDesc>> per_stream;  // reused across calls (capacity retained)
+    PinnedArena arenas[2];
+    int arena_idx = 0;
+    std::vector<int64_t> s_base, s_cnt, out_count;  // per-stream scratch of a synth call
     int channels = 0, size0 = 0, size1 = 0, clip = 0;
     int n_streams = 0;
     std::vector<vpz_floor1_config> floors;
@@ -84,18 +92,19 @@ struct Decoder {
     int32_t *d_clipped = nullptr;
     uint8_t *d_steps = nullptr;              // coupling steps of all mappings, pairs (mag, ang)
     std::vector<int32_t> mapping_steps_off;  // per mapping: offset into d_steps (pairs*2), -1 none
-    DevBuf b_frames, b_runs, b_recfloor, b_curve, b_cpk, b_temp, b_outoff;
+    DevBuf b_curve, b_temp;
     DevBuf b_in_res, b_in_posts, b_in_counts, b_out;  // VPZ_MEM_HOST staging
-    DevBuf b_gframes, b_glists, b_ybuf;               // any-block-size path
+    DevBuf b_ybuf;                                    // any-block-size path
     bool generic = false;  // block sizes other than 256 / 2048: three-pass path (synth_kernels.hip)
     // type-0 floors (Floor0.cs)
     std::vector<uint8_t> floor_types;
     std::vector<vpz_floor0_config> floors0;
     void *d_floors0 = nullptr;
     int32_t *d_bark_maps = nullptr;
-    DevBuf b_f0recs, b_in_amp, b_in_coeff;
+    DevBuf b_in_amp, b_in_coeff;
     const float *f0_amp = nullptr, *f0_coeff = nullptr;
     int32_t f0_stride = 0;
+    PacketInfo packet_info[8];  // Mode.GetPacketInfo by (block | prev << 1 | next << 2) == vpz_packet.flags & 7
     int run_length_override = 0;
     int ablate = 0;  // VPZ_SYNTH_ABLATE, tuning experiments only
     std::vector<int32_t> packet_samples;  // per packet of the last synth call
@@ -135,10 +144,6 @@ static T *arena_alloc(PinnedArena &A, size_t count)
     return p;
 }
 
-// Mode.cs:30-66
-struct PacketInfo {
-    int length, left_use_size1, left_start, left_end, right_start, right_end;
-};
 static PacketInfo get_packet_info(int size0, int size1, bool block_flag, bool prev_flag, bool next_flag)
 {
     PacketInfo pi;
@@ -241,6 +246,8 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         if (D.floor_types[i] == 0 && cfg->floors0) D.floors0[i] = cfg->floors0[i];
     }
     D.mappings.assign(cfg->mappings, cfg->mappings + cfg->mapping_count);
+    static_assert(VPZ_PKT_BLOCK_FLAG == 1 && VPZ_PKT_PREV_FLAG == 2 && VPZ_PKT_NEXT_FLAG == 4, "packet_info index");
+    for (int f = 0; f < 8; ++f) D.packet_info[f] = get_packet_info(D.size0, D.size1, f & 1, f & 2, f & 4);
     if (const char *e = getenv("VPZ_RUN_LENGTH")) D.run_length_override = atoi(e);
     if (const char *e = getenv("VPZ_SYNTH_ABLATE")) D.ablate = atoi(e);
 
@@ -345,8 +352,8 @@ void vpz_decoder_destroy(vpz_decoder *d)
         (void)hipSetDevice(D.ctx->device);
         (void)hipStreamSynchronize(D.ctx->stream);
     }
-    DevBuf *bufs[] = {&D.b_f0recs, &D.b_in_amp, &D.b_in_coeff, &D.b_gframes, &D.b_glists, &D.b_ybuf, &D.b_frames, &D.b_runs, &D.b_recfloor, &D.b_curve, &D.b_cpk, &D.b_temp,
-                      &D.b_outoff, &D.b_in_res, &D.b_in_posts, &D.b_in_counts, &D.b_out};
+    DevBuf *bufs[] = {&D.b_in_amp, &D.b_in_coeff, &D.b_ybuf, &D.b_curve, &D.b_temp, &D.b_in_res, &D.b_in_posts,
+                      &D.b_in_counts, &D.b_out, &D.arenas[0].dev, &D.arenas[1].dev};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (D.d_floors) (void)hipFree(D.d_floors);
@@ -355,8 +362,10 @@ void vpz_decoder_destroy(vpz_decoder *d)
     if (D.d_steps) (void)hipFree(D.d_steps);
     if (D.d_floors0) (void)hipFree(D.d_floors0);
     if (D.d_bark_maps) (void)hipFree(D.d_bark_maps);
-    if (D.arena.base) (void)hipHostFree(D.arena.base);
-    if (D.arena.uploaded) (void)hipEventDestroy(D.arena.uploaded);
+    for (PinnedArena &A : D.arenas) {
+        if (A.base) (void)hipHostFree(A.base);
+        if (A.uploaded) (void)hipEventDestroy(A.uploaded);
+    }
     delete d;
 }
 
@@ -399,23 +408,61 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     D.packet_samples.assign((size_t)n_packets, 0);
     if (n_packets == 0) return VPZ_OK;
 
-    // ---------------- pass 1: per-stream state machine -> frame descriptors
+    static const bool host_profile = getenv("VPZ_HOST_PROFILE") != nullptr;
+    auto tick = [] { return std::chrono::steady_clock::now(); };
+    auto t_begin = tick();
+    int rc;
+    const int64_t n_rec = n_packets * C;
+    const bool have_posts = posts && post_counts && !D.floors.empty();
+    bool has_floor0_type = false;
+    for (uint8_t t : D.floor_types) has_floor0_type |= (t == 0);
+
+    // Every per-call table (frame / run descriptors, coupling packets, per-record floor info, output
+    // offsets, ...) is carved out of ONE pinned arena that goes to its device mirror in a single copy;
+    // two arenas alternate so the host can prepare call k+1 while call k's upload is still queued.
+    const size_t cps = coupling_packet_size();
+    const size_t f0rs = floor0_rec_size();
+    const size_t np = (size_t)n_packets;
+    size_t arena_need = (sizeof(FrameDesc) + sizeof(RunDesc) + cps) * np + sizeof(RunDesc) * ((size_t)D.n_streams + 1) +
+                        (have_posts ? (size_t)n_rec : 0) + sizeof(int64_t) * (size_t)D.n_streams + 4096;
+    if (has_floor0_type) arena_need += f0rs * (size_t)n_rec + 64;
+    if (D.generic) arena_need += (sizeof(GenericFrame) + 4 * sizeof(int64_t) * (size_t)C) * np + sizeof(int32_t) * ((size_t)D.n_streams + 1) + 1024;
+    D.arena_idx ^= 1;
+    PinnedArena &A = D.arenas[D.arena_idx];
+    if ((rc = arena_begin(ctx, A, arena_need)) != VPZ_OK) return rc;
+    if ((rc = grow(ctx, A.dev, A.cap)) != VPZ_OK) return rc;
+    auto dev = [&A](const void *host_ptr) -> void * {
+        return host_ptr ? static_cast<char *>(A.dev.p) + (static_cast<const char *>(host_ptr) - A.base) : nullptr;
+    };
+
+    // ---------------- pass 1: per-stream state machine -> frame descriptors (written in place, stream-major)
     std::vector<StreamState> st = D.states;  // committed only when the whole batch is accepted
-    std::vector<std::vector<FrameDesc>> &per_stream = D.per_stream;
-    per_stream.resize(D.n_streams);
-    for (auto &v : per_stream) v.clear();
+    std::vector<int64_t> &s_base = D.s_base, &s_cnt = D.s_cnt, &out_count = D.out_count;
+    s_base.assign((size_t)D.n_streams + 1, 0);
+    s_cnt.assign((size_t)D.n_streams, 0);
+    out_count.assign((size_t)D.n_streams, 0);
+    if (D.n_streams > 1) {
+        for (int64_t p = 0; p < n_packets; ++p) {
+            const int32_t s = packets[p].stream;
+            if (s < 0 || s >= D.n_streams)
+                return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: packet stream index out of range");
+            ++s_base[(size_t)s + 1];
+        }
+        for (int s = 0; s < D.n_streams; ++s) s_base[(size_t)s + 1] += s_base[(size_t)s];
+    }
     std::vector<uint8_t> stream_started_with_prev(D.n_streams), stream_prev_long(D.n_streams);
     for (int s = 0; s < D.n_streams; ++s) {
         stream_started_with_prev[s] = st[s].has_prev;
         stream_prev_long[s] = st[s].prev_long;
     }
-    std::vector<int64_t> out_count(D.n_streams, 0);
-    std::vector<uint8_t> pkt_used((size_t)n_packets, 0);
+    FrameDesc *frames = arena_alloc<FrameDesc>(A, np);
+    uint8_t *rec_floor = have_posts ? arena_alloc<uint8_t>(A, (size_t)n_rec) : nullptr;
+    if (rec_floor) memset(rec_floor, 0, (size_t)n_rec);
     bool any_floor = false, need_coupling = D.generic;  // the generic path always works on its own planar copy
     int64_t mismatches = 0;
     bool any_floor0 = false;
-    int64_t temp_floats = 0;
-    std::vector<int64_t> temp_off((size_t)n_packets, -1);
+    int64_t res_extent = 0;
+    const int half0 = D.size0 / 2, half1 = D.size1 / 2;
 
     for (int64_t p = 0; p < n_packets; ++p) {
         const vpz_packet &pk = packets[p];
@@ -438,7 +485,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
                 S.current_position += fd.out_count;
                 S.prev_end = S.prev_stop;
                 S.prev_start = S.prev_stop;
-                per_stream[pk.stream].push_back(fd);
+                frames[s_base[pk.stream] + s_cnt[pk.stream]++] = fd;
             }
             continue;
         }
@@ -446,21 +493,15 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         if (!no_floor) {
             if (pk.mapping >= D.mappings.size())
                 return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: packet mapping index out of range");
-            if (!posts || !post_counts || D.floors.empty())
+            if (!have_posts)
                 return set_error(ctx, VPZ_E_INVALID_ARG,
                                  "vpz_decoder_synth: posts and a floor table are required unless VPZ_PKT_NO_FLOOR");
-            any_floor = true;
-            if (D.mappings[pk.mapping].coupling_steps > 0) need_coupling = true;
-            for (int ch = 0; ch < C && !any_floor0; ++ch)
-                if (D.floor_types[D.mappings[pk.mapping].channel_floor[ch]] == 0) any_floor0 = true;
         }
-        if (pk.flags & VPZ_PKT_INTERLEAVED) need_coupling = true;
         if (pk.residue_offset < 0)
             return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: negative residue offset");
 
         const bool bf = pk.flags & VPZ_PKT_BLOCK_FLAG;
-        const PacketInfo pi = get_packet_info(D.size0, D.size1, bf, pk.flags & VPZ_PKT_PREV_FLAG,
-                                              pk.flags & VPZ_PKT_NEXT_FLAG);
+        const PacketInfo &pi = D.packet_info[pk.flags & 7];  // Mode.GetPacketInfo, tabulated at create
         const int packet_len = S.prev_stop - S.prev_end;  // :654
         int right_start = pi.right_start;
         if (pk.granule != -1 && eos) {  // :658-666
@@ -472,7 +513,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         fd.rec = (int32_t)(p * C);
         fd.flags = (bf ? kFrameLong : 0u) | (pi.left_use_size1 ? kFrameSlope1 : 0u) | (no_floor ? kFrameNoFloor : 0u);
         if (S.has_prev) {  // :670-675
-            const int slope_len = (pi.left_use_size1 ? D.size1 : D.size0) / 2;
+            const int slope_len = pi.left_use_size1 ? half1 : half0;
             if (packet_len > slope_len) {
                 // windowSlope.AsSpan(0, packetLen) would throw (:778): that Read fails, the packet is
                 // consumed and the decoder state stays as it was.  The rest of the batch is still
@@ -503,20 +544,37 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         D.packet_samples[(size_t)p] = fd.out_count;
         S.current_position += fd.out_count;
         S.prev_start = S.prev_end;  // everything readable is handed out by this call
-        pkt_used[(size_t)p] = 1;
-        temp_off[(size_t)p] = temp_floats;
-        temp_floats += (int64_t)C * ((bf ? D.size1 : D.size0) / 2);
-        fd.spec_off = pk.residue_offset;  // replaced by temp_off when the coupling pass runs
-        per_stream[pk.stream].push_back(fd);
+        fd.spec_off = pk.residue_offset;  // replaced by the temp offset when the coupling pass runs
+        res_extent = std::max(res_extent, pk.residue_offset + (int64_t)C * (bf ? half1 : half0));
+        if (!no_floor) {
+            any_floor = true;
+            const vpz_mapping_config &mc = D.mappings[pk.mapping];
+            if (mc.coupling_steps > 0) need_coupling = true;
+            const uint8_t long_bit = bf ? 0x80 : 0;
+            for (int ch = 0; ch < C; ++ch) {
+                const uint8_t fl = mc.channel_floor[ch];
+                const bool f0 = D.floor_types[fl] == 0;
+                any_floor0 |= f0;
+                rec_floor[(size_t)(p * C + ch)] = (uint8_t)(fl | long_bit | (f0 ? 0x40 : 0));
+            }
+        }
+        if (pk.flags & VPZ_PKT_INTERLEAVED) need_coupling = true;
+        frames[s_base[pk.stream] + s_cnt[pk.stream]++] = fd;
     }
     for (int s = 0; s < D.n_streams; ++s)
         if (out_count[s] > stream_out_capacity)
             return set_error(ctx, VPZ_E_CAPACITY, "vpz_decoder_synth: stream_out_capacity too small");
 
-    int rc;
-    // ---------------- pass 2: runs
-    int64_t total_frames = 0;
-    for (auto &v : per_stream) total_frames += (int64_t)v.size();
+    auto t_pass1 = tick();
+    // ---------------- pass 2: close the gaps skipped packets left, then cut each stream into runs
+    size_t n_frames = 0;
+    for (int s = 0; s < D.n_streams; ++s) {
+        if (s_cnt[s] && (size_t)s_base[s] != n_frames)
+            memmove(frames + n_frames, frames + s_base[s], sizeof(FrameDesc) * (size_t)s_cnt[s]);
+        s_base[s] = (int64_t)n_frames;
+        n_frames += (size_t)s_cnt[s];
+    }
+    const int64_t total_frames = (int64_t)n_frames;
     for (int s = 0; s < D.n_streams; ++s) samples_written[s] = out_count[s];
     if (total_frames == 0) {
         D.states = st;
@@ -539,195 +597,94 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
             if (best < 0 || cost < best) { best = cost; R = (int)r; }
         }
     }
-    // all per-call descriptor tables live in one pinned arena
-    const size_t max_runs = (size_t)(total_frames / R) + (size_t)D.n_streams + 1;
-    const size_t arena_need = sizeof(FrameDesc) * (size_t)total_frames + sizeof(RunDesc) * max_runs +
-                              coupling_packet_size() * (size_t)total_frames + (size_t)(n_packets * C) +
-                              sizeof(int64_t) * (size_t)D.n_streams + 1024 +
-                              (D.generic ? (sizeof(GenericFrame) + 20 * (size_t)C) * (size_t)total_frames + 4096 : 0);
-    if ((rc = arena_begin(ctx, D.arena, arena_need)) != VPZ_OK) return rc;
-    FrameDesc *frames = arena_alloc<FrameDesc>(D.arena, (size_t)total_frames);
-    RunDesc *runs = arena_alloc<RunDesc>(D.arena, max_runs);
-    size_t n_frames = 0, n_runs = 0;
-    for (int s = 0; s < D.n_streams; ++s) {
-        const auto &v = per_stream[s];
-        if (v.empty()) continue;
-        const int base = (int)n_frames;
-        memcpy(frames + n_frames, v.data(), sizeof(FrameDesc) * v.size());
-        n_frames += v.size();
-        for (int f0 = 0; f0 < (int)v.size(); f0 += R) {
-            RunDesc r{};
-            r.first = base + f0;
-            r.count = std::min(R, (int)v.size() - f0);
-            r.stream = s;
-            if (f0 == 0) {
-                r.pre_kind = stream_started_with_prev[s] ? kPreState : kPreNone;
-                r.prev_long = stream_prev_long[s];
-            } else {
-                r.pre_kind = kPreRecompute;
+    RunDesc *runs = arena_alloc<RunDesc>(A, (size_t)(total_frames / R) + (size_t)D.n_streams + 1);
+    size_t n_runs = 0;
+    if (!D.generic) {
+        for (int s = 0; s < D.n_streams; ++s) {
+            const int cnt = (int)s_cnt[s], base = (int)s_base[s];
+            for (int f0 = 0; f0 < cnt; f0 += R) {
+                RunDesc r{};
+                r.first = base + f0;
+                r.count = std::min(R, cnt - f0);
+                r.stream = s;
+                if (f0 == 0) {
+                    r.pre_kind = stream_started_with_prev[s] ? kPreState : kPreNone;
+                    r.prev_long = stream_prev_long[s];
+                } else {
+                    r.pre_kind = kPreRecompute;
+                }
+                if (f0 + R >= cnt) r.flags |= kRunSaveState;
+                runs[n_runs++] = r;
             }
-            if (f0 + R >= (int)v.size()) r.flags |= kRunSaveState;
-            runs[n_runs++] = r;
         }
     }
 
-    // ---------------- device inputs
-    const float *d_res = residue;
-    const int16_t *d_posts = posts;
-    const uint8_t *d_counts = post_counts;
-    const int64_t n_rec = n_packets * C;
-    if (mem_space == VPZ_MEM_HOST) {
-        int64_t res_floats = 0;
-        for (int64_t p = 0; p < n_packets; ++p) {
-            if (!pkt_used[(size_t)p]) continue;
-            const int half = ((packets[p].flags & VPZ_PKT_BLOCK_FLAG) ? D.size1 : D.size0) / 2;
-            res_floats = std::max(res_floats, packets[p].residue_offset + (int64_t)C * half);
-        }
-        if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)res_floats)) != VPZ_OK) return rc;
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res.p, residue, sizeof(float) * (size_t)res_floats,
-                                        hipMemcpyHostToDevice, ctx->stream));
-        d_res = static_cast<const float *>(D.b_in_res.p);
-        if (any_floor) {
-            if ((rc = grow(ctx, D.b_in_posts, sizeof(int16_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
-            if ((rc = grow(ctx, D.b_in_counts, (size_t)n_rec)) != VPZ_OK) return rc;
-            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_posts.p, posts, sizeof(int16_t) * 64 * (size_t)n_rec,
-                                            hipMemcpyHostToDevice, ctx->stream));
-            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_counts.p, post_counts, (size_t)n_rec, hipMemcpyHostToDevice,
-                                            ctx->stream));
-            d_posts = static_cast<const int16_t *>(D.b_in_posts.p);
-            d_counts = static_cast<const uint8_t *>(D.b_in_counts.p);
-        }
-    }
-
-    // ---------------- optional pass: de-interleave + inverse coupling into a planar temp
-    const float *d_spec = d_res;
+    // coupling packets: de-interleave + inverse coupling into a planar temp laid out in frame order
     if (any_floor0) need_coupling = true;  // type-0 floors are applied in place on the planar temp
+    uint8_t *cpk = nullptr;
+    int n_cpk = 0;
+    int64_t temp_floats = 0;
     if (need_coupling) {
-        if ((rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK) return rc;
-        const size_t cps = coupling_packet_size();
-        uint8_t *cpk = arena_alloc<uint8_t>(D.arena, cps * n_frames);
-        int n_cpk = 0;
+        cpk = arena_alloc<uint8_t>(A, cps * n_frames);
         for (size_t fi = 0; fi < n_frames; ++fi) {
             FrameDesc &fd = frames[fi];
             if (fd.flags & kFrameDrain) continue;
-            const int64_t p = fd.rec / C;
-            const vpz_packet &pk = packets[p];
-            const int half = ((fd.flags & kFrameLong) ? D.size1 : D.size0) / 2;
+            const vpz_packet &pk = packets[fd.rec / C];
+            const int half = (fd.flags & kFrameLong) ? half1 : half0;
             const bool couple = !(fd.flags & kFrameNoFloor) && D.mappings[pk.mapping].coupling_steps > 0;
-            fill_coupling_packet(cpk + (size_t)n_cpk * cps, pk.residue_offset, temp_off[(size_t)p], half,
+            fill_coupling_packet(cpk + (size_t)n_cpk * cps, pk.residue_offset, temp_floats, half,
                                  couple ? D.mapping_steps_off[pk.mapping] : -1,
                                  couple ? D.mappings[pk.mapping].coupling_steps : 0,
                                  (pk.flags & VPZ_PKT_INTERLEAVED) ? 1 : 0);
-            fd.spec_off = temp_off[(size_t)p];
+            fd.spec_off = temp_floats;
+            temp_floats += (int64_t)C * half;
             ++n_cpk;
         }
-        if ((rc = grow(ctx, D.b_cpk, cps * (size_t)n_cpk)) != VPZ_OK) return rc;
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_cpk.p, cpk, cps * (size_t)n_cpk, hipMemcpyHostToDevice, ctx->stream));
-        hipError_t e = launch_coupling(D.b_cpk.p, n_cpk, D.d_steps, C, d_res, static_cast<float *>(D.b_temp.p),
-                                       D.size1 / 2, ctx->stream);
-        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "coupling kernel launch", e);
-        d_spec = static_cast<const float *>(D.b_temp.p);
     }
-
-    // ---------------- optional pass: Floor1.UnwrapPosts
-    if (any_floor) {
-        uint8_t *rec_floor = arena_alloc<uint8_t>(D.arena, (size_t)n_rec);
-        memset(rec_floor, 0, (size_t)n_rec);
-        for (int64_t p = 0; p < n_packets; ++p) {
-            if (!pkt_used[(size_t)p] || (packets[p].flags & VPZ_PKT_NO_FLOOR)) continue;
-            const vpz_mapping_config &mc = D.mappings[packets[p].mapping];
-            const uint8_t long_bit = (packets[p].flags & VPZ_PKT_BLOCK_FLAG) ? 0x80 : 0;
-            for (int ch = 0; ch < C; ++ch)
-                rec_floor[(size_t)(p * C + ch)] = (uint8_t)(mc.channel_floor[ch] | long_bit |
-                                                            (D.floor_types[mc.channel_floor[ch]] == 0 ? 0x40 : 0));
-        }
-        if ((rc = grow(ctx, D.b_recfloor, (size_t)n_rec)) != VPZ_OK) return rc;
-        if ((rc = grow(ctx, D.b_curve, (size_t)n_rec * (size_t)(D.size1 / 2))) != VPZ_OK) return rc;
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_recfloor.p, rec_floor, (size_t)n_rec, hipMemcpyHostToDevice, ctx->stream));
-        hipError_t e = launch_floor1_prepare((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(D.b_recfloor.p),
-                                             D.d_floors, (int)D.floors.size(), D.size0 / 2, D.size1 / 2,
-                                             static_cast<uint8_t *>(D.b_curve.p), D.ablate, ctx->stream);
-        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor1 prepare kernel launch", e);
-    }
-
-    // ---------------- optional pass: Floor0.Apply in place on the temp (rare; Floor0.cs:164-225)
+    // Floor0 records
+    uint8_t *f0recs = nullptr;
+    int n_f0 = 0;
     if (any_floor0) {
         if (!D.f0_amp || !D.f0_coeff || D.f0_stride < 1)
             return set_error(ctx, VPZ_E_INVALID_ARG,
                              "vpz_decoder_synth: type-0 floors need vpz_decoder_set_floor0_data before the call");
-        const float *d_amp = D.f0_amp, *d_coeff = D.f0_coeff;
-        if (mem_space == VPZ_MEM_HOST) {
-            if ((rc = grow(ctx, D.b_in_amp, sizeof(float) * (size_t)n_rec)) != VPZ_OK) return rc;
-            if ((rc = grow(ctx, D.b_in_coeff, sizeof(float) * (size_t)n_rec * D.f0_stride)) != VPZ_OK) return rc;
-            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_amp.p, D.f0_amp, sizeof(float) * (size_t)n_rec, hipMemcpyHostToDevice, ctx->stream));
-            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_coeff.p, D.f0_coeff, sizeof(float) * (size_t)n_rec * D.f0_stride,
-                                            hipMemcpyHostToDevice, ctx->stream));
-            d_amp = static_cast<const float *>(D.b_in_amp.p);
-            d_coeff = static_cast<const float *>(D.b_in_coeff.p);
-        }
-        const size_t rs = floor0_rec_size();
-        std::vector<char> recs;
-        int n_f0 = 0;
+        f0recs = arena_alloc<uint8_t>(A, f0rs * n_frames * (size_t)C);
         for (size_t fi = 0; fi < n_frames; ++fi) {
             const FrameDesc &fd = frames[fi];
             if (fd.flags & (kFrameDrain | kFrameNoFloor)) continue;
-            const vpz_packet &pk = packets[fd.rec / C];
-            const vpz_mapping_config &mc = D.mappings[pk.mapping];
-            const int half = ((fd.flags & kFrameLong) ? D.size1 : D.size0) / 2;
+            const vpz_mapping_config &mc = D.mappings[packets[fd.rec / C].mapping];
+            const int half = (fd.flags & kFrameLong) ? half1 : half0;
             for (int ch = 0; ch < C; ++ch) {
                 const int fl = mc.channel_floor[ch];
                 if (D.floor_types[fl] != 0) continue;
-                recs.resize(recs.size() + rs);
-                fill_floor0_rec(recs.data() + (size_t)n_f0 * rs, fd.spec_off + (int64_t)ch * half, fd.rec + ch, fl, half,
+                fill_floor0_rec(f0recs + (size_t)n_f0 * f0rs, fd.spec_off + (int64_t)ch * half, fd.rec + ch, fl, half,
                                 (fd.flags & kFrameLong) ? 1 : 0);
                 ++n_f0;
             }
         }
-        if ((rc = grow(ctx, D.b_f0recs, recs.size())) != VPZ_OK) return rc;
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_f0recs.p, recs.data(), recs.size(), hipMemcpyHostToDevice, ctx->stream));
-        VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // recs is a local vector
-        hipError_t e = launch_floor0_apply(D.b_f0recs.p, n_f0, D.d_floors0, D.d_bark_maps, d_amp, d_coeff, D.f0_stride,
-                                           static_cast<float *>(D.b_temp.p), static_cast<uint8_t *>(D.b_curve.p),
-                                           D.size1 / 2, ctx->stream);
-        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor0 kernel launch", e);
-        D.f0_amp = D.f0_coeff = nullptr;  // consumed
     }
-
-    // ---------------- output placement
-    float *d_out = pcm_out;
-    const int64_t *d_outoff = nullptr;
-    int64_t out_floats = 0;
-    int64_t *offs = arena_alloc<int64_t>(D.arena, (size_t)D.n_streams);
-    for (int s = 0; s < D.n_streams; ++s) offs[s] = stream_out_offset ? stream_out_offset[s] : 0;
+    // output placement
     if (out_layout == VPZ_OUT_PLANAR && channel_stride < stream_out_capacity && C > 1)
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: channel_stride smaller than stream_out_capacity");
-    if (stream_out_offset) {
-        if ((rc = grow(ctx, D.b_outoff, sizeof(int64_t) * (size_t)D.n_streams)) != VPZ_OK) return rc;
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_outoff.p, offs, sizeof(int64_t) * (size_t)D.n_streams,
-                                        hipMemcpyHostToDevice, ctx->stream));
-        d_outoff = static_cast<const int64_t *>(D.b_outoff.p);
-    }
-    if (mem_space == VPZ_MEM_HOST) {
-        for (int s = 0; s < D.n_streams; ++s) {
-            const int64_t ext = out_layout == VPZ_OUT_INTERLEAVED
-                                    ? offs[s] + out_count[s] * C
-                                    : offs[s] + (int64_t)(C - 1) * channel_stride + out_count[s];
-            if (out_count[s] > 0) out_floats = std::max(out_floats, ext);
-        }
-        if ((rc = grow(ctx, D.b_out, sizeof(float) * (size_t)out_floats)) != VPZ_OK) return rc;
-        d_out = static_cast<float *>(D.b_out.p);
-    }
-
+    int64_t *offs = arena_alloc<int64_t>(A, (size_t)D.n_streams);
+    for (int s = 0; s < D.n_streams; ++s) offs[s] = stream_out_offset ? stream_out_offset[s] : 0;
+    const int64_t *d_outoff = stream_out_offset ? static_cast<const int64_t *>(dev(offs)) : nullptr;
+    // any-block-size path: per-frame records + gather lists of the two exact-IMDCT launches
+    GenericFrame *gf = nullptr;
+    int64_t *src0 = nullptr, *dst0 = nullptr, *src1 = nullptr, *dst1 = nullptr;
+    int32_t *save_list = nullptr;
+    size_t n0 = 0, n1 = 0, n_save = 0;
+    int64_t y_floats = 0;
     if (D.generic) {
-        // ---------------- any-block-size path: floor pass, exact IMDCT per size, OLA pass, state save
-        GenericFrame *gf = arena_alloc<GenericFrame>(D.arena, n_frames);
-        int64_t *src0 = arena_alloc<int64_t>(D.arena, n_frames * (size_t)C), *dst0 = arena_alloc<int64_t>(D.arena, n_frames * (size_t)C);
-        int64_t *src1 = arena_alloc<int64_t>(D.arena, n_frames * (size_t)C), *dst1 = arena_alloc<int64_t>(D.arena, n_frames * (size_t)C);
-        int32_t *save_list = arena_alloc<int32_t>(D.arena, (size_t)D.n_streams + 1);
-        size_t n0 = 0, n1 = 0, n_save = 0, fi = 0;
-        int64_t y_floats = 0;
+        gf = arena_alloc<GenericFrame>(A, n_frames);
+        src0 = arena_alloc<int64_t>(A, n_frames * (size_t)C);
+        dst0 = arena_alloc<int64_t>(A, n_frames * (size_t)C);
+        src1 = arena_alloc<int64_t>(A, n_frames * (size_t)C);
+        dst1 = arena_alloc<int64_t>(A, n_frames * (size_t)C);
+        save_list = arena_alloc<int32_t>(A, (size_t)D.n_streams + 1);
+        size_t fi = 0;
         for (int s = 0; s < D.n_streams; ++s) {
-            const size_t cnt = per_stream[s].size();
+            const size_t cnt = (size_t)s_cnt[s];
             int64_t prev_y = stream_started_with_prev[s] ? -1 : -2;
             int prev_n = stream_prev_long[s] ? D.size1 : D.size0;
             long last_block = -1;
@@ -765,76 +722,130 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
                 save_list[n_save++] = (int32_t)last_block;
             }
         }
-        if ((rc = grow(ctx, D.b_gframes, sizeof(GenericFrame) * n_frames)) != VPZ_OK) return rc;
-        if ((rc = grow(ctx, D.b_glists, sizeof(int64_t) * 4 * n_frames * (size_t)C + sizeof(int32_t) * (n_save + 1))) != VPZ_OK) return rc;
-        if ((rc = grow(ctx, D.b_ybuf, sizeof(float) * (size_t)std::max<int64_t>(y_floats, 1))) != VPZ_OK) return rc;
-        int64_t *d_lists = static_cast<int64_t *>(D.b_glists.p);
-        int64_t *d_src0 = d_lists, *d_dst0 = d_lists + n_frames * C, *d_src1 = d_lists + 2 * n_frames * C,
-                *d_dst1 = d_lists + 3 * n_frames * C;
-        int32_t *d_save = reinterpret_cast<int32_t *>(d_lists + 4 * n_frames * C);
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_gframes.p, gf, sizeof(GenericFrame) * n_frames, hipMemcpyHostToDevice, ctx->stream));
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_src0, src0, sizeof(int64_t) * n0, hipMemcpyHostToDevice, ctx->stream));
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_dst0, dst0, sizeof(int64_t) * n0, hipMemcpyHostToDevice, ctx->stream));
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_src1, src1, sizeof(int64_t) * n1, hipMemcpyHostToDevice, ctx->stream));
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_dst1, dst1, sizeof(int64_t) * n1, hipMemcpyHostToDevice, ctx->stream));
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_save, save_list, sizeof(int32_t) * n_save, hipMemcpyHostToDevice, ctx->stream));
-        VPZ_HIP_TRY(ctx, hipEventRecord(D.arena.uploaded, ctx->stream));
-        D.arena.pending = true;
-        const GenericFrame *d_gf = static_cast<const GenericFrame *>(D.b_gframes.p);
+    }
+    auto t_pass2 = tick();
+
+    // ---------------- device side: input staging (VPZ_MEM_HOST), one descriptor upload, kernels
+    const float *d_res = residue;
+    const int16_t *d_posts = posts;
+    const uint8_t *d_counts = post_counts;
+    const float *d_amp = D.f0_amp, *d_coeff = D.f0_coeff;
+    if (mem_space == VPZ_MEM_HOST) {
+        if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)res_extent)) != VPZ_OK) return rc;
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res.p, residue, sizeof(float) * (size_t)res_extent,
+                                        hipMemcpyHostToDevice, ctx->stream));
+        d_res = static_cast<const float *>(D.b_in_res.p);
+        if (any_floor) {
+            if ((rc = grow(ctx, D.b_in_posts, sizeof(int16_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
+            if ((rc = grow(ctx, D.b_in_counts, (size_t)n_rec)) != VPZ_OK) return rc;
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_posts.p, posts, sizeof(int16_t) * 64 * (size_t)n_rec,
+                                            hipMemcpyHostToDevice, ctx->stream));
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_counts.p, post_counts, (size_t)n_rec, hipMemcpyHostToDevice,
+                                            ctx->stream));
+            d_posts = static_cast<const int16_t *>(D.b_in_posts.p);
+            d_counts = static_cast<const uint8_t *>(D.b_in_counts.p);
+        }
+        if (any_floor0) {
+            if ((rc = grow(ctx, D.b_in_amp, sizeof(float) * (size_t)n_rec)) != VPZ_OK) return rc;
+            if ((rc = grow(ctx, D.b_in_coeff, sizeof(float) * (size_t)n_rec * D.f0_stride)) != VPZ_OK) return rc;
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_amp.p, D.f0_amp, sizeof(float) * (size_t)n_rec, hipMemcpyHostToDevice, ctx->stream));
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_coeff.p, D.f0_coeff, sizeof(float) * (size_t)n_rec * D.f0_stride,
+                                            hipMemcpyHostToDevice, ctx->stream));
+            d_amp = static_cast<const float *>(D.b_in_amp.p);
+            d_coeff = static_cast<const float *>(D.b_in_coeff.p);
+        }
+    }
+    float *d_out = pcm_out;
+    if (mem_space == VPZ_MEM_HOST) {
+        int64_t out_floats = 0;
+        for (int s = 0; s < D.n_streams; ++s) {
+            const int64_t ext = out_layout == VPZ_OUT_INTERLEAVED
+                                    ? offs[s] + out_count[s] * C
+                                    : offs[s] + (int64_t)(C - 1) * channel_stride + out_count[s];
+            if (out_count[s] > 0) out_floats = std::max(out_floats, ext);
+        }
+        if ((rc = grow(ctx, D.b_out, sizeof(float) * (size_t)out_floats)) != VPZ_OK) return rc;
+        d_out = static_cast<float *>(D.b_out.p);
+    }
+    if (need_coupling && (rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK) return rc;
+    if (any_floor && (rc = grow(ctx, D.b_curve, (size_t)n_rec * (size_t)half1)) != VPZ_OK) return rc;
+    if (D.generic && (rc = grow(ctx, D.b_ybuf, sizeof(float) * (size_t)std::max<int64_t>(y_floats, 1))) != VPZ_OK) return rc;
+    VPZ_HIP_TRY(ctx, hipMemcpyAsync(A.dev.p, A.base, A.used, hipMemcpyHostToDevice, ctx->stream));
+    VPZ_HIP_TRY(ctx, hipEventRecord(A.uploaded, ctx->stream));
+    A.pending = true;
+
+    const float *d_spec = d_res;
+    if (need_coupling) {
+        hipError_t e = launch_coupling(dev(cpk), n_cpk, D.d_steps, C, d_res, static_cast<float *>(D.b_temp.p), half1,
+                                       ctx->stream);
+        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "coupling kernel launch", e);
+        d_spec = static_cast<const float *>(D.b_temp.p);
+    }
+    if (any_floor) {  // Floor1.UnwrapPosts + curve render (table indices)
+        hipError_t e = launch_floor1_prepare((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(dev(rec_floor)),
+                                             D.d_floors, (int)D.floors.size(), half0, half1,
+                                             static_cast<uint8_t *>(D.b_curve.p), D.ablate, ctx->stream);
+        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor1 prepare kernel launch", e);
+    }
+    if (any_floor0) {  // Floor0.Apply in place on the temp (rare; Floor0.cs:164-225)
+        hipError_t e = launch_floor0_apply(dev(f0recs), n_f0, D.d_floors0, D.d_bark_maps, d_amp, d_coeff, D.f0_stride,
+                                           static_cast<float *>(D.b_temp.p), static_cast<uint8_t *>(D.b_curve.p),
+                                           half1, ctx->stream);
+        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor0 kernel launch", e);
+        D.f0_amp = D.f0_coeff = nullptr;  // consumed
+    }
+
+    if (D.generic) {
+        // ---------------- any-block-size path: floor pass, exact IMDCT per size, OLA pass, state save
+        const GenericFrame *d_gf = static_cast<const GenericFrame *>(dev(gf));
         float *d_temp = static_cast<float *>(D.b_temp.p);
         float *d_y = static_cast<float *>(D.b_ybuf.p);
         hipError_t e = hipSuccess;
         if (any_floor)
-            e = launch_generic_floor(d_gf, (int)n_frames, C, D.size1 / 2, d_temp, d_counts,
+            e = launch_generic_floor(d_gf, (int)n_frames, C, half1, d_temp, d_counts,
                                      static_cast<const uint8_t *>(D.b_curve.p), ctx->d_inv_db, ctx->stream);
         if (e == hipSuccess && n0)
             e = launch_imdct_exact(D.size0, D.t0->ld, d_temp, d_y, (int64_t)n0, D.t0->d_A, D.t0->d_B, D.t0->d_C,
-                                   D.t0->d_bitrev, ctx->num_cu, ctx->stream, d_src0, d_dst0);
+                                   D.t0->d_bitrev, ctx->num_cu, ctx->stream, static_cast<const int64_t *>(dev(src0)),
+                                   static_cast<const int64_t *>(dev(dst0)));
         if (e == hipSuccess && n1)
             e = launch_imdct_exact(D.size1, D.t1->ld, d_temp, d_y, (int64_t)n1, D.t1->d_A, D.t1->d_B, D.t1->d_C,
-                                   D.t1->d_bitrev, ctx->num_cu, ctx->stream, d_src1, d_dst1);
+                                   D.t1->d_bitrev, ctx->num_cu, ctx->stream, static_cast<const int64_t *>(dev(src1)),
+                                   static_cast<const int64_t *>(dev(dst1)));
         if (e == hipSuccess)
             e = launch_generic_ola(d_gf, (int)n_frames, C, D.size0, D.size1, d_y, D.d_state_h, D.t0->d_slope,
                                    D.t1->d_slope, d_out, d_outoff, channel_stride, out_layout == VPZ_OUT_INTERLEAVED,
                                    D.clip, D.d_clipped, ctx->stream);
         if (e == hipSuccess)
-            e = launch_generic_save_state(d_gf, d_save, (int)n_save, C, D.size1, d_y, D.d_state_h, ctx->stream);
+            e = launch_generic_save_state(d_gf, static_cast<const int32_t *>(dev(save_list)), (int)n_save, C, D.size1, d_y,
+                                          D.d_state_h, ctx->stream);
         if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "generic synthesis kernel launch", e);
     } else {
-    // ---------------- descriptors + launch
-    if ((rc = grow(ctx, D.b_frames, sizeof(FrameDesc) * n_frames)) != VPZ_OK) return rc;
-    if ((rc = grow(ctx, D.b_runs, sizeof(RunDesc) * n_runs)) != VPZ_OK) return rc;
-    VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_frames.p, frames, sizeof(FrameDesc) * n_frames, hipMemcpyHostToDevice,
-                                    ctx->stream));
-    VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_runs.p, runs, sizeof(RunDesc) * n_runs, hipMemcpyHostToDevice, ctx->stream));
-    VPZ_HIP_TRY(ctx, hipEventRecord(D.arena.uploaded, ctx->stream));
-    D.arena.pending = true;
-
-    SynthArgs a{};
-    a.frames = static_cast<const FrameDesc *>(D.b_frames.p);
-    a.runs = static_cast<const RunDesc *>(D.b_runs.p);
-    a.n_runs = (int32_t)n_runs;
-    a.channels = C;
-    a.size0 = D.size0;
-    a.size1 = D.size1;
-    a.spec = d_spec;
-    a.post_counts = any_floor ? d_counts : nullptr;
-    a.curve_y = any_floor ? static_cast<const uint8_t *>(D.b_curve.p) : nullptr;
-    a.inv_db = ctx->d_inv_db;
-    a.state_h = D.d_state_h;
-    a.tw_long = D.t1->d_fast;
-    a.tw_short = D.t0->d_fast;
-    a.slope0 = D.t0->d_slope;
-    a.slope1 = D.t1->d_slope;
-    a.out = d_out;
-    a.stream_out_off = d_outoff;
-    a.channel_stride = channel_stride;
-    a.interleaved = out_layout == VPZ_OUT_INTERLEAVED;
-    a.clip = D.clip;
-    a.clipped = D.d_clipped;
-    a.ablate = D.ablate;
-    hipError_t e = launch_synth(a, any_floor, ctx->stream);
-    if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "synth kernel launch", e);
+        SynthArgs a{};
+        a.frames = static_cast<const FrameDesc *>(dev(frames));
+        a.runs = static_cast<const RunDesc *>(dev(runs));
+        a.n_runs = (int32_t)n_runs;
+        a.channels = C;
+        a.size0 = D.size0;
+        a.size1 = D.size1;
+        a.spec = d_spec;
+        a.post_counts = any_floor ? d_counts : nullptr;
+        a.curve_y = any_floor ? static_cast<const uint8_t *>(D.b_curve.p) : nullptr;
+        a.inv_db = ctx->d_inv_db;
+        a.state_h = D.d_state_h;
+        a.tw_long = D.t1->d_fast;
+        a.tw_short = D.t0->d_fast;
+        a.slope0 = D.t0->d_slope;
+        a.slope1 = D.t1->d_slope;
+        a.out = d_out;
+        a.stream_out_off = d_outoff;
+        a.channel_stride = channel_stride;
+        a.interleaved = out_layout == VPZ_OUT_INTERLEAVED;
+        a.clip = D.clip;
+        a.clipped = D.d_clipped;
+        a.ablate = D.ablate;
+        hipError_t e = launch_synth(a, any_floor, ctx->stream);
+        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "synth kernel launch", e);
     }
 
     if (mem_space == VPZ_MEM_HOST) {
@@ -855,6 +866,12 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     D.states = st;
+    if (host_profile) {
+        auto t_end = tick();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[vpz host] packets %lld: pass1 %.1f us, runs+arena %.1f us, uploads+launch %.1f us\n",
+                (long long)n_packets, us(t_begin, t_pass1), us(t_pass1, t_pass2), us(t_pass2, t_end));
+    }
     if (mismatches)
         return set_error(ctx, VPZ_E_WINDOW_MISMATCH,
                          "vpz_decoder_synth: a packet's previous tail is longer than its window slope "

@@ -162,6 +162,21 @@ class OggVorbisFile:
             raise FrontError(lib().vpzh_last_error(self._h).decode())
         return packets, residue[: self.info.residue_floats], posts, counts
 
+    def decode_into(self, packets, residue, posts, counts, stream_id=0, residue_base=0):
+        """decode_packets into caller-owned arrays (typically slices of one batch buffer shared by many
+        streams): packets [audio_packets] of capi.PACKET_DTYPE, residue float32 [>= info.residue_floats]
+        that starts at float index `residue_base` of the batch buffer, posts int16 [audio_packets * channels,
+        64], counts uint8 [audio_packets * channels].  Distinct handles may be decoded from distinct threads
+        (the call releases the GIL); type-0 floors are not supported here."""
+        n = self.audio_packets
+        assert self.floor0_stride == 0
+        assert len(packets) == n and residue.size >= self.info.residue_floats and len(counts) == n * self.channels
+        assert all(a.flags["C_CONTIGUOUS"] for a in (packets, residue, posts, counts))
+        rc = lib().vpzh_decode_range_ex(self._h, 0, n, stream_id, residue_base, packets.ctypes.data, residue.ctypes.data,
+                                        posts.ctypes.data, counts.ctypes.data, None, None, None, 0)
+        if rc != 0:
+            raise FrontError(lib().vpzh_last_error(self._h).decode())
+
 
 class VorbisReader:
     """Mirror of NVorbis.VorbisReader's read surface (VorbisReader.cs:232-253) on top of the GPU back
