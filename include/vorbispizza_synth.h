@@ -206,6 +206,12 @@ int vpz_decoder_last_packet_samples(vpz_decoder *dec, int32_t *out, int64_t capa
 int vpz_decoder_has_clipped(vpz_decoder *dec, int32_t stream, int32_t *has_clipped);
 /* `_currentPosition` after the last synth call (StreamDecoder.cs:493) */
 int vpz_decoder_position(vpz_decoder *dec, int32_t stream, int64_t *sample_position);
+/* `_currentPosition = value; _hasPosition = true` -- what StreamDecoder.SeekTo does around its pre-roll
+ * (StreamDecoder.cs:851-852, 879-880) and what the SamplePosition setter amounts to.  A seek is, on this side of
+ * the boundary: vpz_decoder_reset(stream); vpz_decoder_set_position(stream, <kept value>) so that the granule
+ * pick-up stays off; synth of the pre-roll packet and the target packet; vpz_decoder_set_position(stream,
+ * target + samples still undelivered).  INTEGRATION.md spells the sequence out. */
+int vpz_decoder_set_position(vpz_decoder *dec, int32_t stream, int64_t sample_position);
 
 #ifdef __cplusplus
 }

@@ -114,3 +114,34 @@ def test_decode_into_shared_batch_buffers_from_threads(front):
         assert np.array_equal(res[k * rf:(k + 1) * rf], res0)
         assert np.array_equal(posts[k * n * C_:(k + 1) * n * C_], posts0)
         assert np.array_equal(counts[k * n * C_:(k + 1) * n * C_], counts0)
+
+
+@pytest.mark.parametrize("name", sorted(FACTS))
+def test_seek_table_matches_the_packet_geometry(front, name):
+    """PacketProvider.SeekTo with preRoll 1: positions are counted from the per-packet SampleCount (the first
+    audio packet only primes the overlap); the answer is the packet BEFORE the one whose span holds the target."""
+    f = front.OggVorbisFile(os.path.join(GOLDEN, name))
+    pk, _, _, _ = f.decode_packets()
+    counts = []
+    for fl in pk["flags"]:
+        if fl & helpers.PKT_NOT_DECODED:
+            counts.append(0)
+            continue
+        bf, pf, nf = fl & 1, bool(fl & 2), bool(fl & 4)
+        size = 2048 if bf else 256
+        left = 0 if (not bf or pf) else (size - 256) // 4
+        right = size // 2 if (not bf or nf) else (size * 3 - 256) // 4
+        counts.append(right - left)
+    cum = np.concatenate([[0], np.cumsum(counts[1:])])
+    assert f.total_samples == min(int(cum[-1]), f.last_granule)
+    rng = np.random.default_rng(1)
+    for g in [0, 1, int(cum[1]) - 1, int(cum[1]), int(cum[-1]) - 1, int(cum[-1])] + [int(v) for v in rng.integers(0, cum[-1], 50)]:
+        first, roll = f.seek(g)
+        k = first + 1
+        assert 0 <= first < len(pk) - 1
+        assert cum[k - 1] <= g and (g < cum[k] or (g == cum[-1] and k == len(pk) - 1))
+        assert roll == g - cum[k - 1]
+    with pytest.raises(front.FrontError):
+        f.seek(int(cum[-1]) + 1)
+    with pytest.raises(front.FrontError):
+        f.seek(-1)

@@ -81,6 +81,7 @@ _SIGNATURES = [
     ("vpz_decoder_last_packet_samples", C.c_int, [_vp, _vp, C.c_int64]),
     ("vpz_decoder_has_clipped", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int32)]),
     ("vpz_decoder_position", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64)]),
+    ("vpz_decoder_set_position", C.c_int, [_vp, C.c_int32, C.c_int64]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -331,3 +332,6 @@ class Decoder:
         v = C.c_int64()
         self.ctx._check(lib().vpz_decoder_position(self._h, stream, C.byref(v)))
         return v.value
+
+    def set_position(self, position, stream=0):
+        self.ctx._check(lib().vpz_decoder_set_position(self._h, stream, int(position)))

@@ -66,6 +66,63 @@ __device__ __forceinline__ void couple(float &m, float &a)
     a = oldM + __uint_as_float(signedA & posA);
 }
 
+// Tile kernel (channels <= kCouplingTileChannels): one workgroup takes `width` bins (256 ... 1024, more for
+// fewer channels so that every thread keeps several loads in flight) of one packet, stages all channels in
+// LDS as [channel][width + 1] (coalesced global reads in either source layout), runs the coupling steps
+// column by column, and writes every planar row once.  HBM traffic: each value read once, written once.
+constexpr int kCouplingTileChannels = 32;
+__host__ __device__ inline int coupling_tile_width(int channels) { return channels <= 4 ? 1024 : (channels <= 8 ? 512 : 256); }
+
+__global__ __launch_bounds__(256) void coupling_tile_kernel(const CouplingPacket *__restrict__ pkts,
+                                                           const uint8_t *__restrict__ steps, int channels,
+                                                           const float *__restrict__ residue, float *__restrict__ temp)
+{
+    extern __shared__ float s_tile[];  // [channels][width + 1]
+    const CouplingPacket pk = pkts[blockIdx.y];
+    const int width = coupling_tile_width(channels), ld = width + 1;
+    const int bin0 = blockIdx.x * width;
+    if (bin0 >= pk.half) return;
+    const int nb = min(width, pk.half - bin0);
+    const int t = threadIdx.x;
+    const float *src = residue + pk.src_off;
+    if (pk.interleaved) {
+        const float *s = src + (size_t)bin0 * channels;
+        const int total = nb * channels;
+        // element i = (bin, channel) = (i / channels, i % channels); i advances by 256 per step
+        int bin = t / channels, c = t - bin * channels;
+        const int dbin = 256 / channels, dc = 256 - dbin * channels;
+#pragma unroll 8
+        for (int i = t; i < total; i += 256) {
+            s_tile[c * ld + bin] = s[i];
+            bin += dbin;
+            c += dc;
+            if (c >= channels) { c -= channels; ++bin; }
+        }
+        __syncthreads();
+    } else {
+        for (int c = 0; c < channels; ++c)
+#pragma unroll 4
+            for (int b = t; b < nb; b += 256) s_tile[c * ld + b] = src[(size_t)c * pk.half + bin0 + b];
+    }
+    if (pk.steps_off >= 0) {
+        const uint8_t *st = steps + pk.steps_off;
+        for (int i = pk.steps - 1; i >= 0; --i) {  // reverse order, Mapping.cs:166
+            float *pm = s_tile + st[2 * i] * ld, *pa = s_tile + st[2 * i + 1] * ld;
+            for (int b = t; b < nb; b += 256) {
+                float m = pm[b], a = pa[b];
+                couple(m, a);
+                pm[b] = m;
+                pa[b] = a;
+            }
+        }
+    }
+    float *dst = temp + pk.dst_off + bin0;
+    for (int c = 0; c < channels; ++c)
+#pragma unroll 4
+        for (int b = t; b < nb; b += 256) dst[(size_t)c * pk.half + b] = s_tile[c * ld + b];
+}
+
+// Fallback for more channels than the tile holds: one thread per (packet, bin), through global memory.
 __global__ __launch_bounds__(256) void coupling_kernel(const CouplingPacket *__restrict__ pkts,
                                                       const uint8_t *__restrict__ steps,
                                                       int channels, const float *__restrict__ residue,
@@ -428,7 +485,7 @@ __device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base,
     for (int m = 0; m < 8; ++m) x[m] = s[k0 + st * m];
 }
 
-template <bool kHasFloor>
+template <bool kHasFloor, bool kInterleaved>
 __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 {
     __shared__ float2 s_twL[512];
@@ -574,17 +631,17 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             // equal block sizes share one slope table (s_slope0 only holds a 128-entry short slope)
             const float *slope = ((fd.flags & kFrameSlope1) || a.size0 == a.size1) ? s_slope1 : s_slope0;
             const int plen = fd.packet_len;
-            float *dst = a.interleaved ? out_base + fd.out_off * a.channels + ch
+            float *dst = kInterleaved ? out_base + fd.out_off * a.channels + ch
                                        : out_base + (int64_t)ch * a.channel_stride + fd.out_off;
             // every window boundary of the 256/2048 geometries is a multiple of 64 samples, so unless
             // an EOS trim cut the packet a float4 never straddles a mirror / overlap boundary
             // (interleaved output keeps the float4 arithmetic and scatters the four samples with the
             // channel stride; the other channels' waves fill the gaps of the same cache lines)
             const bool vec = !drain && ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0 &&
-                             (a.interleaved || (reinterpret_cast<uintptr_t>(dst) & 15) == 0);
-            const int64_t ostep = a.interleaved ? a.channels : 1;
+                             (kInterleaved || (reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+            const int64_t ostep = kInterleaved ? a.channels : 1;
             auto store4 = [&](int g, float o0, float o1, float o2, float o3) {
-                if (a.interleaved) {
+                if (kInterleaved) {
                     float *d = dst + (int64_t)(4 * g) * ostep;
                     d[0] = o0;
                     d[ostep] = o1;
@@ -621,8 +678,18 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         o[r][2] = (hv.z * wl.z) + (pv.y * wr.y);
                         o[r][3] = (hv.w * wl.w) + (pv.x * wr.x);
                     }
+                    if (kInterleaved) {  // scattered stores: finish each group of four at once (short live ranges)
+                        if (a.clip) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                clipped_any |= was_clipped(o[r][c]);
+                                o[r][c] = clip_value(o[r][c]);
+                            }
+                        }
+                        store4(g, o[r][0], o[r][1], o[r][2], o[r][3]);
+                    }
                 }
-                if (a.clip) {
+                if (!kInterleaved && a.clip) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -632,7 +699,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) store4(lane + 64 * r, o[r][0], o[r][1], o[r][2], o[r][3]);
+                for (int r = 0; r < 4; ++r)
+                    if (!kInterleaved) store4(lane + 64 * r, o[r][0], o[r][1], o[r][2], o[r][3]);
             } else if (vec) {
                 // branch-free: lanes past the end clamp their reads and skip only the store; samples
                 // past the overlap take weights (1, 0)
@@ -840,8 +908,14 @@ hipError_t launch_coupling(const void *pkts, int n_pkts, const uint8_t *steps, i
     const CouplingPacket *p = static_cast<const CouplingPacket *>(pkts);
     for (int done = 0; done < n_pkts; done += 65535) {
         int cnt = n_pkts - done < 65535 ? n_pkts - done : 65535;
-        hipLaunchKernelGGL(coupling_kernel, dim3((max_half + 255) / 256, cnt), dim3(256), 0, stream,
-                           p + done, steps, channels, residue, temp, max_half);
+        if (channels <= kCouplingTileChannels)
+            hipLaunchKernelGGL(coupling_tile_kernel,
+                               dim3((max_half + coupling_tile_width(channels) - 1) / coupling_tile_width(channels), cnt),
+                               dim3(256), sizeof(float) * (size_t)(coupling_tile_width(channels) + 1) * (size_t)channels,
+                               stream, p + done, steps, channels, residue, temp);
+        else
+            hipLaunchKernelGGL(coupling_kernel, dim3((max_half + 255) / 256, cnt), dim3(256), 0, stream,
+                               p + done, steps, channels, residue, temp, max_half);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -853,10 +927,15 @@ hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t strea
     const long items = (long)args.n_runs * args.channels;
     if (items <= 0) return hipSuccess;
     const int grid = (int)((items + kSynthWaves - 1) / kSynthWaves);
-    if (has_floor)
-        hipLaunchKernelGGL(synth_kernel<true>, dim3(grid), dim3(kSynthThreads), 0, stream, args);
+    // four instantiations: the interleaved store pattern costs registers the planar steady state needs
+    if (has_floor && args.interleaved)
+        hipLaunchKernelGGL((synth_kernel<true, true>), dim3(grid), dim3(kSynthThreads), 0, stream, args);
+    else if (has_floor)
+        hipLaunchKernelGGL((synth_kernel<true, false>), dim3(grid), dim3(kSynthThreads), 0, stream, args);
+    else if (args.interleaved)
+        hipLaunchKernelGGL((synth_kernel<false, true>), dim3(grid), dim3(kSynthThreads), 0, stream, args);
     else
-        hipLaunchKernelGGL(synth_kernel<false>, dim3(grid), dim3(kSynthThreads), 0, stream, args);
+        hipLaunchKernelGGL((synth_kernel<false, false>), dim3(grid), dim3(kSynthThreads), 0, stream, args);
     return hipGetLastError();
 }
 
@@ -866,8 +945,8 @@ int synth_resident_waves(bool has_floor, int num_cu)
 {
     int per_cu = 0;
     hipError_t e = has_floor
-                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<true>, kSynthThreads, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<false>, kSynthThreads, 0);
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<true, false>, kSynthThreads, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<false, false>, kSynthThreads, 0);
     if (e != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 2;

@@ -912,6 +912,16 @@ int vpz_decoder_has_clipped(vpz_decoder *d, int32_t stream, int32_t *has_clipped
     return VPZ_OK;
 }
 
+int vpz_decoder_set_position(vpz_decoder *d, int32_t stream, int64_t sample_position)
+{
+    if (!d) return VPZ_E_INVALID_ARG;
+    Decoder &D = d->impl;
+    if (stream < 0 || stream >= D.n_streams) return set_error(D.ctx, VPZ_E_INVALID_ARG, "vpz_decoder_set_position: bad stream");
+    D.states[stream].current_position = sample_position;
+    D.states[stream].has_position = true;
+    return VPZ_OK;
+}
+
 int vpz_decoder_position(vpz_decoder *d, int32_t stream, int64_t *sample_position)
 {
     if (!d || !sample_position) return VPZ_E_INVALID_ARG;

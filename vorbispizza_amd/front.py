@@ -78,6 +78,14 @@ def lib():
         L.vpzr_set_clip_samples.restype = C.c_int
         L.vpzr_set_batch_packets.argtypes = [vp, C.c_int]
         L.vpzr_set_batch_packets.restype = C.c_int
+        L.vpzr_seek_to.argtypes = [vp, C.c_int64, C.c_int]
+        L.vpzr_seek_to.restype = C.c_int
+        L.vpzr_total_samples.argtypes = [vp]
+        L.vpzr_total_samples.restype = C.c_int64
+        L.vpzh_total_samples.argtypes = [vp]
+        L.vpzh_total_samples.restype = C.c_int64
+        L.vpzh_seek.argtypes = [vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.vpzh_seek.restype = C.c_int
         L.vpzr_read_samples.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int)]
         L.vpzr_read_samples.restype = C.c_int64
         L.vpzr_read_samples_planar.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int)]
@@ -129,6 +137,19 @@ class OggVorbisFile:
                 "coupling": [(m.coupling_magnitude[j], m.coupling_angle[j]) for j in range(m.coupling_steps)],
                 "channel_floor": list(m.channel_floor[: self.channels])})
         self.residue_types = [lib().vpzh_get_residue_type(self._h, i) for i in range(info.residue_count)]
+
+    @property
+    def total_samples(self):
+        """PacketProvider.GetGranuleCount: counted samples per channel, capped by the last page granule."""
+        return lib().vpzh_total_samples(self._h)
+
+    def seek(self, sample_position):
+        """PacketProvider.SeekTo(pos, preRoll=1): (index of the pre-roll packet, samples of the packet after it
+        that precede the position)."""
+        first, roll = C.c_int64(), C.c_int64()
+        if lib().vpzh_seek(self._h, int(sample_position), C.byref(first), C.byref(roll)) != 0:
+            raise FrontError(lib().vpzh_last_error(self._h).decode())
+        return first.value, roll.value
 
     def close(self):
         if getattr(self, "_h", None):
@@ -195,12 +216,25 @@ class VorbisReader:
             raise FrontError("Could not load the specified container. %s" % msg)
         lib().vpzr_set_clip_samples(self._h, int(clip_samples))
         lib().vpzr_set_batch_packets(self._h, batch_packets)
+        import weakref
+        ctx._children.append(weakref.ref(self))  # the reader owns a decoder: it must go before the context
+
+    def close(self):
+        self.Dispose()
 
     Channels = property(lambda self: lib().vpzr_channels(self._h))
     SampleRate = property(lambda self: lib().vpzr_sample_rate(self._h))
     SamplePosition = property(lambda self: lib().vpzr_sample_position(self._h))
     IsEndOfStream = property(lambda self: bool(lib().vpzr_is_end_of_stream(self._h)))
     HasClipped = property(lambda self: bool(lib().vpzr_has_clipped(self._h)))
+    TotalSamples = property(lambda self: lib().vpzr_total_samples(self._h))
+
+    def SeekTo(self, samplePosition, seekOrigin=0):
+        """StreamDecoder.SeekTo(long, SeekOrigin) (StreamDecoder.cs:815-881); seekOrigin 0 Begin, 1 Current, 2 End.
+        Raises capi.SynthError where the reference throws (SeekOutOfRange / ArgumentOutOfRange / PreRoll)."""
+        rc = lib().vpzr_seek_to(self._h, int(samplePosition), int(seekOrigin))
+        if rc != 0:
+            raise capi.SynthError(rc, lib().vpzr_last_error(self._h).decode())
 
     def ReadSamples(self, buffer, samplesToRead=None, channelStride=None):
         st = C.c_int(0)
@@ -216,7 +250,8 @@ class VorbisReader:
 
     def Dispose(self):
         if getattr(self, "_h", None):
-            lib().vpzr_close(self._h)
+            if getattr(self._ctx, "_h", None):  # a reader outliving its context cannot free device state any more
+                lib().vpzr_close(self._h)
             self._h = None
 
     def __del__(self):

@@ -3,6 +3,8 @@
 // function cites the C# it follows.  Bit-serial / integer work only.
 #include "vorbis_front.h"
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -807,6 +809,31 @@ struct vpzh_stream {
         return (int64_t)channels * ((modes[mode_idx].block_flag ? size1 : size0) / 2);
     }
 
+    // IPacketGranuleCountProvider.GetPacketGranuleCount (StreamDecoder.cs:884-913): what a packet adds to the
+    // sample position, from its mode bits alone -- PacketInfo.SampleCount = RightStart - LeftStart (Mode.cs:30-66)
+    int packet_sample_count(const OggPacket &pk) const
+    {
+        BitReader p;
+        p.init(pk.data.data(), pk.data.size());
+        if (p.read_bits(1) != 0) return 0;
+        const int mode_idx = (int)p.read_bits(mode_field_bits);
+        if (mode_idx >= (int)modes.size()) return 0;
+        const bool bf = modes[mode_idx].block_flag;
+        bool prev = true, next = true;
+        if (bf) {
+            prev = p.read_bit();
+            next = p.read_bit();
+        }
+        if (p.is_short) return 0;
+        const int size = bf ? size1 : size0;
+        const int left_start = prev ? 0 : (size - size0) / 4;
+        const int right_start = next ? size / 2 : (size * 3 - size0) / 4;
+        return right_start - left_start;
+    }
+    // PacketProvider._pageEndGranules, kept per packet: position after packet i when counting starts at the
+    // second audio packet (the first one only primes the overlap; PacketProvider.cs:283-287)
+    std::vector<int64_t> cum_samples;
+
     // StreamDecoder.DecodeNextPacket :696-762 -> Mode.Decode -> Mapping.DecodePacket :98-163
     void decode_packet(const OggPacket &pk, int32_t stream_id, int64_t residue_off, vpz_packet *out, float *residue,
                        int16_t *posts, uint8_t *post_counts, float *f0_amp = nullptr, float *f0_coeff = nullptr,
@@ -927,6 +954,9 @@ int vpzh_open_memory(const uint8_t *data, uint64_t size, vpzh_stream **out)
         s->audio.assign(std::make_move_iterator(packets.begin() + 3), std::make_move_iterator(packets.end()));
         s->residue_floats = 0;
         for (const OggPacket &pk : s->audio) s->residue_floats += s->packet_floats(pk);
+        s->cum_samples.assign(s->audio.size(), 0);
+        for (size_t i = 1; i < s->audio.size(); ++i)
+            s->cum_samples[i] = s->cum_samples[i - 1] + s->packet_sample_count(s->audio[i]);
     } catch (const Unsupported &e) {
         s->error = e.what();
         rc = VPZH_E_UNSUPPORTED;
@@ -1040,6 +1070,32 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
         s->error = e.what();
         return VPZH_E_INVALID_DATA;
     }
+    return VPZH_OK;
+}
+
+int64_t vpzh_total_samples(vpzh_stream *s)
+{
+    // PacketProvider.GetGranuleCount (:35-49): the counted length, capped by the last page's granule position
+    if (!s || s->cum_samples.empty()) return 0;
+    int64_t total = s->cum_samples.back();
+    if (s->last_granule >= 0 && total > s->last_granule) total = s->last_granule;
+    return total;
+}
+
+int vpzh_seek(vpzh_stream *s, int64_t sample_position, int64_t *first_packet, int64_t *roll_forward)
+{
+    // PacketProvider.SeekTo(granulePos, preRoll = 1) (:56-84, GetTargetPageInfo :86-160): the packet whose
+    // span [start, end) holds the position, then one packet back for the pre-roll.
+    if (!s || !first_packet || !roll_forward) return VPZH_E_ARG;
+    const std::vector<int64_t> &cum = s->cum_samples;
+    if (sample_position < 0 || cum.size() < 2 || sample_position > cum.back()) {
+        s->error = "The requested seek position extends beyond the stream.";  // SeekOutOfRangeException
+        return VPZH_E_ARG;
+    }
+    size_t k = (size_t)(std::upper_bound(cum.begin() + 1, cum.end(), sample_position) - cum.begin());
+    if (k >= cum.size()) k = cum.size() - 1;  // position == end of the stream: the last packet, rolled to its end
+    *first_packet = (int64_t)k - 1;
+    *roll_forward = sample_position - cum[k - 1];
     return VPZH_OK;
 }
 

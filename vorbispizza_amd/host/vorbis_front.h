@@ -50,6 +50,14 @@ int vpzh_max_floor0_order(vpzh_stream *s);            /* 0 when the stream has n
 int vpzh_get_mapping(vpzh_stream *s, int index, vpz_mapping_config *out);
 int vpzh_get_residue_type(vpzh_stream *s, int index);
 
+/* Seeking (PacketProvider.SeekTo / GetGranuleCount, Ogg/PacketProvider.cs:35-160).  Positions are counted
+ * samples: the first audio packet only primes the overlap, every later packet adds PacketInfo.SampleCount.
+ * vpzh_seek returns the index of the PRE-ROLL packet (decode from there) and how many samples of the packet
+ * after it lie before `sample_position`; VPZH_E_ARG when the position is outside the stream
+ * (SeekOutOfRangeException). */
+int64_t vpzh_total_samples(vpzh_stream *s);
+int vpzh_seek(vpzh_stream *s, int64_t sample_position, int64_t *first_packet, int64_t *roll_forward);
+
 /* Entropy-decodes every audio packet.  packets[audio_packets], residue[residue_floats],
  * posts[audio_packets*channels*64], post_counts[audio_packets*channels].  `stream_id` is written to
  * vpz_packet.stream, `residue_base` is added to every residue_offset.  Packets whose first bit is set

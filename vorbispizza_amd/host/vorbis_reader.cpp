@@ -197,6 +197,52 @@ int vpzr_sample_rate(vpzr_reader *r) { return r ? r->info.sample_rate : 0; }
 int64_t vpzr_sample_position(vpzr_reader *r) { return r ? r->position : 0; }
 int vpzr_is_end_of_stream(vpzr_reader *r) { return r ? (r->ended && r->cur_remaining == 0 && r->cur_packet >= r->packet_samples.size()) : 1; }
 
+int64_t vpzr_total_samples(vpzr_reader *r) { return r ? vpzh_total_samples(r->front) : 0; }
+
+// StreamDecoder.SeekTo(long, SeekOrigin) (StreamDecoder.cs:815-881)
+int vpzr_seek_to(vpzr_reader *r, int64_t sample_position, int origin)
+{
+    if (!r) return VPZ_E_INVALID_ARG;
+    if (sample_position < 0) return r->fail(VPZ_E_INVALID_ARG, "samplePosition");  // ArgumentOutOfRangeException
+    switch (origin) {
+    case VPZR_SEEK_BEGIN: break;
+    case VPZR_SEEK_CURRENT: sample_position = r->position - sample_position; break;               // :838 (as written there)
+    case VPZR_SEEK_END: sample_position = vpzh_total_samples(r->front) - sample_position; break;  // :842
+    default: return r->fail(VPZ_E_INVALID_ARG, "seekOrigin");
+    }
+    int64_t pre = 0, roll = 0;
+    if (vpzh_seek(r->front, sample_position, &pre, &roll) != VPZH_OK)
+        return r->fail(VPZ_E_INVALID_ARG, "The requested seek position extends beyond the stream.");
+    int rc = r->ensure_decoder();
+    if (rc != VPZ_OK) return rc;
+    // ResetDecoder(); _hasPosition = true (the position VALUE is whatever it was, :851-852)
+    int64_t kept = 0;
+    vpz_decoder_position(r->dec, 0, &kept);
+    vpz_decoder_reset(r->dec, 0);
+    vpz_decoder_set_position(r->dec, 0, kept);
+    r->ended = false;
+    r->next_packet = pre;
+    // the pre-roll packet and the target packet, as one two-packet call (:855-876)
+    const int batch = r->batch;
+    r->batch = 2;
+    rc = r->refill();
+    r->batch = batch;
+    if (rc != VPZ_OK) return rc;
+    if (r->packet_samples.size() < 2) {  // PreRollPacketException
+        r->ended = true;
+        return r->fail(VPZ_E_INVALID_ARG, "Could not read pre-roll packet. Try seeking again prior to reading more samples.");
+    }
+    // _prevPacketStart += rollForward; _currentPosition = samplePosition (:879-880)
+    const int32_t have = r->packet_samples[1];
+    const int32_t skip = (int32_t)std::min<int64_t>(roll, have);
+    r->cur_packet = 2;
+    r->cur_offset = r->packet_samples[0] + skip;
+    r->cur_remaining = have - skip;
+    r->position = sample_position;
+    vpz_decoder_set_position(r->dec, 0, sample_position + r->cur_remaining);
+    return VPZ_OK;
+}
+
 int vpzr_set_clip_samples(vpzr_reader *r, int clip)
 {
     if (!r) return VPZ_E_INVALID_ARG;

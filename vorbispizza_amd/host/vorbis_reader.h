@@ -28,6 +28,15 @@ int     vpzr_has_clipped(vpzr_reader *r);          /* IStreamDecoder.HasClipped 
 int     vpzr_set_clip_samples(vpzr_reader *r, int clip);      /* ClipSamples; default true (VorbisReader.cs:71) */
 int     vpzr_set_batch_packets(vpzr_reader *r, int packets);  /* packets synthesised per GPU call (default 128) */
 
+/* `SeekTo(long samplePosition, SeekOrigin seekOrigin)` (StreamDecoder.cs:815-881) and `TotalSamples`.
+ * Positions are counted samples per channel (see vpzh_seek).  VPZ_E_INVALID_ARG outside the stream
+ * (SeekOutOfRangeException / ArgumentOutOfRangeException) or when the pre-roll cannot be read. */
+#define VPZR_SEEK_BEGIN   0
+#define VPZR_SEEK_CURRENT 1
+#define VPZR_SEEK_END     2
+int     vpzr_seek_to(vpzr_reader *r, int64_t sample_position, int origin);
+int64_t vpzr_total_samples(vpzr_reader *r);
+
 /* `ReadSamples(Span<float> buffer)`: interleaved, returns samples per channel, at most one packet's
  * worth per call, 0 at the end of the stream.  *status receives a VPZ_* code. */
 int64_t vpzr_read_samples(vpzr_reader *r, float *buffer, int64_t buffer_len, int *status);
