@@ -410,6 +410,16 @@ __device__ __forceinline__ float clip_value(float v)
     return v > 0.99999994f ? 0.99999994f : (v < -0.99999994f ? -0.99999994f : v);
 }
 __device__ __forceinline__ bool was_clipped(float v) { return v > 0.99999994f || v < -0.99999994f; }
+// OverlapBuffers' `(v * v_lhs) + (v_prev * v_rhs)` (StreamDecoder.cs:788) with the reference's roundings --
+// two products, one sum, never contracted into an FMA -- so that every emission path of the kernel
+// (float4 / pair / scalar) gives the same bits for the same sample.
+__device__ __forceinline__ float ola(float v, float wl, float t, float wr)
+{
+#pragma clang fp contract(off)
+    const float a = v * wl;
+    const float b = t * wr;
+    return a + b;
+}
 
 // Branch-free addressing of the IMDCT output through its mirror symmetries (Mdct.cs:378-381).
 // y[pos..pos+3] (pos, n4 multiples of 4) = h4[idx] possibly reversed / negated.
@@ -485,9 +495,16 @@ __device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base,
     for (int m = 0; m < 8; ++m) x[m] = s[k0 + st * m];
 }
 
-template <bool kHasFloor, bool kInterleaved>
+// kOut: 0 planar output, 1 interleaved (any channel count: every wave scatters its own channel),
+//       2 interleaved stereo: the two waves of a stream (channels 0 / 1, adjacent in the workgroup) build
+//         their blocks, meet at a workgroup barrier, and each writes HALF of the packet's samples for BOTH
+//         channels -- dense 32-byte (L R L R | L R L R) stores instead of 4-byte stores at an 8-byte stride.
+template <bool kHasFloor, int kOut>
 __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 {
+    constexpr bool kInterleaved = kOut != 0;
+    constexpr bool kPair = kOut == 2;
+    __shared__ int s_iters;
     __shared__ float2 s_twL[512];
     __shared__ float2 s_twAB[512];
     __shared__ float2 s_twBC[64];
@@ -523,10 +540,16 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     // wave-uniform values are forced into SGPRs so the descriptor reads become scalar loads
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int item = blockIdx.x * kSynthWaves + wave;
-    if (item >= a.n_runs * a.channels) return;
-    const int run_idx = item / a.channels;
-    const int ch = item - run_idx * a.channels;
-    const RunDesc run = a.runs[run_idx];
+    const bool active = item < a.n_runs * a.channels;
+    if (!kPair && !active) return;  // (the pair variant keeps idle waves around for its barriers)
+    const int run_idx = active ? item / a.channels : 0;
+    const int ch = active ? item - run_idx * a.channels : (wave & 1);
+    RunDesc run = a.runs[run_idx];
+    if (kPair && !active) {  // an idle wave of the pair variant: nothing to load, emit or save
+        run.count = 0;
+        run.pre_kind = kPreNone;
+        run.flags = 0;
+    }
     const int half1 = a.size1 >> 1;
 
     float *hcur = s_work[wave];
@@ -542,7 +565,16 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         const int hh = (fd.flags & kFrameLong) ? (a.size1 >> 1) : (a.size0 >> 1);
         return a.spec + fd.spec_off + (int64_t)ch * hh;
     };
-    const int fi0 = (run.pre_kind == kPreRecompute) ? -1 : 0;
+    const int fi0 = (run.pre_kind == kPreRecompute && run.count > 0) ? -1 : 0;
+    // trip count: the run's own in the free-running variants, the workgroup's longest in the pair variant
+    int iters = run.count - fi0;
+    if (kPair) {
+        if (threadIdx.x == 0) s_iters = 0;
+        __syncthreads();
+        if (lane == 0) atomicMax(&s_iters, iters);
+        __syncthreads();
+        iters = s_iters;
+    }
     // Stage the run's descriptors in LDS with one coalesced read: per-frame scalar loads from
     // global memory put an L2 round trip on every frame's critical path.
     {
@@ -581,12 +613,14 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     float2 xcur[8];
     uint32_t fycur[8];
     FrameDesc fd_next = frame_at(fi0);
-    if (!(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec)) {
+    if (run.count > 0 && !(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec)) {
         load_spectrum(xcur, spectrum_of(fd_next), is_2048(fd_next.flags), lane);
         if (kHasFloor && !(fd_next.flags & kFrameNoFloor))
             load_floor_indices(fycur, a.curve_y + (size_t)(fd_next.rec + ch) * half1, is_2048(fd_next.flags), lane);
     }
-    for (int fi = fi0; fi < run.count; ++fi) {
+    for (int it = 0; it < iters; ++it) {
+        const int fi = fi0 + it;
+        const bool live = !kPair || fi < run.count;  // wave-uniform; idle iterations only keep the barriers matched
         const FrameDesc fd = fd_next;
         float2 xnext[8];
         uint32_t fynext[8];
@@ -602,7 +636,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         const bool drain = fd.flags & kFrameDrain;
         const bool is_long = is_2048(fd.flags);  // "long" below means: the 2048-point transform
         const int n4 = is_long ? 512 : 64;
-        if (!drain) {
+        if (live && !drain) {
             if (!exec_of(fd.flags, fd.rec)) {
                 // Mapping.cs:190-194: the channel is silent, its whole block is zero
                 for (int i = lane; i < 2 * n4; i += 64) hcur[i] = 0.0f;
@@ -626,7 +660,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             if (kHasFloor) asm volatile("" ::"v"(fynext[m]));
         }
 
-        if (fi >= 0 && fd.out_count > 0 && !(a.ablate & 1)) {
+        if (kPair) __syncthreads();  // both channels' blocks (and tails) are in LDS
+        if (live && fi >= 0 && fd.out_count > 0 && !(a.ablate & 1)) {
             // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 573-591)
             // equal block sizes share one slope table (s_slope0 only holds a 128-entry short slope)
             const float *slope = ((fd.flags & kFrameSlope1) || a.size0 == a.size1) ? s_slope1 : s_slope0;
@@ -651,7 +686,77 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     store_nt(reinterpret_cast<float4 *>(dst) + g, make_float4(o0, o1, o2, o3));
                 }
             };
-            if (vec && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 &&
+            // stereo pair: L / R blocks and tails of this stream sit in the two adjacent wave buffers
+            const float4 *hL4 = reinterpret_cast<const float4 *>(s_work[wave & ~1]);
+            const float4 *hR4 = reinterpret_cast<const float4 *>(s_work[wave | 1]);
+            const float4 *tL4 = reinterpret_cast<const float4 *>(s_tail[wave & ~1]);
+            const float4 *tR4 = reinterpret_cast<const float4 *>(s_tail[wave | 1]);
+            float *pair_row = out_base + fd.out_off * 2;  // sample s of the packet at floats [2s, 2s+1]
+            const bool vec_pair = kPair && !drain && ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0 &&
+                                  (reinterpret_cast<uintptr_t>(pair_row) & 15) == 0;
+            auto store_pair = [&](int g, float l0, float l1, float l2, float l3, float r0, float r1, float r2, float r3) {
+                if (a.clip) {
+                    clipped_any |= was_clipped(l0) || was_clipped(l1) || was_clipped(l2) || was_clipped(l3) ||
+                                   was_clipped(r0) || was_clipped(r1) || was_clipped(r2) || was_clipped(r3);
+                    l0 = clip_value(l0); l1 = clip_value(l1); l2 = clip_value(l2); l3 = clip_value(l3);
+                    r0 = clip_value(r0); r1 = clip_value(r1); r2 = clip_value(r2); r3 = clip_value(r3);
+                }
+                float4 *d = reinterpret_cast<float4 *>(pair_row) + 2 * g;
+                store_nt(d, make_float4(l0, r0, l1, r1));
+                store_nt(d + 1, make_float4(l2, r2, l3, r3));
+            };
+            if (vec_pair && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 &&
+                fd.prev_end == 1024 && fd.out_count == 1024 && prev_n4 == 512 && a.size1 == 2048) {
+                // long after long, long windows (see the single-channel version below): channel-0's wave writes
+                // samples [0, 512) -- the negated mirror half --, channel-1's wave samples [512, 1024)
+                const float4 *s4 = reinterpret_cast<const float4 *>(s_slope1);
+#pragma unroll 1
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int g = lane + 64 * (2 * ch + rr);
+                    const float4 wl = s4[g], wr = s4[255 - g];
+                    if (ch == 0) {
+                        const float4 hl = hL4[127 - g], pl = tL4[g], hr = hR4[127 - g], pr = tR4[g];
+                        store_pair(g, ola(-hl.w, wl.x, pl.x, wr.w), ola(-hl.z, wl.y, pl.y, wr.z),
+                                   ola(-hl.y, wl.z, pl.z, wr.y), ola(-hl.x, wl.w, pl.w, wr.x),
+                                   ola(-hr.w, wl.x, pr.x, wr.w), ola(-hr.z, wl.y, pr.y, wr.z),
+                                   ola(-hr.y, wl.z, pr.z, wr.y), ola(-hr.x, wl.w, pr.w, wr.x));
+                    } else {
+                        const float4 hl = hL4[g - 128], pl = tL4[255 - g], hr = hR4[g - 128], pr = tR4[255 - g];
+                        store_pair(g, ola(hl.x, wl.x, pl.w, wr.w), ola(hl.y, wl.y, pl.z, wr.z),
+                                   ola(hl.z, wl.z, pl.y, wr.y), ola(hl.w, wl.w, pl.x, wr.x),
+                                   ola(hr.x, wl.x, pr.w, wr.w), ola(hr.y, wl.y, pr.z, wr.z),
+                                   ola(hr.z, wl.z, pr.y, wr.y), ola(hr.w, wl.w, pr.x, wr.x));
+                    }
+                }
+            } else if (vec_pair) {
+                // any other aligned geometry: the branch-free form below, for both channels, over this wave's
+                // half of the float4 groups
+                const float4 *s4 = reinterpret_cast<const float4 *>(slope);
+                const int cnt4 = fd.out_count >> 2, mid = (cnt4 + 1) >> 1;
+                const int g0 = ch ? mid : 0, g1 = ch ? cnt4 : mid;
+                const int pn4 = prev_n4;
+                for (int gb = g0; gb < g1; gb += 64) {
+                    const int g = gb + lane;
+                    const bool lv = g < g1;
+                    const int i = (lv ? g : g1 - 1) << 2;
+                    const Y4Map mc = map_y4(fd.left_start + i, n4);
+                    const bool in = i < plen;
+                    const int ii = in ? i : 0;
+                    const int q = fd.prev_end + ii;
+                    const bool pc = q >= 3 * pn4;
+                    int pidx = (pc ? (4 * pn4 - 4 - q) : (q - 2 * pn4)) >> 2;
+                    pidx = in ? pidx : 0;
+                    const int ridx = in ? ((plen - 4 - ii) >> 2) : 0;
+                    const float4 wl = s4[ii >> 2], wr = s4[ridx];
+                    const float4 vl = apply_y4(hL4[mc.idx4], mc.rev, mc.neg), ql = apply_y4(tL4[pidx], pc, false);
+                    const float4 vr = apply_y4(hR4[mc.idx4], mc.rev, mc.neg), qr = apply_y4(tR4[pidx], pc, false);
+                    const float l0 = in ? ola(vl.x, wl.x, ql.x, wr.w) : vl.x, l1 = in ? ola(vl.y, wl.y, ql.y, wr.z) : vl.y;
+                    const float l2 = in ? ola(vl.z, wl.z, ql.z, wr.y) : vl.z, l3 = in ? ola(vl.w, wl.w, ql.w, wr.x) : vl.w;
+                    const float r0 = in ? ola(vr.x, wl.x, qr.x, wr.w) : vr.x, r1 = in ? ola(vr.y, wl.y, qr.y, wr.z) : vr.y;
+                    const float r2 = in ? ola(vr.z, wl.z, qr.z, wr.y) : vr.z, r3 = in ? ola(vr.w, wl.w, qr.w, wr.x) : vr.w;
+                    if (lv) store_pair(g, l0, l1, l2, l3, r0, r1, r2, r3);
+                }
+            } else if (!kPair && vec && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 &&
                 fd.prev_end == 1024 && fd.out_count == 1024 && prev_n4 == 512 && a.size1 == 2048) {
                 // long block after a long block with long windows on both sides (the steady state of
                 // every stream): the geometry is a compile-time constant -- first half of the output
@@ -667,16 +772,16 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     const float4 wl = s4[g], wr = s4[255 - g];
                     if (r < 2) {
                         const float4 hv = h4[127 - g], pv = t4[g];
-                        o[r][0] = (-hv.w * wl.x) + (pv.x * wr.w);
-                        o[r][1] = (-hv.z * wl.y) + (pv.y * wr.z);
-                        o[r][2] = (-hv.y * wl.z) + (pv.z * wr.y);
-                        o[r][3] = (-hv.x * wl.w) + (pv.w * wr.x);
+                        o[r][0] = ola(-hv.w, wl.x, pv.x, wr.w);
+                        o[r][1] = ola(-hv.z, wl.y, pv.y, wr.z);
+                        o[r][2] = ola(-hv.y, wl.z, pv.z, wr.y);
+                        o[r][3] = ola(-hv.x, wl.w, pv.w, wr.x);
                     } else {
                         const float4 hv = h4[g - 128], pv = t4[255 - g];
-                        o[r][0] = (hv.x * wl.x) + (pv.w * wr.w);
-                        o[r][1] = (hv.y * wl.y) + (pv.z * wr.z);
-                        o[r][2] = (hv.z * wl.z) + (pv.y * wr.y);
-                        o[r][3] = (hv.w * wl.w) + (pv.x * wr.x);
+                        o[r][0] = ola(hv.x, wl.x, pv.w, wr.w);
+                        o[r][1] = ola(hv.y, wl.y, pv.z, wr.z);
+                        o[r][2] = ola(hv.z, wl.z, pv.y, wr.y);
+                        o[r][3] = ola(hv.w, wl.w, pv.x, wr.x);
                     }
                     if (kInterleaved) {  // scattered stores: finish each group of four at once (short live ranges)
                         if (a.clip) {
@@ -701,7 +806,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (!kInterleaved) store4(lane + 64 * r, o[r][0], o[r][1], o[r][2], o[r][3]);
-            } else if (vec) {
+            } else if (!kPair && vec) {
                 // branch-free: lanes past the end clamp their reads and skip only the store; samples
                 // past the overlap take weights (1, 0)
                 const float4 *h4 = reinterpret_cast<const float4 *>(hcur);
@@ -731,10 +836,10 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     // (v * v_lhs) + (v_prev * v_rhs), StreamDecoder.cs:788; wr is read reversed.
                     // Scalars only from here on: a float4 that is selected / passed by reference ends
                     // up in scratch memory.
-                    float o0 = (v.x * wl.x) + (t.x * wr.w);
-                    float o1 = (v.y * wl.y) + (t.y * wr.z);
-                    float o2 = (v.z * wl.z) + (t.z * wr.y);
-                    float o3 = (v.w * wl.w) + (t.w * wr.x);
+                    float o0 = ola(v.x, wl.x, t.x, wr.w);
+                    float o1 = ola(v.y, wl.y, t.y, wr.z);
+                    float o2 = ola(v.z, wl.z, t.z, wr.y);
+                    float o3 = ola(v.w, wl.w, t.w, wr.x);
                     o0 = in ? o0 : v.x;
                     o1 = in ? o1 : v.y;
                     o2 = in ? o2 : v.z;
@@ -757,7 +862,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         v = y_from_h(hcur, fd.left_start + i, n4);
                         if (i < plen) {
                             const float t = tail_at(tail, fd.prev_end + i, prev_n4);
-                            v = (v * slope[i]) + (t * slope[plen - 1 - i]);
+                            v = ola(v, slope[i], t, slope[plen - 1 - i]);
                         }
                     }
                     if (a.clip) {
@@ -768,7 +873,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 }
             }
         }
-        if (!drain) {
+        if (kPair) __syncthreads();  // the partner is done reading this wave's block and tail
+        if (live && !drain) {
             // keep what a later block can overlap with: y[N/2 .. N) lives in the upper half of h
             if (is_long) {
                 const float4 *src = reinterpret_cast<const float4 *>(hcur + 512);
@@ -859,7 +965,7 @@ __global__ __launch_bounds__(256) void generic_ola_kernel(const GenericFrame *__
             v = ycur[fr.left_start + i];
             if (i < fr.packet_len) {
                 const float t = yprev[fr.prev_end + i - prev_base];
-                v = (v * slope[i]) + (t * slope[fr.packet_len - 1 - i]);
+                v = ola(v, slope[i], t, slope[fr.packet_len - 1 - i]);
             }
         }
         if (clip) {
@@ -928,14 +1034,19 @@ hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t strea
     if (items <= 0) return hipSuccess;
     const int grid = (int)((items + kSynthWaves - 1) / kSynthWaves);
     // four instantiations: the interleaved store pattern costs registers the planar steady state needs
-    if (has_floor && args.interleaved)
-        hipLaunchKernelGGL((synth_kernel<true, true>), dim3(grid), dim3(kSynthThreads), 0, stream, args);
-    else if (has_floor)
-        hipLaunchKernelGGL((synth_kernel<true, false>), dim3(grid), dim3(kSynthThreads), 0, stream, args);
-    else if (args.interleaved)
-        hipLaunchKernelGGL((synth_kernel<false, true>), dim3(grid), dim3(kSynthThreads), 0, stream, args);
-    else
-        hipLaunchKernelGGL((synth_kernel<false, false>), dim3(grid), dim3(kSynthThreads), 0, stream, args);
+    const int out_kind = !args.interleaved ? 0 : (args.channels == 2 ? 2 : 1);
+#define VPZ_LAUNCH_SYNTH(F, O) \
+    hipLaunchKernelGGL((synth_kernel<F, O>), dim3(grid), dim3(kSynthThreads), 0, stream, args)
+    if (has_floor) {
+        if (out_kind == 0) VPZ_LAUNCH_SYNTH(true, 0);
+        else if (out_kind == 1) VPZ_LAUNCH_SYNTH(true, 1);
+        else VPZ_LAUNCH_SYNTH(true, 2);
+    } else {
+        if (out_kind == 0) VPZ_LAUNCH_SYNTH(false, 0);
+        else if (out_kind == 1) VPZ_LAUNCH_SYNTH(false, 1);
+        else VPZ_LAUNCH_SYNTH(false, 2);
+    }
+#undef VPZ_LAUNCH_SYNTH
     return hipGetLastError();
 }
 
@@ -945,8 +1056,8 @@ int synth_resident_waves(bool has_floor, int num_cu)
 {
     int per_cu = 0;
     hipError_t e = has_floor
-                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<true, false>, kSynthThreads, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<false, false>, kSynthThreads, 0);
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<true, 0>, kSynthThreads, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<false, 0>, kSynthThreads, 0);
     if (e != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 2;
