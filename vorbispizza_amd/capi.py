@@ -173,6 +173,10 @@ class Context:
         except Exception:
             pass
 
+    def last_error(self):
+        """Text of the last failure on this context (what the C# host would put into its exception)."""
+        return lib().vpz_context_last_error(self._h).decode()
+
     def synchronize(self):
         self._check(lib().vpz_context_synchronize(self._h))
 
