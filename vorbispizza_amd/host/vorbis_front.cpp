@@ -64,18 +64,20 @@ struct BitReader {
         int n = (int)(rem < count ? rem : count);
         *bits_read = n;
         if (n <= 0) { *bits_read = 0; return 0; }
-        uint64_t v = 0;
-        int64_t byte = pos >> 3;
-        int shift = (int)(pos & 7);
-        int got = 0;
-        // gather up to 9 bytes
-        int need_bytes = (shift + n + 7) >> 3;
+        const int64_t byte = pos >> 3;
+        const int shift = (int)(pos & 7);
+        if (n <= 56 && byte + 8 <= (total_bits >> 3)) {  // common case: one unaligned 8-byte load covers it
+            uint64_t w;
+            memcpy(&w, data + byte, 8);
+            return (w >> shift) & (((uint64_t)1 << n) - 1);
+        }
+        // near the end of the packet, or more than 56 bits: gather up to 9 bytes
+        const int need_bytes = (shift + n + 7) >> 3;
         unsigned __int128 acc = 0;
         for (int i = 0; i < need_bytes; ++i) acc |= (unsigned __int128)data[byte + i] << (8 * i);
         acc >>= shift;
-        v = (uint64_t)acc;
+        uint64_t v = (uint64_t)acc;
         if (n < 64) v &= ((uint64_t)1 << n) - 1;
-        (void)got;
         return v;
     }
     int skip(int count)  // SkipBits / SkipExtraBits
@@ -256,6 +258,17 @@ struct Codebook {
 
     int decode_scalar(BitReader &p) const  // Codebook.cs:301-335
     {
+        // fast path, same result as the general one below: at least 64 bits left, so the peek cannot come up
+        // short and the skip cannot overrun
+        if (p.pos + 64 <= p.total_bits && !prefix.empty()) {
+            uint64_t w;
+            memcpy(&w, p.data + (p.pos >> 3), 8);
+            const HuffNode &node = prefix[(size_t)((w >> (p.pos & 7)) & (((uint64_t)1 << prefix_bits) - 1))];
+            if (node.length != 0) {
+                p.pos += node.length;
+                return node.value;
+            }
+        }
         int n;
         uint64_t data = p.try_peek(prefix_bits, &n);
         if (n != 0 && !prefix.empty()) {
