@@ -269,6 +269,9 @@ __device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int
     const unsigned w = (unsigned)bitmap[xx >> 5];
     int j = prefix[xx >> 5] + __popc(w & ((2u << (xx & 31)) - 1u)) - 1;
     Seg s = unpack_segment(segA[j], segB[j], segC[j]);
+    // the segment after this one is fetched ahead: a switch inside the bin loop then costs no LDS round trip
+    // (segA/B/C hold 65 entries; entries past the last active post are never switched to)
+    int nA = segA[j + 1], nB = segB[j + 1], nC = segC[j + 1];
     int yy, err;
     {
         const int k = xx - s.x0;
@@ -288,7 +291,10 @@ __device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int
             ++xx;
             if (xx == s.x1 && xx < n) {  // the next segment starts exactly on its post
                 ++j;
-                s = unpack_segment(segA[j], segB[j], segC[j]);
+                s = unpack_segment(nA, nB, nC);
+                nA = segA[j + 1];
+                nB = segB[j + 1];
+                nC = segC[j + 1];
                 yy = s.y0;
                 err = -s.adx;
             } else {
@@ -330,12 +336,20 @@ __global__ __launch_bounds__(64 * kPrepWaves) void floor1_prepare_kernel(int n_r
     // stage the inputs: a per-lane walk over global memory would put one DRAM round trip on every post
     {
         const int first = blockIdx.x * 64;
-        for (int i = threadIdx.x; i < 64 * 32; i += 64 * kPrepWaves) {  // 32 dwords (64 posts) per record
+        constexpr int kIters = 64 * 32 / (64 * kPrepWaves);  // 32 dwords (64 posts) per record
+        uint32_t v[kIters];
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {  // all loads in flight before the first LDS store
+            const int i = threadIdx.x + it * 64 * kPrepWaves;
             const int r = i >> 5, w = i & 31;
-            uint32_t v = 0;
-            if (first + r < n_rec) v = reinterpret_cast<const uint32_t *>(posts + (size_t)(first + r) * 64)[w];
-            s_posts[r][2 * w] = (int16_t)(v & 0xFFFF);
-            s_posts[r][2 * w + 1] = (int16_t)(v >> 16);
+            v[it] = (first + r < n_rec) ? reinterpret_cast<const uint32_t *>(posts + (size_t)(first + r) * 64)[w] : 0u;
+        }
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int i = threadIdx.x + it * 64 * kPrepWaves;
+            const int r = i >> 5, w = i & 31;
+            s_posts[r][2 * w] = (int16_t)(v[it] & 0xFFFF);
+            s_posts[r][2 * w + 1] = (int16_t)(v[it] >> 16);
         }
         const int nf = n_floors < kPrepFloorsInLds ? n_floors : kPrepFloorsInLds;
         const int words = nf * (int)(sizeof(FloorDev) / 4);
