@@ -386,230 +386,267 @@ int vpz_decoder_reset(vpz_decoder *d, int32_t stream)
     return VPZ_OK;
 }
 
-int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packets, const float *residue,
-                      const int16_t *posts, const uint8_t *post_counts, int mem_space, float *pcm_out,
-                      const int64_t *stream_out_offset, int64_t stream_out_capacity, int out_layout,
-                      int64_t channel_stride, int64_t *samples_written)
-{
-    if (!d) return VPZ_E_INVALID_ARG;
-    Decoder &D = d->impl;
-    Context *ctx = D.ctx;
-    if (n_packets < 0 || (n_packets > 0 && (!packets || !residue || !pcm_out)) || !samples_written)
-        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: null argument");
-    if (mem_space != VPZ_MEM_HOST && mem_space != VPZ_MEM_DEVICE)
-        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: bad mem_space");
-    if (out_layout != VPZ_OUT_INTERLEAVED && out_layout != VPZ_OUT_PLANAR)
-        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: bad out_layout");
-    if (n_packets > (int64_t)0x7fffffff / std::max(1, D.channels))
-        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: batch too large");
-    VPZ_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int C = D.channels;
-    for (int s = 0; s < D.n_streams; ++s) samples_written[s] = 0;
-    D.packet_samples.assign((size_t)n_packets, 0);
-    if (n_packets == 0) return VPZ_OK;
+// One vpz_decoder_synth call, stage by stage.  Everything here is host work on integers; the sample
+// arithmetic is in the kernels the last stage enqueues.
+namespace {
 
-    static const bool host_profile = getenv("VPZ_HOST_PROFILE") != nullptr;
-    auto tick = [] { return std::chrono::steady_clock::now(); };
-    auto t_begin = tick();
-    int rc;
-    const int64_t n_rec = n_packets * C;
-    const bool have_posts = posts && post_counts && !D.floors.empty();
-    bool has_floor0_type = false;
-    for (uint8_t t : D.floor_types) has_floor0_type |= (t == 0);
+struct SynthCall {
+    // ---- the call's arguments
+    Decoder &D;
+    Context *ctx;
+    const int64_t n_packets;
+    const vpz_packet *packets;
+    const float *residue;
+    const int16_t *posts;
+    const uint8_t *post_counts;
+    const int mem_space;
+    float *pcm_out;
+    const int64_t *stream_out_offset;
+    const int64_t stream_out_capacity;
+    const int out_layout;
+    const int64_t channel_stride;
+    // ---- derived
+    const int C, half0, half1;
+    const int64_t n_rec;
+    const bool have_posts;
+    PinnedArena *A = nullptr;
+    std::vector<StreamState> st;  // working copy of the stream states: committed when the batch is accepted
+    std::vector<uint8_t> started_with_prev, started_prev_long;
+    // ---- products of the state machine
+    FrameDesc *frames = nullptr;
+    size_t n_frames = 0;
+    uint8_t *rec_floor = nullptr;  // per channel record: floor index | 0x40 type-0 | 0x80 long block
+    bool any_floor = false, any_floor0 = false, need_coupling = false;
+    int64_t mismatches = 0, res_extent = 0;
+    // ---- descriptor tables (pinned arena; dev() gives the device mirror's address)
+    RunDesc *runs = nullptr;
+    size_t n_runs = 0;
+    uint8_t *cpk = nullptr;
+    int n_cpk = 0;
+    int64_t temp_floats = 0;
+    uint8_t *f0recs = nullptr;
+    int n_f0 = 0;
+    int64_t *offs = nullptr;
+    GenericFrame *gf = nullptr;
+    int64_t *src0 = nullptr, *dst0 = nullptr, *src1 = nullptr, *dst1 = nullptr;
+    int32_t *save_list = nullptr;
+    size_t n0 = 0, n1 = 0, n_save = 0;
+    int64_t y_floats = 0;
+    // ---- device views
+    const float *d_res = nullptr, *d_amp = nullptr, *d_coeff = nullptr;
+    const int16_t *d_posts = nullptr;
+    const uint8_t *d_counts = nullptr;
+    float *d_out = nullptr;
+
+    SynthCall(Decoder &dec, int64_t n, const vpz_packet *pk, const float *res, const int16_t *po, const uint8_t *pc,
+              int mem, float *out, const int64_t *out_off, int64_t out_cap, int layout, int64_t stride)
+        : D(dec), ctx(dec.ctx), n_packets(n), packets(pk), residue(res), posts(po), post_counts(pc), mem_space(mem),
+          pcm_out(out), stream_out_offset(out_off), stream_out_capacity(out_cap), out_layout(layout),
+          channel_stride(stride), C(dec.channels), half0(dec.size0 / 2), half1(dec.size1 / 2),
+          n_rec(n * dec.channels), have_posts(po && pc && !dec.floors.empty())
+    {
+    }
+
+    void *dev(const void *host_ptr) const
+    {
+        return host_ptr ? static_cast<char *>(A->dev.p) + (static_cast<const char *>(host_ptr) - A->base) : nullptr;
+    }
 
     // Every per-call table (frame / run descriptors, coupling packets, per-record floor info, output
     // offsets, ...) is carved out of ONE pinned arena that goes to its device mirror in a single copy;
     // two arenas alternate so the host can prepare call k+1 while call k's upload is still queued.
-    const size_t cps = coupling_packet_size();
-    const size_t f0rs = floor0_rec_size();
-    const size_t np = (size_t)n_packets;
-    size_t arena_need = (sizeof(FrameDesc) + sizeof(RunDesc) + cps) * np + sizeof(RunDesc) * ((size_t)D.n_streams + 1) +
-                        (have_posts ? (size_t)n_rec : 0) + sizeof(int64_t) * (size_t)D.n_streams + 4096;
-    if (has_floor0_type) arena_need += f0rs * (size_t)n_rec + 64;
-    if (D.generic) arena_need += (sizeof(GenericFrame) + 4 * sizeof(int64_t) * (size_t)C) * np + sizeof(int32_t) * ((size_t)D.n_streams + 1) + 1024;
-    D.arena_idx ^= 1;
-    PinnedArena &A = D.arenas[D.arena_idx];
-    if ((rc = arena_begin(ctx, A, arena_need)) != VPZ_OK) return rc;
-    if ((rc = grow(ctx, A.dev, A.cap)) != VPZ_OK) return rc;
-    auto dev = [&A](const void *host_ptr) -> void * {
-        return host_ptr ? static_cast<char *>(A.dev.p) + (static_cast<const char *>(host_ptr) - A.base) : nullptr;
-    };
-
-    // ---------------- pass 1: per-stream state machine -> frame descriptors (written in place, stream-major)
-    std::vector<StreamState> st = D.states;  // committed only when the whole batch is accepted
-    std::vector<int64_t> &s_base = D.s_base, &s_cnt = D.s_cnt, &out_count = D.out_count;
-    s_base.assign((size_t)D.n_streams + 1, 0);
-    s_cnt.assign((size_t)D.n_streams, 0);
-    out_count.assign((size_t)D.n_streams, 0);
-    if (D.n_streams > 1) {
-        for (int64_t p = 0; p < n_packets; ++p) {
-            const int32_t s = packets[p].stream;
-            if (s < 0 || s >= D.n_streams)
-                return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: packet stream index out of range");
-            ++s_base[(size_t)s + 1];
-        }
-        for (int s = 0; s < D.n_streams; ++s) s_base[(size_t)s + 1] += s_base[(size_t)s];
+    int open_arena()
+    {
+        bool has_floor0_type = false;
+        for (uint8_t t : D.floor_types) has_floor0_type |= (t == 0);
+        const size_t np = (size_t)n_packets;
+        size_t need = (sizeof(FrameDesc) + sizeof(RunDesc) + coupling_packet_size()) * np +
+                      sizeof(RunDesc) * ((size_t)D.n_streams + 1) + (have_posts ? (size_t)n_rec : 0) +
+                      sizeof(int64_t) * (size_t)D.n_streams + 4096;
+        if (has_floor0_type) need += floor0_rec_size() * (size_t)n_rec + 64;
+        if (D.generic)
+            need += (sizeof(GenericFrame) + 4 * sizeof(int64_t) * (size_t)C) * np +
+                    sizeof(int32_t) * ((size_t)D.n_streams + 1) + 1024;
+        D.arena_idx ^= 1;
+        A = &D.arenas[D.arena_idx];
+        int rc = arena_begin(ctx, *A, need);
+        if (rc != VPZ_OK) return rc;
+        return grow(ctx, A->dev, A->cap);
     }
-    std::vector<uint8_t> stream_started_with_prev(D.n_streams), stream_prev_long(D.n_streams);
-    for (int s = 0; s < D.n_streams; ++s) {
-        stream_started_with_prev[s] = st[s].has_prev;
-        stream_prev_long[s] = st[s].prev_long;
-    }
-    FrameDesc *frames = arena_alloc<FrameDesc>(A, np);
-    uint8_t *rec_floor = have_posts ? arena_alloc<uint8_t>(A, (size_t)n_rec) : nullptr;
-    if (rec_floor) memset(rec_floor, 0, (size_t)n_rec);
-    bool any_floor = false, need_coupling = D.generic;  // the generic path always works on its own planar copy
-    int64_t mismatches = 0;
-    bool any_floor0 = false;
-    int64_t res_extent = 0;
-    const int half0 = D.size0 / 2, half1 = D.size1 / 2;
 
-    for (int64_t p = 0; p < n_packets; ++p) {
-        const vpz_packet &pk = packets[p];
-        if (pk.stream < 0 || pk.stream >= D.n_streams)
-            return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: packet stream index out of range");
-        StreamState &S = st[pk.stream];
-        // Read(): once EOS was seen and the previous packet is drained nothing more is read (:441-447)
-        if (S.eos_found && S.prev_start == S.prev_end) continue;
-        const bool eos = pk.flags & VPZ_PKT_EOS;
-        if (eos) S.eos_found = true;  // _eosFound |= isEndOfStream (:647), before the null check
-        if (pk.flags & VPZ_PKT_NOT_DECODED) {
-            if (eos && S.has_prev && S.prev_stop > S.prev_end) {  // :451-455 drain, un-windowed
-                FrameDesc fd{};
-                fd.flags = kFrameDrain;
-                fd.prev_end = (uint16_t)S.prev_end;
-                fd.out_count = (uint16_t)(S.prev_stop - S.prev_end);
-                fd.out_off = out_count[pk.stream];
-                out_count[pk.stream] += fd.out_count;
-                D.packet_samples[(size_t)p] = fd.out_count;
-                S.current_position += fd.out_count;
-                S.prev_end = S.prev_stop;
-                S.prev_start = S.prev_stop;
-                frames[s_base[pk.stream] + s_cnt[pk.stream]++] = fd;
+    // Pass 1: StreamDecoder.Read / ReadNextPacket per stream (StreamDecoder.cs:418-498, 640-694) -> one
+    // FrameDesc per packet that produces or carries samples, written in place, stream-major.
+    int run_state_machine(int64_t *samples_written)
+    {
+        st = D.states;
+        std::vector<int64_t> &s_base = D.s_base, &s_cnt = D.s_cnt, &out_count = D.out_count;
+        s_base.assign((size_t)D.n_streams + 1, 0);
+        s_cnt.assign((size_t)D.n_streams, 0);
+        out_count.assign((size_t)D.n_streams, 0);
+        if (D.n_streams > 1) {
+            for (int64_t p = 0; p < n_packets; ++p) {
+                const int32_t s = packets[p].stream;
+                if (s < 0 || s >= D.n_streams)
+                    return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: packet stream index out of range");
+                ++s_base[(size_t)s + 1];
             }
-            continue;
+            for (int s = 0; s < D.n_streams; ++s) s_base[(size_t)s + 1] += s_base[(size_t)s];
         }
-        const bool no_floor = pk.flags & VPZ_PKT_NO_FLOOR;
-        if (!no_floor) {
-            if (pk.mapping >= D.mappings.size())
-                return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: packet mapping index out of range");
-            if (!have_posts)
-                return set_error(ctx, VPZ_E_INVALID_ARG,
-                                 "vpz_decoder_synth: posts and a floor table are required unless VPZ_PKT_NO_FLOOR");
+        started_with_prev.resize(D.n_streams);
+        started_prev_long.resize(D.n_streams);
+        for (int s = 0; s < D.n_streams; ++s) {
+            started_with_prev[s] = st[s].has_prev;
+            started_prev_long[s] = st[s].prev_long;
         }
-        if (pk.residue_offset < 0)
-            return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: negative residue offset");
+        frames = arena_alloc<FrameDesc>(*A, (size_t)n_packets);
+        rec_floor = have_posts ? arena_alloc<uint8_t>(*A, (size_t)n_rec) : nullptr;
+        if (rec_floor) memset(rec_floor, 0, (size_t)n_rec);
+        need_coupling = D.generic;  // the generic path always works on its own planar copy
 
-        const bool bf = pk.flags & VPZ_PKT_BLOCK_FLAG;
-        const PacketInfo &pi = D.packet_info[pk.flags & 7];  // Mode.GetPacketInfo, tabulated at create
-        const int packet_len = S.prev_stop - S.prev_end;  // :654
-        int right_start = pi.right_start;
-        if (pk.granule != -1 && eos) {  // :658-666
-            const int64_t actual_end = S.current_position + packet_len;
-            const int diff = (int)(actual_end - pk.granule);
-            if (diff > 0) right_start = std::max(right_start - diff, 0);
-        }
-        FrameDesc fd{};
-        fd.rec = (int32_t)(p * C);
-        fd.flags = (bf ? kFrameLong : 0u) | (pi.left_use_size1 ? kFrameSlope1 : 0u) | (no_floor ? kFrameNoFloor : 0u);
-        if (S.has_prev) {  // :670-675
-            const int slope_len = pi.left_use_size1 ? half1 : half0;
-            if (packet_len > slope_len) {
-                // windowSlope.AsSpan(0, packetLen) would throw (:778): that Read fails, the packet is
-                // consumed and the decoder state stays as it was.  The rest of the batch is still
-                // synthesised; the call reports the condition at the end.
-                ++mismatches;
+        for (int64_t p = 0; p < n_packets; ++p) {
+            const vpz_packet &pk = packets[p];
+            if (pk.stream < 0 || pk.stream >= D.n_streams)
+                return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: packet stream index out of range");
+            StreamState &S = st[pk.stream];
+            // Read(): once EOS was seen and the previous packet is drained nothing more is read (:441-447)
+            if (S.eos_found && S.prev_start == S.prev_end) continue;
+            const bool eos = pk.flags & VPZ_PKT_EOS;
+            if (eos) S.eos_found = true;  // _eosFound |= isEndOfStream (:647), before the null check
+            if (pk.flags & VPZ_PKT_NOT_DECODED) {
+                if (eos && S.has_prev && S.prev_stop > S.prev_end) {  // :451-455 drain, un-windowed
+                    FrameDesc fd{};
+                    fd.flags = kFrameDrain;
+                    fd.prev_end = (uint16_t)S.prev_end;
+                    fd.out_count = (uint16_t)(S.prev_stop - S.prev_end);
+                    fd.out_off = out_count[pk.stream];
+                    out_count[pk.stream] += fd.out_count;
+                    D.packet_samples[(size_t)p] = fd.out_count;
+                    S.current_position += fd.out_count;
+                    S.prev_end = S.prev_stop;
+                    S.prev_start = S.prev_stop;
+                    frames[s_base[pk.stream] + s_cnt[pk.stream]++] = fd;
+                }
                 continue;
             }
-            fd.packet_len = (uint16_t)packet_len;
-            fd.prev_end = (uint16_t)S.prev_end;
-            S.prev_start = pi.left_start;
-        } else {
-            fd.packet_len = 0;
-            S.prev_start = right_start;  // :679 first packet has no valid data before rightStart
+            const bool no_floor = pk.flags & VPZ_PKT_NO_FLOOR;
+            if (!no_floor) {
+                if (pk.mapping >= D.mappings.size())
+                    return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: packet mapping index out of range");
+                if (!have_posts)
+                    return set_error(ctx, VPZ_E_INVALID_ARG,
+                                     "vpz_decoder_synth: posts and a floor table are required unless VPZ_PKT_NO_FLOOR");
+            }
+            if (pk.residue_offset < 0)
+                return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: negative residue offset");
+
+            const bool bf = pk.flags & VPZ_PKT_BLOCK_FLAG;
+            const PacketInfo &pi = D.packet_info[pk.flags & 7];  // Mode.GetPacketInfo, tabulated at create
+            const int packet_len = S.prev_stop - S.prev_end;  // :654
+            int right_start = pi.right_start;
+            if (pk.granule != -1 && eos) {  // :658-666
+                const int64_t actual_end = S.current_position + packet_len;
+                const int diff = (int)(actual_end - pk.granule);
+                if (diff > 0) right_start = std::max(right_start - diff, 0);
+            }
+            FrameDesc fd{};
+            fd.rec = (int32_t)(p * C);
+            fd.flags = (bf ? kFrameLong : 0u) | (pi.left_use_size1 ? kFrameSlope1 : 0u) | (no_floor ? kFrameNoFloor : 0u);
+            if (S.has_prev) {  // :670-675
+                const int slope_len = pi.left_use_size1 ? half1 : half0;
+                if (packet_len > slope_len) {
+                    // windowSlope.AsSpan(0, packetLen) would throw (:778): that Read fails, the packet is
+                    // consumed and the decoder state stays as it was.  The rest of the batch is still
+                    // synthesised; the call reports the condition at the end.
+                    ++mismatches;
+                    continue;
+                }
+                fd.packet_len = (uint16_t)packet_len;
+                fd.prev_end = (uint16_t)S.prev_end;
+                S.prev_start = pi.left_start;
+            } else {
+                fd.packet_len = 0;
+                S.prev_start = right_start;  // :679 first packet has no valid data before rightStart
+            }
+            fd.left_start = (uint16_t)S.prev_start;  // emission starts at the new _prevPacketStart
+            S.prev_end = right_start;
+            S.prev_stop = pi.right_end;
+            S.has_prev = true;
+            S.prev_long = bf;
+            if (pk.granule != -1 && !S.has_position) {  // :459-463 (idx == 0 here)
+                S.has_position = true;
+                S.current_position = pk.granule - (S.prev_end - S.prev_start);
+            }
+            // a trim below LeftStart would make the reference spin (copyLen <= 0, :469-472): emit nothing
+            fd.out_count = (uint16_t)std::max(0, S.prev_end - S.prev_start);
+            fd.out_off = out_count[pk.stream];
+            out_count[pk.stream] += fd.out_count;
+            D.packet_samples[(size_t)p] = fd.out_count;
+            S.current_position += fd.out_count;
+            S.prev_start = S.prev_end;  // everything readable is handed out by this call
+            fd.spec_off = pk.residue_offset;  // replaced by the temp offset when the coupling pass runs
+            res_extent = std::max(res_extent, pk.residue_offset + (int64_t)C * (bf ? half1 : half0));
+            if (!no_floor) {
+                any_floor = true;
+                const vpz_mapping_config &mc = D.mappings[pk.mapping];
+                if (mc.coupling_steps > 0) need_coupling = true;
+                const uint8_t long_bit = bf ? 0x80 : 0;
+                for (int ch = 0; ch < C; ++ch) {
+                    const uint8_t fl = mc.channel_floor[ch];
+                    const bool f0 = D.floor_types[fl] == 0;
+                    any_floor0 |= f0;
+                    rec_floor[(size_t)(p * C + ch)] = (uint8_t)(fl | long_bit | (f0 ? 0x40 : 0));
+                }
+            }
+            if (pk.flags & VPZ_PKT_INTERLEAVED) need_coupling = true;
+            frames[s_base[pk.stream] + s_cnt[pk.stream]++] = fd;
         }
-        fd.left_start = (uint16_t)S.prev_start;  // emission starts at the new _prevPacketStart
-        S.prev_end = right_start;
-        S.prev_stop = pi.right_end;
-        S.has_prev = true;
-        S.prev_long = bf;
-        if (pk.granule != -1 && !S.has_position) {  // :459-463 (idx == 0 here)
-            S.has_position = true;
-            S.current_position = pk.granule - (S.prev_end - S.prev_start);
+        for (int s = 0; s < D.n_streams; ++s)
+            if (out_count[s] > stream_out_capacity)
+                return set_error(ctx, VPZ_E_CAPACITY, "vpz_decoder_synth: stream_out_capacity too small");
+        // close the gaps skipped packets left between the streams' frame ranges
+        for (int s = 0; s < D.n_streams; ++s) {
+            if (s_cnt[s] && (size_t)s_base[s] != n_frames)
+                memmove(frames + n_frames, frames + s_base[s], sizeof(FrameDesc) * (size_t)s_cnt[s]);
+            s_base[s] = (int64_t)n_frames;
+            n_frames += (size_t)s_cnt[s];
         }
-        // a trim below LeftStart would make the reference spin (copyLen <= 0, :469-472): emit nothing
-        fd.out_count = (uint16_t)std::max(0, S.prev_end - S.prev_start);
-        fd.out_off = out_count[pk.stream];
-        out_count[pk.stream] += fd.out_count;
-        D.packet_samples[(size_t)p] = fd.out_count;
-        S.current_position += fd.out_count;
-        S.prev_start = S.prev_end;  // everything readable is handed out by this call
-        fd.spec_off = pk.residue_offset;  // replaced by the temp offset when the coupling pass runs
-        res_extent = std::max(res_extent, pk.residue_offset + (int64_t)C * (bf ? half1 : half0));
-        if (!no_floor) {
-            any_floor = true;
-            const vpz_mapping_config &mc = D.mappings[pk.mapping];
-            if (mc.coupling_steps > 0) need_coupling = true;
-            const uint8_t long_bit = bf ? 0x80 : 0;
-            for (int ch = 0; ch < C; ++ch) {
-                const uint8_t fl = mc.channel_floor[ch];
-                const bool f0 = D.floor_types[fl] == 0;
-                any_floor0 |= f0;
-                rec_floor[(size_t)(p * C + ch)] = (uint8_t)(fl | long_bit | (f0 ? 0x40 : 0));
+        for (int s = 0; s < D.n_streams; ++s) samples_written[s] = out_count[s];
+        if (any_floor0) need_coupling = true;  // type-0 floors are applied in place on the planar temp
+        return VPZ_OK;
+    }
+
+    // Pass 2: cut each stream's frames into runs.  A wavefront synthesises R consecutive blocks of one channel
+    // (+1 recomputed block in front); R (<= 32) is the value for which the run count fills k whole rounds of
+    // the resident waves with the least total work k * (R + 1); short batches fall back to R = 4.
+    void cut_runs()
+    {
+        const int64_t total_frames = (int64_t)n_frames;
+        int R = std::min(D.run_length_override, kMaxRunLength);
+        if (R <= 0) {
+            const int64_t slots = std::max(1, synth_resident_waves(any_floor, ctx->num_cu));
+            const int64_t work = total_frames * C;
+            R = 4;
+            int64_t best = -1;
+            for (int k = 1; k <= 64; ++k) {
+                int64_t r = (work + k * slots - 1) / (k * slots);
+                if (r > kMaxRunLength) continue;
+                if (r < 4) break;
+                const int64_t cost = (int64_t)k * (r + 1);
+                if (best < 0 || cost < best) { best = cost; R = (int)r; }
             }
         }
-        if (pk.flags & VPZ_PKT_INTERLEAVED) need_coupling = true;
-        frames[s_base[pk.stream] + s_cnt[pk.stream]++] = fd;
-    }
-    for (int s = 0; s < D.n_streams; ++s)
-        if (out_count[s] > stream_out_capacity)
-            return set_error(ctx, VPZ_E_CAPACITY, "vpz_decoder_synth: stream_out_capacity too small");
-
-    auto t_pass1 = tick();
-    // ---------------- pass 2: close the gaps skipped packets left, then cut each stream into runs
-    size_t n_frames = 0;
-    for (int s = 0; s < D.n_streams; ++s) {
-        if (s_cnt[s] && (size_t)s_base[s] != n_frames)
-            memmove(frames + n_frames, frames + s_base[s], sizeof(FrameDesc) * (size_t)s_cnt[s]);
-        s_base[s] = (int64_t)n_frames;
-        n_frames += (size_t)s_cnt[s];
-    }
-    const int64_t total_frames = (int64_t)n_frames;
-    for (int s = 0; s < D.n_streams; ++s) samples_written[s] = out_count[s];
-    if (total_frames == 0) {
-        D.states = st;
-        return mismatches ? set_error(ctx, VPZ_E_WINDOW_MISMATCH, "vpz_decoder_synth: window mismatch, packet skipped") : VPZ_OK;
-    }
-    // Run length: a wavefront synthesises R consecutive blocks of one channel (+1 recomputed block in
-    // front).  Pick the R (<= 32) for which the run count fills k whole rounds of the resident waves
-    // with the least total work k * (R + 1); short batches fall back to R = 4.
-    int R = std::min(D.run_length_override, kMaxRunLength);
-    if (R <= 0) {
-        const int64_t slots = std::max(1, synth_resident_waves(any_floor, ctx->num_cu));
-        const int64_t work = total_frames * C;
-        R = 4;
-        int64_t best = -1;
-        for (int k = 1; k <= 64; ++k) {
-            int64_t r = (work + k * slots - 1) / (k * slots);
-            if (r > kMaxRunLength) continue;
-            if (r < 4) break;
-            const int64_t cost = (int64_t)k * (r + 1);
-            if (best < 0 || cost < best) { best = cost; R = (int)r; }
-        }
-    }
-    RunDesc *runs = arena_alloc<RunDesc>(A, (size_t)(total_frames / R) + (size_t)D.n_streams + 1);
-    size_t n_runs = 0;
-    if (!D.generic) {
+        runs = arena_alloc<RunDesc>(*A, (size_t)(total_frames / R) + (size_t)D.n_streams + 1);
+        if (D.generic) return;
         for (int s = 0; s < D.n_streams; ++s) {
-            const int cnt = (int)s_cnt[s], base = (int)s_base[s];
+            const int cnt = (int)D.s_cnt[s], base = (int)D.s_base[s];
             for (int f0 = 0; f0 < cnt; f0 += R) {
                 RunDesc r{};
                 r.first = base + f0;
                 r.count = std::min(R, cnt - f0);
                 r.stream = s;
                 if (f0 == 0) {
-                    r.pre_kind = stream_started_with_prev[s] ? kPreState : kPreNone;
-                    r.prev_long = stream_prev_long[s];
+                    r.pre_kind = started_with_prev[s] ? kPreState : kPreNone;
+                    r.prev_long = started_prev_long[s];
                 } else {
                     r.pre_kind = kPreRecompute;
                 }
@@ -620,12 +657,11 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     }
 
     // coupling packets: de-interleave + inverse coupling into a planar temp laid out in frame order
-    if (any_floor0) need_coupling = true;  // type-0 floors are applied in place on the planar temp
-    uint8_t *cpk = nullptr;
-    int n_cpk = 0;
-    int64_t temp_floats = 0;
-    if (need_coupling) {
-        cpk = arena_alloc<uint8_t>(A, cps * n_frames);
+    void build_coupling_packets()
+    {
+        if (!need_coupling) return;
+        const size_t cps = coupling_packet_size();
+        cpk = arena_alloc<uint8_t>(*A, cps * n_frames);
         for (size_t fi = 0; fi < n_frames; ++fi) {
             FrameDesc &fd = frames[fi];
             if (fd.flags & kFrameDrain) continue;
@@ -641,14 +677,15 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
             ++n_cpk;
         }
     }
-    // Floor0 records
-    uint8_t *f0recs = nullptr;
-    int n_f0 = 0;
-    if (any_floor0) {
+
+    int build_floor0_records()
+    {
+        if (!any_floor0) return VPZ_OK;
         if (!D.f0_amp || !D.f0_coeff || D.f0_stride < 1)
             return set_error(ctx, VPZ_E_INVALID_ARG,
                              "vpz_decoder_synth: type-0 floors need vpz_decoder_set_floor0_data before the call");
-        f0recs = arena_alloc<uint8_t>(A, f0rs * n_frames * (size_t)C);
+        const size_t rs = floor0_rec_size();
+        f0recs = arena_alloc<uint8_t>(*A, rs * n_frames * (size_t)C);
         for (size_t fi = 0; fi < n_frames; ++fi) {
             const FrameDesc &fd = frames[fi];
             if (fd.flags & (kFrameDrain | kFrameNoFloor)) continue;
@@ -657,36 +694,38 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
             for (int ch = 0; ch < C; ++ch) {
                 const int fl = mc.channel_floor[ch];
                 if (D.floor_types[fl] != 0) continue;
-                fill_floor0_rec(f0recs + (size_t)n_f0 * f0rs, fd.spec_off + (int64_t)ch * half, fd.rec + ch, fl, half,
+                fill_floor0_rec(f0recs + (size_t)n_f0 * rs, fd.spec_off + (int64_t)ch * half, fd.rec + ch, fl, half,
                                 (fd.flags & kFrameLong) ? 1 : 0);
                 ++n_f0;
             }
         }
+        return VPZ_OK;
     }
-    // output placement
-    if (out_layout == VPZ_OUT_PLANAR && channel_stride < stream_out_capacity && C > 1)
-        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: channel_stride smaller than stream_out_capacity");
-    int64_t *offs = arena_alloc<int64_t>(A, (size_t)D.n_streams);
-    for (int s = 0; s < D.n_streams; ++s) offs[s] = stream_out_offset ? stream_out_offset[s] : 0;
-    const int64_t *d_outoff = stream_out_offset ? static_cast<const int64_t *>(dev(offs)) : nullptr;
+
+    int build_output_offsets()
+    {
+        if (out_layout == VPZ_OUT_PLANAR && channel_stride < stream_out_capacity && C > 1)
+            return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: channel_stride smaller than stream_out_capacity");
+        offs = arena_alloc<int64_t>(*A, (size_t)D.n_streams);
+        for (int s = 0; s < D.n_streams; ++s) offs[s] = stream_out_offset ? stream_out_offset[s] : 0;
+        return VPZ_OK;
+    }
+
     // any-block-size path: per-frame records + gather lists of the two exact-IMDCT launches
-    GenericFrame *gf = nullptr;
-    int64_t *src0 = nullptr, *dst0 = nullptr, *src1 = nullptr, *dst1 = nullptr;
-    int32_t *save_list = nullptr;
-    size_t n0 = 0, n1 = 0, n_save = 0;
-    int64_t y_floats = 0;
-    if (D.generic) {
-        gf = arena_alloc<GenericFrame>(A, n_frames);
-        src0 = arena_alloc<int64_t>(A, n_frames * (size_t)C);
-        dst0 = arena_alloc<int64_t>(A, n_frames * (size_t)C);
-        src1 = arena_alloc<int64_t>(A, n_frames * (size_t)C);
-        dst1 = arena_alloc<int64_t>(A, n_frames * (size_t)C);
-        save_list = arena_alloc<int32_t>(A, (size_t)D.n_streams + 1);
+    void build_generic_lists()
+    {
+        if (!D.generic) return;
+        gf = arena_alloc<GenericFrame>(*A, n_frames);
+        src0 = arena_alloc<int64_t>(*A, n_frames * (size_t)C);
+        dst0 = arena_alloc<int64_t>(*A, n_frames * (size_t)C);
+        src1 = arena_alloc<int64_t>(*A, n_frames * (size_t)C);
+        dst1 = arena_alloc<int64_t>(*A, n_frames * (size_t)C);
+        save_list = arena_alloc<int32_t>(*A, (size_t)D.n_streams + 1);
         size_t fi = 0;
         for (int s = 0; s < D.n_streams; ++s) {
-            const size_t cnt = (size_t)s_cnt[s];
-            int64_t prev_y = stream_started_with_prev[s] ? -1 : -2;
-            int prev_n = stream_prev_long[s] ? D.size1 : D.size0;
+            const size_t cnt = (size_t)D.s_cnt[s];
+            int64_t prev_y = started_with_prev[s] ? -1 : -2;
+            int prev_n = started_prev_long[s] ? D.size1 : D.size0;
             long last_block = -1;
             for (size_t k = 0; k < cnt; ++k, ++fi) {
                 const FrameDesc &fd = frames[fi];
@@ -723,104 +762,113 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
             }
         }
     }
-    auto t_pass2 = tick();
 
-    // ---------------- device side: input staging (VPZ_MEM_HOST), one descriptor upload, kernels
-    const float *d_res = residue;
-    const int16_t *d_posts = posts;
-    const uint8_t *d_counts = post_counts;
-    const float *d_amp = D.f0_amp, *d_coeff = D.f0_coeff;
-    if (mem_space == VPZ_MEM_HOST) {
-        if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)res_extent)) != VPZ_OK) return rc;
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res.p, residue, sizeof(float) * (size_t)res_extent,
-                                        hipMemcpyHostToDevice, ctx->stream));
-        d_res = static_cast<const float *>(D.b_in_res.p);
-        if (any_floor) {
-            if ((rc = grow(ctx, D.b_in_posts, sizeof(int16_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
-            if ((rc = grow(ctx, D.b_in_counts, (size_t)n_rec)) != VPZ_OK) return rc;
-            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_posts.p, posts, sizeof(int16_t) * 64 * (size_t)n_rec,
+    // Device side, part 1: VPZ_MEM_HOST inputs are staged, work buffers grown, the arena uploaded.
+    int stage_inputs()
+    {
+        int rc;
+        d_res = residue;
+        d_posts = posts;
+        d_counts = post_counts;
+        d_amp = D.f0_amp;
+        d_coeff = D.f0_coeff;
+        d_out = pcm_out;
+        if (mem_space == VPZ_MEM_HOST) {
+            if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)res_extent)) != VPZ_OK) return rc;
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res.p, residue, sizeof(float) * (size_t)res_extent,
                                             hipMemcpyHostToDevice, ctx->stream));
-            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_counts.p, post_counts, (size_t)n_rec, hipMemcpyHostToDevice,
-                                            ctx->stream));
-            d_posts = static_cast<const int16_t *>(D.b_in_posts.p);
-            d_counts = static_cast<const uint8_t *>(D.b_in_counts.p);
+            d_res = static_cast<const float *>(D.b_in_res.p);
+            if (any_floor) {
+                if ((rc = grow(ctx, D.b_in_posts, sizeof(int16_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
+                if ((rc = grow(ctx, D.b_in_counts, (size_t)n_rec)) != VPZ_OK) return rc;
+                VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_posts.p, posts, sizeof(int16_t) * 64 * (size_t)n_rec,
+                                                hipMemcpyHostToDevice, ctx->stream));
+                VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_counts.p, post_counts, (size_t)n_rec, hipMemcpyHostToDevice,
+                                                ctx->stream));
+                d_posts = static_cast<const int16_t *>(D.b_in_posts.p);
+                d_counts = static_cast<const uint8_t *>(D.b_in_counts.p);
+            }
+            if (any_floor0) {
+                if ((rc = grow(ctx, D.b_in_amp, sizeof(float) * (size_t)n_rec)) != VPZ_OK) return rc;
+                if ((rc = grow(ctx, D.b_in_coeff, sizeof(float) * (size_t)n_rec * D.f0_stride)) != VPZ_OK) return rc;
+                VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_amp.p, D.f0_amp, sizeof(float) * (size_t)n_rec,
+                                                hipMemcpyHostToDevice, ctx->stream));
+                VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_coeff.p, D.f0_coeff, sizeof(float) * (size_t)n_rec * D.f0_stride,
+                                                hipMemcpyHostToDevice, ctx->stream));
+                d_amp = static_cast<const float *>(D.b_in_amp.p);
+                d_coeff = static_cast<const float *>(D.b_in_coeff.p);
+            }
+            int64_t out_floats = 0;
+            for (int s = 0; s < D.n_streams; ++s) {
+                const int64_t ext = out_layout == VPZ_OUT_INTERLEAVED
+                                        ? offs[s] + D.out_count[s] * C
+                                        : offs[s] + (int64_t)(C - 1) * channel_stride + D.out_count[s];
+                if (D.out_count[s] > 0) out_floats = std::max(out_floats, ext);
+            }
+            if ((rc = grow(ctx, D.b_out, sizeof(float) * (size_t)out_floats)) != VPZ_OK) return rc;
+            d_out = static_cast<float *>(D.b_out.p);
         }
-        if (any_floor0) {
-            if ((rc = grow(ctx, D.b_in_amp, sizeof(float) * (size_t)n_rec)) != VPZ_OK) return rc;
-            if ((rc = grow(ctx, D.b_in_coeff, sizeof(float) * (size_t)n_rec * D.f0_stride)) != VPZ_OK) return rc;
-            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_amp.p, D.f0_amp, sizeof(float) * (size_t)n_rec, hipMemcpyHostToDevice, ctx->stream));
-            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_coeff.p, D.f0_coeff, sizeof(float) * (size_t)n_rec * D.f0_stride,
-                                            hipMemcpyHostToDevice, ctx->stream));
-            d_amp = static_cast<const float *>(D.b_in_amp.p);
-            d_coeff = static_cast<const float *>(D.b_in_coeff.p);
-        }
-    }
-    float *d_out = pcm_out;
-    if (mem_space == VPZ_MEM_HOST) {
-        int64_t out_floats = 0;
-        for (int s = 0; s < D.n_streams; ++s) {
-            const int64_t ext = out_layout == VPZ_OUT_INTERLEAVED
-                                    ? offs[s] + out_count[s] * C
-                                    : offs[s] + (int64_t)(C - 1) * channel_stride + out_count[s];
-            if (out_count[s] > 0) out_floats = std::max(out_floats, ext);
-        }
-        if ((rc = grow(ctx, D.b_out, sizeof(float) * (size_t)out_floats)) != VPZ_OK) return rc;
-        d_out = static_cast<float *>(D.b_out.p);
-    }
-    if (need_coupling && (rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK) return rc;
-    if (any_floor && (rc = grow(ctx, D.b_curve, (size_t)n_rec * (size_t)half1)) != VPZ_OK) return rc;
-    if (D.generic && (rc = grow(ctx, D.b_ybuf, sizeof(float) * (size_t)std::max<int64_t>(y_floats, 1))) != VPZ_OK) return rc;
-    VPZ_HIP_TRY(ctx, hipMemcpyAsync(A.dev.p, A.base, A.used, hipMemcpyHostToDevice, ctx->stream));
-    VPZ_HIP_TRY(ctx, hipEventRecord(A.uploaded, ctx->stream));
-    A.pending = true;
-
-    const float *d_spec = d_res;
-    if (need_coupling) {
-        hipError_t e = launch_coupling(dev(cpk), n_cpk, D.d_steps, C, d_res, static_cast<float *>(D.b_temp.p), half1,
-                                       ctx->stream);
-        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "coupling kernel launch", e);
-        d_spec = static_cast<const float *>(D.b_temp.p);
-    }
-    if (any_floor) {  // Floor1.UnwrapPosts + curve render (table indices)
-        hipError_t e = launch_floor1_prepare((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(dev(rec_floor)),
-                                             D.d_floors, (int)D.floors.size(), half0, half1,
-                                             static_cast<uint8_t *>(D.b_curve.p), D.ablate, ctx->stream);
-        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor1 prepare kernel launch", e);
-    }
-    if (any_floor0) {  // Floor0.Apply in place on the temp (rare; Floor0.cs:164-225)
-        hipError_t e = launch_floor0_apply(dev(f0recs), n_f0, D.d_floors0, D.d_bark_maps, d_amp, d_coeff, D.f0_stride,
-                                           static_cast<float *>(D.b_temp.p), static_cast<uint8_t *>(D.b_curve.p),
-                                           half1, ctx->stream);
-        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor0 kernel launch", e);
-        D.f0_amp = D.f0_coeff = nullptr;  // consumed
+        if (need_coupling && (rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK) return rc;
+        if (any_floor && (rc = grow(ctx, D.b_curve, (size_t)n_rec * (size_t)half1)) != VPZ_OK) return rc;
+        if (D.generic && (rc = grow(ctx, D.b_ybuf, sizeof(float) * (size_t)std::max<int64_t>(y_floats, 1))) != VPZ_OK)
+            return rc;
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(A->dev.p, A->base, A->used, hipMemcpyHostToDevice, ctx->stream));
+        VPZ_HIP_TRY(ctx, hipEventRecord(A->uploaded, ctx->stream));
+        A->pending = true;
+        return VPZ_OK;
     }
 
-    if (D.generic) {
-        // ---------------- any-block-size path: floor pass, exact IMDCT per size, OLA pass, state save
-        const GenericFrame *d_gf = static_cast<const GenericFrame *>(dev(gf));
-        float *d_temp = static_cast<float *>(D.b_temp.p);
-        float *d_y = static_cast<float *>(D.b_ybuf.p);
-        hipError_t e = hipSuccess;
-        if (any_floor)
-            e = launch_generic_floor(d_gf, (int)n_frames, C, half1, d_temp, d_counts,
-                                     static_cast<const uint8_t *>(D.b_curve.p), ctx->d_inv_db, ctx->stream);
-        if (e == hipSuccess && n0)
-            e = launch_imdct_exact(D.size0, D.t0->ld, d_temp, d_y, (int64_t)n0, D.t0->d_A, D.t0->d_B, D.t0->d_C,
-                                   D.t0->d_bitrev, ctx->num_cu, ctx->stream, static_cast<const int64_t *>(dev(src0)),
-                                   static_cast<const int64_t *>(dev(dst0)));
-        if (e == hipSuccess && n1)
-            e = launch_imdct_exact(D.size1, D.t1->ld, d_temp, d_y, (int64_t)n1, D.t1->d_A, D.t1->d_B, D.t1->d_C,
-                                   D.t1->d_bitrev, ctx->num_cu, ctx->stream, static_cast<const int64_t *>(dev(src1)),
-                                   static_cast<const int64_t *>(dev(dst1)));
-        if (e == hipSuccess)
-            e = launch_generic_ola(d_gf, (int)n_frames, C, D.size0, D.size1, d_y, D.d_state_h, D.t0->d_slope,
-                                   D.t1->d_slope, d_out, d_outoff, channel_stride, out_layout == VPZ_OUT_INTERLEAVED,
-                                   D.clip, D.d_clipped, ctx->stream);
-        if (e == hipSuccess)
-            e = launch_generic_save_state(d_gf, static_cast<const int32_t *>(dev(save_list)), (int)n_save, C, D.size1, d_y,
-                                          D.d_state_h, ctx->stream);
-        if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "generic synthesis kernel launch", e);
-    } else {
+    // Device side, part 2: the kernels, all asynchronous on the context's stream.
+    int launch()
+    {
+        const float *d_spec = d_res;
+        const int64_t *d_outoff = stream_out_offset ? static_cast<const int64_t *>(dev(offs)) : nullptr;
+        if (need_coupling) {
+            hipError_t e = launch_coupling(dev(cpk), n_cpk, D.d_steps, C, d_res, static_cast<float *>(D.b_temp.p), half1,
+                                           ctx->stream);
+            if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "coupling kernel launch", e);
+            d_spec = static_cast<const float *>(D.b_temp.p);
+        }
+        if (any_floor) {  // Floor1.UnwrapPosts + curve render (table indices)
+            hipError_t e = launch_floor1_prepare((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(dev(rec_floor)),
+                                                 D.d_floors, (int)D.floors.size(), half0, half1,
+                                                 static_cast<uint8_t *>(D.b_curve.p), D.ablate, ctx->stream);
+            if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor1 prepare kernel launch", e);
+        }
+        if (any_floor0) {  // Floor0.Apply in place on the temp (rare; Floor0.cs:164-225)
+            hipError_t e = launch_floor0_apply(dev(f0recs), n_f0, D.d_floors0, D.d_bark_maps, d_amp, d_coeff, D.f0_stride,
+                                               static_cast<float *>(D.b_temp.p), static_cast<uint8_t *>(D.b_curve.p),
+                                               half1, ctx->stream);
+            if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor0 kernel launch", e);
+            D.f0_amp = D.f0_coeff = nullptr;  // consumed
+        }
+        if (D.generic) {
+            // any-block-size path: floor pass, exact IMDCT per size, OLA pass, state save
+            const GenericFrame *d_gf = static_cast<const GenericFrame *>(dev(gf));
+            float *d_temp = static_cast<float *>(D.b_temp.p);
+            float *d_y = static_cast<float *>(D.b_ybuf.p);
+            hipError_t e = hipSuccess;
+            if (any_floor)
+                e = launch_generic_floor(d_gf, (int)n_frames, C, half1, d_temp, d_counts,
+                                         static_cast<const uint8_t *>(D.b_curve.p), ctx->d_inv_db, ctx->stream);
+            if (e == hipSuccess && n0)
+                e = launch_imdct_exact(D.size0, D.t0->ld, d_temp, d_y, (int64_t)n0, D.t0->d_A, D.t0->d_B, D.t0->d_C,
+                                       D.t0->d_bitrev, ctx->num_cu, ctx->stream, static_cast<const int64_t *>(dev(src0)),
+                                       static_cast<const int64_t *>(dev(dst0)));
+            if (e == hipSuccess && n1)
+                e = launch_imdct_exact(D.size1, D.t1->ld, d_temp, d_y, (int64_t)n1, D.t1->d_A, D.t1->d_B, D.t1->d_C,
+                                       D.t1->d_bitrev, ctx->num_cu, ctx->stream, static_cast<const int64_t *>(dev(src1)),
+                                       static_cast<const int64_t *>(dev(dst1)));
+            if (e == hipSuccess)
+                e = launch_generic_ola(d_gf, (int)n_frames, C, D.size0, D.size1, d_y, D.d_state_h, D.t0->d_slope,
+                                       D.t1->d_slope, d_out, d_outoff, channel_stride, out_layout == VPZ_OUT_INTERLEAVED,
+                                       D.clip, D.d_clipped, ctx->stream);
+            if (e == hipSuccess)
+                e = launch_generic_save_state(d_gf, static_cast<const int32_t *>(dev(save_list)), (int)n_save, C, D.size1,
+                                              d_y, D.d_state_h, ctx->stream);
+            if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "generic synthesis kernel launch", e);
+            return VPZ_OK;
+        }
         SynthArgs a{};
         a.frames = static_cast<const FrameDesc *>(dev(frames));
         a.runs = static_cast<const RunDesc *>(dev(runs));
@@ -846,37 +894,88 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         a.ablate = D.ablate;
         hipError_t e = launch_synth(a, any_floor, ctx->stream);
         if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "synth kernel launch", e);
+        return VPZ_OK;
     }
 
-    if (mem_space == VPZ_MEM_HOST) {
+    // VPZ_MEM_HOST: PCM back to the caller's buffer, synchronously
+    int copy_back()
+    {
+        if (mem_space != VPZ_MEM_HOST) return VPZ_OK;
         for (int s = 0; s < D.n_streams; ++s) {
-            if (out_count[s] <= 0) continue;
+            if (D.out_count[s] <= 0) continue;
             if (out_layout == VPZ_OUT_INTERLEAVED) {
                 VPZ_HIP_TRY(ctx, hipMemcpyAsync(pcm_out + offs[s], d_out + offs[s],
-                                                sizeof(float) * (size_t)(out_count[s] * C), hipMemcpyDeviceToHost,
+                                                sizeof(float) * (size_t)(D.out_count[s] * C), hipMemcpyDeviceToHost,
                                                 ctx->stream));
             } else {
                 for (int ch = 0; ch < C; ++ch)
                     VPZ_HIP_TRY(ctx, hipMemcpyAsync(pcm_out + offs[s] + (int64_t)ch * channel_stride,
                                                     d_out + offs[s] + (int64_t)ch * channel_stride,
-                                                    sizeof(float) * (size_t)out_count[s], hipMemcpyDeviceToHost,
+                                                    sizeof(float) * (size_t)D.out_count[s], hipMemcpyDeviceToHost,
                                                     ctx->stream));
             }
         }
         VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return VPZ_OK;
     }
-    D.states = st;
+};
+
+}  // namespace
+
+int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packets, const float *residue,
+                      const int16_t *posts, const uint8_t *post_counts, int mem_space, float *pcm_out,
+                      const int64_t *stream_out_offset, int64_t stream_out_capacity, int out_layout,
+                      int64_t channel_stride, int64_t *samples_written)
+{
+    if (!d) return VPZ_E_INVALID_ARG;
+    Decoder &D = d->impl;
+    Context *ctx = D.ctx;
+    if (n_packets < 0 || (n_packets > 0 && (!packets || !residue || !pcm_out)) || !samples_written)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: null argument");
+    if (mem_space != VPZ_MEM_HOST && mem_space != VPZ_MEM_DEVICE)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: bad mem_space");
+    if (out_layout != VPZ_OUT_INTERLEAVED && out_layout != VPZ_OUT_PLANAR)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: bad out_layout");
+    if (n_packets > (int64_t)0x7fffffff / std::max(1, D.channels))
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: batch too large");
+    VPZ_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int s = 0; s < D.n_streams; ++s) samples_written[s] = 0;
+    D.packet_samples.assign((size_t)n_packets, 0);
+    if (n_packets == 0) return VPZ_OK;
+
+    static const bool host_profile = getenv("VPZ_HOST_PROFILE") != nullptr;
+    auto tick = [] { return std::chrono::steady_clock::now(); };
+    const auto t_begin = tick();
+    SynthCall call(D, n_packets, packets, residue, posts, post_counts, mem_space, pcm_out, stream_out_offset,
+                   stream_out_capacity, out_layout, channel_stride);
+    int rc;
+    if ((rc = call.open_arena()) != VPZ_OK) return rc;
+    if ((rc = call.run_state_machine(samples_written)) != VPZ_OK) return rc;
+    const auto t_pass1 = tick();
+    const char *mismatch_text =
+        "vpz_decoder_synth: a packet's previous tail is longer than its window slope (StreamDecoder.cs:777-778 "
+        "throws); the packet was skipped, everything else was synthesised";
+    if (call.n_frames == 0) {
+        D.states = call.st;
+        return call.mismatches ? set_error(ctx, VPZ_E_WINDOW_MISMATCH, mismatch_text) : VPZ_OK;
+    }
+    call.cut_runs();
+    call.build_coupling_packets();
+    if ((rc = call.build_floor0_records()) != VPZ_OK) return rc;
+    if ((rc = call.build_output_offsets()) != VPZ_OK) return rc;
+    call.build_generic_lists();
+    const auto t_pass2 = tick();
+    if ((rc = call.stage_inputs()) != VPZ_OK) return rc;
+    if ((rc = call.launch()) != VPZ_OK) return rc;
+    if ((rc = call.copy_back()) != VPZ_OK) return rc;
+    D.states = call.st;
     if (host_profile) {
-        auto t_end = tick();
+        const auto t_end = tick();
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         fprintf(stderr, "[vpz host] packets %lld: pass1 %.1f us, runs+arena %.1f us, uploads+launch %.1f us\n",
                 (long long)n_packets, us(t_begin, t_pass1), us(t_pass1, t_pass2), us(t_pass2, t_end));
     }
-    if (mismatches)
-        return set_error(ctx, VPZ_E_WINDOW_MISMATCH,
-                         "vpz_decoder_synth: a packet's previous tail is longer than its window slope "
-                         "(StreamDecoder.cs:777-778 throws); the packet was skipped, everything else was synthesised");
-    return VPZ_OK;
+    return call.mismatches ? set_error(ctx, VPZ_E_WINDOW_MISMATCH, mismatch_text) : VPZ_OK;
 }
 
 int vpz_decoder_set_floor0_data(vpz_decoder *d, const float *amp, const float *coeff, int32_t coeff_stride)
