@@ -847,6 +847,9 @@ struct vpzh_stream {
     // second audio packet (the first one only primes the overlap; PacketProvider.cs:283-287)
     std::vector<int64_t> cum_samples;
 
+    std::vector<float> scratch_decode;  // per-handle scratch of decode_packet (one thread per handle)
+    std::vector<uint8_t> one_flag;
+
     // StreamDecoder.DecodeNextPacket :696-762 -> Mode.Decode -> Mapping.DecodePacket :98-163
     void decode_packet(const OggPacket &pk, int32_t stream_id, int64_t residue_off, vpz_packet *out, float *residue,
                        int16_t *posts, uint8_t *post_counts, float *f0_amp = nullptr, float *f0_coeff = nullptr,
@@ -912,8 +915,27 @@ struct vpzh_stream {
         // submap without clearing (reference behaviour, matters only for multi-submap residue 0/1).
         float *dst = residue;  // planar [ch][half] unless the interleaved shortcut below is taken
         memset(dst, 0, sizeof(float) * (size_t)channels * half);
-        std::vector<float> decode_buffer((size_t)channels * block_size, 0.f);
         const int submaps = (int)map.submap_residue.size();
+        if (submaps == 1 && channels > 1 && residues[map.submap_residue[0]].type == 2) {
+            // The common stereo / multichannel case, one Residue2 submap over every channel: decode the
+            // interleaved vector straight into the output and let the GPU de-interleave (Residue2.cs:42-51) --
+            // same values as the general path below, without its scratch buffers.
+            bool all_mux0 = true, any = false;
+            for (int j = 0; j < channels; ++j) {
+                all_mux0 &= map.mux[j] == 0;
+                any |= !no_execute[j];
+            }
+            if (all_mux0) {
+                if (any) {
+                    one_flag.assign(1, 0);
+                    residues[map.submap_residue[0]].decode(p, one_flag, block_size * channels, dst, half * channels, books);
+                    out->flags |= VPZ_PKT_INTERLEAVED;
+                }
+                return;
+            }
+        }
+        std::vector<float> &decode_buffer = scratch_decode;
+        decode_buffer.assign((size_t)channels * block_size, 0.f);
         for (int i = 0; i < submaps; ++i) {
             std::vector<uint8_t> dnd;
             std::vector<int> members;
