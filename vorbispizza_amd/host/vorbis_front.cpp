@@ -131,6 +131,8 @@ struct Codebook {
             int len = (int)p.read_bits(5) + 1;
             for (int i = 0; i < entries;) {
                 int cnt = (int)p.read_bits(ilog(entries - i));
+                // codeword lengths above 32 index past the reference's `available` table (an exception there)
+                if (cnt > 0 && len > 32) throw InvalidData("codeword length above 32");
                 while (--cnt >= 0) {
                     if (i >= entries) throw InvalidData("ordered codebook overruns its entry count");
                     lengths[i++] = len;
@@ -354,6 +356,8 @@ struct Floor1 {
             int csub = (1 << cbits) - 1;
             uint32_t cval = 0;
             if (cbits > 0) {
+                // the reference indexes its codebook array unchecked here (IndexOutOfRangeException)
+                if (class_masterbooks[cls] >= books.size()) throw InvalidData("floor1 master book out of range");
                 int v = books[class_masterbooks[cls]].decode_scalar(p);
                 if (v == -1) return 0;  // bad value: bail, PostCount = 0
                 cval = (uint32_t)v;
@@ -401,7 +405,8 @@ struct Floor0 {
     {
         for (int i = 0; i < order; ++i) coeff[i] = 0.f;
         const uint64_t amp_raw = p.read_bits(amp_bits);
-        const double amp_div = (double)((1 << amp_bits) - 1);
+        // C# `(1 << _ampBits) - 1` on int: the shift count is taken modulo 32 and the subtraction wraps
+        const double amp_div = (double)(int32_t)((1u << (amp_bits & 31)) - 1u);
         float amp = (float)((double)(amp_raw * (uint64_t)amp_ofs) / amp_div);  // (float)(amp * _ampOfs / ampDiv)
         const uint32_t book_num = (uint32_t)p.read_bits(ilog((int)book_list.size()));
         if (book_num >= book_list.size()) return 0.f;
@@ -525,6 +530,7 @@ struct Residue {
         int partition_count = n / partition_size;
         const Codebook &cb = cbs[class_book];
         int dim = cb.dimensions;
+        if (dim < 1) throw InvalidData("residue class book without dimensions");  // DivideByZeroException there
         int partition_words = (partition_count + dim - 1) / dim;
         part_word_cache.assign((size_t)count * partition_words, 0);
         for (int stage = 0; stage < max_stages; ++stage) {
