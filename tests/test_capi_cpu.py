@@ -71,3 +71,35 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "orc_" not in text and "import oracle" not in text and "liboracle" not in text, f
+
+
+def test_header_is_plain_c_and_struct_layouts_match_the_bindings(tmp_path):
+    """include/vorbispizza_synth.h must compile as C99 (the boundary is a C ABI) and the ctypes mirrors in
+    vorbispizza_amd/capi.py -- and therefore the C# LayoutKind.Sequential structs of INTEGRATION.md, which have
+    the same fields in the same order -- must have the C compiler's sizes and offsets."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from vorbispizza_amd import capi
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"vpz_floor1_config": capi.Floor1Config, "vpz_floor0_config": capi.Floor0Config,
+               "vpz_mapping_config": capi.MappingConfig, "vpz_stream_config": capi.StreamConfig,
+               "vpz_packet": capi.Packet}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vorbispizza_synth.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src),
+                    "-o", str(exe)], check=True, capture_output=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
