@@ -179,6 +179,99 @@ __device__ __forceinline__ void imdct256_wave8(const float2 (&xa)[8], float2 *sc
     }
 }
 
+// value held by lane (lane ^ MASK)
+template <int MASK>
+__device__ __forceinline__ float lane_xor(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, __float_as_int(v)));
+}
+template <int MASK>
+__device__ __forceinline__ float2 lane_xor2(float2 v, int lane)
+{
+    return make_float2(lane_xor<MASK>(v.x, lane), lane_xor<MASK>(v.y, lane));
+}
+
+// -------------------------------------------------------------------------------------------
+// N = 512 (R = 2) and N = 1024 (R = 4): the N/4 = 64*R point transform over L = 8*R lanes, 8 points per
+// lane, so a wavefront holds 8/R channel-blocks (block b = lane / L, l = lane % L = l0 + 8*l1).
+//   input  k = l0 + 8*l1 + L*m        (m = register)
+//   output j = p + 8*q1 + L*q0        p: 8-point DFT over m (registers), q1: R-point DFT over l1 (lane
+//                                     exchanges, no LDS), q0: 8-point DFT over l0 (one LDS transpose)
+// The R-point stage leaves its output digit bit-reversed in the lane index: after it lane l0 + 8*l1 holds
+// q1 = rev(l1); s_twBC and the final indices account for that.
+//   s_tw   : 64*R float2  tw[k] = exp(2*pi*i*(k + 1/8)/N)
+//   s_twAB : 64*R float2  exp(2*pi*i*p*l/(64*R)) at [p*L + l]
+//   s_twBC :  8*R float2  exp(2*pi*i*rev(l1)*l0/(8*R)) at [l]
+// On return h[b*(N/2) .. (b+1)*(N/2)) holds block b's h in natural order.
+// -------------------------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ void imdct_mid_wave(const float2 (&xa)[8], float2 *scratch, const float2 *s_tw,
+                                               const float2 *s_twAB, const float2 *s_twBC, int lane)
+{
+    static_assert(R == 2 || R == 4, "N = 512 or 1024");
+    constexpr int L = 8 * R, M = 64 * R;
+    const int l = lane & (L - 1), b = lane / L, l1 = l >> 3;
+    float2 z[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        // X[N/2-1-2k] sits in the .y half of the pair loaded by lane l ^ (L-1) of the block for point 7-m
+        const float re = lane_xor<L - 1>(xa[7 - m].y, lane);
+        z[m] = cmul(make_float2(re, xa[m].x), s_tw[l + L * m]);
+    }
+    radix8_inverse(z);  // over m, output digit p
+#pragma unroll
+    for (int p = 1; p < 8; ++p) z[p] = cmul(z[p], s_twAB[p * L + l]);
+    // R-point inverse DFT over l1, across lanes
+    if (R == 2) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float2 o = lane_xor2<8>(z[p], lane);
+            z[p] = l1 == 0 ? cadd(z[p], o) : csub(o, z[p]);
+        }
+    } else {
+        const bool hi = l1 & 2, lo = l1 & 1;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            // a[l1] -> e_t = a_t + a_{t+2} (lanes l1 = t), o_t = a_t - a_{t+2} (lanes l1 = t + 2)
+            const float2 o = lane_xor2<16>(z[p], lane);
+            const float2 s1 = hi ? csub(o, z[p]) : cadd(z[p], o);
+            // even outputs from the e lanes, odd ones from the o lanes: lane l1 ends up with q1 = rev(l1)
+            const float2 t = lane_xor2<8>(s1, lane);
+            if (!hi) z[p] = lo ? csub(t, s1) : cadd(s1, t);                 // b[2] = e0 - e1 ; b[0] = e0 + e1
+            else z[p] = lo ? csub(t, cmul_i(s1)) : cadd(s1, cmul_i(t));     // b[3] = o0 - i*o1 ; b[1] = o0 + i*o1
+        }
+    }
+    {
+        const float2 w = s_twBC[l];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) z[p] = cmul(z[p], w);
+    }
+    // transpose inside each group of 8 lanes: (lane l0, reg p) -> (lane p, reg l0); row stride 9 as in the
+    // N = 256 version
+    const int g = lane >> 3, l0 = lane & 7;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) scratch[72 * g + 9 * p + l0] = z[p];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) z[r] = scratch[72 * g + 9 * l0 + r];
+    radix8_inverse(z);  // over l0, output digit q0;  lane holds Z[j], j = jl + L*q0
+    const int q1 = R == 2 ? l1 : (((l1 & 1) << 1) | (l1 >> 1));
+    const int jl = l0 + 8 * q1;
+    float wim[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float2 w = cmul(z[q], s_tw[jl + L * q]);
+        z[q].x = w.x;
+        wim[q] = -w.y;
+    }
+    // h[2j] = Re W[j];  h[2j+1] = -Im W[M-1-j]: digits (7-p, R-1-q1, 7-q0) = lane ^ (L-1), register 7-q0
+    float2 *h2 = scratch + b * M;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float hi2 = lane_xor<L - 1>(wim[7 - q], lane);
+        h2[jl + L * q] = make_float2(z[q].x, hi2);
+    }
+}
+
 // Value of the full IMDCT output y[pos] given h (natural order, N/2 floats), N = 4*n4.
 __device__ __forceinline__ float y_from_h(const float *h, int pos, int n4)
 {

@@ -122,6 +122,42 @@ __global__ __launch_bounds__(kThreads) void imdct256_kernel(const float *__restr
     }
 }
 
+// N = 512 (R = 2) / N = 1024 (R = 4): 8/R channel-blocks per wavefront
+template <int R>
+__global__ __launch_bounds__(kThreads) void imdct_mid_kernel(const float *__restrict__ spectra, float *__restrict__ out,
+                                                            long count, const float2 *__restrict__ tables)
+{
+    constexpr int L = 8 * R, M = 64 * R, N = 256 * R, B = 8 / R;
+    __shared__ float2 s_tw[M];
+    __shared__ float2 s_twAB[M];
+    __shared__ float2 s_twBC[L];
+    __shared__ float2 s_scratch[kWavesPerGroup][kWaveScratchFloat2];
+    for (int i = threadIdx.x; i < M; i += kThreads) {
+        s_tw[i] = tables[kFastTwOffset + i];
+        s_twAB[i] = tables[kFastTwABOffset + i];
+    }
+    if (threadIdx.x < L) s_twBC[threadIdx.x] = tables[kFastTwBCOffset + threadIdx.x];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int b = lane / L, l = lane & (L - 1);
+    float2 *scratch = s_scratch[wave];
+    const long stride = (long)gridDim.x * kWavesPerGroup * B;
+    for (long base = ((long)blockIdx.x * kWavesPerGroup + wave) * B; base < count; base += stride) {
+        const long blk = base + b;
+        const bool live = blk < count;
+        const long ld = live ? blk : count - 1;
+        float2 xa[8];
+        const float2 *src = reinterpret_cast<const float2 *>(spectra + ld * (N / 2));
+#pragma unroll
+        for (int m = 0; m < 8; ++m) xa[m] = src[l + L * m];
+        imdct_mid_wave<R>(xa, scratch, s_tw, s_twAB, s_twBC, lane);
+        if (live)
+            store_full_block<N, L>(reinterpret_cast<const float *>(scratch) + b * (N / 2), out + blk * N, l);
+    }
+}
+
 // Persistent grid: exactly as many workgroups as the chip keeps resident (CUs x measured
 // occupancy), so that every workgroup gets the same share of the batch and there is no partial
 // last round of workgroups.
@@ -171,6 +207,28 @@ hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count
     int grid = grid_for((count + per_group - 1) / per_group, resident);
     hipLaunchKernelGGL(imdct256_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out,
                        (long)count, tw);
+    return hipGetLastError();
+}
+
+hipError_t launch_imdct_fast_mid(int n, const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
+                                 hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    if (n == 512) {
+        static int resident = 0;
+        if (!resident) resident = resident_groups(imdct_mid_kernel<2>, num_cu);
+        const int64_t per_group = kWavesPerGroup * 4;
+        hipLaunchKernelGGL(imdct_mid_kernel<2>, dim3(grid_for((count + per_group - 1) / per_group, resident)),
+                           dim3(kThreads), 0, stream, spectra, out, (long)count, tw);
+    } else if (n == 1024) {
+        static int resident = 0;
+        if (!resident) resident = resident_groups(imdct_mid_kernel<4>, num_cu);
+        const int64_t per_group = kWavesPerGroup * 2;
+        hipLaunchKernelGGL(imdct_mid_kernel<4>, dim3(grid_for((count + per_group - 1) / per_group, resident)),
+                           dim3(kThreads), 0, stream, spectra, out, (long)count, tw);
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -122,6 +122,28 @@ int get_tables(Context *ctx, int n, BlockTables **out)
             }
     }
 
+    if (n == 512 || n == 1024) {
+        // imdct_mid_wave<R>: tw[k], twAB[p*L + l] = exp(2*pi*i*p*l/(64R)), twBC[l] = exp(2*pi*i*rev(l1)*l0/(8R))
+        const int R = n / 256, L = 8 * R, M = 64 * R;
+        fast.assign(kFastTableCount, make_float2(0.f, 0.f));
+        const double two_pi = 6.283185307179586476925286766559;
+        for (int k = 0; k < M; ++k) {
+            double a = two_pi * ((double)k + 0.125) / (double)n;
+            fast[kFastTwOffset + k] = make_float2((float)cos(a), (float)sin(a));
+        }
+        for (int p = 0; p < 8; ++p)
+            for (int l = 0; l < L; ++l) {
+                double a = two_pi * (double)(p * l) / (double)M;
+                fast[kFastTwABOffset + p * L + l] = make_float2((float)cos(a), (float)sin(a));
+            }
+        for (int l = 0; l < L; ++l) {
+            const int l0 = l & 7, l1 = l >> 3;
+            const int q1 = R == 2 ? l1 : (((l1 & 1) << 1) | (l1 >> 1));
+            double a = two_pi * (double)(q1 * l0) / (double)L;
+            fast[kFastTwBCOffset + l] = make_float2((float)cos(a), (float)sin(a));
+        }
+    }
+
     int rc;
     if ((rc = upload(ctx, &t.d_A, A)) != VPZ_OK) return rc;
     if ((rc = upload(ctx, &t.d_B, B)) != VPZ_OK) return rc;
@@ -318,6 +340,8 @@ int vpz_imdct_batch(vpz_context *c, int n, int64_t count, const float *spectra, 
         e = vpz::launch_imdct_fast_2048(d_in, d_out, count, t->d_fast, ctx->num_cu, ctx->stream);
     else if (fast && n == 256)
         e = vpz::launch_imdct_fast_256(d_in, d_out, count, t->d_fast, ctx->num_cu, ctx->stream);
+    else if (fast && (n == 512 || n == 1024))
+        e = vpz::launch_imdct_fast_mid(n, d_in, d_out, count, t->d_fast, ctx->num_cu, ctx->stream);
     else
         e = vpz::launch_imdct_exact(n, t->ld, d_in, d_out, count, t->d_A, t->d_B, t->d_C, t->d_bitrev,
                                     ctx->num_cu, ctx->stream);

@@ -62,6 +62,8 @@ hipError_t launch_imdct_fast_2048(const float *spectra, float *out, int64_t coun
                                   const float2 *tw, int num_cu, hipStream_t stream);
 hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count,
                                  const float2 *tw, int num_cu, hipStream_t stream);
+hipError_t launch_imdct_fast_mid(int n, const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
+                                 hipStream_t stream);  // n = 512 or 1024
 hipError_t launch_imdct_exact(int n, int ld, const float *spectra, float *out, int64_t count,
                               const float *A, const float *B, const float *C,
                               const uint16_t *bitrev, int num_cu, hipStream_t stream,
