@@ -291,7 +291,10 @@ def random_xlist(rng, half, posts):
 
 
 @pytest.mark.parametrize("size0,size1", [(2048, 2048), (64, 64), (64, 512), (128, 1024), (256, 256), (512, 4096), (1024, 8192),
-                                         (2048, 8192), (256, 4096)])
+                                         (2048, 8192), (256, 4096),
+                                         # pairs the general variant of the fused kernel takes
+                                         (512, 512), (1024, 1024), (512, 1024), (256, 512), (256, 1024), (512, 2048),
+                                         (1024, 2048)])
 def test_any_block_size_pair_decodes(ctx, oracle, size0, size1):
     """Block sizes other than 256/2048 take the three-pass path (floor, exact IMDCT, OLA).  Its IMDCT is
     the reference's own schedule, so for N = 64/128 it reproduces the reference's literal output (q1)."""
@@ -413,4 +416,57 @@ def test_floor0_matches_oracle(ctx, oracle, size0, size1, order, bark):
     got = dec.synth(pk, res, posts, counts)[0]
     assert got.shape == ref.shape and np.isfinite(ref).all()
     assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+    dec.close()
+
+
+@pytest.mark.parametrize("size0,size1", [(512, 1024), (256, 1024), (1024, 2048), (512, 512)])
+@pytest.mark.parametrize("channels", [2, 3])
+def test_general_sizes_layouts_streams_and_eos(ctx, oracle, size0, size1, channels):
+    """The general variant of the fused kernel (block sizes 512 / 1024 in the mix): several streams with
+    different window sequences in one batch, planar vs interleaved output (stereo takes the wave-pair store)
+    bit for bit, an EOS trim on the last packet, all against the oracle."""
+    from vorbispizza_amd import Decoder, capi, make_packets
+    n_streams, frames = 3, 70
+    per_stream, pks, spectra = [], [], []
+    off = 0
+    for s in range(n_streams):
+        flags = helpers.markov_block_flags(frames, seed=100 * size0 + 10 * channels + s, start_long=bool(s % 2))
+        if size0 == size1:
+            flags &= ~np.uint8(PKT_BLOCK_FLAG | PKT_PREV_FLAG | PKT_NEXT_FLAG)
+        pk = make_packets(frames)
+        opk = []
+        for f in range(frames):
+            half = (size1 if flags[f] & 1 else size0) // 2
+            x = helpers.gaussian_spectra((channels, half), seed=7 * s + f)
+            pk[f]["stream"], pk[f]["flags"], pk[f]["granule"], pk[f]["residue_offset"] = s, flags[f] | capi.PKT_NO_FLOOR, -1, off
+            off += x.size
+            spectra.append(x.reshape(-1))
+            opk.append({"flags": int(flags[f]) | capi.PKT_NO_FLOOR, "granule": -1, "residue": x.reshape(-1)})
+        # EOS with a granule 37 samples short of the natural end: the last packet is trimmed (:658-666)
+        natural, _, _ = helpers.oracle_decode(oracle, channels, size0, size1, opk)
+        g = natural.shape[1] - 37
+        pk[frames - 1]["flags"] |= capi.PKT_EOS
+        pk[frames - 1]["granule"] = g
+        opk[-1]["flags"] |= capi.PKT_EOS
+        opk[-1]["granule"] = g
+        ref, pos, _ = helpers.oracle_decode(oracle, channels, size0, size1, opk)
+        assert ref.shape[1] == g
+        per_stream.append((ref, pos))
+        pks.append(pk)
+    # interleave the streams' packets in the batch (packets of one stream stay in order)
+    order = np.argsort(np.concatenate([np.arange(frames) * n_streams + s for s in range(n_streams)]), kind="stable")
+    pk_all = np.concatenate(pks)[order]
+    res = np.concatenate(spectra)
+    dec = Decoder(ctx, channels, size0, size1, n_streams=n_streams)
+    planar = dec.synth(pk_all, res, out_layout=capi.OUT_PLANAR)
+    dec.reset(-1)
+    for s in range(n_streams):
+        dec.set_position(0, stream=s)
+    inter = dec.synth(pk_all, res, out_layout=capi.OUT_INTERLEAVED)
+    for s in range(n_streams):
+        ref, pos = per_stream[s]
+        assert planar[s].shape == ref.shape
+        assert np.abs(planar[s] - ref).max() <= TOL
+        assert np.array_equal(inter[s], planar[s].T)
+        assert dec.position(s) == pos
     dec.close()

@@ -28,6 +28,7 @@ struct FrameDesc {        // 32 bytes: staged per run into LDS by the wavefront 
 };
 static_assert(sizeof(FrameDesc) == 32, "FrameDesc is staged as two 16-byte words");
 constexpr int kMaxRunLength = 32;
+constexpr int kMaxRunLengthGeneral = 16;  // the general-size kernel variant trades descriptor space for tables
 
 // any-block-size path (generic_*_kernel): one record per packet, full IMDCT outputs live in HBM
 constexpr uint32_t kFrameSaveState = 16u;  // last block of its stream in this batch

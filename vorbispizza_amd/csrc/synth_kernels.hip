@@ -491,20 +491,22 @@ __device__ __forceinline__ void build_block(uint32_t fd_flags, int lane, float2 
 }
 
 // the two floor-table indices (bytes) of bins 2k, 2k+1 for each of the lane's 8 points
-__device__ __forceinline__ void load_floor_indices(uint32_t (&fy)[8], const uint8_t *row, bool is_long, int lane)
+// (`lpb`: lanes per block = block size / 32: 64 for 2048, 32 / 16 for 1024 / 512, 8 for 256; a block smaller than
+// 2048 is transformed by every lane group of the wave at once, the first group's copy is the one used)
+__device__ __forceinline__ void load_floor_indices(uint32_t (&fy)[8], const uint8_t *row, int lpb, int lane)
 {
     const uint16_t *s = reinterpret_cast<const uint16_t *>(row);
-    const int k0 = is_long ? lane : (lane & 7);
-    const int st = is_long ? 64 : 8;
+    const int k0 = lane & (lpb - 1);
+    const int st = lpb;
 #pragma unroll
     for (int m = 0; m < 8; ++m) fy[m] = s[k0 + st * m];
 }
 
-__device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base, bool is_long, int lane)
+__device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base, int lpb, int lane)
 {
     const float2 *s = reinterpret_cast<const float2 *>(base);
-    const int k0 = is_long ? lane : (lane & 7);
-    const int st = is_long ? 64 : 8;
+    const int k0 = lane & (lpb - 1);
+    const int st = lpb;
 #pragma unroll
     for (int m = 0; m < 8; ++m) x[m] = s[k0 + st * m];
 }
@@ -513,32 +515,44 @@ __device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base,
 //       2 interleaved stereo: the two waves of a stream (channels 0 / 1, adjacent in the workgroup) build
 //         their blocks, meet at a workgroup barrier, and each writes HALF of the packet's samples for BOTH
 //         channels -- dense 32-byte (L R L R | L R L R) stores instead of 4-byte stores at an 8-byte stride.
-template <bool kHasFloor, int kOut>
+// kGeneral: block sizes from {256, 512, 1024, 2048} in any combination (speech-rate and low-bitrate streams use
+//       512 / 1024); the plain variant is the 256 / 2048 kernel with its geometry folded at compile time.
+template <bool kHasFloor, int kOut, bool kGeneral>
 __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 {
     constexpr bool kInterleaved = kOut != 0;
     constexpr bool kPair = kOut == 2;
+    constexpr int kRunMax = kGeneral ? kMaxRunLengthGeneral : kMaxRunLength;
     __shared__ int s_iters;
-    __shared__ float2 s_twL[512];
-    __shared__ float2 s_twAB[512];
-    __shared__ float2 s_twBC[64];
-    __shared__ float2 s_twS[64];
+    // tables: the plain variant keeps exactly what 2048 / 256 need; the general one holds the whole fast table
+    // of the larger size (tw 512 | twAB 512 | twBC 64) and a compacted one of the smaller (256 | 256 | 64)
+    __shared__ float2 s_twL[kGeneral ? 1088 : 512];
+    __shared__ float2 s_twAB[kGeneral ? 1 : 512];
+    __shared__ float2 s_twBC[kGeneral ? 1 : 64];
+    __shared__ float2 s_twS[kGeneral ? 576 : 64];
     __shared__ float s_slope1[1024];
-    __shared__ float s_slope0[128];
+    __shared__ float s_slope0[kGeneral ? 512 : 128];
     __shared__ float s_db[kHasFloor ? 256 : 1];
     __shared__ float s_work[kSynthWaves][kWaveBufFloats];   // h of the block being built
     __shared__ float s_tail[kSynthWaves][kWaveTailFloats];  // upper half of the previous block's h
-    __shared__ uint4 s_desc[kSynthWaves][(kMaxRunLength + 1) * 2];  // the run's frame descriptors
+    __shared__ uint4 s_desc[kSynthWaves][(kRunMax + 1) * 2];  // the run's frame descriptors
 
-    const bool has_long = a.size1 == 2048 || a.size0 == 2048;
-    const bool has_short = a.size0 == 256 || a.size1 == 256;
-    for (int i = threadIdx.x; i < 512; i += kSynthThreads) {
-        if (has_long) {
-            s_twL[i] = a.tw_long[kFastTwOffset + i];
-            s_twAB[i] = a.tw_long[kFastTwABOffset + i];
+    if (kGeneral) {
+        for (int i = threadIdx.x; i < kFastTableCount; i += kSynthThreads) s_twL[i] = a.tw_long[i];
+        for (int i = threadIdx.x; i < 256; i += kSynthThreads) {
+            s_twS[i] = a.tw_short[kFastTwOffset + i];
+            s_twS[256 + i] = a.tw_short[kFastTwABOffset + i];
         }
-    }
-    {
+        if (threadIdx.x < 64) s_twS[512 + threadIdx.x] = a.tw_short[kFastTwBCOffset + threadIdx.x];
+    } else {
+        const bool has_long = a.size1 == 2048 || a.size0 == 2048;
+        const bool has_short = a.size0 == 256 || a.size1 == 256;
+        for (int i = threadIdx.x; i < 512; i += kSynthThreads) {
+            if (has_long) {
+                s_twL[i] = a.tw_long[kFastTwOffset + i];
+                s_twAB[i] = a.tw_long[kFastTwABOffset + i];
+            }
+        }
         const float2 *any = has_long ? a.tw_long : a.tw_short;
         if (threadIdx.x < 64) {
             s_twBC[threadIdx.x] = any[kFastTwBCOffset + threadIdx.x];
@@ -546,7 +560,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         }
     }
     for (int i = threadIdx.x; i < a.size1 / 2; i += kSynthThreads) s_slope1[i] = a.slope1[i];
-    for (int i = threadIdx.x; i < a.size0 / 2 && i < 128; i += kSynthThreads) s_slope0[i] = a.slope0[i];
+    for (int i = threadIdx.x; i < a.size0 / 2 && i < (kGeneral ? 512 : 128); i += kSynthThreads) s_slope0[i] = a.slope0[i];
     if (kHasFloor && threadIdx.x < 256) s_db[threadIdx.x] = a.inv_db[threadIdx.x];
     __syncthreads();
 
@@ -574,7 +588,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         return a.post_counts == nullptr || (flags & kFrameNoFloor) || a.post_counts[rec + ch] != 0;
     };
     // which transform a frame takes depends on its block SIZE, not on its flag (size0 may be 2048 too)
-    auto is_2048 = [&](uint32_t flags) -> bool { return ((flags & kFrameLong) ? a.size1 : a.size0) == 2048; };
+    auto size_of = [&](uint32_t flags) -> int { return (flags & kFrameLong) ? a.size1 : a.size0; };
+    // lanes per block of a frame; the plain variant only knows 2048 (64) and 256 (8)
+    auto lpb_of = [&](uint32_t flags) -> int { return kGeneral ? (size_of(flags) >> 5) : (size_of(flags) == 2048 ? 64 : 8); };
     auto spectrum_of = [&](const FrameDesc &fd) -> const float * {
         const int hh = (fd.flags & kFrameLong) ? (a.size1 >> 1) : (a.size0 >> 1);
         return a.spec + fd.spec_off + (int64_t)ch * hh;
@@ -628,9 +644,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     uint32_t fycur[8];
     FrameDesc fd_next = frame_at(fi0);
     if (run.count > 0 && !(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec)) {
-        load_spectrum(xcur, spectrum_of(fd_next), is_2048(fd_next.flags), lane);
+        load_spectrum(xcur, spectrum_of(fd_next), lpb_of(fd_next.flags), lane);
         if (kHasFloor && !(fd_next.flags & kFrameNoFloor))
-            load_floor_indices(fycur, a.curve_y + (size_t)(fd_next.rec + ch) * half1, is_2048(fd_next.flags), lane);
+            load_floor_indices(fycur, a.curve_y + (size_t)(fd_next.rec + ch) * half1, lpb_of(fd_next.flags), lane);
     }
     for (int it = 0; it < iters; ++it) {
         const int fi = fi0 + it;
@@ -641,15 +657,16 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         if (fi + 1 < run.count) {
             fd_next = frame_at(fi + 1);
             if (!(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec) && !(a.ablate & 4)) {
-                load_spectrum(xnext, spectrum_of(fd_next), is_2048(fd_next.flags), lane);
+                load_spectrum(xnext, spectrum_of(fd_next), lpb_of(fd_next.flags), lane);
                 if (kHasFloor && !(fd_next.flags & kFrameNoFloor))
                     load_floor_indices(fynext, a.curve_y + (size_t)(fd_next.rec + ch) * half1,
-                                       is_2048(fd_next.flags), lane);
+                                       lpb_of(fd_next.flags), lane);
             }
         }
         const bool drain = fd.flags & kFrameDrain;
-        const bool is_long = is_2048(fd.flags);  // "long" below means: the 2048-point transform
-        const int n4 = is_long ? 512 : 64;
+        const int nblk = size_of(fd.flags);
+        const bool is_long = nblk == 2048;  // "long" below means: the 2048-point transform
+        const int n4 = kGeneral ? (nblk >> 2) : (is_long ? 512 : 64);
         if (live && !drain) {
             if (!exec_of(fd.flags, fd.rec)) {
                 // Mapping.cs:190-194: the channel is silent, its whole block is zero
@@ -658,6 +675,24 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 float2 *h2 = reinterpret_cast<float2 *>(hcur);
 #pragma unroll
                 for (int m = 0; m < 8; ++m) h2[lane + 64 * m] = xcur[m];
+            } else if (kGeneral) {
+                // tables of this frame's size: the long set keeps the global layout, the short set is compacted
+                const bool use_long = (fd.flags & kFrameLong) || a.size0 == a.size1;
+                const float2 *tw = use_long ? s_twL : s_twS;
+                const float2 *ab = use_long ? s_twL + kFastTwABOffset : s_twS + 256;
+                const float2 *bc = use_long ? s_twL + kFastTwBCOffset : s_twS + 512;
+                if (kHasFloor && !(fd.flags & kFrameNoFloor)) {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        xcur[m].x *= s_db[fycur[m] & 0xFFu];
+                        xcur[m].y *= s_db[(fycur[m] >> 8) & 0xFFu];
+                    }
+                }
+                float2 *h2 = reinterpret_cast<float2 *>(hcur);
+                if (nblk == 2048) imdct2048_wave(xcur, h2, tw, ab, bc, lane);
+                else if (nblk == 1024) imdct_mid_wave<4>(xcur, h2, tw, ab, bc, lane);
+                else if (nblk == 512) imdct_mid_wave<2>(xcur, h2, tw, ab, bc, lane);
+                else imdct256_wave8(xcur, h2, tw, bc, lane);
             } else if (is_long) {
                 build_block<kHasFloor, true>(fd.flags, lane, xcur, fycur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
             } else {
@@ -890,7 +925,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         if (kPair) __syncthreads();  // the partner is done reading this wave's block and tail
         if (live && !drain) {
             // keep what a later block can overlap with: y[N/2 .. N) lives in the upper half of h
-            if (is_long) {
+            if (kGeneral && !is_long) {
+                for (int i = lane; i < n4; i += 64) tail[i] = hcur[n4 + i];
+            } else if (is_long) {
                 const float4 *src = reinterpret_cast<const float4 *>(hcur + 512);
                 float4 *dt = reinterpret_cast<float4 *>(tail);
                 const float4 t0 = src[lane], t1 = src[lane + 64];
@@ -1042,6 +1079,18 @@ hipError_t launch_coupling(const void *pkts, int n_pkts, const uint8_t *steps, i
     return hipSuccess;
 }
 
+// block-size pairs the fused kernel takes at all, and those among them that need its general variant
+bool synth_supports_sizes(int size0, int size1)
+{
+    auto ok = [](int n) { return n == 256 || n == 512 || n == 1024 || n == 2048; };
+    return ok(size0) && ok(size1);
+}
+bool synth_needs_general(int size0, int size1)
+{
+    auto plain = [](int n) { return n == 256 || n == 2048; };
+    return !(plain(size0) && plain(size1));
+}
+
 hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t stream)
 {
     const long items = (long)args.n_runs * args.channels;
@@ -1049,17 +1098,23 @@ hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t strea
     const int grid = (int)((items + kSynthWaves - 1) / kSynthWaves);
     // four instantiations: the interleaved store pattern costs registers the planar steady state needs
     const int out_kind = !args.interleaved ? 0 : (args.channels == 2 ? 2 : 1);
-#define VPZ_LAUNCH_SYNTH(F, O) \
-    hipLaunchKernelGGL((synth_kernel<F, O>), dim3(grid), dim3(kSynthThreads), 0, stream, args)
+#define VPZ_LAUNCH_SYNTH(F, O, G) \
+    hipLaunchKernelGGL((synth_kernel<F, O, G>), dim3(grid), dim3(kSynthThreads), 0, stream, args)
+#define VPZ_LAUNCH_SYNTH_OUT(F, G)                      \
+    do {                                                \
+        if (out_kind == 0) VPZ_LAUNCH_SYNTH(F, 0, G);   \
+        else if (out_kind == 1) VPZ_LAUNCH_SYNTH(F, 1, G); \
+        else VPZ_LAUNCH_SYNTH(F, 2, G);                 \
+    } while (0)
+    const bool general = synth_needs_general(args.size0, args.size1);
     if (has_floor) {
-        if (out_kind == 0) VPZ_LAUNCH_SYNTH(true, 0);
-        else if (out_kind == 1) VPZ_LAUNCH_SYNTH(true, 1);
-        else VPZ_LAUNCH_SYNTH(true, 2);
+        if (general) VPZ_LAUNCH_SYNTH_OUT(true, true);
+        else VPZ_LAUNCH_SYNTH_OUT(true, false);
     } else {
-        if (out_kind == 0) VPZ_LAUNCH_SYNTH(false, 0);
-        else if (out_kind == 1) VPZ_LAUNCH_SYNTH(false, 1);
-        else VPZ_LAUNCH_SYNTH(false, 2);
+        if (general) VPZ_LAUNCH_SYNTH_OUT(false, true);
+        else VPZ_LAUNCH_SYNTH_OUT(false, false);
     }
+#undef VPZ_LAUNCH_SYNTH_OUT
 #undef VPZ_LAUNCH_SYNTH
     return hipGetLastError();
 }
@@ -1070,8 +1125,8 @@ int synth_resident_waves(bool has_floor, int num_cu)
 {
     int per_cu = 0;
     hipError_t e = has_floor
-                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<true, 0>, kSynthThreads, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<false, 0>, kSynthThreads, 0);
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<true, 0, false>, kSynthThreads, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<false, 0, false>, kSynthThreads, 0);
     if (e != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 2;

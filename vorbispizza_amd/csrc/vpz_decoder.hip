@@ -21,6 +21,8 @@ hipError_t launch_floor1_prepare(int n_rec, const int16_t *posts, const uint8_t 
 hipError_t launch_coupling(const void *pkts, int n_pkts, const uint8_t *steps, int channels,
                            const float *residue, float *temp, int max_half, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t stream);
+bool synth_supports_sizes(int size0, int size1);
+bool synth_needs_general(int size0, int size1);
 int synth_resident_waves(bool has_floor, int num_cu);
 hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, int half1, float *spec,
                                 const uint8_t *post_counts, const uint8_t *curve_y, const float *inv_db,
@@ -197,7 +199,6 @@ static int build_floor(const vpz_floor1_config &c, FloorDev *f)
     return VPZ_OK;
 }
 
-static bool supported_size(int n) { return n == 256 || n == 2048; }
 
 }  // namespace vpz
 
@@ -235,7 +236,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     D.size1 = cfg->block_size1;
     D.clip = cfg->clip_samples ? 1 : 0;
     D.n_streams = n_streams;
-    D.generic = !(supported_size(cfg->block_size0) && supported_size(cfg->block_size1));
+    D.generic = !synth_supports_sizes(cfg->block_size0, cfg->block_size1);
     D.states.assign(n_streams, StreamState());
     D.floors.assign((size_t)cfg->floor_count, vpz_floor1_config{});
     D.floor_types.assign((size_t)cfg->floor_count, 1);
@@ -621,7 +622,8 @@ struct SynthCall {
     void cut_runs()
     {
         const int64_t total_frames = (int64_t)n_frames;
-        int R = std::min(D.run_length_override, kMaxRunLength);
+        const int r_max = synth_needs_general(D.size0, D.size1) ? kMaxRunLengthGeneral : kMaxRunLength;
+        int R = std::min(D.run_length_override, r_max);
         if (R <= 0) {
             const int64_t slots = std::max(1, synth_resident_waves(any_floor, ctx->num_cu));
             const int64_t work = total_frames * C;
@@ -629,7 +631,7 @@ struct SynthCall {
             int64_t best = -1;
             for (int k = 1; k <= 64; ++k) {
                 int64_t r = (work + k * slots - 1) / (k * slots);
-                if (r > kMaxRunLength) continue;
+                if (r > r_max) continue;
                 if (r < 4) break;
                 const int64_t cost = (int64_t)k * (r + 1);
                 if (best < 0 || cost < best) { best = cost; R = (int)r; }
