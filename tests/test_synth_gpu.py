@@ -296,8 +296,9 @@ def random_xlist(rng, half, posts):
                                          (512, 512), (1024, 1024), (512, 1024), (256, 512), (256, 1024), (512, 2048),
                                          (1024, 2048)])
 def test_any_block_size_pair_decodes(ctx, oracle, size0, size1):
-    """Block sizes other than 256/2048 take the three-pass path (floor, exact IMDCT, OLA).  Its IMDCT is
-    the reference's own schedule, so for N = 64/128 it reproduces the reference's literal output (q1)."""
+    """Every Vorbis block-size pair decodes: sizes out of {256, 512, 1024, 2048} through the fused kernel (its
+    general variant when 512 / 1024 take part), the others through the three-pass path (floor, exact IMDCT, OLA)
+    whose IMDCT is the reference's own schedule -- for N = 64/128 it reproduces the reference's literal output (q1)."""
     from vorbispizza_amd import Decoder, make_packets
     rng = np.random.default_rng(size0 * 7 + size1)
     channels, frames = 2, 30

@@ -958,7 +958,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 //   generic_floor_kernel : Floor1 curve x spectrum in place (or zeros for a silent channel)
 //   imdct_exact_kernel   : the reference's own IMDCT schedule (imdct_exact.hip), gathered by offset
 //   generic_ola_kernel   : window + overlap-add + clip + store from the full IMDCT outputs
-// It exists so that every Vorbis block-size pair decodes; the 256/2048 pair takes the fused kernel.
+// It exists so that every Vorbis block-size pair decodes; sizes out of {256, 512, 1024, 2048} take the fused kernel.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void generic_floor_kernel(const GenericFrame *__restrict__ frames, int channels,
                                                            int half1, float *__restrict__ spec,

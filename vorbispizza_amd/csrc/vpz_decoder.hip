@@ -97,7 +97,7 @@ struct Decoder {
     DevBuf b_curve, b_temp;
     DevBuf b_in_res, b_in_posts, b_in_counts, b_out;  // VPZ_MEM_HOST staging
     DevBuf b_ybuf;                                    // any-block-size path
-    bool generic = false;  // block sizes other than 256 / 2048: three-pass path (synth_kernels.hip)
+    bool generic = false;  // a block size outside {256, 512, 1024, 2048}: three-pass path (synth_kernels.hip)
     // type-0 floors (Floor0.cs)
     std::vector<uint8_t> floor_types;
     std::vector<vpz_floor0_config> floors0;
