@@ -77,6 +77,39 @@ __device__ __forceinline__ void radix8_inverse(float2 (&v)[8])
 constexpr int kWaveScratchFloat2 = 576;  // 72*8 (stage A->B), 66*7+64 = 526 (stage B->C), 512 (h)
 
 // -------------------------------------------------------------------------------------------
+// 512-point unnormalised inverse DFT across a wavefront: z[m] holds point k = lane + 64*m on entry and
+// Z[j], j = lane + 64*q, in z[q] on return.  Three radix-8 stages, two transposes through `scratch`
+// (>= 576 float2, wave-private).
+//   s_twAB : 512 float2  exp(2*pi*i*l*p/512) at [p*64 + l]
+//   s_twBC :  64 float2  exp(2*pi*i*l0*q/64) at [l0*8 + q]
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dft512_wave(float2 (&z)[8], float2 *scratch, const float2 *s_twAB,
+                                            const float2 *s_twBC, int lane)
+{
+    // stage A: DFT over the top input digit (stride 64), output digit p
+    radix8_inverse(z);
+#pragma unroll
+    for (int p = 1; p < 8; ++p) z[p] = cmul(z[p], s_twAB[p * 64 + lane]);
+    // transpose 1: (lane l = l0 + 8*l1, reg p) -> (lane l0 + 8*p, reg l1); rows padded to 72
+#pragma unroll
+    for (int p = 0; p < 8; ++p) scratch[72 * p + lane] = z[p];
+    const int l0 = lane & 7, pp = lane >> 3;
+#pragma unroll
+    for (int l1 = 0; l1 < 8; ++l1) z[l1] = scratch[72 * pp + l0 + 8 * l1];
+    // stage B: DFT over l1, output digit q1
+    radix8_inverse(z);
+#pragma unroll
+    for (int q = 1; q < 8; ++q) z[q] = cmul(z[q], s_twBC[l0 * 8 + q]);
+    // transpose 2: (lane l0 + 8*p, reg q1) -> (lane p + 8*q1, reg l0); row stride 66
+#pragma unroll
+    for (int q = 0; q < 8; ++q) scratch[66 * l0 + pp + 8 * q] = z[q];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) z[r] = scratch[66 * r + lane];
+    // stage C: DFT over l0, output digit q0
+    radix8_inverse(z);
+}
+
+// -------------------------------------------------------------------------------------------
 // N = 2048.  xa[m] = (X[2k], X[2k+1]) for k = lane + 64*m, already floor-multiplied if needed.
 // On return the wave-private LDS area `h` holds h[0..1024) as floats in natural order.
 //   s_tw   : 512 float2  tw[k]
@@ -97,27 +130,7 @@ __device__ __forceinline__ void imdct2048_wave(const float2 (&xa)[8], float2 *sc
         float re = lane_mirror64(xa[7 - m].y, lane);
         z[m] = cmul(make_float2(re, xa[m].x), tw[m]);
     }
-    // stage A: DFT over the top input digit (stride 64), output digit p
-    radix8_inverse(z);
-#pragma unroll
-    for (int p = 1; p < 8; ++p) z[p] = cmul(z[p], s_twAB[p * 64 + lane]);
-    // transpose 1: (lane l = l0 + 8*l1, reg p) -> (lane l0 + 8*p, reg l1); rows padded to 72
-#pragma unroll
-    for (int p = 0; p < 8; ++p) scratch[72 * p + lane] = z[p];
-    const int l0 = lane & 7, pp = lane >> 3;
-#pragma unroll
-    for (int l1 = 0; l1 < 8; ++l1) z[l1] = scratch[72 * pp + l0 + 8 * l1];
-    // stage B: DFT over l1, output digit q1
-    radix8_inverse(z);
-#pragma unroll
-    for (int q = 1; q < 8; ++q) z[q] = cmul(z[q], s_twBC[l0 * 8 + q]);
-    // transpose 2: (lane l0 + 8*p, reg q1) -> (lane p + 8*q1, reg l0); row stride 66
-#pragma unroll
-    for (int q = 0; q < 8; ++q) scratch[66 * l0 + pp + 8 * q] = z[q];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) z[r] = scratch[66 * r + lane];
-    // stage C: DFT over l0, output digit q0;  lane now holds Z[j], j = lane + 64*q0
-    radix8_inverse(z);
+    dft512_wave(z, scratch, s_twAB, s_twBC, lane);  // lane now holds Z[j], j = lane + 64*q0
     float wim[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -176,6 +189,50 @@ __device__ __forceinline__ void imdct256_wave8(const float2 (&xa)[8], float2 *sc
     for (int q = 0; q < 8; ++q) {
         float hi = lane_mirror8(wim[7 - q], lane);
         reinterpret_cast<float2 *>(h)[g * 64 + l + 8 * q] = make_float2(z[q].x, hi);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// N = 4096: the 1024-point transform as two 512-point ones (even / odd input points) and one radix-2 step.
+// xa[m] = X[4k' .. 4k'+3] for k' = lane + 64*m.  On return `h` (>= 1024 float2, wave-private; its first 576
+// float2 double as the transposes' scratch) holds h[0..2048) in natural order.
+//   s_tw   : 1024 float2  tw[k] = exp(2*pi*i*(k + 1/8)/4096)
+//   s_twAB / s_twBC : the 512-point tables of dft512_wave
+//   s_w    :  512 float2  exp(2*pi*i*j/1024)
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void imdct4096_wave(const float4 (&xa)[8], float2 *h, const float2 *s_tw,
+                                               const float2 *s_twAB, const float2 *s_twBC, const float2 *s_w, int lane)
+{
+    float2 e[8], o[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        // point k = 2k' (even) and 2k'+1 (odd): z[k] = (X[N/2-1-2k] + i*X[2k]) * tw[k]; the mirrored X values sit
+        // in the .w / .y components of the float4 loaded by lane 63-lane for its point 7-m
+        const int kp = lane + 64 * m;
+        const float re_e = lane_mirror64(xa[7 - m].w, lane), re_o = lane_mirror64(xa[7 - m].y, lane);
+        e[m] = cmul(make_float2(re_e, xa[m].x), s_tw[2 * kp]);
+        o[m] = cmul(make_float2(re_o, xa[m].z), s_tw[2 * kp + 1]);
+    }
+    dft512_wave(e, h, s_twAB, s_twBC, lane);
+    dft512_wave(o, h, s_twAB, s_twBC, lane);
+    // Z[j] = E[j] + w^j O[j], Z[j + 512] = E[j] - w^j O[j];  then W = Z * tw
+    float2 wl[8], wu[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = lane + 64 * q;
+        const float2 t = cmul(o[q], s_w[j]);
+        wl[q] = cmul(cadd(e[q], t), s_tw[j]);
+        wu[q] = cmul(csub(e[q], t), s_tw[j + 512]);
+    }
+    // h[2J] = Re W[J], h[2J+1] = -Im W[1023-J]: for J = j the partner is the UPPER value of lane 63-lane,
+    // register 7-q (1023 - j = 512 + (511 - j)); for J = j + 512 it is that lane's LOWER value
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float from_upper = lane_mirror64(-wu[7 - q].y, lane);
+        const float from_lower = lane_mirror64(-wl[7 - q].y, lane);
+        const int j = lane + 64 * q;
+        h[j] = make_float2(wl[q].x, from_upper);
+        h[j + 512] = make_float2(wu[q].x, from_lower);
     }
 }
 

@@ -125,7 +125,9 @@ __global__ __launch_bounds__(kThreads) void imdct256_kernel(const float *__restr
 // N = 512 (R = 2) / N = 1024 (R = 4): 8/R channel-blocks per wavefront
 template <int R>
 __global__ __launch_bounds__(kThreads) void imdct_mid_kernel(const float *__restrict__ spectra, float *__restrict__ out,
-                                                            long count, const float2 *__restrict__ tables)
+                                                            long count, const float2 *__restrict__ tables,
+                                                            const int64_t *__restrict__ src_off,
+                                                            const int64_t *__restrict__ dst_off)
 {
     constexpr int L = 8 * R, M = 64 * R, N = 256 * R, B = 8 / R;
     __shared__ float2 s_tw[M];
@@ -149,12 +151,45 @@ __global__ __launch_bounds__(kThreads) void imdct_mid_kernel(const float *__rest
         const bool live = blk < count;
         const long ld = live ? blk : count - 1;
         float2 xa[8];
-        const float2 *src = reinterpret_cast<const float2 *>(spectra + ld * (N / 2));
+        const float2 *src = reinterpret_cast<const float2 *>(spectra + (src_off ? src_off[ld] : ld * (N / 2)));
 #pragma unroll
         for (int m = 0; m < 8; ++m) xa[m] = src[l + L * m];
         imdct_mid_wave<R>(xa, scratch, s_tw, s_twAB, s_twBC, lane);
         if (live)
-            store_full_block<N, L>(reinterpret_cast<const float *>(scratch) + b * (N / 2), out + blk * N, l);
+            store_full_block<N, L>(reinterpret_cast<const float *>(scratch) + b * (N / 2),
+                                   out + (dst_off ? dst_off[blk] : blk * N), l);
+    }
+}
+
+// N = 4096: one wavefront per channel-block, 16-byte loads (X[4k' .. 4k'+3] per lane and point)
+__global__ __launch_bounds__(kThreads) void imdct4096_kernel(const float *__restrict__ spectra, float *__restrict__ out,
+                                                            long count, const float2 *__restrict__ tables,
+                                                            const int64_t *__restrict__ src_off,
+                                                            const int64_t *__restrict__ dst_off)
+{
+    __shared__ float2 s_tw[1024];
+    __shared__ float2 s_twAB[512];
+    __shared__ float2 s_twBC[64];
+    __shared__ float2 s_w[512];
+    __shared__ float2 s_h[kWavesPerGroup][1024];
+    for (int i = threadIdx.x; i < 1024; i += kThreads) s_tw[i] = tables[kFast4096TwOffset + i];
+    for (int i = threadIdx.x; i < 512; i += kThreads) {
+        s_twAB[i] = tables[kFast4096TwABOffset + i];
+        s_w[i] = tables[kFast4096WOffset + i];
+    }
+    if (threadIdx.x < 64) s_twBC[threadIdx.x] = tables[kFast4096TwBCOffset + threadIdx.x];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long stride = (long)gridDim.x * kWavesPerGroup;
+    for (long blk = (long)blockIdx.x * kWavesPerGroup + wave; blk < count; blk += stride) {
+        const float4 *src = reinterpret_cast<const float4 *>(spectra + (src_off ? src_off[blk] : blk * 2048));
+        float4 xa[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) xa[m] = src[lane + 64 * m];
+        imdct4096_wave(xa, s_h[wave], s_tw, s_twAB, s_twBC, s_w, lane);
+        store_full_block<4096, 64>(reinterpret_cast<const float *>(s_h[wave]), out + (dst_off ? dst_off[blk] : blk * 4096), lane);
     }
 }
 
@@ -210,8 +245,20 @@ hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count
     return hipGetLastError();
 }
 
+hipError_t launch_imdct_fast_4096(const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
+                                  hipStream_t stream, const int64_t *src_off, const int64_t *dst_off)
+{
+    if (count <= 0) return hipSuccess;
+    static int resident = 0;
+    if (!resident) resident = resident_groups(imdct4096_kernel, num_cu);
+    const int grid = grid_for((count + kWavesPerGroup - 1) / kWavesPerGroup, resident);
+    hipLaunchKernelGGL(imdct4096_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out, (long)count, tw, src_off,
+                       dst_off);
+    return hipGetLastError();
+}
+
 hipError_t launch_imdct_fast_mid(int n, const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
-                                 hipStream_t stream)
+                                 hipStream_t stream, const int64_t *src_off, const int64_t *dst_off)
 {
     if (count <= 0) return hipSuccess;
     if (n == 512) {
@@ -219,13 +266,13 @@ hipError_t launch_imdct_fast_mid(int n, const float *spectra, float *out, int64_
         if (!resident) resident = resident_groups(imdct_mid_kernel<2>, num_cu);
         const int64_t per_group = kWavesPerGroup * 4;
         hipLaunchKernelGGL(imdct_mid_kernel<2>, dim3(grid_for((count + per_group - 1) / per_group, resident)),
-                           dim3(kThreads), 0, stream, spectra, out, (long)count, tw);
+                           dim3(kThreads), 0, stream, spectra, out, (long)count, tw, src_off, dst_off);
     } else if (n == 1024) {
         static int resident = 0;
         if (!resident) resident = resident_groups(imdct_mid_kernel<4>, num_cu);
         const int64_t per_group = kWavesPerGroup * 2;
         hipLaunchKernelGGL(imdct_mid_kernel<4>, dim3(grid_for((count + per_group - 1) / per_group, resident)),
-                           dim3(kThreads), 0, stream, spectra, out, (long)count, tw);
+                           dim3(kThreads), 0, stream, spectra, out, (long)count, tw, src_off, dst_off);
     } else {
         return hipErrorInvalidValue;
     }

@@ -853,14 +853,22 @@ struct SynthCall {
             if (any_floor)
                 e = launch_generic_floor(d_gf, (int)n_frames, C, half1, d_temp, d_counts,
                                          static_cast<const uint8_t *>(D.b_curve.p), ctx->d_inv_db, ctx->stream);
+            // per block size: the gathered FAST transform where one exists (512, 1024, 4096), else the reference's
+            // own schedule (64 and 128 must take it: quirk q1)
+            auto imdct_gathered = [&](int n, BlockTables *t, int64_t cnt, const int64_t *so, const int64_t *dof) {
+                if (n == 4096 && t->d_fast)
+                    return launch_imdct_fast_4096(d_temp, d_y, cnt, t->d_fast, ctx->num_cu, ctx->stream, so, dof);
+                if ((n == 512 || n == 1024) && t->d_fast)
+                    return launch_imdct_fast_mid(n, d_temp, d_y, cnt, t->d_fast, ctx->num_cu, ctx->stream, so, dof);
+                return launch_imdct_exact(n, t->ld, d_temp, d_y, cnt, t->d_A, t->d_B, t->d_C, t->d_bitrev, ctx->num_cu,
+                                          ctx->stream, so, dof);
+            };
             if (e == hipSuccess && n0)
-                e = launch_imdct_exact(D.size0, D.t0->ld, d_temp, d_y, (int64_t)n0, D.t0->d_A, D.t0->d_B, D.t0->d_C,
-                                       D.t0->d_bitrev, ctx->num_cu, ctx->stream, static_cast<const int64_t *>(dev(src0)),
-                                       static_cast<const int64_t *>(dev(dst0)));
+                e = imdct_gathered(D.size0, D.t0, (int64_t)n0, static_cast<const int64_t *>(dev(src0)),
+                                   static_cast<const int64_t *>(dev(dst0)));
             if (e == hipSuccess && n1)
-                e = launch_imdct_exact(D.size1, D.t1->ld, d_temp, d_y, (int64_t)n1, D.t1->d_A, D.t1->d_B, D.t1->d_C,
-                                       D.t1->d_bitrev, ctx->num_cu, ctx->stream, static_cast<const int64_t *>(dev(src1)),
-                                       static_cast<const int64_t *>(dev(dst1)));
+                e = imdct_gathered(D.size1, D.t1, (int64_t)n1, static_cast<const int64_t *>(dev(src1)),
+                                   static_cast<const int64_t *>(dev(dst1)));
             if (e == hipSuccess)
                 e = launch_generic_ola(d_gf, (int)n_frames, C, D.size0, D.size1, d_y, D.d_state_h, D.t0->d_slope,
                                        D.t1->d_slope, d_out, d_outoff, channel_stride, out_layout == VPZ_OUT_INTERLEAVED,

@@ -62,8 +62,12 @@ hipError_t launch_imdct_fast_2048(const float *spectra, float *out, int64_t coun
                                   const float2 *tw, int num_cu, hipStream_t stream);
 hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count,
                                  const float2 *tw, int num_cu, hipStream_t stream);
+// N = 4096; optional gather lists (float offsets of each block's spectrum / output) for the three-pass decoder path
+hipError_t launch_imdct_fast_4096(const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
+                                  hipStream_t stream, const int64_t *src_off = nullptr, const int64_t *dst_off = nullptr);
 hipError_t launch_imdct_fast_mid(int n, const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
-                                 hipStream_t stream);  // n = 512 or 1024
+                                 hipStream_t stream, const int64_t *src_off = nullptr,
+                                 const int64_t *dst_off = nullptr);  // n = 512 or 1024
 hipError_t launch_imdct_exact(int n, int ld, const float *spectra, float *out, int64_t count,
                               const float *A, const float *B, const float *C,
                               const uint16_t *bitrev, int num_cu, hipStream_t stream,
@@ -74,6 +78,9 @@ constexpr int kFastTwOffset = 0;       // tw[k] = exp(+2*pi*i*(k + 1/8)/n), k < 
 constexpr int kFastTwABOffset = 512;   // twAB[p*64 + l] = exp(+2*pi*i*l*p/512)
 constexpr int kFastTwBCOffset = 1024;  // twBC[l0*8 + q] = exp(+2*pi*i*l0*q/64)
 constexpr int kFastTableCount = 1024 + 64;
+// N = 4096 keeps its own layout: tw[1024] | twAB[512] | twBC[64] | w[512] = exp(2*pi*i*j/1024)
+constexpr int kFast4096TwOffset = 0, kFast4096TwABOffset = 1024, kFast4096TwBCOffset = 1536, kFast4096WOffset = 1600;
+constexpr int kFast4096TableCount = 2112;
 
 }  // namespace vpz
 
