@@ -46,7 +46,11 @@ extern "C" {
 /* ---- where caller pointers live ---- */
 #define VPZ_MEM_HOST   0   /* host memory (what a pinned C# array is); call is synchronous */
 #define VPZ_MEM_DEVICE 1   /* device memory on the context's GPU; call is asynchronous on the
-                              context stream, order with vpz_context_synchronize */
+                              context stream, order with vpz_context_synchronize.  The library never
+                              looks at other streams: whoever produced the input buffers on another
+                              HIP stream finishes (or synchronises) that work before the call, and
+                              consumers of the output wait for vpz_context_synchronize or an event on
+                              vpz_context_stream */
 
 typedef struct vpz_context vpz_context;   /* one GPU + one HIP stream + tables */
 typedef struct vpz_decoder vpz_decoder;   /* synthesis state of a group of streams */
