@@ -33,12 +33,14 @@ def gaussian_spectra(shape, seed, sigma=2.0 ** -8):
 
 
 def oracle_decode(orc, channels, size0, size1, packets, floors=(), mappings=(), clip=False,
-                  interleave=False):
+                  interleave=False, state=None, keep_state=False):
     """Runs one stream through the oracle.  packets: list of dicts with keys
     flags, granule (default -1), mapping (default 0), residue (np [channels*half] as laid out for the
     ABI), posts (np [channels, <=64]), post_count (np [channels]).  Returns PCM [channels, T] or [T, channels]."""
     L = orc.lib()
-    st = L.orc_stream_create(channels, size0, size1)
+    # `state`: continue on an oracle stream a previous call kept (keep_state=True returns it as a 4th value,
+    # e.g. to put an orc_stream_reset between two calls)
+    st = state if state is not None else L.orc_stream_create(channels, size0, size1)
     ofl = [orc.floor1_init(*f) if not isinstance(f, dict) else None for f in floors]
     chunks = []
     mismatches = []
@@ -121,9 +123,12 @@ def oracle_decode(orc, channels, size0, size1, packets, floors=(), mappings=(), 
         take()
     pos = L.orc_stream_position(st)
     clipped = bool(L.orc_stream_has_clipped(st))
-    L.orc_stream_destroy(st)
+    if not keep_state:
+        L.orc_stream_destroy(st)
     pcm = np.concatenate(chunks, axis=1) if chunks else np.zeros((channels, 0), dtype=np.float32)
     oracle_decode.last_mismatches = len(mismatches)
+    if keep_state:
+        return (pcm.T.copy() if interleave else pcm), pos, clipped, st
     return (pcm.T.copy() if interleave else pcm), pos, clipped
 
 
