@@ -114,3 +114,39 @@ def stereo_floor0(seed=4):
 
 ALL = {"mono_floor1_res1": mono_floor1_res1, "stereo_coupled_res2": stereo_coupled_res2,
        "three_channels_two_submaps": three_channels_two_submaps, "stereo_floor0": stereo_floor0}
+
+
+def random_stream(seed):
+    """A random setup: 1-3 channels, any block-size pair 64..4096, floor 1 on every mapping, one or two submaps,
+    residue types 0 / 1 / 2 at random, 0-2 coupling steps, one or two long modes."""
+    rng = np.random.default_rng(seed)
+    channels = int(rng.integers(1, 4))
+    logs = sorted(int(v) for v in rng.integers(6, 13, size=2))      # block sizes 64 .. 4096
+    h0, h1 = (1 << logs[0]) // 2, (1 << logs[1]) // 2
+    books = []
+    submaps = 2 if (channels > 1 and rng.random() < 0.4) else 1
+    mux = [0] * channels if submaps == 1 else [int(v) for v in rng.integers(0, 2, size=channels)]
+    if submaps == 2 and len(set(mux)) == 1:
+        mux[-1] = 1 - mux[0]
+    floors, residues, maps = [], [], []
+    for half in (h0, h1):
+        sub_floor, sub_res = [], []
+        for s in range(submaps):
+            floors.append(_floor1(rng, books, half, int(rng.integers(2, 6)) if half >= 64 else 2, int(rng.integers(1, 5))))
+            sub_floor.append(len(floors) - 1)
+            members = sum(1 for m in mux if m == s)
+            rtype = int(rng.integers(0, 3))
+            size = half * members if rtype == 2 else half
+            psize = int(rng.choice([8, 16, 32])) if size >= 128 else 8
+            residues.append(_residue(rng, books, rtype, size, psize, int(rng.integers(2, 5)), int(rng.integers(1, 3)),
+                                     [(2, 1, 9), (4, 1, 16), (2, 2, 7), (8, 1, 256)][: int(rng.integers(2, 5))]))
+            sub_res.append(len(residues) - 1)
+        coupling = []
+        if channels > 1:
+            for _ in range(int(rng.integers(0, 3))):
+                m, a = (int(v) for v in rng.choice(channels, size=2, replace=False))
+                coupling.append((m, a))
+        maps.append(vw.Mapping(channels, coupling, mux, sub_floor, sub_res))
+    modes = [(0, 0), (1, 1)] + ([(1, 1)] if rng.random() < 0.3 else [])
+    return vw.Stream(channels, int(rng.choice([8000, 22050, 44100])), logs[0], logs[1], books, floors, residues, maps,
+                     modes), rng

@@ -106,3 +106,10 @@ def test_granules_follow_the_page_that_completes_the_packet(front):
             total += ((stream.bs1 if p else stream.bs0) + (stream.bs1 if e["blockflag"] else stream.bs0)) // 4
         want.append(total)
     assert list(pk["granule"]) == want and f.last_granule == want[-1]
+
+
+@pytest.mark.parametrize("seed", range(40, 56))
+def test_random_setups(front, seed):
+    stream, rng = ss.random_stream(seed)
+    ogg, exps = stream.build(rng, 14, packets_per_page=int(rng.integers(1, 6)))
+    _check(front, stream, exps, ogg)

@@ -263,7 +263,7 @@ class Floor1:
         bw.write(len(self.partition_class), 5)
         for c in self.partition_class:
             bw.write(c, 4)
-        for c in range(len(self.class_dims)):
+        for c in range(max(self.partition_class) + 1):  # the header carries classes 0 .. max used (spec 7.2.2)
             bw.write(self.class_dims[c] - 1, 3)
             bw.write(self.class_subclasses[c], 2)
             if self.class_subclasses[c]:
