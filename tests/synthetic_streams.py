@@ -3,6 +3,7 @@ do not: Floor0, residue type 0, several submaps, ordered / sparse codebooks, loo
 other than 256/2048, three modes, and packets continued over page boundaries."""
 import numpy as np
 
+import helpers
 import vorbis_writer as vw
 
 
@@ -45,6 +46,14 @@ def _residue(rng, books, rtype, half, partition_size, classifications, class_dim
     begin = int(rng.integers(0, 3)) * partition_size
     end = half - int(rng.integers(0, 2)) * partition_size
     return vw.Residue(rtype, begin, end, partition_size, classbook, cascade, rbooks)
+
+
+def _lsp_book(rng, dims):
+    # ascending-ish LSP coefficients in (0, pi): min > 0, small positive steps, sequence_p
+    entries = 16
+    return vw.Codebook(dims, [4] * entries, 1,
+                       minv=vw.float32_pack(5, 788 - 5), delta=vw.float32_pack(1, 788 - 5), value_bits=2,
+                       seq_p=True, mults=[int(v) for v in rng.integers(0, 4, size=vw.lookup1_values(entries, dims))])
 
 
 def mono_floor1_res1(seed=1):
@@ -94,17 +103,8 @@ def stereo_floor0(seed=4):
     """stereo, Floor0 on both block sizes (two LSP books to choose from), residue 1, equal 512/512 blocks."""
     rng = np.random.default_rng(seed)
     books = []
-
-    def lsp_book(dims):
-        # ascending-ish LSP coefficients in (0, pi): min > 0, small positive steps, sequence_p
-        entries = 16
-        b = vw.Codebook(dims, [4] * entries, 1,
-                        minv=vw.float32_pack(5, 788 - 5), delta=vw.float32_pack(1, 788 - 5), value_bits=2,
-                        seq_p=True, mults=[int(v) for v in rng.integers(0, 4, size=vw.lookup1_values(entries, dims))])
-        return b
-
-    books.append(lsp_book(2))
-    books.append(lsp_book(4))
+    books.append(_lsp_book(rng, 2))
+    books.append(_lsp_book(rng, 4))
     f0 = vw.Floor0(8, 16000, 128, 6, 40, [0, 1], max_amp_raw=3)
     f1 = vw.Floor0(12, 16000, 200, 5, 30, [1, 0], max_amp_raw=2)
     r = _residue(rng, books, 1, 256, 16, 3, 2, [(2, 1, 25), (4, 1, 81)])
@@ -117,8 +117,8 @@ ALL = {"mono_floor1_res1": mono_floor1_res1, "stereo_coupled_res2": stereo_coupl
 
 
 def random_stream(seed):
-    """A random setup: 1-3 channels, any block-size pair 64..4096, floor 1 on every mapping, one or two submaps,
-    residue types 0 / 1 / 2 at random, 0-2 coupling steps, one or two long modes."""
+    """A random setup: 1-3 channels, any block-size pair 64..4096, one or two submaps, floor 1 (or, one time in
+    four, floor 0 on every submap), residue types 0 / 1 / 2 at random, 0-2 coupling steps, one or two long modes."""
     rng = np.random.default_rng(seed)
     channels = int(rng.integers(1, 4))
     logs = sorted(int(v) for v in rng.integers(6, 13, size=2))      # block sizes 64 .. 4096
@@ -129,10 +129,23 @@ def random_stream(seed):
     if submaps == 2 and len(set(mux)) == 1:
         mux[-1] = 1 - mux[0]
     floors, residues, maps = [], [], []
+    use_floor0 = rng.random() < 0.25
+    if use_floor0:
+        lsp = len(books)
+        books += [_lsp_book(rng, 2), _lsp_book(rng, 4)]
     for half in (h0, h1):
         sub_floor, sub_res = [], []
         for s in range(submaps):
-            floors.append(_floor1(rng, books, half, int(rng.integers(2, 6)) if half >= 64 else 2, int(rng.integers(1, 5))))
+            if use_floor0:
+                # bark_map_size <= the smaller half block: the reference indexes its w map out of range otherwise
+                # 16 amplitude bits and an amplitude capped where the curve reaches +20 dB: random LSP roots make
+                # far peakier filters than an encoder would (exp(0.115 * (amp / sqrt(p + q) - ofs)))
+                fl = vw.Floor0(int(rng.choice([4, 8, 12])), 16000, int(rng.integers(8, h0 + 1)), 16,
+                               int(rng.integers(45, 64)), [lsp, lsp + 1][: int(rng.integers(1, 3))])
+                fl.amp_policy = (lambda c, fl=fl: helpers.floor0_safe_amp(c, fl.bark_map_size, fl.amp_ofs) * 1.3)
+                floors.append(fl)
+            else:
+                floors.append(_floor1(rng, books, half, int(rng.integers(2, 6)) if half >= 64 else 2, int(rng.integers(1, 5))))
             sub_floor.append(len(floors) - 1)
             members = sum(1 for m in mux if m == s)
             rtype = int(rng.integers(0, 3))

@@ -130,7 +130,7 @@ def test_synthetic_stream_through_the_reader_mirror(ctx, oracle):
     r.Dispose()
 
 
-@pytest.mark.parametrize("seed", range(40, 56))
+@pytest.mark.parametrize("seed", range(40, 64))
 def test_random_synthetic_setups_decode_like_the_oracle(ctx, oracle, seed):
     """Random setups from the spec-based writer (1-3 channels, any block-size pair 64..4096, residue 0 / 1 / 2,
     one or two submaps, up to two coupling steps): container to PCM, planar and interleaved, against the oracle."""
@@ -149,11 +149,15 @@ def test_random_synthetic_setups_decode_like_the_oracle(ctx, oracle, seed):
     assert ref.shape[1] == f.total_samples and np.isfinite(ref).all()
     scale = max(1.0, float(np.abs(ref).max()))
     dec = Decoder(ctx, f.channels, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings)
+    if f.floor0_data is not None:
+        dec.set_floor0_data(*f.floor0_data)
     planar = dec.synth(pk, res, posts, counts, out_layout=capi.OUT_PLANAR)[0]
     assert planar.shape == ref.shape and dec.position(0) == pos
     assert np.abs(planar - ref).max() <= 1e-5 * scale
     dec.reset(0)
     dec.set_position(0)
+    if f.floor0_data is not None:
+        dec.set_floor0_data(*f.floor0_data)
     inter = dec.synth(pk, res, posts, counts, out_layout=capi.OUT_INTERLEAVED)[0]
     assert np.array_equal(inter, planar.T)
     dec.close()

@@ -349,26 +349,7 @@ def test_any_block_size_pair_decodes(ctx, oracle, size0, size1):
         dec.close()
 
 
-def floor0_safe_amp(coeff, bark_map_size, amp_ofs):
-    """Largest amp for which Floor0's curve stays <= 0 dB: amp_ofs * min_k sqrt(p(k) + q(k))."""
-    c = 2.0 * np.cos(coeff.astype(np.float64))
-    w = 2.0 * np.cos(np.pi / bark_map_size * np.arange(bark_map_size))
-    p = np.full_like(w, 0.5)
-    q = np.full_like(w, 0.5)
-    order = len(c)
-    j = 1
-    while j < order:
-        q *= w - c[j - 1]
-        p *= w - c[j]
-        j += 2
-    if j == order:
-        q *= w - c[j - 1]
-        p *= p * (4.0 - w * w)
-        q *= q
-    else:
-        p *= p * (2.0 - w)
-        q *= q * (2.0 + w)
-    return float(amp_ofs * np.sqrt(np.maximum(p + q, 1e-30)).min())
+floor0_safe_amp = helpers.floor0_safe_amp
 
 
 @pytest.mark.parametrize("size0,size1,order,bark", [(2048, 2048, 8, 256), (256, 2048, 9, 64), (512, 1024, 16, 128)])

@@ -317,6 +317,7 @@ class Floor0:
         # random LSP roots make a far peakier filter than an encoder would; a small amplitude keeps the
         # curve exp(0.115 * (amp / sqrt(p + q) - amp_ofs)) inside float range
         self.max_amp_raw = max_amp_raw or (1 << amp_bits) - 1
+        self.amp_policy = None  # optional: coeff -> largest amplitude (float) that keeps the curve in range
 
     def write_header(self, bw):
         bw.write(self.order, 8)
@@ -329,26 +330,32 @@ class Floor0:
             bw.write(b, 8)
 
     def write_packet(self, bw, books, rng):
-        """Returns (amp float32, coeff float32[order]) -- never a zero amplitude (see module docstring)."""
-        amp_raw = int(rng.integers(1, self.max_amp_raw + 1))
-        bw.write(amp_raw, self.amp_bits)
-        amp = np.float32(amp_raw * self.amp_ofs / float((1 << self.amp_bits) - 1))
+        """Returns (amp float32, coeff float32[order]) -- never a zero amplitude (see module docstring).  The book
+        entries are drawn first so that `amp_policy(coeff) -> largest sensible amplitude` (if set) can keep the curve
+        in range; the bitstream order is amplitude, book number, entries."""
         bi = int(rng.integers(len(self.book_list)))
-        bw.write(bi, ilog(len(self.book_list)))
         book = books[self.book_list[bi]]
-        coeff = []
+        assert self.order % book.dims == 0  # (else the reference's `last` differs from the spec's; keep them equal)
+        entries, coeff = [], []
         last = np.float32(0)
         while len(coeff) < self.order:
             e = int(rng.choice(book.used))
-            book.write_entry(bw, e)
-            vec = book.vector(e)
-            chunk = [np.float32(v + last) for v in vec]
+            entries.append(e)
+            chunk = [np.float32(v + last) for v in book.vector(e)]
             last = chunk[-1]
             coeff += chunk
-        # the reference keeps `order` values and carries `last` from the last KEPT value of each chunk,
-        # which only matters when order is not a multiple of the book dimension: keep them equal here
-        assert self.order % book.dims == 0
-        return amp, np.array(coeff[: self.order], dtype=np.float32)
+        coeff = np.array(coeff[: self.order], dtype=np.float32)
+        top = self.max_amp_raw
+        if self.amp_policy is not None:
+            limit = self.amp_policy(coeff) * ((1 << self.amp_bits) - 1) / float(self.amp_ofs)
+            top = max(1, min(top, int(limit)))
+        amp_raw = int(rng.integers(max(1, top // 2), top + 1))
+        bw.write(amp_raw, self.amp_bits)
+        amp = np.float32(amp_raw * self.amp_ofs / float((1 << self.amp_bits) - 1))
+        bw.write(bi, ilog(len(self.book_list)))
+        for e in entries:
+            book.write_entry(bw, e)
+        return amp, coeff
 
 
 class Residue:
