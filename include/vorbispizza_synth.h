@@ -86,7 +86,7 @@ int vpz_memcpy_d2h(vpz_context *ctx, void *host_dst, const void *dev_src, uint64
  * out:     [count][n]   float32 (the whole span after the call).  n is a power of two,
  * 64 <= n <= 8192 (Vorbis block sizes).  n = 64/128 reproduce the reference's literal (non-IMDCT)
  * output, quirk q1 of SURVEY.md 7.2.  `mode`: VPZ_IMDCT_FAST uses the wavefront FFT factorisation
- * (<= 1e-5 abs error for |PCM| <= 1; n = 256, 512, 1024, 2048, 4096 -- other sizes fall back to EXACT);
+ * (<= 1e-5 abs error for |PCM| <= 1; every n from 256 up -- 64 and 128 fall back to EXACT);
  * VPZ_IMDCT_EXACT runs the reference's own butterfly schedule (Mdct.cs:98-414) and is bit-identical
  * to it.
  * ------------------------------------------------------------------------------------------ */

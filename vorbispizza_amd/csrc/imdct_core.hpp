@@ -236,6 +236,61 @@ __device__ __forceinline__ void imdct4096_wave(const float4 (&xa)[8], float2 *h,
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// N = 8192: the 2048-point transform as four 512-point ones (input points k = 4k' + r) and two radix-2 levels.
+// lo[m] = X[8k' .. 8k'+3], hi[m] = X[8k'+4 .. 8k'+7] for k' = lane + 64*m.  On return `h` (>= 2048 float2,
+// wave-private; its first 576 float2 double as the transposes' scratch) holds h[0..4096) in natural order.
+//   g_tw  : 2048 float2 tw[k] = exp(2*pi*i*(k + 1/8)/8192)   (global memory: read once per block and lane)
+//   g_w2  : 1024 float2 exp(2*pi*i*J/2048)                    (global memory)
+//   s_w1  :  512 float2 exp(2*pi*i*j/1024), s_twAB / s_twBC: the 512-point tables (LDS)
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void imdct8192_wave(const float4 (&lo)[8], const float4 (&hi)[8], float2 *h,
+                                               const float2 *g_tw, const float2 *g_w2, const float2 *s_w1,
+                                               const float2 *s_twAB, const float2 *s_twBC, int lane)
+{
+    float2 a0[8], a1[8], a2[8], a3[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        // z[k] = (X[N/2-1-2k] + i*X[2k]) * tw[k], k = 4k' + r: X[2k] is component 2r of this lane's group of 8,
+        // X[N/2-1-2k] component 7-2r of the group lane 63-lane loaded for its point 7-m
+        const int k = 4 * (lane + 64 * m);
+        const float r0 = lane_mirror64(hi[7 - m].w, lane), r1 = lane_mirror64(hi[7 - m].y, lane);
+        const float r2 = lane_mirror64(lo[7 - m].w, lane), r3 = lane_mirror64(lo[7 - m].y, lane);
+        a0[m] = cmul(make_float2(r0, lo[m].x), g_tw[k]);
+        a1[m] = cmul(make_float2(r1, lo[m].z), g_tw[k + 1]);
+        a2[m] = cmul(make_float2(r2, hi[m].x), g_tw[k + 2]);
+        a3[m] = cmul(make_float2(r3, hi[m].z), g_tw[k + 3]);
+    }
+    dft512_wave(a0, h, s_twAB, s_twBC, lane);
+    dft512_wave(a1, h, s_twAB, s_twBC, lane);
+    dft512_wave(a2, h, s_twAB, s_twBC, lane);
+    dft512_wave(a3, h, s_twAB, s_twBC, lane);
+    // level 1: E = DFT1024 of the even points (a0 | a2), O of the odd ones (a1 | a3);
+    // level 2: Z[J] = E[J] + w2^J O[J], Z[J + 1024] = E[J] - w2^J O[J]
+    float2 z0[8], z1[8], z2[8], z3[8];  // Z[j], Z[j + 512], Z[j + 1024], Z[j + 1536]
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = lane + 64 * q;
+        const float2 te = cmul(a2[q], s_w1[j]), to = cmul(a3[q], s_w1[j]);
+        const float2 el = cadd(a0[q], te), eu = csub(a0[q], te);
+        const float2 ol = cadd(a1[q], to), ou = csub(a1[q], to);
+        const float2 tl = cmul(ol, g_w2[j]), tu = cmul(ou, g_w2[j + 512]);
+        z0[q] = cmul(cadd(el, tl), g_tw[j]);
+        z1[q] = cmul(cadd(eu, tu), g_tw[j + 512]);
+        z2[q] = cmul(csub(el, tl), g_tw[j + 1024]);
+        z3[q] = cmul(csub(eu, tu), g_tw[j + 1536]);
+    }
+    // h[2J] = Re W[J], h[2J+1] = -Im W[2047-J]: the partner of quarter s is quarter 3-s of lane 63-lane, register 7-q
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = lane + 64 * q;
+        h[j] = make_float2(z0[q].x, lane_mirror64(-z3[7 - q].y, lane));
+        h[j + 512] = make_float2(z1[q].x, lane_mirror64(-z2[7 - q].y, lane));
+        h[j + 1024] = make_float2(z2[q].x, lane_mirror64(-z1[7 - q].y, lane));
+        h[j + 1536] = make_float2(z3[q].x, lane_mirror64(-z0[7 - q].y, lane));
+    }
+}
+
 // value held by lane (lane ^ MASK)
 template <int MASK>
 __device__ __forceinline__ float lane_xor(float v, int lane)

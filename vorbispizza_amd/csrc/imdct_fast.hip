@@ -40,10 +40,15 @@ __device__ __forceinline__ void store_full_block(const float *h, float *out, int
     }
 }
 
+// kGather: block b reads at spectra + src_off[b] and writes at out + dst_off[b] (the three-pass decoder path);
+// the plain instantiation is the dense batch of vpz_imdct_batch, untouched by this option
+template <bool kGather>
 __global__ __launch_bounds__(kThreads) void imdct2048_kernel(const float *__restrict__ spectra,
                                                              float *__restrict__ out,
                                                              long count,
-                                                             const float2 *__restrict__ tables)
+                                                             const float2 *__restrict__ tables,
+                                                             const int64_t *__restrict__ src_off,
+                                                             const int64_t *__restrict__ dst_off)
 {
     __shared__ float2 s_tw[512];
     __shared__ float2 s_twAB[512];
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void imdct2048_kernel(const float *__rest
 
     float2 cur[8];
     {
-        const float2 *src = reinterpret_cast<const float2 *>(spectra + blk * 1024);
+        const float2 *src = reinterpret_cast<const float2 *>(spectra + (kGather ? src_off[blk] : blk * 1024));
 #pragma unroll
         for (int m = 0; m < 8; ++m) cur[m] = src[lane + 64 * m];
     }
@@ -74,12 +79,12 @@ __global__ __launch_bounds__(kThreads) void imdct2048_kernel(const float *__rest
         const long nxt = blk + stride;
         float2 pre[8];
         if (nxt < count) {
-            const float2 *src = reinterpret_cast<const float2 *>(spectra + nxt * 1024);
+            const float2 *src = reinterpret_cast<const float2 *>(spectra + (kGather ? src_off[nxt] : nxt * 1024));
 #pragma unroll
             for (int m = 0; m < 8; ++m) pre[m] = src[lane + 64 * m];
         }
         imdct2048_wave(cur, scratch, s_tw, s_twAB, s_twBC, lane);
-        store_full_block<2048, 64>(reinterpret_cast<const float *>(scratch), out + blk * 2048, lane);
+        store_full_block<2048, 64>(reinterpret_cast<const float *>(scratch), out + (kGather ? dst_off[blk] : blk * 2048), lane);
         if (nxt >= count) break;
 #pragma unroll
         for (int m = 0; m < 8; ++m) cur[m] = pre[m];
@@ -87,10 +92,13 @@ __global__ __launch_bounds__(kThreads) void imdct2048_kernel(const float *__rest
     }
 }
 
+template <bool kGather>
 __global__ __launch_bounds__(kThreads) void imdct256_kernel(const float *__restrict__ spectra,
                                                             float *__restrict__ out,
                                                             long count,
-                                                            const float2 *__restrict__ tables)
+                                                            const float2 *__restrict__ tables,
+                                                            const int64_t *__restrict__ src_off,
+                                                            const int64_t *__restrict__ dst_off)
 {
     __shared__ float2 s_tw[64];
     __shared__ float2 s_twBC[64];
@@ -112,13 +120,13 @@ __global__ __launch_bounds__(kThreads) void imdct256_kernel(const float *__restr
         const bool live = blk < count;
         const long ld = live ? blk : count - 1;
         float2 xa[8];
-        const float2 *src = reinterpret_cast<const float2 *>(spectra + ld * 128);
+        const float2 *src = reinterpret_cast<const float2 *>(spectra + (kGather ? src_off[ld] : ld * 128));
 #pragma unroll
         for (int m = 0; m < 8; ++m) xa[m] = src[l + 8 * m];
         imdct256_wave8(xa, scratch, s_tw, s_twBC, lane);
         if (live)
             store_full_block<256, 8>(reinterpret_cast<const float *>(scratch) + g * 128,
-                                     out + blk * 256, l);
+                                     out + (kGather ? dst_off[blk] : blk * 256), l);
     }
 }
 
@@ -193,6 +201,40 @@ __global__ __launch_bounds__(kThreads) void imdct4096_kernel(const float *__rest
     }
 }
 
+// N = 8192: one wavefront per channel-block, two 16-byte loads per lane and point; the two big twiddle tables stay
+// in global memory (every entry is read once per block), the 512-point stage tables and w1 in LDS
+__global__ __launch_bounds__(kThreads) void imdct8192_kernel(const float *__restrict__ spectra, float *__restrict__ out,
+                                                            long count, const float2 *__restrict__ tables,
+                                                            const int64_t *__restrict__ src_off,
+                                                            const int64_t *__restrict__ dst_off)
+{
+    __shared__ float2 s_twAB[512];
+    __shared__ float2 s_twBC[64];
+    __shared__ float2 s_w1[512];
+    __shared__ float2 s_h[kWavesPerGroup][2048];
+    for (int i = threadIdx.x; i < 512; i += kThreads) {
+        s_twAB[i] = tables[kFast8192TwABOffset + i];
+        s_w1[i] = tables[kFast8192W1Offset + i];
+    }
+    if (threadIdx.x < 64) s_twBC[threadIdx.x] = tables[kFast8192TwBCOffset + threadIdx.x];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long stride = (long)gridDim.x * kWavesPerGroup;
+    for (long blk = (long)blockIdx.x * kWavesPerGroup + wave; blk < count; blk += stride) {
+        const float4 *src = reinterpret_cast<const float4 *>(spectra + (src_off ? src_off[blk] : blk * 4096));
+        float4 lo[8], hi[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            lo[m] = src[2 * (lane + 64 * m)];
+            hi[m] = src[2 * (lane + 64 * m) + 1];
+        }
+        imdct8192_wave(lo, hi, s_h[wave], tables + kFast8192TwOffset, tables + kFast8192W2Offset, s_w1, s_twAB, s_twBC, lane);
+        store_full_block<8192, 64>(reinterpret_cast<const float *>(s_h[wave]), out + (dst_off ? dst_off[blk] : blk * 8192), lane);
+    }
+}
+
 // Persistent grid: exactly as many workgroups as the chip keeps resident (CUs x measured
 // occupancy), so that every workgroup gets the same share of the batch and there is no partial
 // last round of workgroups.
@@ -221,27 +263,37 @@ static int grid_for(int64_t work_groups, int resident)
 }
 
 hipError_t launch_imdct_fast_2048(const float *spectra, float *out, int64_t count,
-                                  const float2 *tw, int num_cu, hipStream_t stream)
+                                  const float2 *tw, int num_cu, hipStream_t stream, const int64_t *src_off,
+                                  const int64_t *dst_off)
 {
     if (count <= 0) return hipSuccess;
     static int resident = 0;
-    if (!resident) resident = resident_groups(imdct2048_kernel, num_cu);
+    if (!resident) resident = resident_groups(imdct2048_kernel<false>, num_cu);
     int grid = grid_for((count + kWavesPerGroup - 1) / kWavesPerGroup, resident);
-    hipLaunchKernelGGL(imdct2048_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out,
-                       (long)count, tw);
+    if (src_off && dst_off)
+        hipLaunchKernelGGL(imdct2048_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, spectra, out, (long)count, tw,
+                           src_off, dst_off);
+    else
+        hipLaunchKernelGGL(imdct2048_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, spectra, out, (long)count, tw,
+                           nullptr, nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count,
-                                 const float2 *tw, int num_cu, hipStream_t stream)
+                                 const float2 *tw, int num_cu, hipStream_t stream, const int64_t *src_off,
+                                 const int64_t *dst_off)
 {
     if (count <= 0) return hipSuccess;
     static int resident = 0;
-    if (!resident) resident = resident_groups(imdct256_kernel, num_cu);
+    if (!resident) resident = resident_groups(imdct256_kernel<false>, num_cu);
     int64_t per_group = kWavesPerGroup * 8;
     int grid = grid_for((count + per_group - 1) / per_group, resident);
-    hipLaunchKernelGGL(imdct256_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out,
-                       (long)count, tw);
+    if (src_off && dst_off)
+        hipLaunchKernelGGL(imdct256_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, spectra, out, (long)count, tw,
+                           src_off, dst_off);
+    else
+        hipLaunchKernelGGL(imdct256_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, spectra, out, (long)count, tw,
+                           nullptr, nullptr);
     return hipGetLastError();
 }
 
@@ -253,6 +305,18 @@ hipError_t launch_imdct_fast_4096(const float *spectra, float *out, int64_t coun
     if (!resident) resident = resident_groups(imdct4096_kernel, num_cu);
     const int grid = grid_for((count + kWavesPerGroup - 1) / kWavesPerGroup, resident);
     hipLaunchKernelGGL(imdct4096_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out, (long)count, tw, src_off,
+                       dst_off);
+    return hipGetLastError();
+}
+
+hipError_t launch_imdct_fast_8192(const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
+                                  hipStream_t stream, const int64_t *src_off, const int64_t *dst_off)
+{
+    if (count <= 0) return hipSuccess;
+    static int resident = 0;
+    if (!resident) resident = resident_groups(imdct8192_kernel, num_cu);
+    const int grid = grid_for((count + kWavesPerGroup - 1) / kWavesPerGroup, resident);
+    hipLaunchKernelGGL(imdct8192_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out, (long)count, tw, src_off,
                        dst_off);
     return hipGetLastError();
 }

@@ -145,6 +145,32 @@ int get_tables(Context *ctx, int n, BlockTables **out)
             fast[kFast4096WOffset + j] = make_float2((float)cos(a), (float)sin(a));
         }
     }
+    if (n == 8192) {
+        fast.assign(kFast8192TableCount, make_float2(0.f, 0.f));
+        const double two_pi = 6.283185307179586476925286766559;
+        for (int k = 0; k < 2048; ++k) {
+            double a = two_pi * ((double)k + 0.125) / 8192.0;
+            fast[kFast8192TwOffset + k] = make_float2((float)cos(a), (float)sin(a));
+        }
+        for (int p = 0; p < 8; ++p)
+            for (int l = 0; l < 64; ++l) {
+                double a = two_pi * (double)(l * p) / 512.0;
+                fast[kFast8192TwABOffset + p * 64 + l] = make_float2((float)cos(a), (float)sin(a));
+            }
+        for (int l0 = 0; l0 < 8; ++l0)
+            for (int q = 0; q < 8; ++q) {
+                double a = two_pi * (double)(l0 * q) / 64.0;
+                fast[kFast8192TwBCOffset + l0 * 8 + q] = make_float2((float)cos(a), (float)sin(a));
+            }
+        for (int j = 0; j < 512; ++j) {
+            double a = two_pi * (double)j / 1024.0;
+            fast[kFast8192W1Offset + j] = make_float2((float)cos(a), (float)sin(a));
+        }
+        for (int j = 0; j < 1024; ++j) {
+            double a = two_pi * (double)j / 2048.0;
+            fast[kFast8192W2Offset + j] = make_float2((float)cos(a), (float)sin(a));
+        }
+    }
     if (n == 512 || n == 1024) {
         // imdct_mid_wave<R>: tw[k], twAB[p*L + l] = exp(2*pi*i*p*l/(64R)), twBC[l] = exp(2*pi*i*rev(l1)*l0/(8R))
         const int R = n / 256, L = 8 * R, M = 64 * R;
@@ -367,6 +393,8 @@ int vpz_imdct_batch(vpz_context *c, int n, int64_t count, const float *spectra, 
         e = vpz::launch_imdct_fast_mid(n, d_in, d_out, count, t->d_fast, ctx->num_cu, ctx->stream);
     else if (fast && n == 4096)
         e = vpz::launch_imdct_fast_4096(d_in, d_out, count, t->d_fast, ctx->num_cu, ctx->stream);
+    else if (fast && n == 8192)
+        e = vpz::launch_imdct_fast_8192(d_in, d_out, count, t->d_fast, ctx->num_cu, ctx->stream);
     else
         e = vpz::launch_imdct_exact(n, t->ld, d_in, d_out, count, t->d_A, t->d_B, t->d_C, t->d_bitrev,
                                     ctx->num_cu, ctx->stream);

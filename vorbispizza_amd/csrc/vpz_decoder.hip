@@ -853,11 +853,17 @@ struct SynthCall {
             if (any_floor)
                 e = launch_generic_floor(d_gf, (int)n_frames, C, half1, d_temp, d_counts,
                                          static_cast<const uint8_t *>(D.b_curve.p), ctx->d_inv_db, ctx->stream);
-            // per block size: the gathered FAST transform where one exists (512, 1024, 4096), else the reference's
-            // own schedule (64 and 128 must take it: quirk q1)
+            // per block size: the gathered FAST transform (every size from 256 up), else the reference's own
+            // schedule (64 and 128 must take it: quirk q1)
             auto imdct_gathered = [&](int n, BlockTables *t, int64_t cnt, const int64_t *so, const int64_t *dof) {
                 if (n == 4096 && t->d_fast)
                     return launch_imdct_fast_4096(d_temp, d_y, cnt, t->d_fast, ctx->num_cu, ctx->stream, so, dof);
+                if (n == 8192 && t->d_fast)
+                    return launch_imdct_fast_8192(d_temp, d_y, cnt, t->d_fast, ctx->num_cu, ctx->stream, so, dof);
+                if (n == 2048 && t->d_fast)
+                    return launch_imdct_fast_2048(d_temp, d_y, cnt, t->d_fast, ctx->num_cu, ctx->stream, so, dof);
+                if (n == 256 && t->d_fast)
+                    return launch_imdct_fast_256(d_temp, d_y, cnt, t->d_fast, ctx->num_cu, ctx->stream, so, dof);
                 if ((n == 512 || n == 1024) && t->d_fast)
                     return launch_imdct_fast_mid(n, d_temp, d_y, cnt, t->d_fast, ctx->num_cu, ctx->stream, so, dof);
                 return launch_imdct_exact(n, t->ld, d_temp, d_y, cnt, t->d_A, t->d_B, t->d_C, t->d_bitrev, ctx->num_cu,

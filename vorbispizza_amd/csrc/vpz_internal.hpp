@@ -58,12 +58,17 @@ int ensure_stage(Context *ctx, void **buf, size_t *have, size_t need);
 
 // ---- kernel launchers (imdct_fast.hip / imdct_exact.hip / synth_kernels.hip) ----
 // spectra [count][n/2] -> out [count][n], device pointers, asynchronous on `stream`.
+// optional gather lists (float offsets of each block's spectrum / output) serve the three-pass decoder path
 hipError_t launch_imdct_fast_2048(const float *spectra, float *out, int64_t count,
-                                  const float2 *tw, int num_cu, hipStream_t stream);
+                                  const float2 *tw, int num_cu, hipStream_t stream,
+                                  const int64_t *src_off = nullptr, const int64_t *dst_off = nullptr);
 hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count,
-                                 const float2 *tw, int num_cu, hipStream_t stream);
+                                 const float2 *tw, int num_cu, hipStream_t stream,
+                                 const int64_t *src_off = nullptr, const int64_t *dst_off = nullptr);
 // N = 4096; optional gather lists (float offsets of each block's spectrum / output) for the three-pass decoder path
 hipError_t launch_imdct_fast_4096(const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
+                                  hipStream_t stream, const int64_t *src_off = nullptr, const int64_t *dst_off = nullptr);
+hipError_t launch_imdct_fast_8192(const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
                                   hipStream_t stream, const int64_t *src_off = nullptr, const int64_t *dst_off = nullptr);
 hipError_t launch_imdct_fast_mid(int n, const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
                                  hipStream_t stream, const int64_t *src_off = nullptr,
@@ -81,6 +86,10 @@ constexpr int kFastTableCount = 1024 + 64;
 // N = 4096 keeps its own layout: tw[1024] | twAB[512] | twBC[64] | w[512] = exp(2*pi*i*j/1024)
 constexpr int kFast4096TwOffset = 0, kFast4096TwABOffset = 1024, kFast4096TwBCOffset = 1536, kFast4096WOffset = 1600;
 constexpr int kFast4096TableCount = 2112;
+// N = 8192: tw[2048] | twAB[512] | twBC[64] | w1[512] = exp(2*pi*i*j/1024) | w2[1024] = exp(2*pi*i*J/2048)
+constexpr int kFast8192TwOffset = 0, kFast8192TwABOffset = 2048, kFast8192TwBCOffset = 2560, kFast8192W1Offset = 2624,
+              kFast8192W2Offset = 3136;
+constexpr int kFast8192TableCount = 4160;
 
 }  // namespace vpz
 
