@@ -98,16 +98,18 @@ int vpz_imdct_batch(vpz_context *ctx, int n, int64_t count, const float *spectra
 /* ------------------------------------------------------------------------------------------
  * Stream configuration: the setup-header products the synthesis path reads.
  * ------------------------------------------------------------------------------------------ */
-#define VPZ_MAX_FLOOR1_POSTS 65
-#define VPZ_POSTS_STRIDE     64   /* `Data.Posts = new int[64]`, Floor1.cs:17 */
+#define VPZ_MAX_FLOOR1_POSTS 65   /* array bound of vpz_floor1_config.x_list (the specification's maximum) */
+#define VPZ_POSTS_STRIDE     64   /* `Data.Posts = new int[64]`, Floor1.cs:17: the reference cannot hold a 65th post
+                                     (its Unpack would throw), so x_count <= 64 is what every entry point accepts */
 #define VPZ_MAX_CHANNELS     255
 #define VPZ_MAX_COUPLING     256
 
 typedef struct vpz_floor1_config {        /* Floor1.cs:30-31 (`_xList`, `_multiplier`) */
-    int32_t x_count;                      /* length of _xList, 2..65 */
+    int32_t x_count;                      /* length of _xList, 2..VPZ_POSTS_STRIDE */
     int32_t multiplier;                   /* _multiplier, 1..4 (range = {256,128,86,64}) */
-    int32_t x_list[VPZ_MAX_FLOOR1_POSTS]; /* _xList in bitstream order; the library derives
-                                             _lNeigh/_hNeigh/_sortIdx as Floor1.cs:108-149 does */
+    int32_t x_list[VPZ_MAX_FLOOR1_POSTS]; /* _xList in bitstream order, distinct values; x_list[0] must be 0 and
+                                             x_list[1] > 0 as Floor1.cs:96-97 constructs them (0 and 1 << rangeBits);
+                                             the library derives _lNeigh/_hNeigh/_sortIdx as Floor1.cs:108-149 does */
 } vpz_floor1_config;
 
 typedef struct vpz_floor0_config {        /* Floor0.cs:29-35 (LSP floor, "virtually unused") */
@@ -148,6 +150,10 @@ typedef struct vpz_stream_config {
                                       (Residue2.cs:31-34) instead of planar [channels][n/2] */
 #define VPZ_PKT_NO_FLOOR     0x40  /* residue already is the floored spectrum: skip coupling and
                                       Floor1 (boundary variant "between Mapping.cs:187 and :188") */
+#define VPZ_PKT_RESYNC       0x80  /* packet.IsResync (StreamDecoder.cs:718-722): the container lost sync before
+                                      this packet, so `_hasPosition = false` -- the stream picks its position up
+                                      again from the next packet that carries a granule position (:459-463).
+                                      Applies to not-decoded packets as well (the check precedes the type bit) */
 typedef struct vpz_packet {
     int32_t stream;          /* 0 .. n_streams-1 */
     uint8_t flags;           /* VPZ_PKT_* */

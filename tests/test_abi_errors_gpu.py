@@ -56,6 +56,14 @@ def test_create_rejects_bad_configurations(ctx):
     assert _status(lambda: Decoder(ctx, 2, 256, 2048, floors=[([0, 128, 5], 7)], mappings=ok_map)) == capi.E_INVALID_ARG
     f0 = {"order": 0, "rate": 44100, "bark_map_size": 64, "amp_bits": 6, "amp_ofs": 40}
     assert _status(lambda: Decoder(ctx, 2, 256, 2048, floors=[f0], mappings=ok_map)) == capi.E_INVALID_ARG
+    # Floor1.cs:96-97 builds _xList[0] = 0, _xList[1] = 1 << rangeBits: the render relies on the post at x = 0,
+    # and `Posts = new int[64]` (Floor1.cs:17) cannot hold a 65th post
+    assert _status(lambda: Decoder(ctx, 2, 256, 2048, floors=[([3, 128, 5], 2)], mappings=ok_map)) == capi.E_INVALID_ARG
+    assert _status(lambda: Decoder(ctx, 2, 256, 2048, floors=[([0, 0x7FFF + 1, 5], 2)], mappings=ok_map)) == capi.E_INVALID_ARG
+    x65 = [0, 1024] + list(range(1, 64))
+    assert len(x65) == 65
+    assert _status(lambda: Decoder(ctx, 2, 256, 2048, floors=[(x65, 2)], mappings=ok_map)) == capi.E_INVALID_ARG
+    Decoder(ctx, 2, 256, 2048, floors=[(x65[:64], 2)], mappings=ok_map).close()
 
 
 def test_synth_rejects_bad_calls_and_keeps_its_state(ctx):

@@ -35,6 +35,25 @@ def test_mutated_containers_never_touch_memory_they_do_not_own(fuzz_binary, tmp_
         path = tmp_path / (name + ".ogg")
         path.write_bytes(ogg)
         seeds.append(str(path))
+    # regression seeds of the round-1 advisor findings: mux == submap count (heap read past `submap_floor`) and a
+    # residue value book without dimensions (division by zero in write_vectors)
+    import vorbis_writer as vw
+    stream, rng = ss.three_channels_two_submaps()
+    ogg_ok, _ = stream.build(rng, 6)
+    for mp in stream.mappings:
+        mp.mux = [0, 0, 2]
+    hdr = vw.ogg_mux(stream.headers(), [0, 0, 0])
+    # the audio pages of the well-formed build follow the malformed setup header
+    n_hdr_ok = len(vw.ogg_mux(ss.three_channels_two_submaps()[0].headers(), [0, 0, 0]))
+    (tmp_path / "mux_out_of_range.ogg").write_bytes(hdr + ogg_ok[n_hdr_ok:])
+    seeds.append(str(tmp_path / "mux_out_of_range.ogg"))
+    stream, rng = ss.mono_floor1_res1()
+    victim = next(b for row in stream.residues[0].books for b in row if b is not None)
+    old = stream.books[victim]
+    stream.books[victim] = vw.Codebook(0, old.lengths, 2, minv=vw.float32_pack(0, 788), delta=vw.float32_pack(1, 788),
+                                       value_bits=4, mults=[], sparse=old.sparse, ordered=old.ordered)
+    (tmp_path / "zero_dimensions.ogg").write_bytes(vw.ogg_mux(stream.headers(), [0, 0, 0]))
+    seeds.append(str(tmp_path / "zero_dimensions.ogg"))
     r = subprocess.run([fuzz_binary, "60"] + seeds, capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, FUZZ_SEED="5", ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0, r.stderr[-3000:]

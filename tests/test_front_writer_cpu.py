@@ -113,3 +113,67 @@ def test_random_setups(front, seed):
     stream, rng = ss.random_stream(seed)
     ogg, exps = stream.build(rng, 14, packets_per_page=int(rng.integers(1, 6)))
     _check(front, stream, exps, ogg)
+
+
+# ---- malformed setup headers the reference rejects with a managed exception (round-1 advisor findings) ----
+def test_mux_equal_to_submap_count_is_rejected_at_open(front):
+    # Mapping.cs:60 lets mux == submapCount through, :89-93 then indexes _submapFloor out of range and the
+    # constructor dies; the front end must refuse the header instead of reading past its vector
+    stream, rng = ss.three_channels_two_submaps()
+    for mp in stream.mappings:
+        mp.mux = [0, 0, 2]
+    # the writer's own packet model cannot use submap 2: only the headers matter here
+    ogg = vw.ogg_mux(stream.headers(), [0, 0, 0])
+    with pytest.raises(front.FrontError) as e:
+        front.OggVorbisFile(ogg)
+    assert "mux" in str(e.value)
+
+
+def test_residue_value_book_without_dimensions_is_rejected_at_open(front):
+    # dimensions == 0 with lookup type 2 parses (0 multiplicands); Residue0.cs:213 would divide by it
+    stream, rng = ss.mono_floor1_res1()
+    res = stream.residues[0]
+    victim = next(b for row in res.books for b in row if b is not None)
+    old = stream.books[victim]
+    stream.books[victim] = vw.Codebook(0, old.lengths, 2, minv=vw.float32_pack(0, 788), delta=vw.float32_pack(1, 788),
+                                       value_bits=4, mults=[], sparse=old.sparse, ordered=old.ordered)
+    ogg = vw.ogg_mux(stream.headers(), [0, 0, 0])
+    with pytest.raises(front.FrontError) as e:
+        front.OggVorbisFile(ogg)
+    assert "dimensions" in str(e.value)
+
+
+def test_a_packet_that_throws_costs_only_itself(front):
+    # "Unused mode index." (StreamDecoder.cs:727-730): three modes need 2 mode bits, index 3 does not exist.
+    # The reference's exception consumes that packet and nothing else.
+    stream, rng = ss.mono_floor1_res1(seed=9)
+    ogg, exps = stream.build(rng, 12, packets_per_page=1)
+    # find the page of audio packet 5 (3 header packets sit on the first pages) and set its mode bits to 3
+    pages, pos = [], 0
+    while pos < len(ogg):
+        nseg = ogg[pos + 26]
+        body = sum(ogg[pos + 27: pos + 27 + nseg])
+        pages.append((pos, 27 + nseg, body))
+        pos += 27 + nseg + body
+    good = front.OggVorbisFile(ogg)
+    pk_good, res_good, posts_good, counts_good = good.decode_packets()
+    # audio packets are one per page here; the header packets may share pages, so count from the end
+    ppos, hdr, body = pages[len(pages) - 12 + 5]
+    raw = bytearray(ogg)
+    raw[ppos + hdr] |= 0b110        # bit 0 = packet type (0), bits 1..2 = mode index -> 3
+    vw_crc = vw._crc
+    raw[ppos + 22: ppos + 26] = b"\0\0\0\0"
+    c = vw_crc(bytes(raw[ppos: ppos + hdr + body]))
+    raw[ppos + 22: ppos + 26] = int(c).to_bytes(4, "little")
+    bad = front.OggVorbisFile(bytes(raw))
+    pk, res, posts, counts = bad.decode_packets()
+    assert bad.decode_failures() == (1, 5) and "mode" in bad.last_error().lower()
+    assert pk["flags"][5] == helpers.PKT_NOT_DECODED
+    keep = np.arange(12) != 5
+    np.testing.assert_array_equal(pk["flags"][keep], pk_good["flags"][keep])
+    C = stream.channels
+    np.testing.assert_array_equal(posts.reshape(12, -1)[keep], posts_good.reshape(12, -1)[keep])
+    for i in np.nonzero(keep)[0]:
+        half = (stream.bs1 if pk["flags"][i] & 1 else stream.bs0) // 2
+        a, b = int(pk["residue_offset"][i]), int(pk_good["residue_offset"][i])
+        np.testing.assert_array_equal(res[a: a + C * half], res_good[b: b + C * half])

@@ -146,3 +146,92 @@ def test_seek_then_read_equals_sequential_decode(ctx, name):
         pass
     assert r.IsEndOfStream
     r.Dispose()
+
+
+def test_failed_open_handle_refuses_every_entry_point(ctx):
+    """vpzr_open_memory hands a handle back even when it fails (it carries the error text); channels == 0 must not
+    reach the `% channels` of the read entry points (round-1 advisor finding)."""
+    import ctypes as C
+    from vorbispizza_amd import capi, front
+    L = front.lib()
+    data = np.frombuffer(b"definitely not ogg" * 8, dtype=np.uint8)
+    h = C.c_void_p()
+    assert L.vpzr_open_memory(ctx._h, data.ctypes.data, data.size, C.byref(h)) != 0 and h
+    assert L.vpzr_last_error(h)
+    buf = np.zeros(64, dtype=np.float32)
+    st = C.c_int(0)
+    assert L.vpzr_read_samples(h, buf.ctypes.data, buf.size, C.byref(st)) == 0 and st.value == capi.E_INVALID_ARG
+    st = C.c_int(0)
+    assert L.vpzr_read_samples_planar(h, buf.ctypes.data, buf.size, 8, 32, C.byref(st)) == 0
+    assert st.value == capi.E_INVALID_ARG
+    assert L.vpzr_seek_to(h, 0, 0) == capi.E_INVALID_ARG
+    assert L.vpzr_channels(h) == 0 and L.vpzr_total_samples(h) == 0
+    L.vpzr_close(h)
+
+
+def test_planar_read_checks_the_last_channel_against_the_buffer(ctx):
+    """`buffer.Slice(ch * channelStride + offset, count)` throws in the reference when the stride puts a channel
+    outside the span (StreamDecoder.cs:594-638); here it must be an error, not a write past the buffer."""
+    from vorbispizza_amd import SynthError, capi
+    from vorbispizza_amd.front import VorbisReader
+    rdr = VorbisReader(ctx, os.path.join(GOLDEN, "3test.ogg"), batch_packets=4)
+    guard = np.full(1024, 7.0, dtype=np.float32)
+    buf = guard[:512]
+    with pytest.raises(SynthError) as e:
+        rdr.ReadSamples(buf, samplesToRead=256, channelStride=300)   # 300 + 256 > 512
+    assert e.value.status == capi.E_INVALID_ARG
+    with pytest.raises(SynthError):
+        rdr.ReadSamples(buf, samplesToRead=16, channelStride=-1)
+    assert (guard == 7.0).all()
+    assert rdr.ReadSamples(buf, samplesToRead=256, channelStride=256) > 0
+    assert (guard[512:] == 7.0).all()
+    rdr.Dispose()
+
+
+def test_a_throwing_packet_surfaces_once_and_the_stream_goes_on(ctx, oracle):
+    """An exception out of DecodeNextPacket ("Unused mode index.") costs the reference that packet only: the Read
+    that reaches it throws, the next Read continues with the following packet.  The batched reader must neither get
+    stuck on the batch nor lose the packets in front of the bad one (round-1 advisor finding)."""
+    import synthetic_streams as ss
+    import vorbis_writer as vw
+    from vorbispizza_amd import SynthError
+    from vorbispizza_amd.front import OggVorbisFile, VorbisReader
+    stream, rng = ss.mono_floor1_res1(seed=9)
+    ogg, exps = stream.build(rng, 12, packets_per_page=1)
+    pages, pos = [], 0
+    while pos < len(ogg):
+        nseg = ogg[pos + 26]
+        body = sum(ogg[pos + 27: pos + 27 + nseg])
+        pages.append((pos, 27 + nseg, body))
+        pos += 27 + nseg + body
+    ppos, hdr, body = pages[len(pages) - 12 + 5]
+    raw = bytearray(ogg)
+    raw[ppos + hdr] |= 0b110  # mode index 3 of 3 modes
+    raw[ppos + 22: ppos + 26] = b"\0\0\0\0"
+    raw[ppos + 22: ppos + 26] = int(vw._crc(bytes(raw[ppos: ppos + hdr + body]))).to_bytes(4, "little")
+    raw = bytes(raw)
+    # truth: the oracle over the same packets, the bad one handed over as "not decoded" without EOS
+    f = OggVorbisFile(raw)
+    pk, res, posts, counts = f.decode_packets()
+    assert f.decode_failures() == (1, 5)
+    ref, _, _ = helpers.oracle_decode(oracle, f.channels, f.block_size0, f.block_size1,
+                                      helpers.packets_for_oracle(f, pk, res, posts, counts),
+                                      floors=f.floors, mappings=f.mappings, clip=True, interleave=True)
+    for batch in (1, 4, 128):
+        rdr = VorbisReader(ctx, raw, batch_packets=batch)
+        buf = np.zeros(4096, dtype=np.float32)
+        chunks, errors = [], 0
+        for _ in range(64):
+            try:
+                n = rdr.ReadSamples(buf)
+            except SynthError as e:
+                errors += 1
+                assert "mode" in str(e).lower()
+                continue
+            if n == 0:
+                break
+            chunks.append(buf[:n].copy())
+        got = np.concatenate(chunks)
+        assert errors == 1, (batch, errors)
+        assert got.shape[0] == ref.shape[0] and np.abs(got - ref[:, 0]).max() <= 1e-5
+        rdr.Dispose()

@@ -17,7 +17,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 IMDCT_FAST, IMDCT_EXACT = 0, 1
 OUT_INTERLEAVED, OUT_PLANAR = 0, 1
 PKT_BLOCK_FLAG, PKT_PREV_FLAG, PKT_NEXT_FLAG, PKT_EOS = 0x01, 0x02, 0x04, 0x08
-PKT_NOT_DECODED, PKT_INTERLEAVED, PKT_NO_FLOOR = 0x10, 0x20, 0x40
+PKT_NOT_DECODED, PKT_INTERLEAVED, PKT_NO_FLOOR, PKT_RESYNC = 0x10, 0x20, 0x40, 0x80
 MAX_FLOOR1_POSTS, POSTS_STRIDE, MAX_CHANNELS, MAX_COUPLING = 65, 64, 255, 256
 
 

@@ -177,6 +177,9 @@ static int build_floor(const vpz_floor1_config &c, FloorDev *f)
         if (c.x_list[i] < 0 || c.x_list[i] > 32767) return VPZ_E_INVALID_ARG;
         f->x_list[i] = (int16_t)c.x_list[i];
     }
+    // Floor1.cs:96-97: `_xList[0] = 0; _xList[1] = 1 << rangeBits`.  The render starts its first segment at the
+    // post with x == 0 (bin 0 looks its segment up by counting the posts at or below it)
+    if (c.x_list[0] != 0 || c.x_list[1] <= 0) return VPZ_E_INVALID_ARG;
     std::vector<int> order(c.x_count);
     for (int i = 0; i < c.x_count; ++i) order[i] = i;
     // sortIdx[0], [1] start as 0, 1 and take part in the exchange sort like every other entry
@@ -511,6 +514,8 @@ struct SynthCall {
             StreamState &S = st[pk.stream];
             // Read(): once EOS was seen and the previous packet is drained nothing more is read (:441-447)
             if (S.eos_found && S.prev_start == S.prev_end) continue;
+            // DecodeNextPacket :718-722, before the packet's first bit is looked at
+            if (pk.flags & VPZ_PKT_RESYNC) S.has_position = false;
             const bool eos = pk.flags & VPZ_PKT_EOS;
             if (eos) S.eos_found = true;  // _eosFound |= isEndOfStream (:647), before the null check
             if (pk.flags & VPZ_PKT_NOT_DECODED) {

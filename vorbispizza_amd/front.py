@@ -62,6 +62,8 @@ def lib():
         L.vpzh_decode_range.argtypes = [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int64, vp, vp, vp, vp,
                                         C.POINTER(C.c_int64)]
         L.vpzh_decode_range.restype = C.c_int
+        L.vpzh_decode_failures.argtypes = [vp, C.POINTER(C.c_int64)]
+        L.vpzh_decode_failures.restype = C.c_int64
         # VorbisReader mirror (vorbis_reader.h)
         L.vpzr_open_memory.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp)]
         L.vpzr_open_memory.restype = C.c_int
@@ -161,6 +163,16 @@ class OggVorbisFile:
             self.close()
         except Exception:
             pass
+
+    def decode_failures(self):
+        """(count, index of the first) packets of the last decode call whose entropy decode threw the way the
+        reference's DecodeNextPacket does; they were handed over as not-decoded packets."""
+        first = C.c_int64(-1)
+        n = lib().vpzh_decode_failures(self._h, C.byref(first))
+        return int(n), int(first.value)
+
+    def last_error(self):
+        return lib().vpzh_last_error(self._h).decode()
 
     def decode_packets(self, stream_id=0, residue_base=0):
         """Entropy-decode every audio packet.  Returns (packets, residue, posts, post_counts) in the

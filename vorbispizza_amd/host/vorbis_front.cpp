@@ -458,6 +458,9 @@ struct Residue {
         for (auto &b : book_nums) {
             b = (uint8_t)p.read_bits(8);
             if (b >= cbs.size() || cbs[b].map_type == 0) throw InvalidData("residue book without value mapping");
+            // a value book without dimensions: `partitionSize / dimensions` (Residue0.cs:213) is the reference's
+            // DivideByZeroException, and Residue1's `i += dimensions` would never advance
+            if (cbs[b].dimensions < 1) throw InvalidData("residue book with zero dimensions");
         }
         if (class_book >= (int)cbs.size()) throw InvalidData("residue class book out of range");
         const Codebook &cb = cbs[class_book];
@@ -601,6 +604,10 @@ struct Mapping {  // Mapping.cs:19-95
             submap_floor.push_back((uint8_t)fl);
             submap_residue.push_back((uint8_t)rs);
         }
+        // Mapping.cs:89-93: `floors[_submapFloor[mux[c]]]` -- the check above lets mux == submapCount through
+        // and the reference's constructor then dies with IndexOutOfRangeException; same outcome here
+        for (int c = 0; c < channels; ++c)
+            if (mux[c] >= submaps) throw InvalidData("Channel mux submap index out of range in mapping header!");
     }
 };
 
@@ -652,6 +659,7 @@ struct vpzh_stream {
     int64_t last_granule = -1;
     int pages = 0, bad_crc = 0;
     int64_t residue_floats = 0;
+    int64_t decode_failures = 0, first_failed_packet = -1;  // of the last vpzh_decode_range* call
 
     // ---- container: Ogg/PageReaderBase.cs:286-361 (sync, CRC), Ogg/PacketProvider.cs:427-560 (packets)
     void demux(const uint8_t *d, size_t size, std::vector<OggPacket> &packets)
@@ -1059,7 +1067,7 @@ int vpzh_get_floor1(vpzh_stream *s, int index, vpz_floor1_config *out)
     if (!s || !out || index < 0 || index >= (int)s->floors.size() || s->floor_types[index] != 1) return VPZH_E_ARG;
     const Floor1 &f = s->floors[index];
     memset(out, 0, sizeof *out);
-    if (f.x_list.size() > VPZ_MAX_FLOOR1_POSTS) return VPZH_E_INVALID_DATA;
+    if (f.x_list.size() > VPZ_POSTS_STRIDE) return VPZH_E_INVALID_DATA;  // `Posts = new int[64]`, Floor1.cs:17
     out->x_count = (int32_t)f.x_list.size();
     out->multiplier = f.multiplier;
     for (size_t i = 0; i < f.x_list.size(); ++i) out->x_list[i] = f.x_list[i];
@@ -1094,24 +1102,47 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
         first + count > (int64_t)s->audio.size())
         return VPZH_E_ARG;
     if (f0_amp && (!f0_coeff || f0_stride < s->max_floor0_order)) return VPZH_E_ARG;
-    try {
-        int64_t off = 0;
-        const size_t C = (size_t)s->channels;
-        for (int64_t k = 0; k < count; ++k) {
-            const OggPacket &pk = s->audio[(size_t)(first + k)];
-            const int64_t n = s->packet_floats(pk);
+    s->decode_failures = 0;
+    s->first_failed_packet = -1;
+    int64_t off = 0;
+    const size_t C = (size_t)s->channels;
+    for (int64_t k = 0; k < count; ++k) {
+        const OggPacket &pk = s->audio[(size_t)(first + k)];
+        const int64_t n = s->packet_floats(pk);
+        try {
             s->decode_packet(pk, stream_id, residue_base + off, &packets[k], residue + off,
                              posts + (size_t)k * 64 * C, post_counts + (size_t)k * C,
                              f0_amp ? f0_amp + (size_t)k * C : nullptr,
                              f0_coeff ? f0_coeff + (size_t)k * C * (size_t)f0_stride : nullptr, f0_stride);
-            off += n;
+        } catch (const std::exception &e) {
+            // An exception out of DecodeNextPacket (StreamDecoder.cs:696-762: "Unused mode index.", a residue vector
+            // overrun, ...) costs the reference exactly that packet: it is consumed, no decoder state has changed
+            // yet -- not even `_eosFound |= isEndOfStream` (:647) -- and the next Read goes on with the following
+            // packet.  Same here: the packet is handed over as "not decoded" without its EOS flag, the batch goes on,
+            // and vpzh_decode_failures reports where it happened.
+            if (s->decode_failures++ == 0) {
+                s->first_failed_packet = k;
+                s->error = e.what();
+            }
+            const uint8_t resync = packets[k].flags & VPZ_PKT_RESYNC;
+            memset(&packets[k], 0, sizeof packets[k]);
+            packets[k].stream = stream_id;
+            packets[k].granule = -1;
+            packets[k].residue_offset = residue_base + off;
+            packets[k].flags = (uint8_t)(VPZ_PKT_NOT_DECODED | resync);
+            for (size_t c = 0; c < C; ++c) post_counts[(size_t)k * C + c] = 0;
         }
-        if (residue_floats_used) *residue_floats_used = off;
-    } catch (const std::exception &e) {
-        s->error = e.what();
-        return VPZH_E_INVALID_DATA;
+        off += n;
     }
+    if (residue_floats_used) *residue_floats_used = off;
     return VPZH_OK;
+}
+
+int64_t vpzh_decode_failures(vpzh_stream *s, int64_t *first_failed_packet)
+{
+    if (!s) return 0;
+    if (first_failed_packet) *first_failed_packet = s->first_failed_packet;
+    return s->decode_failures;
 }
 
 int64_t vpzh_total_samples(vpzh_stream *s)

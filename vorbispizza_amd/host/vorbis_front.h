@@ -77,6 +77,14 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
                          vpz_packet *packets, float *residue, int16_t *posts, uint8_t *post_counts,
                          int64_t *residue_floats_used, float *f0_amp, float *f0_coeff, int32_t f0_stride);
 
+/* Packets of the LAST vpzh_decode_range* / vpzh_decode_all call whose entropy decode failed the way the reference's
+ * DecodeNextPacket throws (InvalidDataException "Unused mode index.", a residue vector overrunning its block, ...).
+ * Such a packet costs only itself, like the reference's exception: it is handed over with VPZ_PKT_NOT_DECODED and
+ * WITHOUT its EOS flag (the reference has not executed `_eosFound |= isEndOfStream` when the exception leaves), the
+ * rest of the range decodes normally and the call returns VPZH_OK.  Returns the number of such packets;
+ * *first_failed_packet = index of the first one relative to `first` (-1 if none); vpzh_last_error has its text. */
+int64_t vpzh_decode_failures(vpzh_stream *s, int64_t *first_failed_packet);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,11 @@ struct vpzr_reader {
     int32_t cur_remaining = 0;        // samples left in the current packet
     int64_t position = 0;
     bool ended = false;
+    bool opened = false;              // headers parsed: every read / seek entry point refuses a reader that is not
+    // a packet of the current batch whose entropy decode threw (the reference's exception out of
+    // DecodeNextPacket): surfaced once by the Read that reaches it, the packets around it are unaffected
+    int64_t failed_packet = -1;
+    std::string failed_text;
     // scratch for the front end
     std::vector<vpz_packet> packets;
     std::vector<float> residue;
@@ -84,6 +89,7 @@ struct vpzr_reader {
         cur_packet = 0;
         cur_offset = 0;
         cur_remaining = 0;
+        failed_packet = -1;
         if (next_packet >= info.audio_packets) { ended = true; return VPZ_OK; }
         int rc = ensure_decoder();
         if (rc != VPZ_OK) return rc;
@@ -104,6 +110,14 @@ struct vpzr_reader {
                                  &used, f0_stride ? f0_amp.data() : nullptr, f0_stride ? f0_coeff.data() : nullptr,
                                  f0_stride) != VPZH_OK)
             return fail(VPZ_E_INVALID_ARG, vpzh_last_error(front));
+        {   // a packet that threw is consumed and changes nothing (StreamDecoder.cs:696-762: the exception leaves
+            // DecodeNextPacket before any state is touched); the front end handed it over as "not decoded"
+            int64_t first_failed = -1;
+            if (vpzh_decode_failures(front, &first_failed) > 0) {
+                failed_packet = first_failed;
+                failed_text = vpzh_last_error(front);
+            }
+        }
         if (f0_stride > 0) vpz_decoder_set_floor0_data(dec, f0_amp.data(), f0_coeff.data(), f0_stride);
         next_packet += n;
         const int64_t cap = n * half1 + info.block_size1;
@@ -126,8 +140,15 @@ struct vpzr_reader {
     {
         const int C = info.channels;
         *status = VPZ_OK;
+        if (!opened || C < 1) { *status = fail(VPZ_E_INVALID_ARG, "the reader has no open stream"); return 0; }
         if (buffer_len % C != 0) { *status = fail(VPZ_E_INVALID_ARG, "Length must be a multiple of Channels."); return 0; }
-        if (buffer_len < samples_to_read * C) { *status = fail(VPZ_E_INVALID_ARG, "The buffer is too small for the requested amount."); return 0; }
+        if (samples_to_read < 0 || buffer_len < samples_to_read * C) { *status = fail(VPZ_E_INVALID_ARG, "The buffer is too small for the requested amount."); return 0; }
+        // StoreContiguous slices `buffer[ch * channelStride + offset ..]` (StreamDecoder.cs:594-638): a stride that puts
+        // the last channel's samples outside the span throws there (ArgumentOutOfRangeException)
+        if (!interleave && (channel_stride < 0 || (int64_t)(C - 1) * channel_stride + samples_to_read > buffer_len)) {
+            *status = fail(VPZ_E_INVALID_ARG, "channelStride puts the last channel outside the buffer.");
+            return 0;
+        }
         int64_t idx = 0;
         while (idx == 0) {
             if (cur_remaining == 0) {
@@ -135,6 +156,12 @@ struct vpzr_reader {
                 bool have = false;
                 while (!have) {
                     if (cur_packet < packet_samples.size()) {
+                        if ((int64_t)cur_packet == failed_packet) {  // the reference's Read throws here, once
+                            failed_packet = -1;
+                            ++cur_packet;
+                            *status = fail(VPZ_E_INVALID_ARG, failed_text.c_str());
+                            return idx;
+                        }
                         cur_remaining = packet_samples[cur_packet++];
                         have = true;
                     } else {
@@ -174,11 +201,13 @@ int vpzr_open_memory(vpz_context *ctx, const uint8_t *data, uint64_t size, vpzr_
     r->ctx = ctx;
     int rc = vpzh_open_memory(data, size, &r->front);
     if (rc != VPZH_OK) {
+        // the handle only carries the error text; every other entry point refuses it
         r->error = r->front ? vpzh_last_error(r->front) : "could not load the specified container";
         *out = r.release();
         return rc == VPZH_E_UNSUPPORTED ? VPZ_E_UNSUPPORTED : VPZ_E_INVALID_ARG;
     }
     vpzh_get_info(r->front, &r->info);
+    r->opened = r->info.channels >= 1;
     *out = r.release();
     return VPZ_OK;
 }
@@ -192,17 +221,18 @@ void vpzr_close(vpzr_reader *r)
 }
 
 const char *vpzr_last_error(vpzr_reader *r) { return r ? r->error.c_str() : ""; }
-int vpzr_channels(vpzr_reader *r) { return r ? r->info.channels : 0; }
-int vpzr_sample_rate(vpzr_reader *r) { return r ? r->info.sample_rate : 0; }
+int vpzr_channels(vpzr_reader *r) { return r && r->opened ? r->info.channels : 0; }
+int vpzr_sample_rate(vpzr_reader *r) { return r && r->opened ? r->info.sample_rate : 0; }
 int64_t vpzr_sample_position(vpzr_reader *r) { return r ? r->position : 0; }
 int vpzr_is_end_of_stream(vpzr_reader *r) { return r ? (r->ended && r->cur_remaining == 0 && r->cur_packet >= r->packet_samples.size()) : 1; }
 
-int64_t vpzr_total_samples(vpzr_reader *r) { return r ? vpzh_total_samples(r->front) : 0; }
+int64_t vpzr_total_samples(vpzr_reader *r) { return r && r->opened ? vpzh_total_samples(r->front) : 0; }
 
 // StreamDecoder.SeekTo(long, SeekOrigin) (StreamDecoder.cs:815-881)
 int vpzr_seek_to(vpzr_reader *r, int64_t sample_position, int origin)
 {
     if (!r) return VPZ_E_INVALID_ARG;
+    if (!r->opened) return r->fail(VPZ_E_INVALID_ARG, "the reader has no open stream");
     if (sample_position < 0) return r->fail(VPZ_E_INVALID_ARG, "samplePosition");  // ArgumentOutOfRangeException
     switch (origin) {
     case VPZR_SEEK_BEGIN: break;
@@ -268,7 +298,8 @@ int vpzr_has_clipped(vpzr_reader *r)
 int64_t vpzr_read_samples(vpzr_reader *r, float *buffer, int64_t buffer_len, int *status)
 {
     int st = VPZ_OK;
-    if (!r || (!buffer && buffer_len)) { if (status) *status = VPZ_E_INVALID_ARG; return 0; }
+    if (!r || (!buffer && buffer_len) || buffer_len < 0) { if (status) *status = VPZ_E_INVALID_ARG; return 0; }
+    if (!r->opened) { if (status) *status = r->fail(VPZ_E_INVALID_ARG, "the reader has no open stream"); return 0; }
     const int C = r->info.channels;
     const int64_t count = buffer_len - buffer_len % C;  // VorbisReader.cs:235
     int64_t n = count == 0 ? 0 : r->read(buffer, count, count / C, 0, true, &st);
@@ -280,7 +311,8 @@ int64_t vpzr_read_samples_planar(vpzr_reader *r, float *buffer, int64_t buffer_l
                                  int64_t channel_stride, int *status)
 {
     int st = VPZ_OK;
-    if (!r || (!buffer && buffer_len)) { if (status) *status = VPZ_E_INVALID_ARG; return 0; }
+    if (!r || (!buffer && buffer_len) || buffer_len < 0) { if (status) *status = VPZ_E_INVALID_ARG; return 0; }
+    if (!r->opened) { if (status) *status = r->fail(VPZ_E_INVALID_ARG, "the reader has no open stream"); return 0; }
     const int C = r->info.channels;
     const int64_t count = buffer_len - buffer_len % C;  // VorbisReader.cs:246
     int64_t n = count == 0 ? 0 : r->read(buffer, count, samples_to_read, channel_stride, false, &st);
