@@ -73,6 +73,8 @@ def lib():
         L.orc_floor1_apply.restype = None
         L.orc_floor1_render.argtypes = [C.POINTER(Floor1), i32p, u8p, C.c_int, C.c_int, f32p]
         L.orc_floor1_render.restype = None
+        L.orc_floor1_render_indices.argtypes = [C.POINTER(Floor1), i32p, u8p, C.c_int, C.c_int, i32p]
+        L.orc_floor1_render_indices.restype = None
         L.orc_floor1_inverse_db_table.argtypes = []
         L.orc_floor1_inverse_db_table.restype = f32p
         L.orc_floor0_apply.argtypes = [C.POINTER(Floor0), f32p, C.c_float, C.c_int, f32p]
@@ -179,6 +181,17 @@ def floor1_unwrap(f, posts, post_count):
     lib().orc_floor1_unwrap_posts(C.byref(f), p.ctypes.data_as(C.POINTER(C.c_int)), post_count,
                                   flags.ctypes.data_as(C.POINTER(C.c_uint8)))
     return p, flags
+
+
+def floor1_indices(f, posts, post_count, n):
+    """UnwrapPosts + the render walk of Apply (Floor1.cs:222-268) as integers only: returns (finalY [64],
+    step flags [64], table index per bin [n] -- unclamped, as the reference indexes its table)."""
+    final_y, flags = floor1_unwrap(f, posts, post_count)
+    out = np.zeros(n, dtype=np.int32)
+    i32p, u8p = C.POINTER(C.c_int), C.POINTER(C.c_uint8)
+    lib().orc_floor1_render_indices(C.byref(f), final_y.ctypes.data_as(i32p), flags.ctypes.data_as(u8p), post_count, n,
+                                    out.ctypes.data_as(i32p))
+    return final_y, flags, out
 
 
 def floor1_apply(f, posts, post_count, block_size, residue):

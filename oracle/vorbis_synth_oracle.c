@@ -673,6 +673,56 @@ void orc_floor1_render(const orc_floor1 *f, const int *final_y, const uint8_t *s
     if (lx < n) render_line_multi(lx, ly, n, ly, db, residue);
 }
 
+/* The integers of the render alone: the table index `y` RenderLineMulti (Floor1.cs:372-397) uses for every bin,
+ * through the same walk as Apply (:236-262).  out_y[0..n), unclamped (the reference indexes its table with it). */
+static void render_line_indices(int x0, int y0, int x1, int y1, int *out)
+{
+    int dy = y1 - y0;
+    int adx = x1 - x0;
+    int ady = iabs(dy);
+    int sy = 1 - (((dy >> 31) & 1) * 2);
+    int b = dy / adx;
+    int x = x0;
+    int y = y0;
+    int err = -adx;
+
+    out[x] = y;
+    ady -= iabs(b) * adx;
+
+    while (++x < x1) {
+        y += b;
+        err += ady;
+        if (err >= 0) {
+            err -= adx;
+            y += sy;
+        }
+        out[x] = y;
+    }
+}
+
+void orc_floor1_render_indices(const orc_floor1 *f, const int *final_y, const uint8_t *step_flags,
+                               int post_count, int n, int *out_y)
+{
+    int lx = 0;
+    int ly = final_y[0] * f->multiplier;
+    int i;
+    for (i = 1; i < post_count; ++i) {
+        int idx = f->sortidx[i];
+        if (step_flags[idx]) {
+            int hx = f->xlist[idx];
+            int hy = final_y[idx] * f->multiplier;
+            if (lx < n) {
+                int x1 = hx < n ? hx : n; /* Math.Min(hx, n) enters the slope: quirk q2 (:248) */
+                render_line_indices(lx, ly, x1, hy, out_y);
+            }
+            lx = hx;
+            ly = hy;
+        }
+        if (lx >= n) break;
+    }
+    if (lx < n) render_line_indices(lx, ly, n, ly, out_y);
+}
+
 /* Floor1.cs:222-268 */
 void orc_floor1_apply(const orc_floor1 *f, int *posts, int post_count, int block_size, float *residue)
 {

@@ -75,6 +75,9 @@ void orc_floor1_apply(const orc_floor1 *f, int *posts, int post_count, int block
 /* render only, given final Y + step flags (for tests of the GPU render stage) */
 void orc_floor1_render(const orc_floor1 *f, const int *final_y, const uint8_t *step_flags,
                        int post_count, int n, float *residue);
+/* the same walk, but the table INDEX of every bin instead of the product: out_y[0..n), unclamped */
+void orc_floor1_render_indices(const orc_floor1 *f, const int *final_y, const uint8_t *step_flags,
+                               int post_count, int n, int *out_y);
 const float *orc_floor1_inverse_db_table(void);
 
 /* ---- Floor0.cs (LSP floor; "virtually unused", no fixture) ----

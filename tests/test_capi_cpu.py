@@ -19,10 +19,10 @@ def capi():
     return m
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "vorbispizza_synth.h")).read()
+def header_symbols(name="vorbispizza_synth.h", prefix="vpz_"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(vpz_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(%s[a-z0-9_]+)\s*\(" % prefix, text)))
 
 
 def test_header_symbols_are_exported(capi):
@@ -32,6 +32,11 @@ def test_header_symbols_are_exported(capi):
     for s in syms:
         assert hasattr(L, s), "missing export " + s
     assert sorted(capi.EXPORTED_SYMBOLS) == syms
+    # the test-only header: exported too, bound by the ctypes layer, and NOT part of the product header
+    dbg = header_symbols("vorbispizza_synth_debug.h")
+    assert dbg and sorted(capi.DEBUG_SYMBOLS) == dbg and not set(dbg) & set(syms)
+    for s in dbg:
+        assert hasattr(L, s), "missing export " + s
 
 
 def test_abi_version_and_error_strings(capi):

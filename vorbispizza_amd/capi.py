@@ -83,7 +83,12 @@ _SIGNATURES = [
     ("vpz_decoder_position", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64)]),
     ("vpz_decoder_set_position", C.c_int, [_vp, C.c_int32, C.c_int64]),
 ]
+# include/vorbispizza_synth_debug.h (test-only entry points, not part of the surface a C# host binds)
+_DEBUG_SIGNATURES = [
+    ("vpz_debug_floor1_indices", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+DEBUG_SYMBOLS = [s[0] for s in _DEBUG_SIGNATURES]
 
 _lib = None
 
@@ -111,7 +116,7 @@ def lib():
             except ImportError:
                 pass
         L = C.CDLL(LIB_PATH)
-        for name, restype, argtypes in _SIGNATURES:
+        for name, restype, argtypes in _SIGNATURES + _DEBUG_SIGNATURES:
             fn = getattr(L, name)
             fn.restype = restype
             fn.argtypes = argtypes
@@ -315,6 +320,25 @@ class Decoder:
             else:
                 res.append(blk[: written[s] * C_].reshape(written[s], C_).copy())
         return res
+
+    def debug_floor1_indices(self, posts, post_counts, record_floor, record_long):
+        """Test-only (vorbispizza_synth_debug.h): the integers of the Floor1 device path for a batch of channel
+        records.  Returns (curve [records, size1/2] uint8, final_y [records, 64] int16, step_flags [records, 64]
+        uint8, active_count [records] uint8)."""
+        posts = np.ascontiguousarray(posts, dtype=np.int16).reshape(-1, 64)
+        n = posts.shape[0]
+        post_counts = np.ascontiguousarray(post_counts, dtype=np.uint8)
+        record_floor = np.ascontiguousarray(record_floor, dtype=np.uint8)
+        record_long = np.ascontiguousarray(record_long, dtype=np.uint8)
+        assert len(post_counts) == len(record_floor) == len(record_long) == n
+        curve = np.full((n, self.size1 // 2), 0xEE, dtype=np.uint8)
+        final_y = np.zeros((n, 64), dtype=np.int16)
+        flags = np.zeros((n, 64), dtype=np.uint8)
+        active = np.zeros(n, dtype=np.uint8)
+        self.ctx._check(lib().vpz_debug_floor1_indices(self._h, n, _ptr(posts), _ptr(post_counts), _ptr(record_floor),
+                                                       _ptr(record_long), _ptr(curve), _ptr(final_y), _ptr(flags),
+                                                       _ptr(active)))
+        return curve, final_y, flags, active
 
     def set_floor0_data(self, amp, coeff):
         """amp [records], coeff [records, stride] (numpy, host memory) for the next synth call."""

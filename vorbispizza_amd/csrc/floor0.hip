@@ -1,7 +1,7 @@
 // Floor0.Apply (Floor0.cs:164-225) -- the LSP floor the reference itself calls "virtually unused".
 // One workgroup per (packet, channel) record that has a type-0 floor: the spectrum in the planar temp is
-// multiplied in place and the record's row of floor-1 table indices is set to 255 (table[255] == 1.0), so
-// the synthesis kernels downstream need no floor-0 variant.  Compiled with -ffp-contract=off.  The LSP
+// multiplied in place; floor1_unwrap_kernel gives the record the one-post curve "index 255" (table[255] == 1.0),
+// so the synthesis kernels downstream need no floor-0 variant.  Compiled with -ffp-contract=off.  The LSP
 // product is ill conditioned next to a root (w - c_j cancels), where a 1-ulp difference between two cosf
 // implementations shows up as 1e-4 of the output; cos / sqrt / exp / divide are therefore evaluated in
 // double and rounded once, which reproduces a correctly rounded host libm (the reference's MathF).
@@ -17,7 +17,7 @@ struct Floor0Dev {
 
 struct Floor0Rec {        // one record to process
     int64_t spec_off;     // float offset of this channel's spectrum in the temp
-    int32_t rec;          // channel record (index into amp / coeff / curve_y rows)
+    int32_t rec;          // channel record (index into amp / coeff rows)
     int32_t floor;        // index into Floor0Dev table
     int32_t half;         // blocksize / 2
     int32_t is_long;
@@ -28,17 +28,13 @@ __global__ __launch_bounds__(256) void floor0_apply_kernel(const Floor0Rec *__re
                                                           const int32_t *__restrict__ bark_maps,
                                                           const float *__restrict__ amp,
                                                           const float *__restrict__ coeff, int coeff_stride,
-                                                          float *__restrict__ spec, uint8_t *__restrict__ curve_y,
-                                                          int half1)
+                                                          float *__restrict__ spec)
 {
     __shared__ float s_c[256];
     const Floor0Rec r = recs[blockIdx.x];
     const Floor0Dev f = floors[r.floor];
     float *x = spec + r.spec_off;
-    uint8_t *row = curve_y ? curve_y + (size_t)r.rec * half1 : nullptr;
     const float a = amp[r.rec];
-    if (row)
-        for (int i = threadIdx.x; i < r.half; i += 256) row[i] = 255;
     if (a <= 0.0f) {  // :169-173
         for (int i = threadIdx.x; i < r.half; i += 256) x[i] = 0.0f;
         return;
@@ -74,12 +70,12 @@ __global__ __launch_bounds__(256) void floor0_apply_kernel(const Floor0Rec *__re
 
 hipError_t launch_floor0_apply(const void *recs, int n_recs, const void *floors, const int32_t *bark_maps,
                                const float *amp, const float *coeff, int coeff_stride, float *spec,
-                               uint8_t *curve_y, int half1, hipStream_t stream)
+                               hipStream_t stream)
 {
     if (n_recs <= 0) return hipSuccess;
     hipLaunchKernelGGL(floor0_apply_kernel, dim3(n_recs), dim3(256), 0, stream,
                        static_cast<const Floor0Rec *>(recs), static_cast<const Floor0Dev *>(floors), bark_maps, amp,
-                       coeff, coeff_stride, spec, curve_y, half1);
+                       coeff, coeff_stride, spec);
     return hipGetLastError();
 }
 

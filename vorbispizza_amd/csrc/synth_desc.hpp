@@ -15,6 +15,13 @@ constexpr uint32_t kFrameSlope1 = 2u;      // PacketInfo.LeftUseSize1: overlap u
 constexpr uint32_t kFrameNoFloor = 8u;     // spectrum is already floored (VPZ_PKT_NO_FLOOR)
 constexpr uint32_t kFrameDrain = 4u;       // no new block: emit the previous tail un-windowed
                                            // (StreamDecoder.cs:451-455, quirk q4)
+// group mode (the waves of a packet's channels share a workgroup and stage the packet in LDS):
+constexpr uint32_t kFrameInterleaved = 16u;  // spec_off addresses the Residue2 vector [n/2][channels]
+constexpr uint32_t kFrameStage = 32u;        // de-interleave and / or inverse coupling needed before the floor
+constexpr int kFrameStepsShift = 8;          // bits 8..15: coupling steps of the packet's mapping
+constexpr int kFrameStepsOffShift = 16;      // bits 16..31: first step (pair index) in the steps table
+constexpr int kGroupMaxChannels = 8;         // channels that fit one workgroup of 8 waves
+constexpr int kGroupMaxStepPairs = 128;      // coupling steps (pairs) of all mappings staged in LDS
 
 struct FrameDesc {        // 32 bytes: staged per run into LDS by the wavefront that owns the run
     int64_t spec_off;     // float offset of channel 0's spectrum; channel c at + c*(blocksize/2)
@@ -77,9 +84,14 @@ struct SynthArgs {
     int32_t n_runs;
     int32_t channels;
     int32_t size0, size1;
-    const float *spec;          // planar spectra (caller residue or the coupling temp)
-    const uint8_t *post_counts; // [rec] PostCount; nullptr => every channel executes, no floor
-    const uint8_t *curve_y;     // [rec][size1/2] inverse-dB table index per bin (floor1_prepare_kernel)
+    const float *spec;          // spectra: caller residue (planar, or interleaved in group mode) or the coupling temp
+    const uint8_t *ccount;      // [rec] active floor posts (floor1_unwrap_kernel); 0 => ExecuteChannel false;
+                                // nullptr => every channel executes, no floor
+    const int32_t *cposts;      // [rec][64] active posts in X order: x | (finalY * multiplier) << 16
+    const uint8_t *steps;       // coupling steps of all mappings, pairs (mag, ang)   (group mode)
+    int32_t n_step_pairs;
+    int32_t max_steps;          // most steps any mapping has: barriers per frame in group mode
+    int32_t group;              // 1: channels of a run share a workgroup (LDS staging), 0: waves are independent
     const float *inv_db;        // 256 floats
     float *state_h;             // [stream][channel][size1/2]
     const float2 *tw_long;      // fast tables of size1 (BlockTables::d_fast)

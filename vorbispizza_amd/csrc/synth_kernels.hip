@@ -190,43 +190,30 @@ __device__ __forceinline__ Seg unpack_segment(int A, int B, int C)
 }
 
 // kWords = bitmap words (32 bins each) the block size needs: 32 for n <= 1024, 128 for n <= 4096.
-// aux layout (ints): [0..kWords) bitmap, [kWords..2*kWords) exclusive prefix popcounts, then four
-// arrays of 65: compacted active posts (x | y << 16) and the packed segments A, B, C.
-// sy / sf: this record's unwrapped posts (finalY * multiplier) and step flags, element i at [i * stride].
-// Output: one byte per bin = index into the inverse dB table.  Every lane renders a contiguous run of
-// bins: one exact division for its first bin (closed form of the DDA: y = y0 + trunc(dy*k/adx), error
+// aux layout (ints, wave-private LDS): [0..kWords) bitmap of active post x, [kWords..2*kWords) exclusive prefix
+// popcounts, then the packed segments A, B, C (65 entries each).
+// cp: this lane's active post (lane < m), x | (finalY * multiplier) << 16, in X order -- what floor1_unwrap_kernel
+// leaves per record.  Output: one byte per bin = index into the inverse dB table.  Every lane renders a contiguous
+// run of bins: one exact division for its first bin (closed form of the DDA: y = y0 + trunc(dy*k/adx), error
 // term (|dy|*k mod adx) - adx), then the reference's DDA (Floor1.cs:386-396) step by step.
+constexpr int render_aux_ints(int words) { return 2 * words + 3 * 65; }
+
 template <int kWords>
-__device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int n, const FloorDev &f,
-                                                     const int *sy, const uint8_t *sf, int stride, int lane)
+__device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int n, int cp, int m, int lane)
 {
-    const int pc = f.x_count;
-    int *bitmap = aux, *prefix = aux + kWords, *cxy = aux + 2 * kWords;
-    int *segA = cxy + 65, *segB = segA + 65, *segC = segB + 65;
+    int *bitmap = aux, *prefix = aux + kWords;
+    int *segA = aux + 2 * kWords, *segB = segA + 65, *segC = segB + 65;
     for (int w = lane; w < kWords; w += 64) bitmap[w] = 0;
-    // compact the active posts in X order (Floor1.cs:238-252)
-    bool active = false;
-    int x = 0, y = 0;
-    if (lane < pc) {
-        const int idx = f.sort_idx[lane];
-        active = (lane == 0) || sf[idx * stride] != 0;
-        x = f.x_list[idx];
-        y = sy[idx * stride];
-    }
-    const unsigned long long mask = __ballot(active);
-    const int m = __popcll(mask);
-    if (active) {
-        const int pos = __popcll(mask & ((1ull << lane) - 1ull));
-        cxy[pos] = (x & 0xFFFF) | (y << 16);
-        if (x < n) atomicOr(reinterpret_cast<unsigned int *>(&bitmap[x >> 5]), 1u << (x & 31));
-    }
-    // one lane per segment: slope parameters, with the only division a segment needs
+    __builtin_amdgcn_wave_barrier();
+    // one lane per segment between two active posts (Floor1.cs:238-252): slope parameters, with the only division a
+    // segment needs; the next post comes from the neighbouring lane
+    const int p1 = __shfl_down(cp, 1);
     if (lane < m) {
-        const int p0 = cxy[lane];
-        const int x0 = p0 & 0xFFFF, y0 = p0 >> 16;
+        const int x0 = cp & 0xFFFF, y0 = cp >> 16;
+        if (x0 < n) atomicOr(reinterpret_cast<unsigned int *>(&bitmap[x0 >> 5]), 1u << (x0 & 31));
         int x1raw = n, y1 = y0;  // flat tail after the last active post (Floor1.cs:259-262)
-        if (lane + 1 < m) { const int p1 = cxy[lane + 1]; x1raw = p1 & 0xFFFF; y1 = p1 >> 16; }
-        const int x1 = x1raw < n ? x1raw : n;
+        if (lane + 1 < m) { x1raw = p1 & 0xFFFF; y1 = p1 >> 16; }
+        const int x1 = x1raw < n ? x1raw : n;  // Math.Min(hx, n) enters the slope: quirk q2 (Floor1.cs:248)
         const int adx = x1 - x0;
         const int dy = y1 - y0;
         const int ady = iabs(dy);
@@ -237,6 +224,7 @@ __device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int
         segB[lane] = (y0 & 0xFFFF) | (base << 16);
         segC[lane] = (adx > 0 ? adx : 0) | (rseg << 13) | (dy < 0 ? (int)0x80000000 : 0);
     }
+    __builtin_amdgcn_wave_barrier();
     // exclusive prefix popcount over the bitmap words
     if (kWords <= 32) {
         int c = (lane < kWords) ? __popc((unsigned)bitmap[lane]) : 0;
@@ -263,6 +251,7 @@ __device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int
 #pragma unroll
         for (int i = 0; i < per; ++i) { prefix[lane * per + i] = run; run += c[i]; }
     }
+    __builtin_amdgcn_wave_barrier();
     const int per_lane = n >= 256 ? (n >> 6) : 4;  // bins per lane, a multiple of 4
     int xx = lane * per_lane;
     if (xx >= n) return;
@@ -286,7 +275,7 @@ __device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int
         uint32_t packed = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int yi = yy < 0 ? 0 : (yy > 255 ? 255 : yy);  // the reference would throw outside 0..255
+            const int yi = yy < 0 ? 0 : (yy > 255 ? 255 : yy);  // the reference would index outside its table
             packed |= (uint32_t)yi << (8 * t);
             ++xx;
             if (xx == s.x1 && xx < n) {  // the next segment starts exactly on its post
@@ -308,62 +297,65 @@ __device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// floor1_prepare_kernel: everything integer about Floor1 for 64 channel-records per wavefront.
-//   phase 1: Floor1.UnwrapPosts (Floor1.cs:270-353), one LANE per record, results in LDS;
-//   phase 2: for each of the 64 records the whole wavefront renders the curve (Floor1.cs:236-262,
-//            372-397) as one table index per bin -> curve_y[rec][bin] (uint8).
-// The synthesis kernels then only look the indices up in the inverse dB table and multiply.
-// rec_info[rec]: floor index in bits 0..5, bit 6 = type-0 floor (handled by floor0.hip), bit 7 = long block.
+// floor1_unwrap_kernel: everything serial about Floor1, one LANE per channel-record (64 records per wavefront):
+// Floor1.UnwrapPosts (Floor1.cs:270-353) and the walk over the posts in X order that picks the ones a line is drawn
+// to (Floor1.cs:236-252: post 0 and every post whose step flag is set).  Output per record: the active posts in X
+// order as x | (finalY * multiplier) << 16 (Apply's `* _multiplier`, Floor1.cs:237,245) and their count -- 0 when
+// ExecuteChannel is false.  Integers only, bit-exact; the curve itself is rendered by whoever consumes the posts
+// (synth_kernel in LDS, floor1_render_kernel into memory).
+// rec_info[rec]: floor index in bits 0..5, bit 6 = type-0 floor, bit 7 = long block.  A type-0 record gets the
+// one-post curve "index 255 everywhere" (table[255] == 1.0): floor0_apply_kernel has multiplied its spectrum already.
+// dbg_y / dbg_f (test entry only): finalY * multiplier and the step flags per post, [rec][64].
 // ---------------------------------------------------------------------------------------------
-constexpr int kPrepWaves = 8;
 constexpr int kPrepFloorsInLds = 8;
 
-__global__ __launch_bounds__(64 * kPrepWaves) void floor1_prepare_kernel(int n_rec, const int16_t *__restrict__ posts,
-                                                                        const uint8_t *__restrict__ post_counts,
-                                                                        const uint8_t *__restrict__ rec_info,
-                                                                        const FloorDev *__restrict__ g_floors,
-                                                                        int n_floors, int half0, int half1,
-                                                                        uint8_t *__restrict__ curve_y, int ablate)
+__global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int16_t *__restrict__ posts,
+                                                          const uint8_t *__restrict__ post_counts,
+                                                          const uint8_t *__restrict__ rec_info,
+                                                          const FloorDev *__restrict__ g_floors, int n_floors,
+                                                          int32_t *__restrict__ cposts, uint8_t *__restrict__ ccount,
+                                                          int16_t *__restrict__ dbg_y, uint8_t *__restrict__ dbg_f)
 {
-    __shared__ int s_y[64][65];       // [post][record], padded
-    __shared__ uint8_t s_f[64][65];
-    __shared__ int s_aux[kPrepWaves][2 * 128 + 4 * 65];
-    __shared__ uint8_t s_have[64];
-    __shared__ int16_t s_posts[64][66];          // raw posts of the 64 records, staged with coalesced loads
+    __shared__ int s_y[64][65];          // [post][record], padded
+    __shared__ uint8_t s_f[64][68];
+    __shared__ int16_t s_posts[64][66];  // raw posts of the 64 records, staged with coalesced loads
+    __shared__ int s_out[64][65];        // [record][slot]
+    __shared__ uint8_t s_cnt[64];
     __shared__ FloorDev s_floors[kPrepFloorsInLds];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x;
+    const int first = blockIdx.x * 64;
     // stage the inputs: a per-lane walk over global memory would put one DRAM round trip on every post
     {
-        const int first = blockIdx.x * 64;
-        constexpr int kIters = 64 * 32 / (64 * kPrepWaves);  // 32 dwords (64 posts) per record
-        uint32_t v[kIters];
+        uint32_t v[32];
 #pragma unroll
-        for (int it = 0; it < kIters; ++it) {  // all loads in flight before the first LDS store
-            const int i = threadIdx.x + it * 64 * kPrepWaves;
+        for (int it = 0; it < 32; ++it) {  // all loads in flight before the first LDS store
+            const int i = lane + it * 64;
             const int r = i >> 5, w = i & 31;
             v[it] = (first + r < n_rec) ? reinterpret_cast<const uint32_t *>(posts + (size_t)(first + r) * 64)[w] : 0u;
         }
 #pragma unroll
-        for (int it = 0; it < kIters; ++it) {
-            const int i = threadIdx.x + it * 64 * kPrepWaves;
+        for (int it = 0; it < 32; ++it) {
+            const int i = lane + it * 64;
             const int r = i >> 5, w = i & 31;
             s_posts[r][2 * w] = (int16_t)(v[it] & 0xFFFF);
             s_posts[r][2 * w + 1] = (int16_t)(v[it] >> 16);
         }
         const int nf = n_floors < kPrepFloorsInLds ? n_floors : kPrepFloorsInLds;
         const int words = nf * (int)(sizeof(FloorDev) / 4);
-        for (int i = threadIdx.x; i < words; i += 64 * kPrepWaves)
+        for (int i = lane; i < words; i += 64)
             reinterpret_cast<uint32_t *>(s_floors)[i] = reinterpret_cast<const uint32_t *>(g_floors)[i];
     }
     __syncthreads();
     const FloorDev *floors = (n_floors <= kPrepFloorsInLds) ? s_floors : g_floors;
-    if (wave == 0 && !(ablate & 16)) {  // phase 1: one lane per record
-        const int rec = blockIdx.x * 64 + lane;
-        bool have = false;
-        if (rec < n_rec && post_counts[rec] != 0 && !(rec_info[rec] & 0x40)) {  // bit 6: type-0 floor, not ours
-            have = true;
-            const FloorDev &f = floors[rec_info[rec] & 0x3F];
+    const int rec = first + lane;
+    int count = 0;
+    if (rec < n_rec && post_counts[rec] != 0) {
+        const uint8_t info = rec_info[rec];
+        if (info & 0x40) {  // type-0 floor: already applied, the curve is 1.0
+            s_out[lane][0] = 255 << 16;
+            count = 1;
+        } else {
+            const FloorDev &f = floors[info & 0x3F];
             const int pc = f.x_count;  // Unpack leaves PostCount == xList.Length or 0 (Floor1.cs:173-218)
             const int16_t *p = s_posts[lane];
             for (int i = 0; i < 64; ++i) s_f[i][lane] = 0;
@@ -395,24 +387,53 @@ __global__ __launch_bounds__(64 * kPrepWaves) void floor1_prepare_kernel(int n_r
                 s_y[i][lane] = result;
             }
             for (int i = 0; i < pc; ++i) {  // Apply multiplies by _multiplier (Floor1.cs:237,245)
-                int v = s_y[i][lane] * f.multiplier;
+                const int v = s_y[i][lane] * f.multiplier;
                 s_y[i][lane] = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
             }
+            // Floor1.cs:236-252: post 0, then every flagged post in X order
+            for (int i = 0; i < pc; ++i) {
+                const int idx = f.sort_idx[i];
+                if (i == 0 || s_f[idx][lane]) s_out[lane][count++] = (f.x_list[idx] & 0xFFFF) | (s_y[idx][lane] << 16);
+            }
+            if (dbg_y) {
+                for (int i = 0; i < 64; ++i) {
+                    dbg_y[(size_t)rec * 64 + i] = i < pc ? (int16_t)s_y[i][lane] : (int16_t)0;
+                    dbg_f[(size_t)rec * 64 + i] = i < pc ? s_f[i][lane] : (uint8_t)0;
+                }
+            }
         }
-        s_have[lane] = have ? 1 : 0;
     }
+    s_cnt[lane] = (uint8_t)count;
+    if (rec < n_rec) ccount[rec] = (uint8_t)count;
     __syncthreads();
-    // phase 2: every wavefront renders its share of the 64 records
-    for (int r = wave; r < 64; r += kPrepWaves) {
-        if (!s_have[r] || (ablate & 32)) continue;
-        const int rr = blockIdx.x * 64 + r;
-        const uint8_t info = rec_info[rr];
-        const FloorDev &f = floors[info & 0x3F];
-        const int n = (info & 0x80) ? half1 : half0;
-        uint8_t *row = curve_y + (size_t)rr * half1;
-        if (n <= 1024) render_floor_indices<32>(row, s_aux[wave], n, f, &s_y[0][r], &s_f[0][r], 65, lane);
-        else render_floor_indices<128>(row, s_aux[wave], n, f, &s_y[0][r], &s_f[0][r], 65, lane);
+    // coalesced write of the 64 records' posts (whole halves of 32 slots: full 128-byte lines)
+    for (int it = 0; it < 64; ++it) {
+        const int cnt = s_cnt[it];
+        if (first + it < n_rec && lane < ((cnt + 31) & ~31)) cposts[(size_t)(first + it) * 64 + lane] = lane < cnt ? s_out[it][lane] : 0;
     }
+}
+
+// floor1_render_kernel: the curve of every record as one table index per bin in memory, curve_y[rec][half1] -- for
+// the any-block-size path (generic_floor_kernel reads it) and for the test entry that reads the integers back.
+// One wavefront per record, the same render_floor_indices the fused kernel runs in LDS.
+constexpr int kRenderWaves = 4;
+__global__ __launch_bounds__(64 * kRenderWaves) void floor1_render_kernel(int n_rec, const int32_t *__restrict__ cposts,
+                                                                         const uint8_t *__restrict__ ccount,
+                                                                         const uint8_t *__restrict__ rec_info,
+                                                                         int half0, int half1,
+                                                                         uint8_t *__restrict__ curve_y)
+{
+    __shared__ int s_aux[kRenderWaves][render_aux_ints(128)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rec = blockIdx.x * kRenderWaves + wave;
+    if (rec >= n_rec) return;
+    const int m = ccount[rec];
+    if (m == 0) return;
+    const int cp = lane < m ? cposts[(size_t)rec * 64 + lane] : 0;
+    const int n = (rec_info[rec] & 0x80) ? half1 : half0;
+    uint8_t *row = curve_y + (size_t)rec * half1;
+    if (n <= 1024) render_floor_indices<32>(row, s_aux[wave], n, cp, m, lane);
+    else render_floor_indices<128>(row, s_aux[wave], n, cp, m, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -502,6 +523,7 @@ __device__ __forceinline__ void load_floor_indices(uint32_t (&fy)[8], const uint
     for (int m = 0; m < 8; ++m) fy[m] = s[k0 + st * m];
 }
 
+// this wave's channel of a planar packet: (X[2k], X[2k+1]) for the lane's 8 points (global memory or an LDS row)
 __device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base, int lpb, int lane)
 {
     const float2 *s = reinterpret_cast<const float2 *>(base);
@@ -511,17 +533,74 @@ __device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base,
     for (int m = 0; m < 8; ++m) x[m] = s[k0 + st * m];
 }
 
+// Group mode, Residue2-interleaved packet ([half][C] floats, Residue2.cs:31-34): the C waves of the packet's channels
+// split the vector into 16-byte pieces, piece q = lane + 64*w + 64*C*j (w: wave in the group) -- every wave-load is
+// one contiguous 1 KiB span -- and keep them in the registers a planar spectrum would occupy (x[2j], x[2j+1]).
+__device__ __forceinline__ void load_interleaved_share(float2 (&x)[8], const float *packet, int C, int half, int w,
+                                                       int lane)
+{
+    const float4 *s4 = reinterpret_cast<const float4 *>(packet);
+    const int total4 = (C * half) >> 2;
+    asm volatile("" : "+v"(lane));  // the piece numbers are frame-invariant: keep them out of long-lived registers
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = lane + 64 * w + 64 * C * j;
+        if (q < total4) {
+            const float4 v = s4[q];
+            x[2 * j] = make_float2(v.x, v.y);
+            x[2 * j + 1] = make_float2(v.z, v.w);
+        }
+    }
+}
+
+// ... and the de-interleave (Residue2.cs:42-51) into the group's LDS rows: element e = bin * C + channel goes to
+// rows[channel][bin].  `magic` = ceil(2^18 / C): e / C == (e * magic) >> 18 for every e < 8192, C <= 8.
+__device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *rows, int C, uint32_t magic, int half,
+                                                  int w, int lane)
+{
+    const int total4 = (C * half) >> 2;
+    // The 16 LDS addresses below do not depend on the frame: left alone, the compiler computes them once before the
+    // frame loop and then has to park them in scratch memory.  An opaque lane id keeps them inside the loop.
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = lane + 64 * w + 64 * C * j;
+        if (q < total4) {
+            const float v[4] = {x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y};
+            if (C == 2) {  // (L R L R): two bins of each channel, 8-byte stores
+                reinterpret_cast<float2 *>(rows)[q] = make_float2(v[0], v[2]);
+                reinterpret_cast<float2 *>(rows + kWaveBufFloats)[q] = make_float2(v[1], v[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t e = 4u * (uint32_t)q + (uint32_t)i;
+                    const uint32_t bin = (e * magic) >> 18;
+                    const uint32_t c = e - bin * (uint32_t)C;
+                    rows[c * kWaveBufFloats + bin] = v[i];
+                }
+            }
+        }
+    }
+}
+
 // kOut: 0 planar output, 1 interleaved (any channel count: every wave scatters its own channel),
 //       2 interleaved stereo: the two waves of a stream (channels 0 / 1, adjacent in the workgroup) build
 //         their blocks, meet at a workgroup barrier, and each writes HALF of the packet's samples for BOTH
 //         channels -- dense 32-byte (L R L R | L R L R) stores instead of 4-byte stores at an 8-byte stride.
 // kGeneral: block sizes from {256, 512, 1024, 2048} in any combination (speech-rate and low-bitrate streams use
 //       512 / 1024); the plain variant is the 256 / 2048 kernel with its geometry folded at compile time.
-template <bool kHasFloor, int kOut, bool kGeneral>
+// kGroup: the waves of one run's channels (<= 8) sit in one workgroup and work on the same packet at the same
+//       time: the packet -- planar or the Residue2-interleaved vector -- is staged in their LDS rows, de-interleaved
+//       on the way (Residue2.cs:42-51), the coupling steps run there in reverse order (Mapping.cs:166-172), and
+//       every wave then picks its own channel up.  No de-interleaved / de-coupled copy of the residue exists in HBM.
+// Floor: the wave renders its channel's curve (Floor1.cs:236-262, 372-397) from the record's active posts into its
+//       LDS row as one table index per bin, right before the row is needed for anything else.
+template <bool kHasFloor, int kOut, bool kGeneral, bool kGroup>
 __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 {
     constexpr bool kInterleaved = kOut != 0;
     constexpr bool kPair = kOut == 2;
+    constexpr bool kSync = kPair || kGroup;  // the workgroup's waves run their loops in lock step
     constexpr int kRunMax = kGeneral ? kMaxRunLengthGeneral : kMaxRunLength;
     __shared__ int s_iters;
     // tables: the plain variant keeps exactly what 2048 / 256 need; the general one holds the whole fast table
@@ -533,6 +612,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     __shared__ float s_slope1[1024];
     __shared__ float s_slope0[kGeneral ? 512 : 128];
     __shared__ float s_db[kHasFloor ? 256 : 1];
+    __shared__ uint8_t s_steps[kGroup ? 2 * kGroupMaxStepPairs : 4];
     __shared__ float s_work[kSynthWaves][kWaveBufFloats];   // h of the block being built
     __shared__ float s_tail[kSynthWaves][kWaveTailFloats];  // upper half of the previous block's h
     __shared__ uint4 s_desc[kSynthWaves][(kRunMax + 1) * 2];  // the run's frame descriptors
@@ -562,18 +642,39 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     for (int i = threadIdx.x; i < a.size1 / 2; i += kSynthThreads) s_slope1[i] = a.slope1[i];
     for (int i = threadIdx.x; i < a.size0 / 2 && i < (kGeneral ? 512 : 128); i += kSynthThreads) s_slope0[i] = a.slope0[i];
     if (kHasFloor && threadIdx.x < 256) s_db[threadIdx.x] = a.inv_db[threadIdx.x];
+    if (kGroup)
+        for (int i = threadIdx.x; i < 2 * a.n_step_pairs && i < 2 * kGroupMaxStepPairs; i += kSynthThreads)
+            s_steps[i] = a.steps[i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     // wave-uniform values are forced into SGPRs so the descriptor reads become scalar loads
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = blockIdx.x * kSynthWaves + wave;
-    const bool active = item < a.n_runs * a.channels;
-    if (!kPair && !active) return;  // (the pair variant keeps idle waves around for its barriers)
-    const int run_idx = active ? item / a.channels : 0;
-    const int ch = active ? item - run_idx * a.channels : (wave & 1);
+    const int C = a.channels;
+    // which run and channel this wave owns.  Free-running waves are numbered through the grid; in group mode a
+    // workgroup holds floor(8 / C) whole runs (the remaining waves idle but keep the barriers matched).
+    int run_idx, ch, gw0 = 0;  // gw0: first wave of this wave's group
+    bool active;
+    if (kGroup) {
+        // (uniform values: keep them out of the vector registers the integer division would leave them in)
+        const int groups = __builtin_amdgcn_readfirstlane(kSynthWaves / C);
+        const int slot = __builtin_amdgcn_readfirstlane(wave / C);
+        ch = wave - slot * C;
+        gw0 = slot * C;
+        run_idx = blockIdx.x * groups + slot;
+        active = slot < groups && run_idx < a.n_runs;
+    } else {
+        const int item = blockIdx.x * kSynthWaves + wave;
+        active = item < a.n_runs * C;
+        run_idx = active ? item / C : 0;
+        ch = active ? item - run_idx * C : (wave & 1);
+    }
+    const uint32_t div_magic =
+        kGroup ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(((1u << 18) + (uint32_t)C - 1u) / (uint32_t)C)) : 0u;
+    if (!kSync && !active) return;  // (the lock-step variants keep idle waves around for their barriers)
+    if (!active) { run_idx = 0; if (kGroup) ch = 0; }
     RunDesc run = a.runs[run_idx];
-    if (kPair && !active) {  // an idle wave of the pair variant: nothing to load, emit or save
+    if (kSync && !active) {  // an idle wave: nothing to load, emit or save
         run.count = 0;
         run.pre_kind = kPreNone;
         run.flags = 0;
@@ -585,7 +686,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     int prev_n4 = 0;  // n/4 of the previous block (0: none yet)
 
     auto exec_of = [&](uint32_t flags, int rec) -> bool {
-        return a.post_counts == nullptr || (flags & kFrameNoFloor) || a.post_counts[rec + ch] != 0;
+        return a.ccount == nullptr || (flags & kFrameNoFloor) || a.ccount[rec + ch] != 0;
     };
     // which transform a frame takes depends on its block SIZE, not on its flag (size0 may be 2048 too)
     auto size_of = [&](uint32_t flags) -> int { return (flags & kFrameLong) ? a.size1 : a.size0; };
@@ -595,10 +696,27 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         const int hh = (fd.flags & kFrameLong) ? (a.size1 >> 1) : (a.size0 >> 1);
         return a.spec + fd.spec_off + (int64_t)ch * hh;
     };
+    // the raw input of a frame into registers: this wave's channel, or -- for an interleaved packet in group mode --
+    // this wave's share of the packet.  cp: this lane's active floor post (lane < count).
+    auto prefetch = [&](const FrameDesc &fd, float2 (&x)[8], int &cp) {
+        const bool shared_input = kGroup && (fd.flags & kFrameInterleaved);
+        const bool ex = exec_of(fd.flags, fd.rec);
+        if (shared_input) {
+            load_interleaved_share(x, a.spec + fd.spec_off, C, size_of(fd.flags) >> 1, ch, lane);
+        } else if (ex || (kGroup && (fd.flags & kFrameStage))) {
+            load_spectrum(x, spectrum_of(fd), lpb_of(fd.flags), lane);
+        }
+        if (kHasFloor && ex && !(fd.flags & kFrameNoFloor)) {
+            const int m = a.ccount[fd.rec + ch];
+            int l = lane;
+            asm volatile("" : "+v"(l));  // keeps `cposts + lane` out of the registers that live across the frame loop
+            cp = l < m ? a.cposts[(size_t)(fd.rec + ch) * 64 + l] : 0;
+        }
+    };
     const int fi0 = (run.pre_kind == kPreRecompute && run.count > 0) ? -1 : 0;
-    // trip count: the run's own in the free-running variants, the workgroup's longest in the pair variant
+    // trip count: the run's own in the free-running variants, the workgroup's longest in the lock-step ones
     int iters = run.count - fi0;
-    if (kPair) {
+    if (kSync) {
         if (threadIdx.x == 0) s_iters = 0;
         __syncthreads();
         if (lane == 0) atomicMax(&s_iters, iters);
@@ -639,36 +757,78 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     float *out_base = a.out + (a.stream_out_off ? a.stream_out_off[run.stream] : 0);
     bool clipped_any = false;
 
-    // ---- software pipeline: the spectrum of frame i+1 is in flight while frame i is synthesised
+    // ---- software pipeline: the input of frame i+1 is in flight while frame i is synthesised
     float2 xcur[8];
-    uint32_t fycur[8];
+    int cpcur = 0;
     FrameDesc fd_next = frame_at(fi0);
-    if (run.count > 0 && !(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec)) {
-        load_spectrum(xcur, spectrum_of(fd_next), lpb_of(fd_next.flags), lane);
-        if (kHasFloor && !(fd_next.flags & kFrameNoFloor))
-            load_floor_indices(fycur, a.curve_y + (size_t)(fd_next.rec + ch) * half1, lpb_of(fd_next.flags), lane);
-    }
+    if (run.count > 0 && !(fd_next.flags & kFrameDrain)) prefetch(fd_next, xcur, cpcur);
     for (int it = 0; it < iters; ++it) {
         const int fi = fi0 + it;
-        const bool live = !kPair || fi < run.count;  // wave-uniform; idle iterations only keep the barriers matched
+        const bool live = !kSync || fi < run.count;  // wave-uniform; idle iterations only keep the barriers matched
         const FrameDesc fd = fd_next;
         float2 xnext[8];
-        uint32_t fynext[8];
+        int cpnext = 0;
         if (fi + 1 < run.count) {
             fd_next = frame_at(fi + 1);
-            if (!(fd_next.flags & kFrameDrain) && exec_of(fd_next.flags, fd_next.rec) && !(a.ablate & 4)) {
-                load_spectrum(xnext, spectrum_of(fd_next), lpb_of(fd_next.flags), lane);
-                if (kHasFloor && !(fd_next.flags & kFrameNoFloor))
-                    load_floor_indices(fynext, a.curve_y + (size_t)(fd_next.rec + ch) * half1,
-                                       lpb_of(fd_next.flags), lane);
-            }
+            if (!(fd_next.flags & kFrameDrain) && !(a.ablate & 4)) prefetch(fd_next, xnext, cpnext);
         }
         const bool drain = fd.flags & kFrameDrain;
         const int nblk = size_of(fd.flags);
         const bool is_long = nblk == 2048;  // "long" below means: the 2048-point transform
         const int n4 = kGeneral ? (nblk >> 2) : (is_long ? 512 : 64);
-        if (live && !drain) {
-            if (!exec_of(fd.flags, fd.rec)) {
+        const bool build = live && !drain;
+        const bool exec = build && exec_of(fd.flags, fd.rec);
+        // ---- group mode: the packet goes through the group's LDS rows (de-interleave, inverse coupling)
+        if (kGroup) {
+            const bool stage = build && (fd.flags & kFrameStage);
+            __syncthreads();  // every wave of the group is done with its row (previous block emitted)
+            if (stage) {
+                if (fd.flags & kFrameInterleaved) {
+                    stage_interleaved(xcur, s_work[gw0], C, div_magic, nblk >> 1, ch, lane);
+                } else {
+                    float2 *row2 = reinterpret_cast<float2 *>(hcur);
+                    const int lpb = lpb_of(fd.flags);
+                    if (lane < lpb) {
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) row2[lane + lpb * m] = xcur[m];
+                    }
+                }
+            }
+            __syncthreads();
+            const int steps = (fd.flags >> kFrameStepsShift) & 0xFF;
+            const uint8_t *st = s_steps + 2 * (fd.flags >> kFrameStepsOffShift);
+            for (int sidx = a.max_steps - 1; sidx >= 0; --sidx) {  // reverse order, Mapping.cs:166
+                if (stage && sidx < steps) {
+                    float4 *pm = reinterpret_cast<float4 *>(s_work[gw0 + st[2 * sidx]]);
+                    float4 *pa = reinterpret_cast<float4 *>(s_work[gw0 + st[2 * sidx + 1]]);
+                    for (int g = lane + 64 * ch; g < (nblk >> 3); g += 64 * C) {
+                        float4 m4 = pm[g], a4 = pa[g];
+                        couple(m4.x, a4.x);
+                        couple(m4.y, a4.y);
+                        couple(m4.z, a4.z);
+                        couple(m4.w, a4.w);
+                        pm[g] = m4;
+                        pa[g] = a4;
+                    }
+                }
+                __syncthreads();
+            }
+            if (stage && exec) load_spectrum(xcur, hcur, lpb_of(fd.flags), lane);
+        }
+        // ---- Floor1 curve of this wave's channel: table indices into the LDS row (free until the transform needs
+        // it: in group mode the wave has just taken its spectrum out of it), the lane's 16 indices into fycur
+        uint32_t fycur[8];
+        if (kHasFloor && exec && !(fd.flags & kFrameNoFloor) && !(a.ablate & 8)) {
+            // lanes below the record's post count hold a post; only post 0 (x = 0) can be all zero bits
+            const int m = __builtin_amdgcn_readfirstlane(__popcll(__ballot(cpcur != 0 || lane == 0)));
+            render_floor_indices<32>(reinterpret_cast<uint8_t *>(hcur), reinterpret_cast<int *>(hcur) + 256, nblk >> 1,
+                                     cpcur, m, lane);
+            __builtin_amdgcn_wave_barrier();
+            load_floor_indices(fycur, reinterpret_cast<const uint8_t *>(hcur), lpb_of(fd.flags), lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (build) {
+            if (!exec) {
                 // Mapping.cs:190-194: the channel is silent, its whole block is zero
                 for (int i = lane; i < 2 * n4; i += 64) hcur[i] = 0.0f;
             } else if (a.ablate & 2) {
@@ -701,13 +861,11 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         }
 
         // gfx950's vmcnt counts stores as well as loads, in issue order, and the number of stores below
-        // is data dependent -- so the wait for the prefetched spectrum is forced HERE, before this
+        // is data dependent -- so the wait for the prefetched input is forced HERE, before this
         // frame's stores are issued; otherwise it would also wait for them (HBM write latency).
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            asm volatile("" ::"v"(xnext[m].x), "v"(xnext[m].y));
-            if (kHasFloor) asm volatile("" ::"v"(fynext[m]));
-        }
+        for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(xnext[m].x), "v"(xnext[m].y));
+        if (kHasFloor) asm volatile("" ::"v"(cpnext));
 
         if (kPair) __syncthreads();  // both channels' blocks (and tails) are in LDS
         if (live && fi >= 0 && fd.out_count > 0 && !(a.ablate & 1)) {
@@ -864,8 +1022,10 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 const int cnt4 = fd.out_count >> 2;
                 const int nr = (cnt4 + 63) >> 6;
                 const int pn4 = prev_n4;
+                int lv = lane;
+                asm volatile("" : "+v"(lv));  // (see stage_interleaved: no address of this path may outlive a frame)
                 for (int r = 0; r < nr; ++r) {
-                    const int g = lane + 64 * r;
+                    const int g = lv + 64 * r;
                     const bool live = g < cnt4;
                     const int i = (live ? g : cnt4 - 1) << 2;
                     const Y4Map mc = map_y4(fd.left_start + i, n4);
@@ -903,7 +1063,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     if (live) store4(g, o0, o1, o2, o3);
                 }
             } else {
-                for (int i = lane; i < fd.out_count; i += 64) {
+                int l0 = lane;
+                asm volatile("" : "+v"(l0));  // (rare path: its addresses must not be computed ahead of the frame loop)
+                for (int i = l0; i < fd.out_count; i += 64) {
                     float v;
                     if (drain) {
                         v = tail_at(tail, fd.prev_end + i, prev_n4);
@@ -939,10 +1101,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             prev_n4 = n4;
         }
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            xcur[m] = xnext[m];
-            if (kHasFloor) fycur[m] = fynext[m];
-        }
+        for (int m = 0; m < 8; ++m) xcur[m] = xnext[m];
+        cpcur = cpnext;
     }
 
     // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
@@ -962,7 +1122,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void generic_floor_kernel(const GenericFrame *__restrict__ frames, int channels,
                                                            int half1, float *__restrict__ spec,
-                                                           const uint8_t *__restrict__ post_counts,
+                                                           const uint8_t *__restrict__ ccount,
                                                            const uint8_t *__restrict__ curve_y,
                                                            const float *__restrict__ inv_db)
 {
@@ -971,7 +1131,7 @@ __global__ __launch_bounds__(256) void generic_floor_kernel(const GenericFrame *
     if (fr.flags & (kFrameDrain | kFrameNoFloor)) return;
     const int half = fr.n >> 1;
     float *x = spec + fr.spec_off + (int64_t)ch * half;
-    if (post_counts[fr.rec + ch] == 0) {  // Mapping.cs:190-194
+    if (ccount[fr.rec + ch] == 0) {  // Mapping.cs:190-194
         for (int i = threadIdx.x; i < half; i += 256) x[i] = 0.0f;
         return;
     }
@@ -1047,13 +1207,22 @@ __global__ __launch_bounds__(256) void generic_save_state_kernel(const GenericFr
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_floor1_prepare(int n_rec, const int16_t *posts, const uint8_t *post_counts,
-                                 const uint8_t *rec_info, const FloorDev *floors, int n_floors, int half0, int half1,
-                                 uint8_t *curve_y, int ablate, hipStream_t stream)
+hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *post_counts, const uint8_t *rec_info,
+                                const FloorDev *floors, int n_floors, int32_t *cposts, uint8_t *ccount, int16_t *dbg_y,
+                                uint8_t *dbg_f, hipStream_t stream)
 {
     if (n_rec <= 0) return hipSuccess;
-    hipLaunchKernelGGL(floor1_prepare_kernel, dim3((n_rec + 63) / 64), dim3(64 * kPrepWaves), 0, stream, n_rec, posts,
-                       post_counts, rec_info, floors, n_floors, half0, half1, curve_y, ablate);
+    hipLaunchKernelGGL(floor1_unwrap_kernel, dim3((n_rec + 63) / 64), dim3(64), 0, stream, n_rec, posts, post_counts,
+                       rec_info, floors, n_floors, cposts, ccount, dbg_y, dbg_f);
+    return hipGetLastError();
+}
+
+hipError_t launch_floor1_render(int n_rec, const int32_t *cposts, const uint8_t *ccount, const uint8_t *rec_info,
+                                int half0, int half1, uint8_t *curve_y, hipStream_t stream)
+{
+    if (n_rec <= 0) return hipSuccess;
+    hipLaunchKernelGGL(floor1_render_kernel, dim3((n_rec + kRenderWaves - 1) / kRenderWaves), dim3(64 * kRenderWaves), 0,
+                       stream, n_rec, cposts, ccount, rec_info, half0, half1, curve_y);
     return hipGetLastError();
 }
 
@@ -1091,56 +1260,67 @@ bool synth_needs_general(int size0, int size1)
     return !(plain(size0) && plain(size1));
 }
 
+// group mode needs every channel of a run inside one workgroup
+bool synth_group_supported(int channels) { return channels >= 2 && channels <= kGroupMaxChannels; }
+
 hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t stream)
 {
     const long items = (long)args.n_runs * args.channels;
     if (items <= 0) return hipSuccess;
-    const int grid = (int)((items + kSynthWaves - 1) / kSynthWaves);
-    // four instantiations: the interleaved store pattern costs registers the planar steady state needs
+    const bool group = args.group != 0;
+    const int grid = group ? (int)((args.n_runs + kSynthWaves / args.channels - 1) / (kSynthWaves / args.channels))
+                           : (int)((items + kSynthWaves - 1) / kSynthWaves);
+    // the interleaved store patterns cost registers the planar steady state needs: one instantiation each
     const int out_kind = !args.interleaved ? 0 : (args.channels == 2 ? 2 : 1);
-#define VPZ_LAUNCH_SYNTH(F, O, G) \
-    hipLaunchKernelGGL((synth_kernel<F, O, G>), dim3(grid), dim3(kSynthThreads), 0, stream, args)
-#define VPZ_LAUNCH_SYNTH_OUT(F, G)                      \
-    do {                                                \
-        if (out_kind == 0) VPZ_LAUNCH_SYNTH(F, 0, G);   \
-        else if (out_kind == 1) VPZ_LAUNCH_SYNTH(F, 1, G); \
-        else VPZ_LAUNCH_SYNTH(F, 2, G);                 \
+#define VPZ_LAUNCH_SYNTH(F, O, G, R) \
+    hipLaunchKernelGGL((synth_kernel<F, O, G, R>), dim3(grid), dim3(kSynthThreads), 0, stream, args)
+#define VPZ_LAUNCH_SYNTH_OUT(F, G, R)                      \
+    do {                                                   \
+        if (out_kind == 0) VPZ_LAUNCH_SYNTH(F, 0, G, R);   \
+        else if (out_kind == 1) VPZ_LAUNCH_SYNTH(F, 1, G, R); \
+        else VPZ_LAUNCH_SYNTH(F, 2, G, R);                 \
     } while (0)
-    const bool general = synth_needs_general(args.size0, args.size1);
+#define VPZ_LAUNCH_SYNTH_GEN(F, R)                                       \
+    do {                                                                 \
+        if (synth_needs_general(args.size0, args.size1)) VPZ_LAUNCH_SYNTH_OUT(F, true, R); \
+        else VPZ_LAUNCH_SYNTH_OUT(F, false, R);                          \
+    } while (0)
     if (has_floor) {
-        if (general) VPZ_LAUNCH_SYNTH_OUT(true, true);
-        else VPZ_LAUNCH_SYNTH_OUT(true, false);
+        if (group) VPZ_LAUNCH_SYNTH_GEN(true, true);
+        else VPZ_LAUNCH_SYNTH_GEN(true, false);
     } else {
-        if (general) VPZ_LAUNCH_SYNTH_OUT(false, true);
-        else VPZ_LAUNCH_SYNTH_OUT(false, false);
+        if (group) VPZ_LAUNCH_SYNTH_GEN(false, true);
+        else VPZ_LAUNCH_SYNTH_GEN(false, false);
     }
+#undef VPZ_LAUNCH_SYNTH_GEN
 #undef VPZ_LAUNCH_SYNTH_OUT
 #undef VPZ_LAUNCH_SYNTH
     return hipGetLastError();
 }
 
-// wavefronts of synth_kernel the chip keeps resident (for sizing runs so that the grid fills an
-// integral number of rounds)
-int synth_resident_waves(bool has_floor, int num_cu)
+// wavefronts of synth_kernel the chip keeps resident and busy (for sizing runs so that the grid fills an
+// integral number of rounds); in group mode only floor(8 / channels) * channels waves of a workgroup own work
+int synth_resident_waves(bool has_floor, int num_cu, int channels, bool group)
 {
     int per_cu = 0;
     hipError_t e = has_floor
-                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<true, 0, false>, kSynthThreads, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<false, 0, false>, kSynthThreads, 0);
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<true, 0, false, false>, kSynthThreads, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<false, 0, false, false>, kSynthThreads, 0);
     if (e != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 2;
     }
-    return num_cu * per_cu * kSynthWaves;
+    const int busy = group ? (kSynthWaves / channels) * channels : kSynthWaves;
+    return num_cu * per_cu * busy;
 }
 
 hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, int half1, float *spec,
-                                const uint8_t *post_counts, const uint8_t *curve_y, const float *inv_db,
+                                const uint8_t *ccount, const uint8_t *curve_y, const float *inv_db,
                                 hipStream_t stream)
 {
     if (n_frames <= 0) return hipSuccess;
     hipLaunchKernelGGL(generic_floor_kernel, dim3(n_frames * channels), dim3(256), 0, stream, frames, channels, half1,
-                       spec, post_counts, curve_y, inv_db);
+                       spec, ccount, curve_y, inv_db);
     return hipGetLastError();
 }
 

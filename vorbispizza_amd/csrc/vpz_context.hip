@@ -282,6 +282,7 @@ void vpz_context_destroy(vpz_context *c)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->tables) vpz::free_tables(kv.second);
+    if (ctx->host_pool && ctx->host_pool_free) ctx->host_pool_free(ctx->host_pool);
     if (ctx->d_inv_db) (void)hipFree(ctx->d_inv_db);
     if (ctx->stage_in) (void)hipFree(ctx->stage_in);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);

@@ -10,20 +10,25 @@
 #include <new>
 #include <vector>
 
+#include "host_pool.hpp"
 #include "synth_desc.hpp"
 #include "vpz_internal.hpp"
+#include "../../include/vorbispizza_synth_debug.h"
 
 namespace vpz {
 
-hipError_t launch_floor1_prepare(int n_rec, const int16_t *posts, const uint8_t *post_counts,
-                                 const uint8_t *rec_info, const FloorDev *floors, int n_floors, int half0, int half1,
-                                 uint8_t *curve_y, int ablate, hipStream_t stream);
+hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *post_counts, const uint8_t *rec_info,
+                                const FloorDev *floors, int n_floors, int32_t *cposts, uint8_t *ccount, int16_t *dbg_y,
+                                uint8_t *dbg_f, hipStream_t stream);
+hipError_t launch_floor1_render(int n_rec, const int32_t *cposts, const uint8_t *ccount, const uint8_t *rec_info,
+                                int half0, int half1, uint8_t *curve_y, hipStream_t stream);
 hipError_t launch_coupling(const void *pkts, int n_pkts, const uint8_t *steps, int channels,
                            const float *residue, float *temp, int max_half, hipStream_t stream);
 hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t stream);
 bool synth_supports_sizes(int size0, int size1);
 bool synth_needs_general(int size0, int size1);
-int synth_resident_waves(bool has_floor, int num_cu);
+int synth_resident_waves(bool has_floor, int num_cu, int channels, bool group);
+bool synth_group_supported(int channels);
 hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, int half1, float *spec,
                                 const uint8_t *post_counts, const uint8_t *curve_y, const float *inv_db,
                                 hipStream_t stream);
@@ -35,7 +40,7 @@ hipError_t launch_generic_save_state(const GenericFrame *frames, const int32_t *
                                      int size1, const float *ybuf, float *state_y, hipStream_t stream);
 hipError_t launch_floor0_apply(const void *recs, int n_recs, const void *floors, const int32_t *bark_maps,
                                const float *amp, const float *coeff, int coeff_stride, float *spec,
-                               uint8_t *curve_y, int half1, hipStream_t stream);
+                               hipStream_t stream);
 size_t floor0_dev_size();
 size_t floor0_rec_size();
 void fill_floor0_dev(void *dst, int order, int bark_map_size, int amp_ofs, int64_t off_short, int64_t off_long);
@@ -94,7 +99,12 @@ struct Decoder {
     int32_t *d_clipped = nullptr;
     uint8_t *d_steps = nullptr;              // coupling steps of all mappings, pairs (mag, ang)
     std::vector<int32_t> mapping_steps_off;  // per mapping: offset into d_steps (pairs*2), -1 none
-    DevBuf b_curve, b_temp;
+    DevBuf b_curve, b_temp, b_cposts, b_ccount;
+    // group mode of synth_kernel (channels of a packet share a workgroup; de-interleave + coupling in LDS)
+    bool group_ok = false;       // channel count, step tables and floor types allow it
+    int max_steps = 0, n_step_pairs = 0;
+    int host_threads = 0;        // parties of the parallel state machine (VPZ_HOST_THREADS; 0: pick)
+    int64_t par_min_packets = 16384;  // batches below this take the serial state machine (VPZ_PAR_MIN_PACKETS)
     DevBuf b_in_res, b_in_posts, b_in_counts, b_out;  // VPZ_MEM_HOST staging
     DevBuf b_ybuf;                                    // any-block-size path
     bool generic = false;  // a block size outside {256, 512, 1024, 2048}: three-pass path (synth_kernels.hip)
@@ -254,6 +264,8 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     for (int f = 0; f < 8; ++f) D.packet_info[f] = get_packet_info(D.size0, D.size1, f & 1, f & 2, f & 4);
     if (const char *e = getenv("VPZ_RUN_LENGTH")) D.run_length_override = atoi(e);
     if (const char *e = getenv("VPZ_SYNTH_ABLATE")) D.ablate = atoi(e);
+    if (const char *e = getenv("VPZ_HOST_THREADS")) D.host_threads = atoi(e);
+    if (const char *e = getenv("VPZ_PAR_MIN_PACKETS")) D.par_min_packets = atoll(e);
 
     int rc = VPZ_OK;
     std::vector<FloorDev> fdev(std::max<size_t>(1, D.floors.size()));
@@ -281,6 +293,15 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         }
         for (int ch = 0; ch < D.channels && rc == VPZ_OK; ++ch)
             if (D.floors.size() && mc.channel_floor[ch] >= D.floors.size()) rc = VPZ_E_INVALID_ARG;
+        D.max_steps = std::max(D.max_steps, (int)mc.coupling_steps);
+    }
+    D.n_step_pairs = (int)(steps.size() / 2);
+    {
+        bool has_floor0 = false;
+        for (uint8_t t : D.floor_types) has_floor0 |= (t == 0);
+        const char *no_group = getenv("VPZ_NO_GROUP");  // tuning / A-B tests: force the separate coupling pass
+        D.group_ok = synth_group_supported(D.channels) && !D.generic && !has_floor0 && D.max_steps <= 255 &&
+                     D.n_step_pairs <= kGroupMaxStepPairs && !(no_group && atoi(no_group));
     }
     if (rc != VPZ_OK) {
         delete d;
@@ -356,7 +377,7 @@ void vpz_decoder_destroy(vpz_decoder *d)
         (void)hipSetDevice(D.ctx->device);
         (void)hipStreamSynchronize(D.ctx->stream);
     }
-    DevBuf *bufs[] = {&D.b_in_amp, &D.b_in_coeff, &D.b_ybuf, &D.b_curve, &D.b_temp, &D.b_in_res, &D.b_in_posts,
+    DevBuf *bufs[] = {&D.b_in_amp, &D.b_in_coeff, &D.b_ybuf, &D.b_curve, &D.b_temp, &D.b_cposts, &D.b_ccount, &D.b_in_res, &D.b_in_posts,
                       &D.b_in_counts, &D.b_out, &D.arenas[0].dev, &D.arenas[1].dev};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -421,6 +442,8 @@ struct SynthCall {
     size_t n_frames = 0;
     uint8_t *rec_floor = nullptr;  // per channel record: floor index | 0x40 type-0 | 0x80 long block
     bool any_floor = false, any_floor0 = false, need_coupling = false;
+    bool group_align_ok = true;   // every interleaved packet starts on a 16-byte boundary (group mode loads 16 bytes)
+    bool use_group = false;       // decided after pass 1: synth_kernel's group mode instead of the coupling pass
     int64_t mismatches = 0, res_extent = 0;
     // ---- descriptor tables (pinned arena; dev() gives the device mirror's address)
     RunDesc *runs = nullptr;
@@ -476,6 +499,227 @@ struct SynthCall {
         int rc = arena_begin(ctx, *A, need);
         if (rc != VPZ_OK) return rc;
         return grow(ctx, A->dev, A->cap);
+    }
+
+    // flag bits of a decoded packet's frame: block / window selection, and what group mode needs to know about the
+    // packet's input (layout, coupling steps of its mapping)
+    uint32_t frame_flags(const vpz_packet &pk, const PacketInfo &pi) const
+    {
+        const bool bf = pk.flags & VPZ_PKT_BLOCK_FLAG, no_floor = pk.flags & VPZ_PKT_NO_FLOOR;
+        uint32_t f = (bf ? kFrameLong : 0u) | (pi.left_use_size1 ? kFrameSlope1 : 0u) | (no_floor ? kFrameNoFloor : 0u);
+        if (D.group_ok) {
+            const int steps = no_floor ? 0 : D.mappings[pk.mapping].coupling_steps;
+            if (pk.flags & VPZ_PKT_INTERLEAVED) f |= kFrameInterleaved | kFrameStage;
+            if (steps > 0)
+                f |= kFrameStage | ((uint32_t)steps << kFrameStepsShift) |
+                     ((uint32_t)(D.mapping_steps_off[pk.mapping] / 2) << kFrameStepsOffShift);
+        }
+        return f;
+    }
+
+    // Pass 1 for large, plain batches, split over the host cores.  "Plain": packets sorted by stream, all decoded,
+    // none flagged EOS / resync, every stream at a known position and not at its end -- then a packet's frame
+    // depends only on its own flags and on the packet before it (its window geometry), and the output offsets are a
+    // prefix sum: chunk-local sums first, the chunks' bases serially, the descriptors in a second sweep.  Anything
+    // else (and every window mismatch) returns false and the serial state machine below runs instead, so there is one
+    // place where the rare paths of StreamDecoder.ReadNextPacket live.
+    // returns 1: done, 0: not applicable (run the serial pass), < 0: error
+    int run_state_machine_parallel(int64_t *samples_written)
+    {
+        if (n_packets < D.par_min_packets) return 0;
+        int parties = D.host_threads;
+        if (parties <= 0) {
+            cpu_set_t set;
+            parties = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+            parties = std::max(1, std::min(parties, 16));
+        }
+        if (parties < 2) return 0;
+        for (int s = 0; s < D.n_streams; ++s)
+            if (D.states[s].eos_found || !D.states[s].has_position) return 0;
+        if (!ctx->host_pool || static_cast<HostPool *>(ctx->host_pool)->parties() != parties) {
+            if (ctx->host_pool) ctx->host_pool_free(ctx->host_pool);
+            ctx->host_pool = new HostPool(parties);
+            ctx->host_pool_free = [](void *p) { delete static_cast<HostPool *>(p); };
+        }
+        HostPool &pool = *static_cast<HostPool *>(ctx->host_pool);
+
+        struct Chunk {
+            int64_t lo = 0, hi = 0;
+            bool ok = true;
+            int64_t lead_sum = 0;   // samples of the packets that continue the previous chunk's last stream
+            int64_t lead_end = 0;   // first packet that does not
+            int64_t tail_sum = 0;   // samples of the chunk's last stream segment
+            int64_t base = 0;       // filled between the sweeps: samples of the leading stream before this chunk
+            int64_t res_extent = 0;
+            bool any_floor = false, any_floor0 = false, need_coupling = false, align_ok = true;
+            char pad[64];
+        };
+        std::vector<Chunk> chunks((size_t)parties);
+        const int64_t per = (n_packets + parties - 1) / parties;
+        for (int c = 0; c < parties; ++c) {
+            chunks[c].lo = std::min<int64_t>(n_packets, per * c);
+            chunks[c].hi = std::min<int64_t>(n_packets, per * (c + 1));
+        }
+        int32_t *psamples = D.packet_samples.data();
+
+        // what precedes packet p in its stream: the packet before it, or the stream's saved state
+        auto prev_of = [&](int64_t p, bool &has_prev, int &prev_end, int &prev_stop) {
+            const vpz_packet &pk = packets[p];
+            if (p > 0 && packets[p - 1].stream == pk.stream) {
+                const PacketInfo &ppi = D.packet_info[packets[p - 1].flags & 7];
+                has_prev = true;
+                prev_end = ppi.right_start;
+                prev_stop = ppi.right_end;
+            } else {
+                const StreamState &S = D.states[pk.stream];
+                has_prev = S.has_prev;
+                prev_end = S.prev_end;
+                prev_stop = S.prev_stop;
+            }
+        };
+
+        // sweep A: validation, samples per packet, chunk-local sums
+        pool.run([&](int c) {
+            Chunk &K = chunks[c];
+            int64_t run = 0;
+            bool leading = true;
+            K.lead_end = K.lo;
+            for (int64_t p = K.lo; p < K.hi; ++p) {
+                const vpz_packet &pk = packets[p];
+                if (pk.stream < 0 || pk.stream >= D.n_streams ||
+                    (pk.flags & (VPZ_PKT_EOS | VPZ_PKT_NOT_DECODED | VPZ_PKT_RESYNC)) || pk.residue_offset < 0 ||
+                    (p > 0 && packets[p - 1].stream > pk.stream)) {
+                    K.ok = false;
+                    return;
+                }
+                const bool no_floor = pk.flags & VPZ_PKT_NO_FLOOR;
+                if (!no_floor && (pk.mapping >= D.mappings.size() || !have_posts)) { K.ok = false; return; }
+                const bool new_stream = p == 0 || packets[p - 1].stream != pk.stream;
+                if (new_stream) {
+                    if (leading) { K.lead_sum = run; K.lead_end = p; leading = false; }
+                    run = 0;
+                }
+                bool has_prev;
+                int prev_end, prev_stop;
+                prev_of(p, has_prev, prev_end, prev_stop);
+                const PacketInfo &pi = D.packet_info[pk.flags & 7];
+                int cnt = 0;
+                if (has_prev) {
+                    if (prev_stop - prev_end > (pi.left_use_size1 ? half1 : half0)) { K.ok = false; return; }  // mismatch
+                    cnt = std::max(0, pi.right_start - pi.left_start);
+                }
+                psamples[p] = cnt;
+                run += cnt;
+                const bool bf = pk.flags & VPZ_PKT_BLOCK_FLAG;
+                K.res_extent = std::max(K.res_extent, pk.residue_offset + (int64_t)C * (bf ? half1 : half0));
+                if (!no_floor) {
+                    K.any_floor = true;
+                    if (D.mappings[pk.mapping].coupling_steps > 0) K.need_coupling = true;
+                }
+                if (pk.flags & VPZ_PKT_INTERLEAVED) {
+                    K.need_coupling = true;
+                    if (pk.residue_offset & 3) K.align_ok = false;
+                }
+            }
+            if (leading) { K.lead_sum = run; K.lead_end = K.hi; }
+            K.tail_sum = run;
+        });
+        for (const Chunk &K : chunks)
+            if (!K.ok) return 0;
+        frames = arena_alloc<FrameDesc>(*A, (size_t)n_packets);
+        rec_floor = have_posts ? arena_alloc<uint8_t>(*A, (size_t)n_rec) : nullptr;
+        st = D.states;
+        std::vector<int64_t> &s_base = D.s_base, &s_cnt = D.s_cnt, &out_count = D.out_count;
+        s_base.assign((size_t)D.n_streams + 1, 0);
+        s_cnt.assign((size_t)D.n_streams, 0);
+        out_count.assign((size_t)D.n_streams, 0);
+        started_with_prev.resize(D.n_streams);
+        started_prev_long.resize(D.n_streams);
+        for (int s = 0; s < D.n_streams; ++s) {
+            started_with_prev[s] = st[s].has_prev;
+            started_prev_long[s] = st[s].prev_long;
+        }
+        // bases of the chunks' leading segments
+        {
+            int32_t cur_stream = -1;
+            int64_t cur_sum = 0;
+            for (Chunk &K : chunks) {
+                if (K.lo >= K.hi) continue;
+                const int32_t first = packets[K.lo].stream, last = packets[K.hi - 1].stream;
+                K.base = first == cur_stream ? cur_sum : 0;
+                if (K.lead_end == K.hi) cur_sum = K.base + K.lead_sum;  // one stream all through
+                else cur_sum = K.tail_sum;
+                cur_stream = last;
+                res_extent = std::max(res_extent, K.res_extent);
+                any_floor |= K.any_floor;
+                need_coupling |= K.need_coupling;
+                group_align_ok &= K.align_ok;
+            }
+        }
+        if (D.generic) need_coupling = true;
+        // sweep B: the descriptors, the per-record floor info, the streams' final state
+        pool.run([&](int c) {
+            Chunk &K = chunks[c];
+            int64_t run = K.base;
+            for (int64_t p = K.lo; p < K.hi; ++p) {
+                const vpz_packet &pk = packets[p];
+                const bool new_stream = p == 0 || packets[p - 1].stream != pk.stream;
+                if (new_stream) { run = 0; s_base[pk.stream] = p; }
+                bool has_prev;
+                int prev_end, prev_stop;
+                prev_of(p, has_prev, prev_end, prev_stop);
+                const PacketInfo &pi = D.packet_info[pk.flags & 7];
+                FrameDesc fd{};
+                fd.rec = (int32_t)(p * C);
+                fd.flags = frame_flags(pk, pi);
+                if (has_prev) {
+                    fd.packet_len = (uint16_t)(prev_stop - prev_end);
+                    fd.prev_end = (uint16_t)prev_end;
+                    fd.left_start = (uint16_t)pi.left_start;
+                } else {
+                    fd.left_start = (uint16_t)pi.right_start;  // StreamDecoder.cs:679
+                }
+                fd.out_count = (uint16_t)psamples[p];
+                fd.out_off = run;
+                fd.spec_off = pk.residue_offset;
+                run += psamples[p];
+                frames[p] = fd;
+                if (rec_floor) {
+                    if (pk.flags & VPZ_PKT_NO_FLOOR) {
+                        for (int ch = 0; ch < C; ++ch) rec_floor[(size_t)(p * C + ch)] = 0;
+                    } else {
+                        const vpz_mapping_config &mc = D.mappings[pk.mapping];
+                        const uint8_t long_bit = (pk.flags & VPZ_PKT_BLOCK_FLAG) ? 0x80 : 0;
+                        for (int ch = 0; ch < C; ++ch) {
+                            const uint8_t fl = mc.channel_floor[ch];
+                            const bool f0 = D.floor_types[fl] == 0;
+                            K.any_floor0 |= f0;
+                            rec_floor[(size_t)(p * C + ch)] = (uint8_t)(fl | long_bit | (f0 ? 0x40 : 0));
+                        }
+                    }
+                }
+                const bool last_of_stream = p + 1 == n_packets || packets[p + 1].stream != pk.stream;
+                if (last_of_stream) {
+                    StreamState &S = st[pk.stream];
+                    S.has_prev = true;
+                    S.prev_long = pk.flags & VPZ_PKT_BLOCK_FLAG;
+                    S.prev_end = pi.right_start;
+                    S.prev_stop = pi.right_end;
+                    S.prev_start = S.prev_end;
+                    S.current_position += run;
+                    out_count[pk.stream] = run;
+                    s_cnt[pk.stream] = p + 1 - s_base[pk.stream];
+                }
+            }
+        });
+        for (int s = 0; s < D.n_streams; ++s)
+            if (out_count[s] > stream_out_capacity)
+                return set_error(ctx, VPZ_E_CAPACITY, "vpz_decoder_synth: stream_out_capacity too small");
+        n_frames = (size_t)n_packets;
+        for (const Chunk &K : chunks) any_floor0 |= K.any_floor0;
+        for (int s = 0; s < D.n_streams; ++s) samples_written[s] = out_count[s];
+        if (any_floor0) need_coupling = true;  // type-0 floors are applied in place on the planar temp
+        return 1;
     }
 
     // Pass 1: StreamDecoder.Read / ReadNextPacket per stream (StreamDecoder.cs:418-498, 640-694) -> one
@@ -556,7 +800,7 @@ struct SynthCall {
             }
             FrameDesc fd{};
             fd.rec = (int32_t)(p * C);
-            fd.flags = (bf ? kFrameLong : 0u) | (pi.left_use_size1 ? kFrameSlope1 : 0u) | (no_floor ? kFrameNoFloor : 0u);
+            fd.flags = frame_flags(pk, pi);
             if (S.has_prev) {  // :670-675
                 const int slope_len = pi.left_use_size1 ? half1 : half0;
                 if (packet_len > slope_len) {
@@ -603,7 +847,10 @@ struct SynthCall {
                     rec_floor[(size_t)(p * C + ch)] = (uint8_t)(fl | long_bit | (f0 ? 0x40 : 0));
                 }
             }
-            if (pk.flags & VPZ_PKT_INTERLEAVED) need_coupling = true;
+            if (pk.flags & VPZ_PKT_INTERLEAVED) {
+                need_coupling = true;
+                if (pk.residue_offset & 3) group_align_ok = false;
+            }
             frames[s_base[pk.stream] + s_cnt[pk.stream]++] = fd;
         }
         for (int s = 0; s < D.n_streams; ++s)
@@ -630,7 +877,7 @@ struct SynthCall {
         const int r_max = synth_needs_general(D.size0, D.size1) ? kMaxRunLengthGeneral : kMaxRunLength;
         int R = std::min(D.run_length_override, r_max);
         if (R <= 0) {
-            const int64_t slots = std::max(1, synth_resident_waves(any_floor, ctx->num_cu));
+            const int64_t slots = std::max(1, synth_resident_waves(any_floor, ctx->num_cu, C, use_group));
             const int64_t work = total_frames * C;
             R = 4;
             int64_t best = -1;
@@ -666,7 +913,9 @@ struct SynthCall {
     // coupling packets: de-interleave + inverse coupling into a planar temp laid out in frame order
     void build_coupling_packets()
     {
-        if (!need_coupling) return;
+        if (!need_coupling || use_group) return;
+        // the separate pass hands planar, de-coupled spectra over: the frames lose their group-mode bits
+        for (size_t fi = 0; fi < n_frames; ++fi) frames[fi].flags &= 0xFu;
         const size_t cps = coupling_packet_size();
         cpk = arena_alloc<uint8_t>(*A, cps * n_frames);
         for (size_t fi = 0; fi < n_frames; ++fi) {
@@ -815,8 +1064,13 @@ struct SynthCall {
             if ((rc = grow(ctx, D.b_out, sizeof(float) * (size_t)out_floats)) != VPZ_OK) return rc;
             d_out = static_cast<float *>(D.b_out.p);
         }
-        if (need_coupling && (rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK) return rc;
-        if (any_floor && (rc = grow(ctx, D.b_curve, (size_t)n_rec * (size_t)half1)) != VPZ_OK) return rc;
+        if (need_coupling && !use_group && (rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK)
+            return rc;
+        if (any_floor) {
+            if ((rc = grow(ctx, D.b_cposts, sizeof(int32_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
+            if ((rc = grow(ctx, D.b_ccount, (size_t)n_rec)) != VPZ_OK) return rc;
+            if (D.generic && (rc = grow(ctx, D.b_curve, (size_t)n_rec * (size_t)half1)) != VPZ_OK) return rc;
+        }
         if (D.generic && (rc = grow(ctx, D.b_ybuf, sizeof(float) * (size_t)std::max<int64_t>(y_floats, 1))) != VPZ_OK)
             return rc;
         VPZ_HIP_TRY(ctx, hipMemcpyAsync(A->dev.p, A->base, A->used, hipMemcpyHostToDevice, ctx->stream));
@@ -830,22 +1084,26 @@ struct SynthCall {
     {
         const float *d_spec = d_res;
         const int64_t *d_outoff = stream_out_offset ? static_cast<const int64_t *>(dev(offs)) : nullptr;
-        if (need_coupling) {
+        if (need_coupling && !use_group) {
             hipError_t e = launch_coupling(dev(cpk), n_cpk, D.d_steps, C, d_res, static_cast<float *>(D.b_temp.p), half1,
                                            ctx->stream);
             if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "coupling kernel launch", e);
             d_spec = static_cast<const float *>(D.b_temp.p);
         }
-        if (any_floor) {  // Floor1.UnwrapPosts + curve render (table indices)
-            hipError_t e = launch_floor1_prepare((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(dev(rec_floor)),
-                                                 D.d_floors, (int)D.floors.size(), half0, half1,
-                                                 static_cast<uint8_t *>(D.b_curve.p), D.ablate, ctx->stream);
-            if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor1 prepare kernel launch", e);
+        const int32_t *d_cposts = static_cast<const int32_t *>(D.b_cposts.p);
+        const uint8_t *d_ccount = static_cast<const uint8_t *>(D.b_ccount.p);
+        if (any_floor) {  // Floor1.UnwrapPosts and the choice of the posts a line is drawn to, per channel record
+            hipError_t e = launch_floor1_unwrap((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(dev(rec_floor)),
+                                                D.d_floors, (int)D.floors.size(), static_cast<int32_t *>(D.b_cposts.p),
+                                                static_cast<uint8_t *>(D.b_ccount.p), nullptr, nullptr, ctx->stream);
+            if (e == hipSuccess && D.generic)  // the three-pass path reads the curve from memory
+                e = launch_floor1_render((int)n_rec, d_cposts, d_ccount, static_cast<uint8_t *>(dev(rec_floor)), half0,
+                                         half1, static_cast<uint8_t *>(D.b_curve.p), ctx->stream);
+            if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor1 unwrap kernel launch", e);
         }
         if (any_floor0) {  // Floor0.Apply in place on the temp (rare; Floor0.cs:164-225)
             hipError_t e = launch_floor0_apply(dev(f0recs), n_f0, D.d_floors0, D.d_bark_maps, d_amp, d_coeff, D.f0_stride,
-                                               static_cast<float *>(D.b_temp.p), static_cast<uint8_t *>(D.b_curve.p),
-                                               half1, ctx->stream);
+                                               static_cast<float *>(D.b_temp.p), ctx->stream);
             if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor0 kernel launch", e);
             D.f0_amp = D.f0_coeff = nullptr;  // consumed
         }
@@ -856,7 +1114,7 @@ struct SynthCall {
             float *d_y = static_cast<float *>(D.b_ybuf.p);
             hipError_t e = hipSuccess;
             if (any_floor)
-                e = launch_generic_floor(d_gf, (int)n_frames, C, half1, d_temp, d_counts,
+                e = launch_generic_floor(d_gf, (int)n_frames, C, half1, d_temp, d_ccount,
                                          static_cast<const uint8_t *>(D.b_curve.p), ctx->d_inv_db, ctx->stream);
             // per block size: the gathered FAST transform (every size from 256 up), else the reference's own
             // schedule (64 and 128 must take it: quirk q1)
@@ -898,8 +1156,12 @@ struct SynthCall {
         a.size0 = D.size0;
         a.size1 = D.size1;
         a.spec = d_spec;
-        a.post_counts = any_floor ? d_counts : nullptr;
-        a.curve_y = any_floor ? static_cast<const uint8_t *>(D.b_curve.p) : nullptr;
+        a.ccount = any_floor ? d_ccount : nullptr;
+        a.cposts = any_floor ? d_cposts : nullptr;
+        a.steps = D.d_steps;
+        a.n_step_pairs = D.n_step_pairs;
+        a.max_steps = D.max_steps;
+        a.group = use_group ? 1 : 0;
         a.inv_db = ctx->d_inv_db;
         a.state_h = D.d_state_h;
         a.tw_long = D.t1->d_fast;
@@ -971,7 +1233,13 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
                    stream_out_capacity, out_layout, channel_stride);
     int rc;
     if ((rc = call.open_arena()) != VPZ_OK) return rc;
-    if ((rc = call.run_state_machine(samples_written)) != VPZ_OK) return rc;
+    rc = call.run_state_machine_parallel(samples_written);
+    if (rc < 0) return rc;
+    if (rc == 0 && (rc = call.run_state_machine(samples_written)) != VPZ_OK) return rc;
+    // group mode of the fused kernel (de-interleave and inverse coupling in LDS) when the batch needs either and
+    // its interleaved packets can be read in 16-byte pieces; otherwise the separate pass through a planar temp
+    call.use_group = D.group_ok && call.need_coupling && !call.any_floor0 && call.group_align_ok &&
+                     (mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
     const auto t_pass1 = tick();
     const char *mismatch_text =
         "vpz_decoder_synth: a packet's previous tail is longer than its window slope (StreamDecoder.cs:777-778 "
@@ -997,6 +1265,55 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
                 (long long)n_packets, us(t_begin, t_pass1), us(t_pass1, t_pass2), us(t_pass2, t_end));
     }
     return call.mismatches ? set_error(ctx, VPZ_E_WINDOW_MISMATCH, mismatch_text) : VPZ_OK;
+}
+
+// test-only: the integers of the Floor1 device path (include/vorbispizza_synth_debug.h)
+int vpz_debug_floor1_indices(vpz_decoder *d, int64_t n_records, const int16_t *posts, const uint8_t *post_counts,
+                             const uint8_t *record_floor, const uint8_t *record_long, uint8_t *curve_out,
+                             int16_t *final_y_out, uint8_t *step_flags_out, uint8_t *active_count_out)
+{
+    if (!d) return VPZ_E_INVALID_ARG;
+    Decoder &D = d->impl;
+    Context *ctx = D.ctx;
+    if (n_records < 0 || n_records > 0x7fffffff / 64 || (n_records > 0 && (!posts || !post_counts || !record_floor || !record_long)))
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_debug_floor1_indices: bad arguments");
+    if (n_records == 0) return VPZ_OK;
+    const size_t n = (size_t)n_records;
+    const int half0 = D.size0 / 2, half1 = D.size1 / 2;
+    std::vector<uint8_t> info(n);
+    for (size_t r = 0; r < n; ++r) {
+        if (record_floor[r] >= D.floors.size() || D.floor_types[record_floor[r]] != 1)
+            return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_debug_floor1_indices: record_floor is not a type-1 floor");
+        info[r] = (uint8_t)(record_floor[r] | (record_long[r] ? 0x80 : 0));
+    }
+    VPZ_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    struct Bufs {
+        void *p[7] = {};
+        ~Bufs() { for (void *q : p) if (q) (void)hipFree(q); }
+    } B;
+    const size_t bytes[7] = {n * 128, n, n, n * 256, n, n * (size_t)half1, n * 64 * 3};
+    for (int i = 0; i < 7; ++i) VPZ_HIP_TRY(ctx, hipMalloc(&B.p[i], bytes[i]));
+    int16_t *d_posts = static_cast<int16_t *>(B.p[0]);
+    uint8_t *d_counts = static_cast<uint8_t *>(B.p[1]), *d_info = static_cast<uint8_t *>(B.p[2]);
+    int32_t *d_cposts = static_cast<int32_t *>(B.p[3]);
+    uint8_t *d_ccount = static_cast<uint8_t *>(B.p[4]), *d_curve = static_cast<uint8_t *>(B.p[5]);
+    int16_t *d_y = static_cast<int16_t *>(B.p[6]);
+    uint8_t *d_f = static_cast<uint8_t *>(B.p[6]) + n * 128;
+    VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_posts, posts, bytes[0], hipMemcpyHostToDevice, ctx->stream));
+    VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_counts, post_counts, n, hipMemcpyHostToDevice, ctx->stream));
+    VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_info, info.data(), n, hipMemcpyHostToDevice, ctx->stream));
+    if (curve_out) VPZ_HIP_TRY(ctx, hipMemcpyAsync(d_curve, curve_out, bytes[5], hipMemcpyHostToDevice, ctx->stream));
+    VPZ_HIP_TRY(ctx, hipMemsetAsync(B.p[6], 0, bytes[6], ctx->stream));
+    hipError_t e = launch_floor1_unwrap((int)n, d_posts, d_counts, d_info, D.d_floors, (int)D.floors.size(), d_cposts,
+                                        d_ccount, d_y, d_f, ctx->stream);
+    if (e == hipSuccess) e = launch_floor1_render((int)n, d_cposts, d_ccount, d_info, half0, half1, d_curve, ctx->stream);
+    if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor1 debug kernels", e);
+    if (curve_out) VPZ_HIP_TRY(ctx, hipMemcpyAsync(curve_out, d_curve, bytes[5], hipMemcpyDeviceToHost, ctx->stream));
+    if (final_y_out) VPZ_HIP_TRY(ctx, hipMemcpyAsync(final_y_out, d_y, n * 128, hipMemcpyDeviceToHost, ctx->stream));
+    if (step_flags_out) VPZ_HIP_TRY(ctx, hipMemcpyAsync(step_flags_out, d_f, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+    if (active_count_out) VPZ_HIP_TRY(ctx, hipMemcpyAsync(active_count_out, d_ccount, n, hipMemcpyDeviceToHost, ctx->stream));
+    VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return VPZ_OK;
 }
 
 int vpz_decoder_set_floor0_data(vpz_decoder *d, const float *amp, const float *coeff, int32_t coeff_stride)

@@ -44,6 +44,9 @@ struct Context {
     void *stage_in = nullptr;  size_t stage_in_bytes = 0;
     void *stage_out = nullptr; size_t stage_out_bytes = 0;
     void *stage_aux = nullptr; size_t stage_aux_bytes = 0;
+    // fork-join pool of the host-side state machine (host_pool.hpp), created by the first large synth batch
+    void *host_pool = nullptr;
+    void (*host_pool_free)(void *) = nullptr;
 };
 
 int set_error(Context *ctx, int status, const char *what, hipError_t e = hipSuccess);
