@@ -1,0 +1,244 @@
+"""The alternative routes through vpz_decoder_synth give the same bits:
+
+* the host state machine split over the host cores (run_state_machine_parallel, large plain batches) against the
+  serial one (StreamDecoder.ReadNextPacket restated packet by packet) -- descriptors, sample counts, positions;
+* the fused group mode of the synthesis kernel (Residue2 de-interleave + inverse coupling in LDS) against the
+  separate coupling pass through a planar temp (VPZ_NO_GROUP=1);
+and batches the parallel pass must refuse (EOS, undecodable packets, unknown position, unsorted streams) still come
+out right through the serial fallback."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import PKT_BLOCK_FLAG, PKT_EOS, PKT_INTERLEAVED, PKT_NEXT_FLAG, PKT_NO_FLOOR, PKT_NOT_DECODED, PKT_PREV_FLAG
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import __graft_entry__ as ge
+    ge.build()
+    from vorbispizza_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+class env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def stream_major_batch(n_streams, frames, channels, seed, floor=False, interleaved=False):
+    from vorbispizza_amd import make_packets
+    rng = np.random.default_rng(seed)
+    pk = make_packets(n_streams * frames)
+    res, posts, counts = [], [], []
+    off, i = 0, 0
+    for s in range(n_streams):
+        flags = helpers.markov_block_flags(frames, seed=seed * 1000 + s, start_long=bool(s & 1))
+        for f in range(frames):
+            half = 1024 if flags[f] & 1 else 128
+            r = (rng.standard_normal((channels, half)) * (4.0 if floor else 2.0 ** -8)).astype(np.float32)
+            if floor:
+                r = np.round(r)
+            pk[i]["stream"] = s
+            pk[i]["flags"] = flags[f] | (0 if floor else PKT_NO_FLOOR) | (PKT_INTERLEAVED if interleaved else 0)
+            pk[i]["granule"] = -1
+            pk[i]["residue_offset"] = off
+            res.append(r.T.reshape(-1) if interleaved else r.reshape(-1))
+            off += channels * half
+            if floor:
+                xl = helpers.LONG_XLIST if flags[f] & 1 else helpers.SHORT_XLIST
+                p, c = helpers.random_posts(rng, xl, 2, channels, silent_prob=0.1)
+                posts.append(p)
+                counts.append(c)
+            i += 1
+    res = np.concatenate(res)
+    if floor:
+        return pk, res, np.concatenate(posts), np.concatenate(counts)
+    return pk, res, None, None
+
+
+def run(ctx, pk, res, posts, counts, n_streams, channels, floors=(), mappings=(), layout=None, splits=1):
+    from vorbispizza_amd import Decoder, capi
+    layout = capi.OUT_PLANAR if layout is None else layout
+    dec = Decoder(ctx, channels, 256, 2048, floors=floors, mappings=mappings, n_streams=n_streams)
+    per_stream = len(pk) // n_streams
+    cap = per_stream * 1024 + 64
+    out = np.zeros(n_streams * channels * cap, dtype=np.float32)
+    offs = np.arange(n_streams, dtype=np.int64) * channels * cap
+    total = np.zeros(n_streams, dtype=np.int64)
+    samples = []
+    # `splits` calls, each over a slice of every stream's packets (stream-major inside the call)
+    idx = np.arange(len(pk)).reshape(n_streams, per_stream)
+    cuts = np.linspace(0, per_stream, splits + 1).astype(int)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        sel = idx[:, a:b].reshape(-1)
+        sub = pk[sel].copy()
+        sub_posts = None if posts is None else np.ascontiguousarray(posts.reshape(len(pk), channels, 64)[sel].reshape(-1, 64))
+        sub_counts = None if counts is None else np.ascontiguousarray(counts.reshape(len(pk), channels)[sel].reshape(-1))
+        step_offs = offs + total * (channels if layout == capi.OUT_INTERLEAVED else 1)
+        w = dec.synth_raw(sub, res, sub_posts, sub_counts, out, step_offs, cap - int(total.max()), layout, cap, capi.MEM_HOST)
+        samples.append(dec.last_packet_samples(len(sub)))
+        total += w
+    pos = [dec.position(s) for s in range(n_streams)]
+    dec.close()
+    return out.copy(), total.copy(), np.concatenate(samples), pos
+
+
+@pytest.mark.parametrize("channels,n_streams,frames", [(2, 1, 700), (2, 37, 40), (1, 5, 333), (3, 16, 64)])
+def test_parallel_state_machine_equals_the_serial_one(ctx, channels, n_streams, frames):
+    pk, res, _, _ = stream_major_batch(n_streams, frames, channels, seed=channels * 100 + n_streams)
+    with env(VPZ_PAR_MIN_PACKETS=1 << 40):
+        serial = run(ctx, pk, res, None, None, n_streams, channels, splits=3)
+    for threads in (2, 5, 16):
+        with env(VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=threads):
+            par = run(ctx, pk, res, None, None, n_streams, channels, splits=3)
+        assert np.array_equal(par[1], serial[1]) and np.array_equal(par[2], serial[2]) and par[3] == serial[3]
+        assert np.array_equal(par[0].view(np.uint32), serial[0].view(np.uint32)), threads
+
+
+def test_parallel_pass_with_floor_and_interleaved_coupled_input(ctx, oracle):
+    channels, n_streams, frames = 2, 9, 50
+    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)]
+    pk, res, posts, counts = stream_major_batch(n_streams, frames, channels, seed=77, floor=True, interleaved=True)
+    pk["mapping"] = pk["flags"] & 1   # mapping 0: short blocks / floor 0, mapping 1: long blocks / floor 1
+    mappings = [{"coupling": [(0, 1)], "channel_floor": [0, 0]}, {"coupling": [(0, 1)], "channel_floor": [1, 1]}]
+    from vorbispizza_amd import capi
+    with env(VPZ_PAR_MIN_PACKETS=1 << 40):
+        serial = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=capi.OUT_INTERLEAVED)
+    with env(VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=7):
+        par = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=capi.OUT_INTERLEAVED)
+    assert np.array_equal(par[1], serial[1]) and np.array_equal(par[2], serial[2]) and par[3] == serial[3]
+    assert np.array_equal(par[0].view(np.uint32), serial[0].view(np.uint32))
+    # ... and the oracle agrees with both (stream 4)
+    s = 4
+    per = frames
+    opk = []
+    for i in range(s * per, (s + 1) * per):
+        half = 1024 if pk["flags"][i] & 1 else 128
+        off = int(pk["residue_offset"][i])
+        opk.append({"flags": int(pk["flags"][i]), "granule": -1, "mapping": int(pk["mapping"][i]),
+                    "residue": res[off: off + channels * half], "posts": posts[i * channels:(i + 1) * channels],
+                    "post_count": counts[i * channels:(i + 1) * channels]})
+    ref, pos, _ = helpers.oracle_decode(oracle, channels, 256, 2048, opk, floors=floors, mappings=mappings, interleave=True)
+    cap = per * 1024 + 64
+    got = par[0][s * channels * cap: s * channels * cap + ref.size].reshape(ref.shape)
+    assert ref.shape[0] == par[1][s] and np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_batches_the_parallel_pass_must_refuse_take_the_serial_route(ctx, oracle):
+    """EOS with a trimming granule, an undecodable packet, a stream whose position is unknown (after a reset), and
+    streams interleaved packet by packet: the parallel pass is asked (threshold 1) and has to decline."""
+    from vorbispizza_amd import Decoder, capi, make_packets
+    frames, channels = 60, 2
+    flags = helpers.markov_block_flags(frames, seed=5)
+    spec = helpers.gaussian_spectra((frames, channels, 1024), seed=6)
+    variants = {"eos": (frames - 1, PKT_EOS, 40000), "undecodable": (20, PKT_NOT_DECODED, -1)}
+    for name, (at, flag, gran) in variants.items():
+        pk = make_packets(frames)
+        opk, chunks, off = [], [], 0
+        for f in range(frames):
+            half = 1024 if flags[f] & 1 else 128
+            fl = int(flags[f]) | PKT_NO_FLOOR | (flag if f == at else 0)
+            pk[f]["flags"], pk[f]["granule"], pk[f]["residue_offset"] = fl, (gran if f == at else -1), off
+            x = spec[f, :, :half].reshape(-1)
+            chunks.append(x)
+            off += x.size
+            opk.append({"flags": fl, "granule": gran if f == at else -1, "residue": x})
+        res = np.concatenate(chunks)
+        with env(VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=4):
+            dec = Decoder(ctx, channels, 256, 2048)
+            got = dec.synth(pk, res)[0]
+            pos = dec.position(0)
+            dec.close()
+        ref, rpos, _ = helpers.oracle_decode(oracle, channels, 256, 2048, opk)
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-5 and pos == rpos, name
+    # unknown position: reset, then a batch with a granule on its third packet
+    pk = make_packets(frames)
+    pk["flags"] = flags | PKT_NO_FLOOR
+    pk["granule"] = -1
+    pk["granule"][2] = 5000
+    halves = np.where(flags & 1, 1024, 128)
+    pk["residue_offset"] = np.concatenate([[0], np.cumsum(halves * channels)[:-1]])
+    res = np.concatenate([spec[f, :, :halves[f]].reshape(-1) for f in range(frames)])
+    with env(VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=4):
+        dec = Decoder(ctx, channels, 256, 2048)
+        dec.reset(0)
+        got = dec.synth(pk, res)[0]
+        pos_par = dec.position(0)
+        dec.close()
+    with env(VPZ_PAR_MIN_PACKETS=1 << 40):
+        dec = Decoder(ctx, channels, 256, 2048)
+        dec.reset(0)
+        want = dec.synth(pk, res)[0]
+        pos_ser = dec.position(0)
+        dec.close()
+    assert np.array_equal(got, want) and pos_par == pos_ser and pos_par != got.shape[1]
+    # round-robin interleaved streams (not stream-major)
+    pk2 = make_packets(2 * frames)
+    pk2[0::2] = pk
+    pk2[1::2] = pk
+    pk2["granule"] = -1
+    pk2["stream"][1::2] = 1
+    with env(VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=4):
+        dec = Decoder(ctx, channels, 256, 2048, n_streams=2)
+        a = dec.synth(pk2, res)
+        dec.close()
+    assert np.array_equal(a[0], a[1]) and a[0].shape[1] > 0
+
+
+@pytest.mark.parametrize("channels,steps", [(2, [(0, 1)]), (3, [(0, 1), (2, 0)]), (6, [(0, 1), (2, 3)]), (8, [(7, 0), (1, 6), (0, 1)]),
+                                            (4, [])])
+@pytest.mark.parametrize("interleaved", [True, False])
+def test_group_mode_equals_the_separate_coupling_pass(ctx, oracle, channels, steps, interleaved):
+    from vorbispizza_amd import capi
+    if not steps and not interleaved:
+        pytest.skip("nothing to stage")
+    n_streams, frames = 3, 30
+    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)]
+    pk, res, posts, counts = stream_major_batch(n_streams, frames, channels, seed=channels, floor=True, interleaved=interleaved)
+    pk["mapping"] = pk["flags"] & 1
+    mappings = [{"coupling": steps, "channel_floor": [0] * channels}, {"coupling": steps, "channel_floor": [1] * channels}]
+    outs = {}
+    for layout in (capi.OUT_PLANAR, capi.OUT_INTERLEAVED):
+        with env(VPZ_NO_GROUP=None):
+            g = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
+        with env(VPZ_NO_GROUP=1):
+            l = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
+        assert np.array_equal(g[1], l[1]) and np.array_equal(g[2], l[2])
+        assert np.array_equal(g[0].view(np.uint32), l[0].view(np.uint32)), (channels, layout)
+        outs[layout] = g
+    # the oracle, stream 1, planar
+    s, per = 1, frames
+    opk = []
+    for i in range(s * per, (s + 1) * per):
+        half = 1024 if pk["flags"][i] & 1 else 128
+        off = int(pk["residue_offset"][i])
+        opk.append({"flags": int(pk["flags"][i]), "granule": -1, "mapping": int(pk["mapping"][i]),
+                    "residue": res[off: off + channels * half], "posts": posts[i * channels:(i + 1) * channels],
+                    "post_count": counts[i * channels:(i + 1) * channels]})
+    ref, _, _ = helpers.oracle_decode(oracle, channels, 256, 2048, opk, floors=floors, mappings=mappings)
+    cap = per * 1024 + 64
+    got = outs[capi.OUT_PLANAR][0][s * channels * cap:(s + 1) * channels * cap].reshape(channels, cap)[:, :ref.shape[1]]
+    assert outs[capi.OUT_PLANAR][1][s] == ref.shape[1]
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))

@@ -625,7 +625,10 @@ struct SynthCall {
             K.tail_sum = run;
         });
         for (const Chunk &K : chunks)
-            if (!K.ok) return 0;
+            if (!K.ok) {  // the serial pass expects the per-packet counts zeroed
+                std::fill(D.packet_samples.begin(), D.packet_samples.end(), 0);
+                return 0;
+            }
         frames = arena_alloc<FrameDesc>(*A, (size_t)n_packets);
         rec_floor = have_posts ? arena_alloc<uint8_t>(*A, (size_t)n_rec) : nullptr;
         st = D.states;
@@ -708,10 +711,13 @@ struct SynthCall {
                     S.prev_start = S.prev_end;
                     S.current_position += run;
                     out_count[pk.stream] = run;
-                    s_cnt[pk.stream] = p + 1 - s_base[pk.stream];
+                    s_cnt[pk.stream] = p + 1;  // END of the stream's packets; becomes a count after the join (the
+                                               // stream's first packet may belong to another chunk: no read of s_base here)
                 }
             }
         });
+        for (int s = 0; s < D.n_streams; ++s)
+            if (s_cnt[s] > 0) s_cnt[s] -= s_base[s];
         for (int s = 0; s < D.n_streams; ++s)
             if (out_count[s] > stream_out_capacity)
                 return set_error(ctx, VPZ_E_CAPACITY, "vpz_decoder_synth: stream_out_capacity too small");
