@@ -88,9 +88,9 @@ struct SynthArgs {
     const uint8_t *ccount;      // [rec] active floor posts (floor1_unwrap_kernel); 0 => ExecuteChannel false;
                                 // nullptr => every channel executes, no floor
     const int32_t *cposts;      // [rec][64] active posts in X order: x | (finalY * multiplier) << 16
-    const uint8_t *steps;       // coupling steps of all mappings, pairs (mag, ang)   (group mode)
+    const uint8_t *steps;       // coupling steps of all mappings, pairs (mag | 0x80 where a level starts, ang)   (group mode)
     int32_t n_step_pairs;
-    int32_t max_steps;          // most steps any mapping has: barriers per frame in group mode
+    int32_t max_steps;          // most coupling LEVELS any mapping has: barriers per frame in group mode
     int32_t group;              // 1: channels of a run share a workgroup (LDS staging), 0: waves are independent
     const float *inv_db;        // 256 floats
     float *state_h;             // [stream][channel][size1/2]

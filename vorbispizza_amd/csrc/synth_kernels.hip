@@ -14,6 +14,8 @@
 // the previous block's output stays in LDS and the only HBM traffic is the spectrum in and the
 // PCM out (8 B per sample for long blocks).  The block before a run's first is recomputed (one
 // redundant IMDCT per run) or taken from the decoder's saved state.
+#include <cstdlib>
+
 #include "imdct_core.hpp"
 #include "synth_desc.hpp"
 #include "vpz_internal.hpp"
@@ -658,6 +660,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     if (kGroup) {
         // (uniform values: keep them out of the vector registers the integer division would leave them in)
         const int groups = __builtin_amdgcn_readfirstlane(kSynthWaves / C);
+        // (waves that own no channel -- 8 - groups * C of them -- idle at the barriers; spreading them over the SIMDs by
+        // rotating the busy set in every other workgroup was measured: no difference)
         const int slot = __builtin_amdgcn_readfirstlane(wave / C);
         ch = wave - slot * C;
         gw0 = slot * C;
@@ -698,9 +702,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     };
     // the raw input of a frame into registers: this wave's channel, or -- for an interleaved packet in group mode --
     // this wave's share of the packet.  cp: this lane's active floor post (lane < count).
-    auto prefetch = [&](const FrameDesc &fd, float2 (&x)[8], int &cp) {
+    auto prefetch = [&](const FrameDesc &fd, float2 (&x)[8], int &cp, bool &ex) {
         const bool shared_input = kGroup && (fd.flags & kFrameInterleaved);
-        const bool ex = exec_of(fd.flags, fd.rec);
+        ex = exec_of(fd.flags, fd.rec);
         if (shared_input) {
             load_interleaved_share(x, a.spec + fd.spec_off, C, size_of(fd.flags) >> 1, ch, lane);
         } else if (ex || (kGroup && (fd.flags & kFrameStage))) {
@@ -760,24 +764,41 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     // ---- software pipeline: the input of frame i+1 is in flight while frame i is synthesised
     float2 xcur[8];
     int cpcur = 0;
+    bool excur = false;
     FrameDesc fd_next = frame_at(fi0);
-    if (run.count > 0 && !(fd_next.flags & kFrameDrain)) prefetch(fd_next, xcur, cpcur);
+    if (run.count > 0 && !(fd_next.flags & kFrameDrain)) prefetch(fd_next, xcur, cpcur, excur);
+    // Floor1 curve of a frame's channel: table indices rendered into this wave's LDS row (it must be free), the
+    // lane's 16 indices into fy.  Group mode renders the NEXT frame's curve at the end of an iteration -- the row is
+    // free then, and the work overlaps the drain of the frame's PCM stores instead of sitting on the barrier chain.
+    auto render_curve = [&](const FrameDesc &f, int cp, uint32_t (&fy)[8]) {
+        // lanes below the record's post count hold a post; only post 0 (x = 0) can be all zero bits
+        const int m = __builtin_amdgcn_readfirstlane(__popcll(__ballot(cp != 0 || lane == 0)));
+        render_floor_indices<32>(reinterpret_cast<uint8_t *>(hcur), reinterpret_cast<int *>(hcur) + 256,
+                                 size_of(f.flags) >> 1, cp, m, lane);
+        __builtin_amdgcn_wave_barrier();
+        load_floor_indices(fy, reinterpret_cast<const uint8_t *>(hcur), lpb_of(f.flags), lane);
+        __builtin_amdgcn_wave_barrier();
+    };
+    uint32_t fycur[8];
+    if (kHasFloor && kGroup && run.count > 0 && !(fd_next.flags & (kFrameDrain | kFrameNoFloor)) && excur && !(a.ablate & 8))
+        render_curve(fd_next, cpcur, fycur);
     for (int it = 0; it < iters; ++it) {
         const int fi = fi0 + it;
         const bool live = !kSync || fi < run.count;  // wave-uniform; idle iterations only keep the barriers matched
         const FrameDesc fd = fd_next;
         float2 xnext[8];
         int cpnext = 0;
+        bool exnext = false;
         if (fi + 1 < run.count) {
             fd_next = frame_at(fi + 1);
-            if (!(fd_next.flags & kFrameDrain) && !(a.ablate & 4)) prefetch(fd_next, xnext, cpnext);
+            if (!(fd_next.flags & kFrameDrain) && !(a.ablate & 4)) prefetch(fd_next, xnext, cpnext, exnext);
         }
         const bool drain = fd.flags & kFrameDrain;
         const int nblk = size_of(fd.flags);
         const bool is_long = nblk == 2048;  // "long" below means: the 2048-point transform
         const int n4 = kGeneral ? (nblk >> 2) : (is_long ? 512 : 64);
         const bool build = live && !drain;
-        const bool exec = build && exec_of(fd.flags, fd.rec);
+        const bool exec = build && excur;
         // ---- group mode: the packet goes through the group's LDS rows (de-interleave, inverse coupling)
         if (kGroup) {
             const bool stage = build && (fd.flags & kFrameStage);
@@ -795,38 +816,36 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 }
             }
             __syncthreads();
-            const int steps = (fd.flags >> kFrameStepsShift) & 0xFF;
+            // inverse coupling, steps in reverse order (Mapping.cs:166); the host has cut each mapping's steps into
+            // LEVELS of steps that touch disjoint channels (bit 7 of a step's first byte: a new level starts here), so
+            // that a workgroup barrier is needed between levels only -- (0,1),(2,3) of a 5.1 mapping run together
+            int sidx = (int)((fd.flags >> kFrameStepsShift) & 0xFF) - 1;
             const uint8_t *st = s_steps + 2 * (fd.flags >> kFrameStepsOffShift);
-            for (int sidx = a.max_steps - 1; sidx >= 0; --sidx) {  // reverse order, Mapping.cs:166
-                if (stage && sidx < steps) {
-                    float4 *pm = reinterpret_cast<float4 *>(s_work[gw0 + st[2 * sidx]]);
-                    float4 *pa = reinterpret_cast<float4 *>(s_work[gw0 + st[2 * sidx + 1]]);
-                    for (int g = lane + 64 * ch; g < (nblk >> 3); g += 64 * C) {
-                        float4 m4 = pm[g], a4 = pa[g];
-                        couple(m4.x, a4.x);
-                        couple(m4.y, a4.y);
-                        couple(m4.z, a4.z);
-                        couple(m4.w, a4.w);
-                        pm[g] = m4;
-                        pa[g] = a4;
+            for (int lvl = 0; lvl < a.max_steps; ++lvl) {
+                if (stage) {
+                    bool first = true;
+                    while (sidx >= 0 && (first || !(st[2 * sidx] & 0x80))) {
+                        float4 *pm = reinterpret_cast<float4 *>(s_work[gw0 + (st[2 * sidx] & 0x7F)]);
+                        float4 *pa = reinterpret_cast<float4 *>(s_work[gw0 + st[2 * sidx + 1]]);
+                        for (int g = lane + 64 * ch; g < (nblk >> 3); g += 64 * C) {
+                            float4 m4 = pm[g], a4 = pa[g];
+                            couple(m4.x, a4.x);
+                            couple(m4.y, a4.y);
+                            couple(m4.z, a4.z);
+                            couple(m4.w, a4.w);
+                            pm[g] = m4;
+                            pa[g] = a4;
+                        }
+                        --sidx;
+                        first = false;
                     }
                 }
                 __syncthreads();
             }
             if (stage && exec) load_spectrum(xcur, hcur, lpb_of(fd.flags), lane);
         }
-        // ---- Floor1 curve of this wave's channel: table indices into the LDS row (free until the transform needs
-        // it: in group mode the wave has just taken its spectrum out of it), the lane's 16 indices into fycur
-        uint32_t fycur[8];
-        if (kHasFloor && exec && !(fd.flags & kFrameNoFloor) && !(a.ablate & 8)) {
-            // lanes below the record's post count hold a post; only post 0 (x = 0) can be all zero bits
-            const int m = __builtin_amdgcn_readfirstlane(__popcll(__ballot(cpcur != 0 || lane == 0)));
-            render_floor_indices<32>(reinterpret_cast<uint8_t *>(hcur), reinterpret_cast<int *>(hcur) + 256, nblk >> 1,
-                                     cpcur, m, lane);
-            __builtin_amdgcn_wave_barrier();
-            load_floor_indices(fycur, reinterpret_cast<const uint8_t *>(hcur), lpb_of(fd.flags), lane);
-            __builtin_amdgcn_wave_barrier();
-        }
+        // ---- free-running waves render the curve here, right before the row is needed for the transform
+        if (kHasFloor && !kGroup && exec && !(fd.flags & kFrameNoFloor) && !(a.ablate & 8)) render_curve(fd, cpcur, fycur);
         if (build) {
             if (!exec) {
                 // Mapping.cs:190-194: the channel is silent, its whole block is zero
@@ -1103,6 +1122,10 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 #pragma unroll
         for (int m = 0; m < 8; ++m) xcur[m] = xnext[m];
         cpcur = cpnext;
+        excur = exnext;
+        if (kHasFloor && kGroup && fi + 1 < run.count && !(fd_next.flags & (kFrameDrain | kFrameNoFloor)) && excur &&
+            !(a.ablate & 8))
+            render_curve(fd_next, cpcur, fycur);
     }
 
     // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
@@ -1272,8 +1295,9 @@ hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t strea
                            : (int)((items + kSynthWaves - 1) / kSynthWaves);
     // the interleaved store patterns cost registers the planar steady state needs: one instantiation each
     const int out_kind = !args.interleaved ? 0 : (args.channels == 2 ? 2 : 1);
+    static const int extra_lds = getenv("VPZ_SYNTH_EXTRA_LDS") ? atoi(getenv("VPZ_SYNTH_EXTRA_LDS")) : 0;  // occupancy experiments
 #define VPZ_LAUNCH_SYNTH(F, O, G, R) \
-    hipLaunchKernelGGL((synth_kernel<F, O, G, R>), dim3(grid), dim3(kSynthThreads), 0, stream, args)
+    hipLaunchKernelGGL((synth_kernel<F, O, G, R>), dim3(grid), dim3(kSynthThreads), extra_lds, stream, args)
 #define VPZ_LAUNCH_SYNTH_OUT(F, G, R)                      \
     do {                                                   \
         if (out_kind == 0) VPZ_LAUNCH_SYNTH(F, 0, G, R);   \

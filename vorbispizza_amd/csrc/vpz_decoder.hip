@@ -74,7 +74,7 @@ struct DevBuf {
 struct PinnedArena {
     char *base = nullptr;
     size_t cap = 0, used = 0;
-    hipEvent_t uploaded = nullptr;
+    hipEvent_t uploaded = nullptr;   // the arena is in its device mirror
     bool pending = false;
     DevBuf dev;  // device mirror, same layout: one hipMemcpyAsync per call
 };
@@ -87,7 +87,7 @@ struct Decoder {
     Context *ctx = nullptr;
     PinnedArena arenas[2];
     int arena_idx = 0;
-    std::vector<int64_t> s_base, s_cnt, out_count;  // per-stream scratch of a synth call
+    std::vector<int64_t> s_base, s_cnt, out_count, anchor_pkt;  // per-stream scratch of a synth call
     int channels = 0, size0 = 0, size1 = 0, clip = 0;
     int n_streams = 0;
     std::vector<vpz_floor1_config> floors;
@@ -98,6 +98,7 @@ struct Decoder {
     float *d_state_h = nullptr;
     int32_t *d_clipped = nullptr;
     uint8_t *d_steps = nullptr;              // coupling steps of all mappings, pairs (mag, ang)
+    uint8_t *d_steps_lvl = nullptr;          // the same with bit 7 of `mag` set where a level of disjoint steps starts
     std::vector<int32_t> mapping_steps_off;  // per mapping: offset into d_steps (pairs*2), -1 none
     DevBuf b_curve, b_temp, b_cposts, b_ccount;
     // group mode of synth_kernel (channels of a packet share a workgroup; de-interleave + coupling in LDS)
@@ -295,6 +296,27 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
             if (D.floors.size() && mc.channel_floor[ch] >= D.floors.size()) rc = VPZ_E_INVALID_ARG;
         D.max_steps = std::max(D.max_steps, (int)mc.coupling_steps);
     }
+    // group mode applies a mapping's steps in reverse order with a workgroup barrier only where a step touches a
+    // channel an earlier step of the same LEVEL touched: mark those steps, count the levels
+    std::vector<uint8_t> steps_lvl = steps;
+    int max_levels = 0;
+    for (size_t m = 0; m < D.mappings.size() && rc == VPZ_OK; ++m) {
+        const int n = D.mappings[m].coupling_steps, off = D.mapping_steps_off[m];
+        int levels = n > 0 ? 1 : 0;
+        uint32_t used[8] = {};
+        for (int i = n - 1; i >= 0; --i) {
+            const uint8_t mag = steps[off + 2 * i], ang = steps[off + 2 * i + 1];
+            const bool clash = (used[mag >> 5] >> (mag & 31) & 1) || (used[ang >> 5] >> (ang & 31) & 1);
+            if (clash) {
+                ++levels;
+                memset(used, 0, sizeof used);
+                if (mag < 128) steps_lvl[off + 2 * i] |= 0x80;
+            }
+            used[mag >> 5] |= 1u << (mag & 31);
+            used[ang >> 5] |= 1u << (ang & 31);
+        }
+        max_levels = std::max(max_levels, levels);
+    }
     D.n_step_pairs = (int)(steps.size() / 2);
     {
         bool has_floor0 = false;
@@ -302,6 +324,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         const char *no_group = getenv("VPZ_NO_GROUP");  // tuning / A-B tests: force the separate coupling pass
         D.group_ok = synth_group_supported(D.channels) && !D.generic && !has_floor0 && D.max_steps <= 255 &&
                      D.n_step_pairs <= kGroupMaxStepPairs && !(no_group && atoi(no_group));
+        D.max_steps = max_levels;  // from here on: the barriers a frame's coupling needs in group mode
     }
     if (rc != VPZ_OK) {
         delete d;
@@ -326,6 +349,9 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     if (e == hipSuccess) e = hipMemset(D.d_clipped, 0, sizeof(int32_t) * (size_t)n_streams);
     if (e == hipSuccess) e = hipMalloc((void **)&D.d_steps, steps.size() ? steps.size() : 1);
     if (e == hipSuccess && !steps.empty()) e = hipMemcpy(D.d_steps, steps.data(), steps.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&D.d_steps_lvl, steps_lvl.size() ? steps_lvl.size() : 1);
+    if (e == hipSuccess && !steps_lvl.empty())
+        e = hipMemcpy(D.d_steps_lvl, steps_lvl.data(), steps_lvl.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         // Floor0 ctor tables (Floor0.cs:82-95): one bark map per block size, n+1 ints, last bin left at 0
         std::vector<int32_t> maps;
@@ -385,6 +411,7 @@ void vpz_decoder_destroy(vpz_decoder *d)
     if (D.d_state_h) (void)hipFree(D.d_state_h);
     if (D.d_clipped) (void)hipFree(D.d_clipped);
     if (D.d_steps) (void)hipFree(D.d_steps);
+    if (D.d_steps_lvl) (void)hipFree(D.d_steps_lvl);
     if (D.d_floors0) (void)hipFree(D.d_floors0);
     if (D.d_bark_maps) (void)hipFree(D.d_bark_maps);
     for (PinnedArena &A : D.arenas) {
@@ -517,13 +544,14 @@ struct SynthCall {
         return f;
     }
 
-    // Pass 1 for large, plain batches, split over the host cores.  "Plain": packets sorted by stream, all decoded,
-    // none flagged EOS / resync, every stream at a known position and not at its end -- then a packet's frame
-    // depends only on its own flags and on the packet before it (its window geometry), and the output offsets are a
-    // prefix sum: chunk-local sums first, the chunks' bases serially, the descriptors in a second sweep.  Anything
-    // else (and every window mismatch) returns false and the serial state machine below runs instead, so there is one
-    // place where the rare paths of StreamDecoder.ReadNextPacket live.
-    // returns 1: done, 0: not applicable (run the serial pass), < 0: error
+    // Pass 1 for large batches, split over the host cores.  It takes the batches real hosts produce: packets sorted by
+    // stream, all decoded, no resync, and the only packet of a stream that may carry an EOS flag or fail the window
+    // check (StreamDecoder.cs:777-778) is the stream's LAST one in the batch.  Then a packet's frame depends only on
+    // its own flags and on the packet before it (its window geometry); output offsets are a prefix sum -- chunk-local
+    // sums first, the chunks' bases serially, the descriptors in a second sweep -- and everything that needs the
+    // stream position (granule pick-up :459-463, EOS trim :658-666) is settled once per stream afterwards.  Any other
+    // batch returns 0 and the serial state machine below runs instead, so the rare paths of ReadNextPacket live in one
+    // place.  Returns 1: done, 0: not applicable, < 0: error.
     int run_state_machine_parallel(int64_t *samples_written)
     {
         if (n_packets < D.par_min_packets) return 0;
@@ -534,22 +562,22 @@ struct SynthCall {
             parties = std::max(1, std::min(parties, 16));
         }
         if (parties < 2) return 0;
-        for (int s = 0; s < D.n_streams; ++s)
-            if (D.states[s].eos_found || !D.states[s].has_position) return 0;
         if (!ctx->host_pool || static_cast<HostPool *>(ctx->host_pool)->parties() != parties) {
             if (ctx->host_pool) ctx->host_pool_free(ctx->host_pool);
             ctx->host_pool = new HostPool(parties);
             ctx->host_pool_free = [](void *p) { delete static_cast<HostPool *>(p); };
         }
         HostPool &pool = *static_cast<HostPool *>(ctx->host_pool);
+        constexpr int64_t kNone = INT64_MAX;
 
         struct Chunk {
             int64_t lo = 0, hi = 0;
             bool ok = true;
-            int64_t lead_sum = 0;   // samples of the packets that continue the previous chunk's last stream
-            int64_t lead_end = 0;   // first packet that does not
-            int64_t tail_sum = 0;   // samples of the chunk's last stream segment
-            int64_t base = 0;       // filled between the sweeps: samples of the leading stream before this chunk
+            int64_t lead_sum = 0;     // samples of the packets that continue the previous chunk's last stream
+            int64_t lead_end = 0;     // first packet that does not
+            int64_t lead_anchor = kNone;  // first packet with a granule position among them
+            int64_t tail_sum = 0;     // samples of the chunk's last stream segment
+            int64_t base = 0;         // filled between the sweeps: samples of the leading stream before this chunk
             int64_t res_extent = 0;
             bool any_floor = false, any_floor0 = false, need_coupling = false, align_ok = true;
             char pad[64];
@@ -561,6 +589,11 @@ struct SynthCall {
             chunks[c].hi = std::min<int64_t>(n_packets, per * (c + 1));
         }
         int32_t *psamples = D.packet_samples.data();
+        std::vector<int64_t> &s_base = D.s_base, &s_cnt = D.s_cnt, &out_count = D.out_count;
+        s_base.assign((size_t)D.n_streams + 1, 0);
+        s_cnt.assign((size_t)D.n_streams, 0);
+        out_count.assign((size_t)D.n_streams, 0);
+        D.anchor_pkt.assign((size_t)D.n_streams, kNone);  // per stream: first packet that carries a granule position
 
         // what precedes packet p in its stream: the packet before it, or the stream's saved state
         auto prev_of = [&](int64_t p, bool &has_prev, int &prev_end, int &prev_stop) {
@@ -577,8 +610,16 @@ struct SynthCall {
                 prev_stop = S.prev_stop;
             }
         };
+        auto is_last_of_stream = [&](int64_t p) { return p + 1 == n_packets || packets[p + 1].stream != packets[p].stream; };
+        auto mismatch_at = [&](int64_t p) {
+            bool has_prev;
+            int prev_end, prev_stop;
+            prev_of(p, has_prev, prev_end, prev_stop);
+            const PacketInfo &pi = D.packet_info[packets[p].flags & 7];
+            return has_prev && prev_stop - prev_end > (pi.left_use_size1 ? half1 : half0);
+        };
 
-        // sweep A: validation, samples per packet, chunk-local sums
+        // sweep A: validation, samples per packet (before any EOS trim), chunk-local sums
         pool.run([&](int c) {
             Chunk &K = chunks[c];
             int64_t run = 0;
@@ -586,16 +627,18 @@ struct SynthCall {
             K.lead_end = K.lo;
             for (int64_t p = K.lo; p < K.hi; ++p) {
                 const vpz_packet &pk = packets[p];
-                if (pk.stream < 0 || pk.stream >= D.n_streams ||
-                    (pk.flags & (VPZ_PKT_EOS | VPZ_PKT_NOT_DECODED | VPZ_PKT_RESYNC)) || pk.residue_offset < 0 ||
-                    (p > 0 && packets[p - 1].stream > pk.stream)) {
+                if (pk.stream < 0 || pk.stream >= D.n_streams || (pk.flags & (VPZ_PKT_NOT_DECODED | VPZ_PKT_RESYNC)) ||
+                    pk.residue_offset < 0 || (p > 0 && packets[p - 1].stream > pk.stream)) {
                     K.ok = false;
                     return;
                 }
                 const bool no_floor = pk.flags & VPZ_PKT_NO_FLOOR;
                 if (!no_floor && (pk.mapping >= D.mappings.size() || !have_posts)) { K.ok = false; return; }
+                const bool last = is_last_of_stream(p);
+                if ((pk.flags & VPZ_PKT_EOS) && !last) { K.ok = false; return; }
                 const bool new_stream = p == 0 || packets[p - 1].stream != pk.stream;
                 if (new_stream) {
+                    if (D.states[pk.stream].eos_found) { K.ok = false; return; }  // Read() ignores the stream from here on
                     if (leading) { K.lead_sum = run; K.lead_end = p; leading = false; }
                     run = 0;
                 }
@@ -604,12 +647,21 @@ struct SynthCall {
                 prev_of(p, has_prev, prev_end, prev_stop);
                 const PacketInfo &pi = D.packet_info[pk.flags & 7];
                 int cnt = 0;
+                bool skipped = false;
                 if (has_prev) {
-                    if (prev_stop - prev_end > (pi.left_use_size1 ? half1 : half0)) { K.ok = false; return; }  // mismatch
-                    cnt = std::max(0, pi.right_start - pi.left_start);
+                    if (prev_stop - prev_end > (pi.left_use_size1 ? half1 : half0)) {  // window mismatch
+                        if (!last) { K.ok = false; return; }
+                        skipped = true;
+                    } else {
+                        cnt = std::max(0, pi.right_start - pi.left_start);
+                    }
                 }
                 psamples[p] = cnt;
                 run += cnt;
+                if (pk.granule != -1 && !skipped) {
+                    if (leading) { if (K.lead_anchor == kNone) K.lead_anchor = p; }
+                    else if (D.anchor_pkt[pk.stream] == kNone) D.anchor_pkt[pk.stream] = p;
+                }
                 const bool bf = pk.flags & VPZ_PKT_BLOCK_FLAG;
                 K.res_extent = std::max(K.res_extent, pk.residue_offset + (int64_t)C * (bf ? half1 : half0));
                 if (!no_floor) {
@@ -632,17 +684,14 @@ struct SynthCall {
         frames = arena_alloc<FrameDesc>(*A, (size_t)n_packets);
         rec_floor = have_posts ? arena_alloc<uint8_t>(*A, (size_t)n_rec) : nullptr;
         st = D.states;
-        std::vector<int64_t> &s_base = D.s_base, &s_cnt = D.s_cnt, &out_count = D.out_count;
-        s_base.assign((size_t)D.n_streams + 1, 0);
-        s_cnt.assign((size_t)D.n_streams, 0);
-        out_count.assign((size_t)D.n_streams, 0);
         started_with_prev.resize(D.n_streams);
         started_prev_long.resize(D.n_streams);
         for (int s = 0; s < D.n_streams; ++s) {
             started_with_prev[s] = st[s].has_prev;
             started_prev_long[s] = st[s].prev_long;
         }
-        // bases of the chunks' leading segments
+        // bases of the chunks' leading segments; a leading segment's first granule packet belongs to the stream
+        // unless an earlier chunk already found one
         {
             int32_t cur_stream = -1;
             int64_t cur_sum = 0;
@@ -650,6 +699,7 @@ struct SynthCall {
                 if (K.lo >= K.hi) continue;
                 const int32_t first = packets[K.lo].stream, last = packets[K.hi - 1].stream;
                 K.base = first == cur_stream ? cur_sum : 0;
+                if (K.lead_anchor != kNone && D.anchor_pkt[first] > K.lead_anchor) D.anchor_pkt[first] = K.lead_anchor;
                 if (K.lead_end == K.hi) cur_sum = K.base + K.lead_sum;  // one stream all through
                 else cur_sum = K.tail_sum;
                 cur_stream = last;
@@ -660,7 +710,7 @@ struct SynthCall {
             }
         }
         if (D.generic) need_coupling = true;
-        // sweep B: the descriptors, the per-record floor info, the streams' final state
+        // sweep B: the descriptors, the per-record floor info, where each stream's packets begin and end
         pool.run([&](int c) {
             Chunk &K = chunks[c];
             int64_t run = K.base;
@@ -672,19 +722,24 @@ struct SynthCall {
                 int prev_end, prev_stop;
                 prev_of(p, has_prev, prev_end, prev_stop);
                 const PacketInfo &pi = D.packet_info[pk.flags & 7];
+                const bool last = is_last_of_stream(p);
                 FrameDesc fd{};
                 fd.rec = (int32_t)(p * C);
-                fd.flags = frame_flags(pk, pi);
-                if (has_prev) {
-                    fd.packet_len = (uint16_t)(prev_stop - prev_end);
-                    fd.prev_end = (uint16_t)prev_end;
-                    fd.left_start = (uint16_t)pi.left_start;
+                if (last && has_prev && prev_stop - prev_end > (pi.left_use_size1 ? half1 : half0)) {
+                    fd.flags = kFrameDrain;  // skipped packet (window mismatch): a frame that does nothing
                 } else {
-                    fd.left_start = (uint16_t)pi.right_start;  // StreamDecoder.cs:679
+                    fd.flags = frame_flags(pk, pi);
+                    if (has_prev) {
+                        fd.packet_len = (uint16_t)(prev_stop - prev_end);
+                        fd.prev_end = (uint16_t)prev_end;
+                        fd.left_start = (uint16_t)pi.left_start;
+                    } else {
+                        fd.left_start = (uint16_t)pi.right_start;  // StreamDecoder.cs:679
+                    }
+                    fd.out_count = (uint16_t)psamples[p];
+                    fd.spec_off = pk.residue_offset;
                 }
-                fd.out_count = (uint16_t)psamples[p];
                 fd.out_off = run;
-                fd.spec_off = pk.residue_offset;
                 run += psamples[p];
                 frames[p] = fd;
                 if (rec_floor) {
@@ -701,23 +756,76 @@ struct SynthCall {
                         }
                     }
                 }
-                const bool last_of_stream = p + 1 == n_packets || packets[p + 1].stream != pk.stream;
-                if (last_of_stream) {
-                    StreamState &S = st[pk.stream];
-                    S.has_prev = true;
-                    S.prev_long = pk.flags & VPZ_PKT_BLOCK_FLAG;
-                    S.prev_end = pi.right_start;
-                    S.prev_stop = pi.right_end;
-                    S.prev_start = S.prev_end;
-                    S.current_position += run;
+                if (last) {
                     out_count[pk.stream] = run;
-                    s_cnt[pk.stream] = p + 1;  // END of the stream's packets; becomes a count after the join (the
-                                               // stream's first packet may belong to another chunk: no read of s_base here)
+                    s_cnt[pk.stream] = p + 1;  // END of the stream's packets; becomes a count below (the stream's first
+                                               // packet may belong to another chunk: no read of s_base here)
                 }
             }
         });
-        for (int s = 0; s < D.n_streams; ++s)
-            if (s_cnt[s] > 0) s_cnt[s] -= s_base[s];
+        // once per stream: its state after the batch (ReadNextPacket :640-694 for the last packet), the position
+        // (:459-463, :493) and the EOS trim (:658-666)
+        for (int s = 0; s < D.n_streams; ++s) {
+            if (s_cnt[s] == 0) continue;
+            const int64_t L = s_cnt[s] - 1;
+            s_cnt[s] -= s_base[s];
+            const vpz_packet &pk = packets[L];
+            StreamState &S = st[s];
+            const PacketInfo &pi = D.packet_info[pk.flags & 7];
+            const bool eos = pk.flags & VPZ_PKT_EOS;
+            if (eos) S.eos_found = true;
+            bool has_prev;
+            int prev_end, prev_stop;
+            prev_of(L, has_prev, prev_end, prev_stop);
+            const bool skipped = frames[L].flags == kFrameDrain && frames[L].out_count == 0 && mismatch_at(L);
+            // position in front of the last packet: the stream's own count, re-based where a granule was picked up
+            int64_t pos_base = S.current_position;
+            bool has_pos = S.has_position;
+            const int64_t anchor = D.anchor_pkt[s];
+            if (!has_pos && anchor != kNone && anchor < L) {
+                has_pos = true;
+                pos_base = packets[anchor].granule - (frames[anchor].out_off + psamples[anchor]);
+            }
+            if (skipped) {
+                ++mismatches;
+                if (s_cnt[s] > 1) {  // the state is the one the packet before it left
+                    const vpz_packet &pp = packets[L - 1];
+                    const PacketInfo &ppi = D.packet_info[pp.flags & 7];
+                    S.has_prev = true;
+                    S.prev_long = pp.flags & VPZ_PKT_BLOCK_FLAG;
+                    S.prev_end = ppi.right_start;
+                    S.prev_stop = ppi.right_end;
+                    S.prev_start = S.prev_end;
+                }
+            } else {
+                int right_start = pi.right_start;
+                if (pk.granule != -1 && eos) {  // :658-666
+                    const int64_t actual_end = pos_base + frames[L].out_off + (has_prev ? prev_stop - prev_end : 0);
+                    const int diff = (int)(actual_end - pk.granule);
+                    if (diff > 0) right_start = std::max(right_start - diff, 0);
+                }
+                const int start = has_prev ? pi.left_start : right_start;  // :674 / :679
+                const int d = right_start - start;
+                const int cnt = std::max(0, d);
+                if (right_start != pi.right_start) {  // trimmed: the last frame, the stream's total
+                    out_count[s] += cnt - psamples[L];
+                    psamples[L] = cnt;
+                    frames[L].out_count = (uint16_t)cnt;
+                    frames[L].left_start = (uint16_t)start;
+                }
+                if (pk.granule != -1 && !has_pos) {  // :459-463 at the last packet itself
+                    has_pos = true;
+                    pos_base = pk.granule - d - frames[L].out_off;
+                }
+                S.has_prev = true;
+                S.prev_long = pk.flags & VPZ_PKT_BLOCK_FLAG;
+                S.prev_end = right_start;
+                S.prev_stop = pi.right_end;
+                S.prev_start = S.prev_end;
+            }
+            S.has_position = has_pos;
+            S.current_position = pos_base + out_count[s];
+        }
         for (int s = 0; s < D.n_streams; ++s)
             if (out_count[s] > stream_out_capacity)
                 return set_error(ctx, VPZ_E_CAPACITY, "vpz_decoder_synth: stream_out_capacity too small");
@@ -1079,6 +1187,8 @@ struct SynthCall {
         }
         if (D.generic && (rc = grow(ctx, D.b_ybuf, sizeof(float) * (size_t)std::max<int64_t>(y_floats, 1))) != VPZ_OK)
             return rc;
+        // (A second stream for this upload, ordered with events so that it overlaps the previous call's kernels, was
+        // measured 2-3x SLOWER per call on MI355X / ROCm 7.2: cross-stream event waits cost more than the copy.)
         VPZ_HIP_TRY(ctx, hipMemcpyAsync(A->dev.p, A->base, A->used, hipMemcpyHostToDevice, ctx->stream));
         VPZ_HIP_TRY(ctx, hipEventRecord(A->uploaded, ctx->stream));
         A->pending = true;
@@ -1164,7 +1274,7 @@ struct SynthCall {
         a.spec = d_spec;
         a.ccount = any_floor ? d_ccount : nullptr;
         a.cposts = any_floor ? d_cposts : nullptr;
-        a.steps = D.d_steps;
+        a.steps = D.d_steps_lvl;
         a.n_step_pairs = D.n_step_pairs;
         a.max_steps = D.max_steps;
         a.group = use_group ? 1 : 0;
@@ -1239,8 +1349,10 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
                    stream_out_capacity, out_layout, channel_stride);
     int rc;
     if ((rc = call.open_arena()) != VPZ_OK) return rc;
+    const auto t_arena = tick();
     rc = call.run_state_machine_parallel(samples_written);
     if (rc < 0) return rc;
+    const bool was_parallel = rc == 1;
     if (rc == 0 && (rc = call.run_state_machine(samples_written)) != VPZ_OK) return rc;
     // group mode of the fused kernel (de-interleave and inverse coupling in LDS) when the batch needs either and
     // its interleaved packets can be read in 16-byte pieces; otherwise the separate pass through a planar temp
@@ -1267,8 +1379,9 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     if (host_profile) {
         const auto t_end = tick();
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        fprintf(stderr, "[vpz host] packets %lld: pass1 %.1f us, runs+arena %.1f us, uploads+launch %.1f us\n",
-                (long long)n_packets, us(t_begin, t_pass1), us(t_pass1, t_pass2), us(t_pass2, t_end));
+        fprintf(stderr, "[vpz host] packets %lld: arena wait %.1f us, pass1 %.1f us (%s), runs %.1f us, uploads+launch %.1f us\n",
+                (long long)n_packets, us(t_begin, t_arena), us(t_arena, t_pass1), was_parallel ? "parallel" : "serial",
+                us(t_pass1, t_pass2), us(t_pass2, t_end));
     }
     return call.mismatches ? set_error(ctx, VPZ_E_WINDOW_MISMATCH, mismatch_text) : VPZ_OK;
 }
