@@ -13,8 +13,11 @@ one channel (N/2 per channel-block).
 Prints ONE JSON line (rank 0) with the contract fields plus
   "roofline":     algorithmic bytes of the dominant kernel / its HIP-event duration vs 8 TB/s,
   "cpu_baseline": the CPU oracle (restated reference, kind "port") timed on the host cores,
-  "extra_workloads": configs[2] (mixed 256/2048 window switching + overlap-add) and configs[3]
-                  (6 channels, Residue2-interleaved, coupled, Floor1 on the GPU), N = 1 only.
+  "extra_workloads": N = 1: north_star's all-long fused line, configs[2] (mixed 256/2048 window switching +
+                  overlap-add), configs[3] (6 channels, Residue2-interleaved, coupled, Floor1 on the GPU), configs[4]
+                  one GPU's share, configs[0]; every N: configs[4]'s whole job -- 1024 real stereo streams
+                  PARTITIONED over the ranks (vorbispizza_amd/sharding.py), GPU stage and end to end, with the
+                  per-rank sample counts and a PCM checksum that does not depend on the partition.
 """
 import argparse
 import json
@@ -106,11 +109,14 @@ def cpu_baseline_imdct(seconds_1thread=4.0, seconds_all=8.0):
     }
 
 
-def build_synth_ola(torch, device, frames=FRAMES):
-    """BASELINE configs[2]: one stereo stream, 65 536 frames, Markov block flags (seed 3)."""
+def build_synth_ola(torch, device, frames=FRAMES, all_long=False):
+    """BASELINE configs[2]: one stereo stream, 65 536 frames, Markov block flags (seed 3); all_long: every block long
+    with long windows on both sides (north_star's "batched stereo N=2048 IMDCT+window+OLA")."""
     import helpers
     from vorbispizza_amd import capi, make_packets
     flags = helpers.markov_block_flags(frames, seed=3)
+    if all_long:
+        flags = np.full(frames, capi.PKT_BLOCK_FLAG | capi.PKT_PREV_FLAG | capi.PKT_NEXT_FLAG, dtype=np.uint8)
     halves = np.where(flags & 1, 1024, 128).astype(np.int64)
     offs = np.concatenate([[0], np.cumsum(halves * CHANNELS)])
     pk = make_packets(frames)
@@ -175,47 +181,70 @@ def build_real_streams(torch, device, name, copies):
     return f, pk_all, d_res, d_posts, d_counts, t_front
 
 
-def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2):
-    """GPU-stage rate over `copies` x 3test.ogg + `copies` x issue6test.ogg, interleaved output."""
+REAL_FIXTURES = (("3test.ogg", 288094), ("issue6test.ogg", 548160))  # (file, decoded samples per channel)
+TOTAL_REAL_STREAMS = 1024  # BASELINE configs[4]; global stream s plays fixture s % 2
+
+
+def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, before_timing=None, reduce_time=None):
+    """GPU-stage rate over real stereo streams, interleaved output, decoded spectra device-resident.
+    `copies` streams of each fixture, or `plan` = [global ids playing fixture 0, global ids playing fixture 1]
+    (one decoder group per fixture: streams of a group share a setup header).  Returns (seconds per step, samples,
+    host entropy-decode seconds a real host would spend, {global id: (samples, PCM checksum)})."""
     from vorbispizza_amd import Decoder, SynthError, capi
+    if plan is None:
+        plan = [list(range(0, 2 * copies, 2)), list(range(1, 2 * copies, 2))]
     groups = []
     total_samples = 0
     t_front_total = 0.0
-    for name, samples in (("3test.ogg", 288094), ("issue6test.ogg", 548160)):
-        f, pk, res, posts, counts, t_front = build_real_streams(torch, device, name, copies)
+    for (name, samples), ids in zip(REAL_FIXTURES, plan):
+        n = len(ids)
+        if n == 0:
+            continue
+        f, pk, res, posts, counts, t_front = build_real_streams(torch, device, name, n)
         dec = Decoder(ctx, f.channels, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings,
-                      n_streams=copies)
+                      n_streams=n)
         cap = samples + 2048
-        out = torch.empty(copies * cap * f.channels, device=device, dtype=torch.float32)
-        offs = np.arange(copies, dtype=np.int64) * cap * f.channels
-        groups.append((dec, pk, res, posts, counts, out, offs, cap, samples, f.channels))
-        total_samples += copies * samples * f.channels
-        t_front_total += t_front * copies  # a real host decodes every stream; we decoded one copy
+        out = torch.empty(n * cap * f.channels, device=device, dtype=torch.float32)
+        offs = np.arange(n, dtype=np.int64) * cap * f.channels
+        groups.append((dec, pk, res, posts, counts, out, offs, cap, samples, f.channels, ids))
+        total_samples += n * samples * f.channels
+        t_front_total += t_front * n  # a real host decodes every stream; we decoded one copy
 
     def step():
-        for dec, pk, res, posts, counts, out, offs, cap, samples, ch in groups:
+        for dec, pk, res, posts, counts, out, offs, cap, samples, ch, ids in groups:
             dec.reset(-1)
             try:
                 w = dec.synth_raw(pk, res, posts, counts, out, offs, cap, capi.OUT_INTERLEAVED, 0, capi.MEM_DEVICE)
             except SynthError as e:  # issue6test.ogg's trailing empty packet (skipped, like the reference's throw)
                 assert e.status == capi.E_WINDOW_MISMATCH
-                continue
-            assert int(w[0]) == samples, (int(w[0]), samples)
+                w = None
+            if w is not None:
+                assert int(w[0]) == samples, (int(w[0]), samples)
 
     for _ in range(warmup):
         step()
     ctx.synchronize()
+    if before_timing:
+        before_timing()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    for g in groups:
-        g[0].close()
-    return dt, total_samples, t_front_total
+    if reduce_time:
+        dt = reduce_time(dt)
+    # per-stream PCM checksum: the sum of the stream's float32 bit patterns as integers (exact, order independent)
+    results = {}
+    for dec, pk, res, posts, counts, out, offs, cap, samples, ch, ids in groups:
+        view = out.view(len(ids), cap * ch)[:, : samples * ch].contiguous().view(torch.int32)
+        sums = view.sum(dim=1, dtype=torch.int64).cpu().numpy()
+        for sid, c in zip(ids, sums):
+            results[sid] = (samples, int(c))
+        dec.close()
+    return dt, total_samples, t_front_total, results
 
 
-def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2):
+def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2, plan=None):
     """configs[4] end to end for one GPU's share: every one of the 2 x `copies` streams is opened and
     entropy-decoded on the host (`threads` host threads, one stream at a time each -- the reference's model
     of one decoder per thread), straight into pinned batch buffers; the streams go to the GPU in sub-batches
@@ -232,21 +261,24 @@ def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2):
     def pinned(n, dtype):
         return torch.empty(n, dtype=dtype, pin_memory=True).numpy()
 
-    sub = min(sub, copies)
-    assert copies % sub == 0
+    per_kind = [copies, copies] if plan is None else [len(ids) for ids in plan]
     lanes = [ctx] + [Context(ctx.device) for _ in range(max(1, synth_lanes) - 1)]
     groups = []
-    for name, samples in (("3test.ogg", 288094), ("issue6test.ogg", 548160)):
+    for (name, samples), copies in zip(REAL_FIXTURES, per_kind):
+        if copies == 0:
+            continue
+        sub_k = max(d for d in range(1, min(sub, copies) + 1) if copies % d == 0)  # streams per synth call
         data = open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
         probe = OggVorbisFile(data)
         n, C_, rf = probe.audio_packets, probe.channels, probe.info.residue_floats
         g = {"data": data, "probe": probe, "n": n, "C": C_, "rf": rf, "samples": samples, "cap": samples + 2048,
+             "copies": copies, "sub": sub_k,
              "pk": capi.make_packets(n * copies), "res": pinned(rf * copies, torch.float32),
              "posts": pinned(n * copies * C_ * 64, torch.int16).reshape(n * copies * C_, 64),
              "counts": pinned(n * copies * C_, torch.uint8),
              "out": pinned(copies * (samples + 2048) * C_, torch.float32),
              "decs": [Decoder(lanes[b % len(lanes)], C_, probe.block_size0, probe.block_size1, floors=probe.floors,
-                              mappings=probe.mappings, n_streams=sub) for b in range(copies // sub)]}
+                              mappings=probe.mappings, n_streams=sub_k) for b in range(copies // sub_k)]}
         groups.append(g)
 
     def decode_one(job):
@@ -254,11 +286,11 @@ def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2):
         f = OggVorbisFile(g["data"])
         n, C_, rf = g["n"], g["C"], g["rf"]
         f.decode_into(g["pk"][k * n:(k + 1) * n], g["res"][k * rf:(k + 1) * rf], g["posts"][k * n * C_:(k + 1) * n * C_],
-                      g["counts"][k * n * C_:(k + 1) * n * C_], stream_id=k % sub, residue_base=(k % sub) * rf)
+                      g["counts"][k * n * C_:(k + 1) * n * C_], stream_id=k % g["sub"], residue_base=(k % g["sub"]) * rf)
         f.close()
 
     def synth_sub(g, b):
-        n, C_, rf, cap = g["n"], g["C"], g["rf"], g["cap"]
+        n, C_, rf, cap, sub = g["n"], g["C"], g["rf"], g["cap"], g["sub"]
         lo, hi = b * sub, (b + 1) * sub
         dec = g["decs"][b]
         dec.reset(-1)
@@ -280,8 +312,8 @@ def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2):
     with ThreadPoolExecutor(max_workers=threads) as pool, ThreadPoolExecutor(max_workers=len(lanes)) as synth_pool:
         for _ in range(3):
             t0 = time.perf_counter()
-            futs = [(g, b, [pool.submit(decode_one, (g, k)) for k in range(b * sub, (b + 1) * sub)])
-                    for g in groups for b in range(copies // sub)]
+            futs = [(g, b, [pool.submit(decode_one, (g, k)) for k in range(b * g["sub"], (b + 1) * g["sub"])])
+                    for g in groups for b in range(g["copies"] // g["sub"])]
             pending = []
             t_dec_done = t0
             for g, b, fs in futs:
@@ -298,7 +330,7 @@ def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2):
             d.close()
     for c in lanes[1:]:
         c.close()
-    total = sum(copies * g["samples"] * g["C"] for g in groups)
+    total = sum(g["copies"] * g["samples"] * g["C"] for g in groups)
     return total, best
 
 
@@ -359,9 +391,15 @@ def main():
     from vorbispizza_amd import sharding
     world, rank, local_rank = sharding.env_world()
     distributed = world > 1
+    # Rehearsal of the N > 1 path on a one-GPU box (never what the driver runs): VPZ_BENCH_REHEARSAL=1 puts every rank
+    # on device 0 and takes gloo for the barrier / reductions (RCCL refuses two ranks on one GPU).
+    rehearsal = distributed and os.environ.get("VPZ_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if distributed:
         torch.cuda.set_device(local_rank)
-        sharding.init("nccl")  # RCCL; used only for the barrier and the max-over-ranks of the timing
+        sharding.init("gloo" if rehearsal else "nccl")  # RCCL; only the barrier, the max-over-ranks of the timing
+                                                        # and the merge of per-stream counts / checksums use it
     if rank == 0:
         ge.build()
     if distributed:
@@ -371,6 +409,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     ctx = Context(local_rank)
+    red_device = "cpu" if rehearsal else device  # where the tiny reduction tensors live
 
     # ---------------- configs[1]: batched long-block IMDCT, device-resident
     count = FRAMES * CHANNELS
@@ -394,8 +433,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if distributed:
-        elapsed = sharding.max_over_ranks(elapsed, device)
-        kernel_ms = sharding.max_over_ranks(kernel_ms, device)
+        elapsed = sharding.max_over_ranks(elapsed, red_device)
+        kernel_ms = sharding.max_over_ranks(kernel_ms, red_device)
         sharding.barrier()
 
     samples_per_step = world * count * (N // 2)
@@ -429,12 +468,28 @@ def main():
         },
     }
 
+    extras = {}
+    if not args.no_extras:
+        del out, spectra
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline_imdct()
         if not args.no_extras:
-            extras = {}
-            del out
+            # north_star's literal line: batched stereo N=2048 IMDCT + window + OLA through the fused kernel
+            pk, residue, samples, res_floats = build_synth_ola(torch, device, args.extras_frames, all_long=True)
+            dec = Decoder(ctx, CHANNELS, 256, 2048)
+            dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 5, 2)
+            byt = 4 * res_floats + 4 * samples * CHANNELS
+            extras["north_star line: all-long N=2048 stereo IMDCT + window + OLA (fused synth kernel), %d frames, planar out"
+                   % args.extras_frames] = {
+                "Msamples_per_s": round(samples * CHANNELS / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
+                "roofline": {"bound": "hbm", "achieved": round(byt / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": byt,
+                             "bytes_per_sample": round(byt / (samples * CHANNELS), 3)},
+                "note": "whole vpz_decoder_synth call incl. host state machine + descriptor upload; 8 B per sample"}
+            dec.close()
+            del residue
             torch.cuda.empty_cache()
             # configs[2]
             pk, residue, samples, res_floats = build_synth_ola(torch, device, args.extras_frames)
@@ -456,18 +511,19 @@ def main():
             extras["configs[3] 6ch Residue2-interleaved + coupling + Floor1 on GPU, N=2048, %d frames" % args.extras_frames6] = {
                 "Msamples_per_s": round(samples6 * 6 / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "3 kernels (unwrap, de-interleave+coupling, fused floor+IMDCT+OLA); whole call"}
+                "note": "2 kernels (Floor1 unwrap; fused de-interleave + coupling + floor + IMDCT + OLA); whole call"}
             dec.close()
             del res6, posts, counts
             torch.cuda.empty_cache()
             # configs[4], one GPU's share: 128 stereo streams (64 x 3test.ogg + 64 x issue6test.ogg)
-            dt, tot, t_front = time_real_streams(ctx, torch, device, 64)
+            dt, tot, t_front, _ = time_real_streams(ctx, torch, device, 64)
             extras["configs[4] share of one GPU: 128 real stereo streams (64x 3test.ogg + 64x issue6test.ogg), "
                    "interleaved out, decoded spectra device-resident"] = {
                 "Msamples_per_s": round(tot / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
+                "algorithmic_GBps": round(8 * tot / dt / 1e9, 1), "frac_of_8TBps": round(8 * tot / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "cpu_entropy_decode_s_for_128_streams_1thread": round(t_front, 3),
                 "end_to_end_Msamples_per_s_incl_cpu_entropy_decode_1thread": round(tot / (dt + t_front) / 1e6, 2),
-                "note": "2 decoder groups (one per setup header); GPU stage = unwrap + de-interleave/coupling + fused synth"}
+                "note": "2 decoder groups (one per setup header); GPU stage = Floor1 unwrap + fused synth (group mode)"}
             thr = host_threads()
             tot_e, (t_all, t_dec, t_syn) = end_to_end_real_streams(ctx, torch, 64, thr)
             extras["configs[4] end to end, one GPU's share: 128 real stereo streams, container bytes in host memory "
@@ -478,7 +534,42 @@ def main():
                 "note": "sub-batches of 16 streams on 2 contexts: synth calls overlap the entropy decode of later sub-batches "
                         "and each other's PCIe copies; best of 3"}
             extras["configs[0] plumbing"] = cpu_plumbing_2test()
-            result["extra_workloads"] = extras
+    if not args.no_extras:
+        # ---------------- configs[4], the whole job: 1024 stereo streams partitioned over the ranks (strong scaling).
+        # Every rank decodes ONLY its contiguous shard of global stream ids (no data-path collective); what crosses
+        # ranks is two int64 vectors: per-stream sample counts and PCM checksums.
+        plan = sharding.plan_stream_shard(TOTAL_REAL_STREAMS, world, rank, n_kinds=len(REAL_FIXTURES))
+        sync = (lambda: sharding.barrier()) if distributed else None
+        reduce_t = (lambda t: sharding.max_over_ranks(t, red_device)) if distributed else None
+        dt, tot_local, _, local = time_real_streams(ctx, torch, device, 0, steps=5, warmup=2, plan=plan,
+                                                    before_timing=sync, reduce_time=reduce_t)
+        samples, sums = sharding.merge_stream_results(TOTAL_REAL_STREAMS, local, red_device)
+        # the same two fixtures decoded alone (one stream, one call): what a single-GPU run of the job produces
+        _, _, _, solo = time_real_streams(ctx, torch, device, 1, steps=1, warmup=0)
+        expect = sharding.combine_stream_checksums([solo[s % 2][1] for s in range(TOTAL_REAL_STREAMS)])
+        job_sum = sharding.combine_stream_checksums(sums)
+        tot = sum(samples) * 2
+        thr = host_threads()
+        tot_e_local, (t_all, t_dec, t_syn) = end_to_end_real_streams(ctx, torch, 0, thr, plan=plan)
+        if distributed:
+            sharding.barrier()
+            t_all = sharding.max_over_ranks(t_all, red_device)
+        per_rank = [sum(samples[s] for s in range(*sharding.shard_range(TOTAL_REAL_STREAMS, world, r))) * 2
+                    for r in range(world)]
+        extras["configs[4] whole job: 1024 real stereo streams (512x 3test.ogg + 512x issue6test.ogg) partitioned over "
+               "%d GPU(s), interleaved out" % world] = {
+            "gpu_stage_Msamples_per_s": round(tot / dt / 1e6, 1), "gpu_stage_ms_per_step_max_over_ranks": round(dt * 1e3, 3),
+            "gpu_stage_frac_of_8TBps_per_gpu": round(8 * tot / world / dt / 1e9 / HBM_PEAK_GBS, 4),
+            "end_to_end_Msamples_per_s": round(tot / t_all / 1e6, 1), "end_to_end_wall_ms_max_over_ranks": round(t_all * 1e3, 2),
+            "host_threads_per_rank": thr, "samples_total": tot, "samples_per_rank": per_rank,
+            "streams_per_rank": [sharding.shard_range(TOTAL_REAL_STREAMS, world, r)[1] -
+                                 sharding.shard_range(TOTAL_REAL_STREAMS, world, r)[0] for r in range(world)],
+            "pcm_checksum": "%016x" % job_sum, "checksum_equals_single_stream_decode": job_sum == expect,
+            "scaling": "strong (1024 streams in total)", "collectives_on_the_data_path": 0,
+            "note": "GPU stage: decoded spectra device-resident, 5 steps, barrier + max over ranks; end to end: container "
+                    "bytes in host memory -> PCM in host memory incl. CPU entropy decode, best of 3 per rank, max over ranks"}
+    if rank == 0 and extras:
+        result["extra_workloads"] = extras
     ctx.close()
     if distributed:
         sharding.finalize()

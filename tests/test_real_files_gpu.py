@@ -161,3 +161,47 @@ def test_random_synthetic_setups_decode_like_the_oracle(ctx, oracle, seed):
     inter = dec.synth(pk, res, posts, counts, out_layout=capi.OUT_INTERLEAVED)[0]
     assert np.array_equal(inter, planar.T)
     dec.close()
+
+
+def test_configs4_share_of_one_gpu_all_128_streams_both_layouts(ctx, oracle):
+    """BASELINE configs[4] at the size one GPU gets out of eight: 64 x 3test.ogg + 64 x issue6test.ogg as 128
+    independent streams, two decoder groups (one per setup header, StreamDecoder.cs:45-49 state per stream), every
+    one of the 128 outputs against the oracle, interleaved and planar."""
+    from vorbispizza_amd import Decoder, SynthError, capi
+    from vorbispizza_amd.front import OggVorbisFile
+    copies = 64
+    for name in ("3test.ogg", "issue6test.ogg"):
+        f = OggVorbisFile(os.path.join(GOLDEN, name))
+        pk, res, posts, counts = f.decode_packets()
+        opk = helpers.packets_for_oracle(f, pk, res, posts, counts)
+        ref, ref_pos, _ = helpers.oracle_decode(oracle, f.channels, f.block_size0, f.block_size1, opk, floors=f.floors,
+                                                mappings=f.mappings, interleave=True)
+        total, C_ = ref.shape
+        tol = 1e-5 * max(1.0, float(np.abs(ref).max()))
+        n = len(pk)
+        pk_all = np.tile(pk, copies)
+        pk_all["stream"] = np.repeat(np.arange(copies, dtype=np.int32), n)
+        # every stream reads its own copy of the residue, as separately decoded files would
+        res_all = np.tile(res, copies)
+        pk_all["residue_offset"] += np.repeat(np.arange(copies, dtype=np.int64) * res.size, n)
+        posts_all, counts_all = np.tile(posts, (copies, 1)), np.tile(counts, copies)
+        cap = total + 2048
+        for layout in (capi.OUT_INTERLEAVED, capi.OUT_PLANAR):
+            dec = Decoder(ctx, C_, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings, n_streams=copies)
+            out = np.zeros(copies * cap * C_, dtype=np.float32)
+            offs = np.arange(copies, dtype=np.int64) * cap * C_
+            try:
+                w = dec.synth_raw(pk_all, res_all, posts_all, counts_all, out, offs, cap, layout, cap, capi.MEM_HOST)
+            except SynthError as e:  # issue6test.ogg's last packet (the reference's OverlapBuffers throws on it)
+                assert e.status == capi.E_WINDOW_MISMATCH and name == "issue6test.ogg"
+                w = dec.last_packet_samples(len(pk_all)).reshape(copies, n).sum(axis=1)
+            assert (np.asarray(w) == total).all()
+            assert [dec.position(s) for s in range(copies)] == [ref_pos] * copies
+            blocks = out.reshape(copies, cap * C_)
+            worst = 0.0
+            for s in range(copies):
+                got = (blocks[s, : total * C_].reshape(total, C_) if layout == capi.OUT_INTERLEAVED
+                       else blocks[s].reshape(C_, cap)[:, :total].T)
+                worst = max(worst, float(np.abs(got - ref).max()))
+            assert worst <= tol, (name, layout, worst)
+            dec.close()

@@ -28,8 +28,18 @@ elapsed = time.perf_counter() - t0
 slowest = sharding.max_over_ranks(elapsed)
 total = sharding.sum_over_ranks(local_samples)
 assert slowest >= 0.1 - 1e-3
+# configs[4]: 1024 streams of two kinds (two fixtures / setup headers), every rank decodes only its shard and the
+# per-stream results (sample count, PCM checksum) are merged with one all-reduce
+plan = sharding.plan_stream_shard(1024, world, rank, n_kinds=2)
+assert [len(p) for p in plan] == [256, 256] and all(s %% 2 == k for k, ids in enumerate(plan) for s in ids)
+fake = lambda s: (288094 if s %% 2 == 0 else 548160, (0x9E3779B97F4A7C15 * (s %% 2 + 1)) & ((1 << 64) - 1))
+local = {s: fake(s) for ids in plan for s in ids}
+samples, sums = sharding.merge_stream_results(1024, local)
+assert samples == [fake(s)[0] for s in range(1024)] and sums == [fake(s)[1] for s in range(1024)]
+job_checksum = sharding.combine_stream_checksums(sums)
 if rank == 0:
-    print(json.dumps({"lo": lo, "hi": hi, "slowest": slowest, "total": total}))
+    print(json.dumps({"lo": lo, "hi": hi, "slowest": slowest, "total": total, "job_checksum": job_checksum,
+                      "job_samples": sum(samples)}))
 sharding.finalize()
 '''
 
@@ -65,3 +75,24 @@ def test_two_rank_gloo_run(tmp_path):
     assert (res["lo"], res["hi"]) == (0, 514)
     assert res["total"] == sum(1000 + s for s in range(1027))
     assert res["slowest"] >= 0.099
+    # the merged job equals what one process computes over all 1024 streams
+    from vorbispizza_amd import sharding
+    fake = lambda s: (288094 if s % 2 == 0 else 548160, (0x9E3779B97F4A7C15 * (s % 2 + 1)) & ((1 << 64) - 1))
+    assert res["job_samples"] == sum(fake(s)[0] for s in range(1024))
+    assert res["job_checksum"] == sharding.combine_stream_checksums([fake(s)[1] for s in range(1024)])
+    solo_samples, solo_sums = sharding.merge_stream_results(1024, {s: fake(s) for s in range(1024)})
+    assert sharding.combine_stream_checksums(solo_sums) == res["job_checksum"]
+
+
+def test_stream_plan_covers_every_stream_once_and_keeps_the_mix():
+    sys.path.insert(0, ROOT)
+    from vorbispizza_amd import sharding
+    for world in (1, 2, 4, 8, 3):
+        seen = []
+        for r in range(world):
+            plan = sharding.plan_stream_shard(1024, world, r, n_kinds=2)
+            seen += [s for ids in plan for s in ids]
+            if 1024 % (2 * world) == 0:
+                assert len(plan[0]) == len(plan[1]) == 512 // world
+        assert sorted(seen) == list(range(1024))
+    assert sharding.combine_stream_checksums({0: 5, 3: 7}) == 5 + 4 * 7

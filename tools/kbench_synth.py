@@ -41,7 +41,7 @@ def main():
               % (dt * 1e3, samples6 * 6 / dt / 1e6, byt / dt / 1e9))
         dec.close()
     if args.which in ("both", "real"):
-        dt, tot, _ = bench.time_real_streams(ctx, torch, dev, 64, steps=args.steps)
+        dt, tot, _, _ = bench.time_real_streams(ctx, torch, dev, 64, steps=args.steps)
         print("configs[4] share (128 real stereo streams, interleaved out): %.3f ms/step  %.1f Msamples/s"
               % (dt * 1e3, tot / dt / 1e6))
     ctx.close()

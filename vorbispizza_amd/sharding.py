@@ -22,6 +22,45 @@ def owner_of(item, n_items, world_size):
     return min(world_size - 1, item // max(per, 1))
 
 
+def plan_stream_shard(n_streams, world_size, rank, n_kinds=1):
+    """The streams a rank decodes: its contiguous range of GLOBAL stream ids, split by kind (global stream s is of
+    kind s % n_kinds -- e.g. which setup header / fixture it uses -- so that every rank gets the same mix and one
+    decoder group per kind).  Returns [ids of kind 0, ids of kind 1, ...]."""
+    lo, hi = shard_range(n_streams, world_size, rank)
+    return [[s for s in range(lo, hi) if s % n_kinds == k] for k in range(n_kinds)]
+
+
+_MASK64 = (1 << 64) - 1
+
+
+def combine_stream_checksums(checksums):
+    """Checksum of per-stream checksums, independent of which rank decoded which stream: {global id: c} or a
+    sequence indexed by global id -> sum of (id + 1) * c mod 2^64."""
+    items = checksums.items() if hasattr(checksums, "items") else enumerate(checksums)
+    total = 0
+    for sid, c in items:
+        total = (total + (int(sid) + 1) * (int(c) & _MASK64)) & _MASK64
+    return total
+
+
+def merge_stream_results(n_streams, local, device="cpu"):
+    """local: {global stream id: (samples, checksum)} of the streams THIS rank decoded.  Returns two lists indexed
+    by global id -- samples per channel and PCM checksum of every stream of the job -- after one SUM all-reduce of
+    two int64 vectors (every stream has exactly one owner; the PCM itself never crosses ranks)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.zeros((2, n_streams), dtype=torch.int64)
+    for sid, (samples, checksum) in local.items():
+        c = int(checksum) & _MASK64
+        t[0, sid] = int(samples)
+        t[1, sid] = c - (1 << 64) if c >= (1 << 63) else c   # two's complement: int64 carries the 64 bits
+    if dist.is_available() and dist.is_initialized():
+        t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t = t.cpu()
+    return [int(v) for v in t[0]], [int(v) & _MASK64 for v in t[1]]
+
+
 def env_world():
     """(world_size, rank, local_rank) from the torch.distributed.run environment."""
     return (int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),
