@@ -1,0 +1,45 @@
+"""Build check (no GPU): no kernel of the library may spill to scratch memory.
+
+Round 1 shipped synth_kernel instantiations with 32-124 B/lane of scratch (interleaved output for channel counts
+other than 2, every 512 / 1024 block-size variant) that nobody had looked at because only three instantiations were
+benchmarked.  This test compiles every translation unit with the compiler's `-Rpass-analysis=kernel-resource-usage`
+remarks (tools/kernel_resources.py) and fails on ScratchSize > 0 -- for ALL kernels, not only the hot ones -- and on
+an occupancy below what the LDS budget of synth_kernel is sized for."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    sys.path.insert(0, ROOT)
+    from vorbispizza_amd import _build
+    if not (shutil.which(_build._hipcc()) or os.path.exists(_build._hipcc())):
+        pytest.skip("no hipcc")
+    import kernel_resources as kr
+    out = {}
+    for src, extra in kr.all_units():
+        for k in kr.analyse(src, extra):
+            out[k["name"]] = dict(k, unit=os.path.basename(src))
+    return out
+
+
+def test_no_kernel_uses_scratch_memory(kernels):
+    assert len(kernels) >= 30
+    spilling = {k["name"]: k["scratch"] for k in kernels.values() if k.get("scratch", 0) > 0}
+    assert not spilling, "kernels with scratch memory (bytes per lane): %r" % spilling
+
+
+def test_every_synth_kernel_instantiation_is_built_and_keeps_two_workgroups_per_cu(kernels):
+    synth = [k for k in kernels.values() if "synth_kernel" in k["name"]]
+    # <floor?, planar / interleaved / stereo pair, general sizes?, group mode?>
+    assert len(synth) == 2 * 3 * 2 * 2
+    for k in synth:
+        assert k["vgprs"] <= 128, k["name"]            # 4 waves per SIMD: 512 / 4
+        assert k["lds"] <= 80 * 1024, (k["name"], k["lds"])  # two 8-wave workgroups per CU (160 KiB)
+        assert k.get("occupancy", 4) >= 4, k["name"]

@@ -490,39 +490,43 @@ __device__ __forceinline__ float tail_at(const float *tail, int q, int pn4)
     return q < 3 * pn4 ? tail[q - 2 * pn4] : tail[4 * pn4 - 1 - q];
 }
 
+// the two floor-table indices (bytes) of bins 2k, 2k+1 for each of the lane's 8 points
+// (`lpb`: lanes per block = block size / 32: 64 for 2048, 32 / 16 for 1024 / 512, 8 for 256; a block smaller than
+// 2048 is transformed by every lane group of the wave at once, the first group's copy is the one used)
+// (packed two points to a register: byte 0 / 1 = point 2j, byte 2 / 3 = point 2j + 1)
+__device__ __forceinline__ void load_floor_indices(uint32_t (&fy)[4], const uint8_t *row, int lpb, int lane)
+{
+    const uint16_t *s = reinterpret_cast<const uint16_t *>(row);
+    const int k0 = lane & (lpb - 1);
+    const int st = lpb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fy[j] = (uint32_t)s[k0 + st * (2 * j)] | ((uint32_t)s[k0 + st * (2 * j + 1)] << 16);
+}
+// Floor1.Apply's multiply (Floor1.cs:383,395) on the lane's 8 points
+__device__ __forceinline__ void apply_floor(float2 (&x)[8], const uint32_t (&fy)[4], const float *s_db)
+{
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const uint32_t v = fy[m >> 1] >> (16 * (m & 1));
+        x[m].x *= s_db[v & 0xFFu];
+        x[m].y *= s_db[(v >> 8) & 0xFFu];
+    }
+}
+
 // Builds h of one channel-block into the wave-private LDS buffer `hbuf`:
 // (optional) Floor1 curve x spectrum, then the inverse MDCT.  kLong selects N = 2048 / 256.
 template <bool kHasFloor, bool kLong>
-__device__ __forceinline__ void build_block(uint32_t fd_flags, int lane, float2 (&x)[8], const uint32_t (&fy)[8],
+__device__ __forceinline__ void build_block(uint32_t fd_flags, int lane, float2 (&x)[8], const uint32_t (&fy)[4],
                                             float *hbuf, const float2 *s_twL, const float2 *s_twAB,
                                             const float2 *s_twBC, const float2 *s_twS, const float *s_db)
 {
-    if (kHasFloor && !(fd_flags & kFrameNoFloor)) {
-        // Floor1.Apply's multiply (Floor1.cs:383,395): fy[m] holds the two table indices of bins 2k, 2k+1
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            x[m].x *= s_db[fy[m] & 0xFFu];
-            x[m].y *= s_db[(fy[m] >> 8) & 0xFFu];
-        }
-    }
+    if (kHasFloor && !(fd_flags & kFrameNoFloor)) apply_floor(x, fy, s_db);
     if (kLong) {
         imdct2048_wave(x, reinterpret_cast<float2 *>(hbuf), s_twL, s_twAB, s_twBC, lane);
     } else {
         // all eight lane groups transform the same short block; group 0's copy lands at hbuf[0..128)
         imdct256_wave8(x, reinterpret_cast<float2 *>(hbuf), s_twS, s_twBC, lane);
     }
-}
-
-// the two floor-table indices (bytes) of bins 2k, 2k+1 for each of the lane's 8 points
-// (`lpb`: lanes per block = block size / 32: 64 for 2048, 32 / 16 for 1024 / 512, 8 for 256; a block smaller than
-// 2048 is transformed by every lane group of the wave at once, the first group's copy is the one used)
-__device__ __forceinline__ void load_floor_indices(uint32_t (&fy)[8], const uint8_t *row, int lpb, int lane)
-{
-    const uint16_t *s = reinterpret_cast<const uint16_t *>(row);
-    const int k0 = lane & (lpb - 1);
-    const int st = lpb;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) fy[m] = s[k0 + st * m];
 }
 
 // this wave's channel of a planar packet: (X[2k], X[2k+1]) for the lane's 8 points (global memory or an LDS row)
@@ -770,7 +774,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     // Floor1 curve of a frame's channel: table indices rendered into this wave's LDS row (it must be free), the
     // lane's 16 indices into fy.  Group mode renders the NEXT frame's curve at the end of an iteration -- the row is
     // free then, and the work overlaps the drain of the frame's PCM stores instead of sitting on the barrier chain.
-    auto render_curve = [&](const FrameDesc &f, int cp, uint32_t (&fy)[8]) {
+    auto render_curve = [&](const FrameDesc &f, int cp, uint32_t (&fy)[4]) {
         // lanes below the record's post count hold a post; only post 0 (x = 0) can be all zero bits
         const int m = __builtin_amdgcn_readfirstlane(__popcll(__ballot(cp != 0 || lane == 0)));
         render_floor_indices<32>(reinterpret_cast<uint8_t *>(hcur), reinterpret_cast<int *>(hcur) + 256,
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         load_floor_indices(fy, reinterpret_cast<const uint8_t *>(hcur), lpb_of(f.flags), lane);
         __builtin_amdgcn_wave_barrier();
     };
-    uint32_t fycur[8];
+    uint32_t fycur[4];
     if (kHasFloor && kGroup && run.count > 0 && !(fd_next.flags & (kFrameDrain | kFrameNoFloor)) && excur && !(a.ablate & 8))
         render_curve(fd_next, cpcur, fycur);
     for (int it = 0; it < iters; ++it) {
@@ -847,6 +851,11 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         // ---- free-running waves render the curve here, right before the row is needed for the transform
         if (kHasFloor && !kGroup && exec && !(fd.flags & kFrameNoFloor) && !(a.ablate & 8)) render_curve(fd, cpcur, fycur);
         if (build) {
+            // The transforms address LDS by lane-derived indices that do not depend on the frame: computed ahead of the
+            // frame loop they would all stay live across it (and spill in the variants that are short of registers);
+            // an opaque lane id keeps them inside the iteration that uses them.
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
             if (!exec) {
                 // Mapping.cs:190-194: the channel is silent, its whole block is zero
                 for (int i = lane; i < 2 * n4; i += 64) hcur[i] = 0.0f;
@@ -860,22 +869,16 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 const float2 *tw = use_long ? s_twL : s_twS;
                 const float2 *ab = use_long ? s_twL + kFastTwABOffset : s_twS + 256;
                 const float2 *bc = use_long ? s_twL + kFastTwBCOffset : s_twS + 512;
-                if (kHasFloor && !(fd.flags & kFrameNoFloor)) {
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) {
-                        xcur[m].x *= s_db[fycur[m] & 0xFFu];
-                        xcur[m].y *= s_db[(fycur[m] >> 8) & 0xFFu];
-                    }
-                }
+                if (kHasFloor && !(fd.flags & kFrameNoFloor)) apply_floor(xcur, fycur, s_db);
                 float2 *h2 = reinterpret_cast<float2 *>(hcur);
-                if (nblk == 2048) imdct2048_wave(xcur, h2, tw, ab, bc, lane);
-                else if (nblk == 1024) imdct_mid_wave<4>(xcur, h2, tw, ab, bc, lane);
-                else if (nblk == 512) imdct_mid_wave<2>(xcur, h2, tw, ab, bc, lane);
-                else imdct256_wave8(xcur, h2, tw, bc, lane);
+                if (nblk == 2048) imdct2048_wave(xcur, h2, tw, ab, bc, ln);
+                else if (nblk == 1024) imdct_mid_wave<4>(xcur, h2, tw, ab, bc, ln);
+                else if (nblk == 512) imdct_mid_wave<2>(xcur, h2, tw, ab, bc, ln);
+                else imdct256_wave8(xcur, h2, tw, bc, ln);
             } else if (is_long) {
-                build_block<kHasFloor, true>(fd.flags, lane, xcur, fycur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
+                build_block<kHasFloor, true>(fd.flags, ln, xcur, fycur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
             } else {
-                build_block<kHasFloor, false>(fd.flags, lane, xcur, fycur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
+                build_block<kHasFloor, false>(fd.flags, ln, xcur, fycur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
             }
         }
 
