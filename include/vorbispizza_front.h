@@ -1,5 +1,5 @@
 /*
- * vorbis_front.h -- C entry points of the C++ CPU front end.
+ * vorbispizza_front.h -- C entry points of the C++ CPU front end, libvorbispizza_host.so.
  *
  * This is the part the real host (the C# VorbisReader / StreamDecoder) keeps on the CPU: Ogg page sync +
  * CRC + lacing -> packets (Ogg/PageReaderBase.cs, Ogg/PacketProvider.cs:427-560), the three Vorbis
@@ -14,7 +14,7 @@
 
 #include <stdint.h>
 
-#include "../../include/vorbispizza_synth.h"
+#include "vorbispizza_synth.h"
 
 #ifdef __cplusplus
 extern "C" {

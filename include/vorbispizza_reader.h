@@ -1,5 +1,5 @@
 /*
- * vorbis_reader.h -- C entry points of the host-side mirror of VorbisReader / StreamDecoder.Read
+ * vorbispizza_reader.h -- C entry points (libvorbispizza_host.so) of the host-side mirror of VorbisReader / StreamDecoder.Read
  * (VorbisReader.cs:232-253, StreamDecoder.cs:407-498) built above the C ABI.  See vorbis_reader.cpp.
  */
 #ifndef VORBISPIZZA_READER_H
@@ -7,7 +7,7 @@
 
 #include <stdint.h>
 
-#include "../../include/vorbispizza_synth.h"
+#include "vorbispizza_synth.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -27,6 +27,11 @@ int     vpzr_is_end_of_stream(vpzr_reader *r);
 int     vpzr_has_clipped(vpzr_reader *r);          /* IStreamDecoder.HasClipped */
 int     vpzr_set_clip_samples(vpzr_reader *r, int clip);      /* ClipSamples; default true (VorbisReader.cs:71) */
 int     vpzr_set_batch_packets(vpzr_reader *r, int packets);  /* packets synthesised per GPU call (default 128) */
+/* Sample format of the read calls, fixed before the first read: float32 (default) or the 16-bit samples the reference's
+ * tests derive from them, `(int)(x * 32768f)` clamped (AssetTest.cs:131-132) -- converted on the GPU. */
+#define VPZR_FORMAT_F32 0
+#define VPZR_FORMAT_S16 1
+int     vpzr_set_sample_format(vpzr_reader *r, int format);
 
 /* `SeekTo(long samplePosition, SeekOrigin seekOrigin)` (StreamDecoder.cs:815-881) and `TotalSamples`.
  * Positions are counted samples per channel (see vpzh_seek).  VPZ_E_INVALID_ARG outside the stream
@@ -40,6 +45,8 @@ int64_t vpzr_total_samples(vpzr_reader *r);
 /* `ReadSamples(Span<float> buffer)`: interleaved, returns samples per channel, at most one packet's
  * worth per call, 0 at the end of the stream.  *status receives a VPZ_* code. */
 int64_t vpzr_read_samples(vpzr_reader *r, float *buffer, int64_t buffer_len, int *status);
+/* The same call delivering 16-bit samples (VPZR_FORMAT_S16 readers only). */
+int64_t vpzr_read_samples_s16(vpzr_reader *r, int16_t *buffer, int64_t buffer_len, int *status);
 /* `ReadSamples(Span<float> buffer, int samplesToRead, int channelStride)`: planar. */
 int64_t vpzr_read_samples_planar(vpzr_reader *r, float *buffer, int64_t buffer_len, int64_t samples_to_read,
                                  int64_t channel_stride, int *status);

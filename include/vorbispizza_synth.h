@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VPZ_ABI_VERSION 1
+#define VPZ_ABI_VERSION 2   /* 2: s16 output layouts, VPZ_PKT_RESYNC, vpz_decoder_set_position; structs unchanged */
 
 /* ---- status codes (negative like the OV_* codes, Vorbisfile.cs:10-24) ---- */
 #define VPZ_OK                 0
@@ -167,6 +167,12 @@ typedef struct vpz_packet {
 /* Output placement == the two public Read overloads (Contracts/IStreamDecoder.cs:126,151). */
 #define VPZ_OUT_INTERLEAVED 0   /* StoreInterleaved: dst[i*channels + ch]            */
 #define VPZ_OUT_PLANAR      1   /* StoreContiguous : dst[ch*channel_stride + off + i] */
+/* The same two placements with 16-bit samples: `pcm_out` points to int16_t, every sample is what the reference's own
+ * tests compute from the float -- `(int)(x * 32768f)` clamped to the short range (NVorbis.Tests/AssetTest.cs:131-132),
+ * applied after the optional clip -- and stream_out_offset / stream_out_capacity / channel_stride count int16
+ * elements.  Fused into the store: half the PCM bytes leave the GPU. */
+#define VPZ_OUT_INTERLEAVED_S16 2
+#define VPZ_OUT_PLANAR_S16      3
 
 int  vpz_decoder_create(vpz_context *ctx, const vpz_stream_config *cfg, int32_t n_streams,
                         vpz_decoder **out);
@@ -195,7 +201,7 @@ int  vpz_decoder_reset(vpz_decoder *dec, int32_t stream);
 int vpz_decoder_synth(vpz_decoder *dec, int64_t n_packets, const vpz_packet *packets,
                       const float *residue, const int16_t *posts, const uint8_t *post_counts,
                       int mem_space,
-                      float *pcm_out, const int64_t *stream_out_offset, int64_t stream_out_capacity,
+                      void *pcm_out, /* float32, or int16 for the _S16 layouts */ const int64_t *stream_out_offset, int64_t stream_out_capacity,
                       int out_layout, int64_t channel_stride,
                       int64_t *samples_written);
 

@@ -39,9 +39,39 @@ def test_header_symbols_are_exported(capi):
         assert hasattr(L, s), "missing export " + s
 
 
+def test_host_library_headers_are_exported_and_plain_c(capi, tmp_path):
+    """include/vorbispizza_front.h (vpzh_*) and include/vorbispizza_reader.h (vpzr_*) -- the C interfaces of
+    libvorbispizza_host.so the drop-in C# reader binds: every declared symbol is exported, the
+    headers compile as C99 on their own, and vpzh_info has the layout the ctypes / C# mirror assumes."""
+    import shutil
+    import subprocess
+    from vorbispizza_amd import front
+    L = front.lib()
+    for header, prefix, least in (("vorbispizza_front.h", "vpzh_", 14), ("vorbispizza_reader.h", "vpzr_", 14)):
+        syms = header_symbols(header, prefix)
+        assert len(syms) >= least, (header, syms)
+        for s in syms:
+            assert hasattr(L, s), "missing export " + s
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    fields = [n for n, _ in front.Info._fields_]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vorbispizza_reader.h"', '#include "vorbispizza_front.h"',
+             '#include "vorbispizza_synth_debug.h"', 'int main(void) {', 'printf("size %zu\\n", sizeof(vpzh_info));']
+    lines += ['printf("%s %%zu\\n", offsetof(vpzh_info, %s));' % (f, f) for f in fields] + ['return 0; }']
+    src = tmp_path / "host_layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "host_layout"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                    "-o", str(exe)], check=True, capture_output=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(got["size"]) == C.sizeof(front.Info)
+    for f in fields:
+        assert int(got[f]) == getattr(front.Info, f).offset, f
+
+
 def test_abi_version_and_error_strings(capi):
     L = capi.lib()
-    assert L.vpz_abi_version() == 1
+    assert L.vpz_abi_version() == 2
     assert L.vpz_error_string(0) == b"ok"
     for code in range(-7, 0):
         assert L.vpz_error_string(code) not in (b"ok", b"unknown status")

@@ -37,8 +37,8 @@ def test_no_kernel_uses_scratch_memory(kernels):
 
 def test_every_synth_kernel_instantiation_is_built_and_keeps_two_workgroups_per_cu(kernels):
     synth = [k for k in kernels.values() if "synth_kernel" in k["name"]]
-    # <floor?, planar / interleaved / stereo pair, general sizes?, group mode?>
-    assert len(synth) == 2 * 3 * 2 * 2
+    # <floor?, planar / interleaved / stereo pair, general sizes?, group mode?, float32 / int16 samples>
+    assert len(synth) == 2 * 3 * 2 * 2 * 2
     for k in synth:
         assert k["vgprs"] <= 128, k["name"]            # 4 waves per SIMD: 512 / 4
         assert k["lds"] <= 80 * 1024, (k["name"], k["lds"])  # two 8-wave workgroups per CU (160 KiB)

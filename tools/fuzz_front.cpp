@@ -5,7 +5,7 @@
 #include <cstdlib>
 #include <random>
 #include <vector>
-#include "vorbis_front.h"
+#include "vorbispizza_front.h"
 static std::vector<uint8_t> slurp(const char *p){ FILE*f=fopen(p,"rb"); std::vector<uint8_t> d; if(!f) return d; fseek(f,0,SEEK_END); long n=ftell(f); fseek(f,0,SEEK_SET); d.resize(n); if(fread(d.data(),1,n,f)!=(size_t)n) d.clear(); fclose(f); return d; }
 static uint32_t crc_tab[256];
 static void crc_init(){ for(uint32_t i=0;i<256;++i){ uint32_t r=i<<24; for(int k=0;k<8;++k) r=(r&0x80000000u)?((r<<1)^0x04C11DB7u):(r<<1); crc_tab[i]=r; } }

@@ -52,8 +52,9 @@ def build_host(force=False, verbose=False):
     the VorbisReader / StreamDecoder.Read mirror, which calls the C ABI of libvorbispizza_synth.so."""
     os.makedirs(LIB_DIR, exist_ok=True)
     srcs = [os.path.join(HOST_DIR, "vorbis_front.cpp"), os.path.join(HOST_DIR, "vorbis_reader.cpp")]
-    deps = srcs + [os.path.join(HOST_DIR, "vorbis_front.h"), os.path.join(HOST_DIR, "vorbis_reader.h"),
-                   os.path.join(_HERE, "..", "include", "vorbispizza_synth.h"), LIB_PATH]
+    inc = os.path.join(_HERE, "..", "include")
+    deps = srcs + [os.path.join(inc, "vorbispizza_front.h"), os.path.join(inc, "vorbispizza_reader.h"),
+                   os.path.join(inc, "vorbispizza_synth.h"), LIB_PATH]
     stale = force or not os.path.exists(HOST_LIB_PATH) or any(
         os.path.exists(d) and os.path.getmtime(d) > os.path.getmtime(HOST_LIB_PATH) for d in deps)
     if stale:

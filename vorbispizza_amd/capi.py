@@ -15,7 +15,7 @@ OK = 0
 E_INVALID_ARG, E_UNSUPPORTED, E_HIP, E_NOMEM, E_WINDOW_MISMATCH, E_NO_DEVICE, E_CAPACITY = -1, -2, -3, -4, -5, -6, -7
 MEM_HOST, MEM_DEVICE = 0, 1
 IMDCT_FAST, IMDCT_EXACT = 0, 1
-OUT_INTERLEAVED, OUT_PLANAR = 0, 1
+OUT_INTERLEAVED, OUT_PLANAR, OUT_INTERLEAVED_S16, OUT_PLANAR_S16 = 0, 1, 2, 3
 PKT_BLOCK_FLAG, PKT_PREV_FLAG, PKT_NEXT_FLAG, PKT_EOS = 0x01, 0x02, 0x04, 0x08
 PKT_NOT_DECODED, PKT_INTERLEAVED, PKT_NO_FLOOR, PKT_RESYNC = 0x10, 0x20, 0x40, 0x80
 MAX_FLOOR1_POSTS, POSTS_STRIDE, MAX_CHANNELS, MAX_COUPLING = 65, 64, 255, 256
@@ -296,7 +296,7 @@ class Decoder:
 
     def synth(self, packets, residue, posts=None, post_counts=None, out_layout=OUT_PLANAR, capacity=None):
         """Host-memory convenience: returns a list (per stream) of PCM arrays, [channels, samples]
-        for OUT_PLANAR or [samples, channels] for OUT_INTERLEAVED."""
+        for OUT_PLANAR or [samples, channels] for OUT_INTERLEAVED (int16 arrays for the _S16 layouts)."""
         packets = np.ascontiguousarray(packets, dtype=PACKET_DTYPE)
         residue = np.ascontiguousarray(residue, dtype=np.float32)
         if posts is not None:
@@ -308,14 +308,15 @@ class Decoder:
                 per[s] += (self.size1 if f & PKT_BLOCK_FLAG else self.size0)
             capacity = int(per.max()) + 1
         C_ = self.channels
-        out = np.zeros(self.n_streams * C_ * capacity, dtype=np.float32)
+        s16 = out_layout in (OUT_INTERLEAVED_S16, OUT_PLANAR_S16)
+        out = np.zeros(self.n_streams * C_ * capacity, dtype=np.int16 if s16 else np.float32)
         offs = np.arange(self.n_streams, dtype=np.int64) * (C_ * capacity)
         written = self.synth_raw(packets, residue, posts, post_counts, out, offs, capacity, out_layout,
                                  capacity, MEM_HOST)
         res = []
         for s in range(self.n_streams):
             blk = out[offs[s]: offs[s] + C_ * capacity]
-            if out_layout == OUT_PLANAR:
+            if out_layout in (OUT_PLANAR, OUT_PLANAR_S16):
                 res.append(blk.reshape(C_, capacity)[:, :written[s]].copy())
             else:
                 res.append(blk[: written[s] * C_].reshape(written[s], C_).copy())

@@ -101,6 +101,7 @@ struct SynthArgs {
     const int64_t *stream_out_off;  // nullptr => 0
     int64_t channel_stride;
     int32_t interleaved;
+    int32_t s16;                // PCM as int16 (`(int)(x * 32768f)` clamped) instead of float32
     int32_t clip;
     int32_t *clipped;           // [stream] sticky HasClipped
     int32_t ablate;             // tuning only (VPZ_SYNTH_ABLATE): 1 skip PCM stores, 2 skip IMDCT, 4 skip loads

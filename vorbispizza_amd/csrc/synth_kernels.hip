@@ -15,6 +15,7 @@
 // PCM out (8 B per sample for long blocks).  The block before a run's first is recomputed (one
 // redundant IMDCT per run) or taken from the decoder's saved state.
 #include <cstdlib>
+#include <type_traits>
 
 #include "imdct_core.hpp"
 #include "synth_desc.hpp"
@@ -458,6 +459,31 @@ __device__ __forceinline__ float ola(float v, float wl, float t, float wr)
     return a + b;
 }
 
+// The reference's own tests turn PCM into 16-bit samples with `(int)(x * 32768f)` clamped to the short range
+// (NVorbis.Tests/AssetTest.cs:131-132); the s16 output layouts do exactly that in the store epilogue, which halves the
+// PCM write traffic.  v_cvt_i32_f32 truncates toward zero like the C# cast and saturates (NaN gives 0).
+__device__ __forceinline__ int to_s16(float v)
+{
+    const int i = (int)(v * 32768.0f);
+    return i < -32768 ? -32768 : (i > 32767 ? 32767 : i);
+}
+__device__ __forceinline__ uint32_t pack_s16(float lo, float hi)
+{
+    return ((uint32_t)to_s16(lo) & 0xFFFFu) | ((uint32_t)to_s16(hi) << 16);
+}
+typedef uint32_t vpz_u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t vpz_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_nt(uint2 *p, uint32_t a, uint32_t b)
+{
+    vpz_u2v t = {a, b};
+    __builtin_nontemporal_store(t, reinterpret_cast<vpz_u2v *>(p));
+}
+__device__ __forceinline__ void store_nt(uint4 *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    vpz_u4v t = {a, b, c, d};
+    __builtin_nontemporal_store(t, reinterpret_cast<vpz_u4v *>(p));
+}
+
 // Branch-free addressing of the IMDCT output through its mirror symmetries (Mdct.cs:378-381).
 // y[pos..pos+3] (pos, n4 multiples of 4) = h4[idx] possibly reversed / negated.
 struct Y4Map {
@@ -601,9 +627,11 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
 //       every wave then picks its own channel up.  No de-interleaved / de-coupled copy of the residue exists in HBM.
 // Floor: the wave renders its channel's curve (Floor1.cs:236-262, 372-397) from the record's active posts into its
 //       LDS row as one table index per bin, right before the row is needed for anything else.
-template <bool kHasFloor, int kOut, bool kGeneral, bool kGroup>
+// kS16: PCM leaves as 16-bit samples (to_s16) instead of float32; offsets and strides count samples either way.
+template <bool kHasFloor, int kOut, bool kGeneral, bool kGroup, bool kS16>
 __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 {
+    using out_t = typename std::conditional<kS16, int16_t, float>::type;
     constexpr bool kInterleaved = kOut != 0;
     constexpr bool kPair = kOut == 2;
     constexpr bool kSync = kPair || kGroup;  // the workgroup's waves run their loops in lock step
@@ -762,7 +790,12 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         prev_n4 = run.prev_long ? (a.size1 >> 2) : (a.size0 >> 2);
         for (int i = lane; i < prev_n4; i += 64) tail[i] = st[i];
     }
-    float *out_base = a.out + (a.stream_out_off ? a.stream_out_off[run.stream] : 0);
+    out_t *out_base = reinterpret_cast<out_t *>(a.out) + (a.stream_out_off ? a.stream_out_off[run.stream] : 0);
+    {   // wave-uniform, but the offset arrives through a vector load: move the pointer to scalar registers
+        const uint64_t ob = reinterpret_cast<uint64_t>(out_base);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)ob), hi = __builtin_amdgcn_readfirstlane((uint32_t)(ob >> 32));
+        out_base = reinterpret_cast<out_t *>(((uint64_t)hi << 32) | lo);
+    }
     bool clipped_any = false;
 
     // ---- software pipeline: the input of frame i+1 is in flight while frame i is synthesised
@@ -895,22 +928,31 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             // equal block sizes share one slope table (s_slope0 only holds a 128-entry short slope)
             const float *slope = ((fd.flags & kFrameSlope1) || a.size0 == a.size1) ? s_slope1 : s_slope0;
             const int plen = fd.packet_len;
-            float *dst = kInterleaved ? out_base + fd.out_off * a.channels + ch
+            out_t *dst = kInterleaved ? out_base + fd.out_off * a.channels + ch
                                        : out_base + (int64_t)ch * a.channel_stride + fd.out_off;
             // every window boundary of the 256/2048 geometries is a multiple of 64 samples, so unless
             // an EOS trim cut the packet a float4 never straddles a mirror / overlap boundary
             // (interleaved output keeps the float4 arithmetic and scatters the four samples with the
             // channel stride; the other channels' waves fill the gaps of the same cache lines)
             const bool vec = !drain && ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0 &&
-                             (kInterleaved || (reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+                             (kInterleaved || (reinterpret_cast<uintptr_t>(dst) & (kS16 ? 7 : 15)) == 0);
             const int64_t ostep = kInterleaved ? a.channels : 1;
             auto store4 = [&](int g, float o0, float o1, float o2, float o3) {
                 if (kInterleaved) {
-                    float *d = dst + (int64_t)(4 * g) * ostep;
-                    d[0] = o0;
-                    d[ostep] = o1;
-                    d[2 * ostep] = o2;
-                    d[3 * ostep] = o3;
+                    out_t *d = dst + (int64_t)(4 * g) * ostep;
+                    if (kS16) {
+                        d[0] = (out_t)to_s16(o0);
+                        d[ostep] = (out_t)to_s16(o1);
+                        d[2 * ostep] = (out_t)to_s16(o2);
+                        d[3 * ostep] = (out_t)to_s16(o3);
+                    } else {
+                        d[0] = (out_t)o0;
+                        d[ostep] = (out_t)o1;
+                        d[2 * ostep] = (out_t)o2;
+                        d[3 * ostep] = (out_t)o3;
+                    }
+                } else if (kS16) {
+                    store_nt(reinterpret_cast<uint2 *>(dst) + g, pack_s16(o0, o1), pack_s16(o2, o3));
                 } else {
                     store_nt(reinterpret_cast<float4 *>(dst) + g, make_float4(o0, o1, o2, o3));
                 }
@@ -920,7 +962,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             const float4 *hR4 = reinterpret_cast<const float4 *>(s_work[wave | 1]);
             const float4 *tL4 = reinterpret_cast<const float4 *>(s_tail[wave & ~1]);
             const float4 *tR4 = reinterpret_cast<const float4 *>(s_tail[wave | 1]);
-            float *pair_row = out_base + fd.out_off * 2;  // sample s of the packet at floats [2s, 2s+1]
+            out_t *pair_row = out_base + fd.out_off * 2;  // sample s of the packet at elements [2s, 2s+1]
             const bool vec_pair = kPair && !drain && ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0 &&
                                   (reinterpret_cast<uintptr_t>(pair_row) & 15) == 0;
             auto store_pair = [&](int g, float l0, float l1, float l2, float l3, float r0, float r1, float r2, float r3) {
@@ -930,9 +972,14 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     l0 = clip_value(l0); l1 = clip_value(l1); l2 = clip_value(l2); l3 = clip_value(l3);
                     r0 = clip_value(r0); r1 = clip_value(r1); r2 = clip_value(r2); r3 = clip_value(r3);
                 }
-                float4 *d = reinterpret_cast<float4 *>(pair_row) + 2 * g;
-                store_nt(d, make_float4(l0, r0, l1, r1));
-                store_nt(d + 1, make_float4(l2, r2, l3, r3));
+                if (kS16) {
+                    store_nt(reinterpret_cast<uint4 *>(pair_row) + g, pack_s16(l0, r0), pack_s16(l1, r1), pack_s16(l2, r2),
+                             pack_s16(l3, r3));
+                } else {
+                    float4 *d = reinterpret_cast<float4 *>(pair_row) + 2 * g;
+                    store_nt(d, make_float4(l0, r0, l1, r1));
+                    store_nt(d + 1, make_float4(l2, r2, l3, r3));
+                }
             };
             if (vec_pair && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 &&
                 fd.prev_end == 1024 && fd.out_count == 1024 && prev_n4 == 512 && a.size1 == 2048) {
@@ -995,9 +1042,11 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 const float4 *t4 = reinterpret_cast<const float4 *>(tail);
                 const float4 *s4 = reinterpret_cast<const float4 *>(s_slope1);
                 float o[4][4];
+                int lf = lane;
+                asm volatile("" : "+v"(lf));  // (no store address of this path may be computed ahead of the frame loop)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int g = lane + 64 * r;
+                    const int g = lf + 64 * r;
                     const float4 wl = s4[g], wr = s4[255 - g];
                     if (r < 2) {
                         const float4 hv = h4[127 - g], pv = t4[g];
@@ -1034,7 +1083,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (!kInterleaved) store4(lane + 64 * r, o[r][0], o[r][1], o[r][2], o[r][3]);
+                    if (!kInterleaved) store4(lf + 64 * r, o[r][0], o[r][1], o[r][2], o[r][3]);
             } else if (!kPair && vec) {
                 // branch-free: lanes past the end clamp their reads and skip only the store; samples
                 // past the overlap take weights (1, 0)
@@ -1102,7 +1151,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         clipped_any |= was_clipped(v);
                         v = clip_value(v);
                     }
-                    dst[i * ostep] = v;
+                    dst[i * ostep] = kS16 ? (out_t)to_s16(v) : (out_t)v;
                 }
             }
         }
@@ -1173,7 +1222,7 @@ __global__ __launch_bounds__(256) void generic_ola_kernel(const GenericFrame *__
                                                          const float *__restrict__ slope1, float *__restrict__ out,
                                                          const int64_t *__restrict__ stream_out_off,
                                                          int64_t channel_stride, int interleaved, int clip,
-                                                         int32_t *__restrict__ clipped)
+                                                         int32_t *__restrict__ clipped, int s16)
 {
     const GenericFrame fr = frames[blockIdx.x / channels];
     const int ch = blockIdx.x % channels;
@@ -1190,8 +1239,11 @@ __global__ __launch_bounds__(256) void generic_ola_kernel(const GenericFrame *__
         prev_base = fr.prev_n >> 1;
     }
     const float *slope = (fr.flags & kFrameSlope1) ? slope1 : slope0;
-    float *base = out + (stream_out_off ? stream_out_off[fr.stream] : 0);
-    float *dst = interleaved ? base + fr.out_off * channels + ch : base + (int64_t)ch * channel_stride + fr.out_off;
+    // element index of the first sample (float32 or, for the s16 layouts, int16 elements)
+    const int64_t first = (stream_out_off ? stream_out_off[fr.stream] : 0) +
+                          (interleaved ? fr.out_off * channels + ch : (int64_t)ch * channel_stride + fr.out_off);
+    float *dst = out + first;
+    int16_t *dst16 = reinterpret_cast<int16_t *>(out) + first;
     const int64_t step = interleaved ? channels : 1;
     bool clipped_any = false;
     for (int i = threadIdx.x; i < fr.out_count; i += 256) {
@@ -1209,7 +1261,8 @@ __global__ __launch_bounds__(256) void generic_ola_kernel(const GenericFrame *__
             clipped_any |= was_clipped(v);
             v = clip_value(v);
         }
-        dst[i * step] = v;
+        if (s16) dst16[i * step] = (int16_t)to_s16(v);
+        else dst[i * step] = v;
     }
     if (clip && clipped_any) atomicOr(&clipped[fr.stream], 1);
 }
@@ -1299,8 +1352,13 @@ hipError_t launch_synth(const SynthArgs &args, bool has_floor, hipStream_t strea
     // the interleaved store patterns cost registers the planar steady state needs: one instantiation each
     const int out_kind = !args.interleaved ? 0 : (args.channels == 2 ? 2 : 1);
     static const int extra_lds = getenv("VPZ_SYNTH_EXTRA_LDS") ? atoi(getenv("VPZ_SYNTH_EXTRA_LDS")) : 0;  // occupancy experiments
-#define VPZ_LAUNCH_SYNTH(F, O, G, R) \
-    hipLaunchKernelGGL((synth_kernel<F, O, G, R>), dim3(grid), dim3(kSynthThreads), extra_lds, stream, args)
+#define VPZ_LAUNCH_SYNTH(F, O, G, R)                                                                                  \
+    do {                                                                                                              \
+        if (args.s16)                                                                                                 \
+            hipLaunchKernelGGL((synth_kernel<F, O, G, R, true>), dim3(grid), dim3(kSynthThreads), extra_lds, stream, args);  \
+        else                                                                                                          \
+            hipLaunchKernelGGL((synth_kernel<F, O, G, R, false>), dim3(grid), dim3(kSynthThreads), extra_lds, stream, args); \
+    } while (0)
 #define VPZ_LAUNCH_SYNTH_OUT(F, G, R)                      \
     do {                                                   \
         if (out_kind == 0) VPZ_LAUNCH_SYNTH(F, 0, G, R);   \
@@ -1331,8 +1389,8 @@ int synth_resident_waves(bool has_floor, int num_cu, int channels, bool group)
 {
     int per_cu = 0;
     hipError_t e = has_floor
-                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<true, 0, false, false>, kSynthThreads, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<false, 0, false, false>, kSynthThreads, 0);
+                       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<true, 0, false, false, false>, kSynthThreads, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_kernel<false, 0, false, false, false>, kSynthThreads, 0);
     if (e != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 2;
@@ -1354,12 +1412,12 @@ hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int ch
 hipError_t launch_generic_ola(const GenericFrame *frames, int n_frames, int channels, int size0, int size1,
                               const float *ybuf, float *state_y, const float *slope0, const float *slope1, float *out,
                               const int64_t *stream_out_off, int64_t channel_stride, int interleaved, int clip,
-                              int32_t *clipped, hipStream_t stream)
+                              int32_t *clipped, int s16, hipStream_t stream)
 {
     if (n_frames <= 0) return hipSuccess;
     hipLaunchKernelGGL(generic_ola_kernel, dim3(n_frames * channels), dim3(256), 0, stream, frames, channels, size0,
                        size1, ybuf, state_y, slope0, slope1, out, stream_out_off, channel_stride, interleaved, clip,
-                       clipped);
+                       clipped, s16);
     return hipGetLastError();
 }
 

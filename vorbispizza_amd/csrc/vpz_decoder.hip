@@ -35,7 +35,7 @@ hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int ch
 hipError_t launch_generic_ola(const GenericFrame *frames, int n_frames, int channels, int size0, int size1,
                               const float *ybuf, float *state_y, const float *slope0, const float *slope1, float *out,
                               const int64_t *stream_out_off, int64_t channel_stride, int interleaved, int clip,
-                              int32_t *clipped, hipStream_t stream);
+                              int32_t *clipped, int s16, hipStream_t stream);
 hipError_t launch_generic_save_state(const GenericFrame *frames, const int32_t *save_list, int n_save, int channels,
                                      int size1, const float *ybuf, float *state_y, hipStream_t stream);
 hipError_t launch_floor0_apply(const void *recs, int n_recs, const void *floors, const int32_t *bark_maps,
@@ -452,7 +452,7 @@ struct SynthCall {
     const int16_t *posts;
     const uint8_t *post_counts;
     const int mem_space;
-    float *pcm_out;
+    void *pcm_out;
     const int64_t *stream_out_offset;
     const int64_t stream_out_capacity;
     const int out_layout;
@@ -461,6 +461,8 @@ struct SynthCall {
     const int C, half0, half1;
     const int64_t n_rec;
     const bool have_posts;
+    const bool out_interleaved, out_s16;  // VPZ_OUT_* decomposed
+    const size_t out_elem;                // bytes per PCM sample
     PinnedArena *A = nullptr;
     std::vector<StreamState> st;  // working copy of the stream states: committed when the batch is accepted
     std::vector<uint8_t> started_with_prev, started_prev_long;
@@ -490,14 +492,17 @@ struct SynthCall {
     const float *d_res = nullptr, *d_amp = nullptr, *d_coeff = nullptr;
     const int16_t *d_posts = nullptr;
     const uint8_t *d_counts = nullptr;
-    float *d_out = nullptr;
+    void *d_out = nullptr;
 
     SynthCall(Decoder &dec, int64_t n, const vpz_packet *pk, const float *res, const int16_t *po, const uint8_t *pc,
-              int mem, float *out, const int64_t *out_off, int64_t out_cap, int layout, int64_t stride)
+              int mem, void *out, const int64_t *out_off, int64_t out_cap, int layout, int64_t stride)
         : D(dec), ctx(dec.ctx), n_packets(n), packets(pk), residue(res), posts(po), post_counts(pc), mem_space(mem),
           pcm_out(out), stream_out_offset(out_off), stream_out_capacity(out_cap), out_layout(layout),
           channel_stride(stride), C(dec.channels), half0(dec.size0 / 2), half1(dec.size1 / 2),
-          n_rec(n * dec.channels), have_posts(po && pc && !dec.floors.empty())
+          n_rec(n * dec.channels), have_posts(po && pc && !dec.floors.empty()),
+          out_interleaved(layout == VPZ_OUT_INTERLEAVED || layout == VPZ_OUT_INTERLEAVED_S16),
+          out_s16(layout == VPZ_OUT_INTERLEAVED_S16 || layout == VPZ_OUT_PLANAR_S16),
+          out_elem(out_s16 ? sizeof(int16_t) : sizeof(float))
     {
     }
 
@@ -1074,7 +1079,7 @@ struct SynthCall {
 
     int build_output_offsets()
     {
-        if (out_layout == VPZ_OUT_PLANAR && channel_stride < stream_out_capacity && C > 1)
+        if (!out_interleaved && channel_stride < stream_out_capacity && C > 1)
             return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: channel_stride smaller than stream_out_capacity");
         offs = arena_alloc<int64_t>(*A, (size_t)D.n_streams);
         for (int s = 0; s < D.n_streams; ++s) offs[s] = stream_out_offset ? stream_out_offset[s] : 0;
@@ -1170,13 +1175,12 @@ struct SynthCall {
             }
             int64_t out_floats = 0;
             for (int s = 0; s < D.n_streams; ++s) {
-                const int64_t ext = out_layout == VPZ_OUT_INTERLEAVED
-                                        ? offs[s] + D.out_count[s] * C
-                                        : offs[s] + (int64_t)(C - 1) * channel_stride + D.out_count[s];
+                const int64_t ext = out_interleaved ? offs[s] + D.out_count[s] * C
+                                                    : offs[s] + (int64_t)(C - 1) * channel_stride + D.out_count[s];
                 if (D.out_count[s] > 0) out_floats = std::max(out_floats, ext);
             }
-            if ((rc = grow(ctx, D.b_out, sizeof(float) * (size_t)out_floats)) != VPZ_OK) return rc;
-            d_out = static_cast<float *>(D.b_out.p);
+            if ((rc = grow(ctx, D.b_out, out_elem * (size_t)out_floats + 16)) != VPZ_OK) return rc;
+            d_out = D.b_out.p;
         }
         if (need_coupling && !use_group && (rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK)
             return rc;
@@ -1256,8 +1260,8 @@ struct SynthCall {
                                    static_cast<const int64_t *>(dev(dst1)));
             if (e == hipSuccess)
                 e = launch_generic_ola(d_gf, (int)n_frames, C, D.size0, D.size1, d_y, D.d_state_h, D.t0->d_slope,
-                                       D.t1->d_slope, d_out, d_outoff, channel_stride, out_layout == VPZ_OUT_INTERLEAVED,
-                                       D.clip, D.d_clipped, ctx->stream);
+                                       D.t1->d_slope, static_cast<float *>(d_out), d_outoff, channel_stride, out_interleaved,
+                                       D.clip, D.d_clipped, out_s16 ? 1 : 0, ctx->stream);
             if (e == hipSuccess)
                 e = launch_generic_save_state(d_gf, static_cast<const int32_t *>(dev(save_list)), (int)n_save, C, D.size1,
                                               d_y, D.d_state_h, ctx->stream);
@@ -1284,10 +1288,11 @@ struct SynthCall {
         a.tw_short = D.t0->d_fast;
         a.slope0 = D.t0->d_slope;
         a.slope1 = D.t1->d_slope;
-        a.out = d_out;
+        a.out = static_cast<float *>(d_out);
         a.stream_out_off = d_outoff;
         a.channel_stride = channel_stride;
-        a.interleaved = out_layout == VPZ_OUT_INTERLEAVED;
+        a.interleaved = out_interleaved;
+        a.s16 = out_s16 ? 1 : 0;
         a.clip = D.clip;
         a.clipped = D.d_clipped;
         a.ablate = D.ablate;
@@ -1302,16 +1307,18 @@ struct SynthCall {
         if (mem_space != VPZ_MEM_HOST) return VPZ_OK;
         for (int s = 0; s < D.n_streams; ++s) {
             if (D.out_count[s] <= 0) continue;
-            if (out_layout == VPZ_OUT_INTERLEAVED) {
-                VPZ_HIP_TRY(ctx, hipMemcpyAsync(pcm_out + offs[s], d_out + offs[s],
-                                                sizeof(float) * (size_t)(D.out_count[s] * C), hipMemcpyDeviceToHost,
+            char *h = static_cast<char *>(pcm_out);
+            const char *dv = static_cast<const char *>(d_out);
+            if (out_interleaved) {
+                VPZ_HIP_TRY(ctx, hipMemcpyAsync(h + out_elem * (size_t)offs[s], dv + out_elem * (size_t)offs[s],
+                                                out_elem * (size_t)(D.out_count[s] * C), hipMemcpyDeviceToHost,
                                                 ctx->stream));
             } else {
-                for (int ch = 0; ch < C; ++ch)
-                    VPZ_HIP_TRY(ctx, hipMemcpyAsync(pcm_out + offs[s] + (int64_t)ch * channel_stride,
-                                                    d_out + offs[s] + (int64_t)ch * channel_stride,
-                                                    sizeof(float) * (size_t)D.out_count[s], hipMemcpyDeviceToHost,
-                                                    ctx->stream));
+                for (int ch = 0; ch < C; ++ch) {
+                    const size_t at = out_elem * (size_t)(offs[s] + (int64_t)ch * channel_stride);
+                    VPZ_HIP_TRY(ctx, hipMemcpyAsync(h + at, dv + at, out_elem * (size_t)D.out_count[s],
+                                                    hipMemcpyDeviceToHost, ctx->stream));
+                }
             }
         }
         VPZ_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1322,7 +1329,7 @@ struct SynthCall {
 }  // namespace
 
 int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packets, const float *residue,
-                      const int16_t *posts, const uint8_t *post_counts, int mem_space, float *pcm_out,
+                      const int16_t *posts, const uint8_t *post_counts, int mem_space, void *pcm_out,
                       const int64_t *stream_out_offset, int64_t stream_out_capacity, int out_layout,
                       int64_t channel_stride, int64_t *samples_written)
 {
@@ -1333,7 +1340,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: null argument");
     if (mem_space != VPZ_MEM_HOST && mem_space != VPZ_MEM_DEVICE)
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: bad mem_space");
-    if (out_layout != VPZ_OUT_INTERLEAVED && out_layout != VPZ_OUT_PLANAR)
+    if (out_layout < VPZ_OUT_INTERLEAVED || out_layout > VPZ_OUT_PLANAR_S16)
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: bad out_layout");
     if (n_packets > (int64_t)0x7fffffff / std::max(1, D.channels))
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: batch too large");

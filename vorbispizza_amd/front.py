@@ -64,7 +64,7 @@ def lib():
         L.vpzh_decode_range.restype = C.c_int
         L.vpzh_decode_failures.argtypes = [vp, C.POINTER(C.c_int64)]
         L.vpzh_decode_failures.restype = C.c_int64
-        # VorbisReader mirror (vorbis_reader.h)
+        # VorbisReader mirror (include/vorbispizza_reader.h)
         L.vpzr_open_memory.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp)]
         L.vpzr_open_memory.restype = C.c_int
         L.vpzr_close.argtypes = [vp]
@@ -92,6 +92,10 @@ def lib():
         L.vpzr_read_samples.restype = C.c_int64
         L.vpzr_read_samples_planar.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int)]
         L.vpzr_read_samples_planar.restype = C.c_int64
+        L.vpzr_read_samples_s16.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int)]
+        L.vpzr_read_samples_s16.restype = C.c_int64
+        L.vpzr_set_sample_format.argtypes = [vp, C.c_int]
+        L.vpzr_set_sample_format.restype = C.c_int
         _lib = L
     return _lib
 
@@ -216,7 +220,7 @@ class VorbisReader:
     end: ReadSamples(buffer) interleaved / ReadSamples(buffer, samplesToRead, channelStride) planar,
     at most one packet's worth per call, 0 at the end."""
 
-    def __init__(self, ctx, path_or_bytes, clip_samples=True, batch_packets=128):
+    def __init__(self, ctx, path_or_bytes, clip_samples=True, batch_packets=128, s16=False):
         data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
         self._data = np.frombuffer(bytes(data), dtype=np.uint8)
         self._ctx = ctx
@@ -227,6 +231,7 @@ class VorbisReader:
             self.Dispose()
             raise FrontError("Could not load the specified container. %s" % msg)
         lib().vpzr_set_clip_samples(self._h, int(clip_samples))
+        lib().vpzr_set_sample_format(self._h, 1 if s16 else 0)
         lib().vpzr_set_batch_packets(self._h, batch_packets)
         import weakref
         ctx._children.append(weakref.ref(self))  # the reader owns a decoder: it must go before the context
@@ -251,7 +256,9 @@ class VorbisReader:
     def ReadSamples(self, buffer, samplesToRead=None, channelStride=None):
         st = C.c_int(0)
         buf = buffer.reshape(-1)
-        if samplesToRead is None:
+        if buf.dtype == np.int16:
+            n = lib().vpzr_read_samples_s16(self._h, buf.ctypes.data, buf.size, C.byref(st))
+        elif samplesToRead is None:
             n = lib().vpzr_read_samples(self._h, buf.ctypes.data, buf.size, C.byref(st))
         else:
             n = lib().vpzr_read_samples_planar(self._h, buf.ctypes.data, buf.size, samplesToRead, channelStride,

@@ -1,7 +1,7 @@
 // C++ CPU front end: Ogg demux + Vorbis setup + per-packet entropy decode.
 // Mirrors the reference's CPU stage so real .ogg files can be pushed through vpz_decoder_synth; every
 // function cites the C# it follows.  Bit-serial / integer work only.
-#include "vorbis_front.h"
+#include "../../include/vorbispizza_front.h"
 
 #include <algorithm>
 

@@ -13,8 +13,8 @@
 #include <string>
 #include <vector>
 
-#include "vorbis_front.h"
-#include "vorbis_reader.h"
+#include "../../include/vorbispizza_front.h"
+#include "../../include/vorbispizza_reader.h"
 
 struct vpzr_reader {
     vpz_context *ctx = nullptr;
@@ -26,7 +26,9 @@ struct vpzr_reader {
     int batch = 128;
     int64_t next_packet = 0;          // first packet not yet synthesised
     // PCM of the current batch, interleaved [sample][channel], and how it splits into packets
+    bool s16 = false;                 // samples leave the GPU as int16 (VPZ_OUT_INTERLEAVED_S16) instead of float32
     std::vector<float> pcm;
+    std::vector<int16_t> pcm16;
     std::vector<int32_t> packet_samples;
     size_t cur_packet = 0;            // index into packet_samples
     int64_t cur_offset = 0;           // samples of the batch already handed out (start of cur_packet + consumed)
@@ -85,6 +87,7 @@ struct vpzr_reader {
     int refill()
     {
         pcm.clear();
+        pcm16.clear();
         packet_samples.clear();
         cur_packet = 0;
         cur_offset = 0;
@@ -121,23 +124,28 @@ struct vpzr_reader {
         if (f0_stride > 0) vpz_decoder_set_floor0_data(dec, f0_amp.data(), f0_coeff.data(), f0_stride);
         next_packet += n;
         const int64_t cap = n * half1 + info.block_size1;
-        pcm.assign((size_t)cap * C, 0.f);
+        if (s16) pcm16.assign((size_t)cap * C, 0);
+        else pcm.assign((size_t)cap * C, 0.f);
         int64_t written = 0;
         rc = vpz_decoder_synth(dec, n, packets.data(), residue.data(), posts.data(), counts.data(), VPZ_MEM_HOST,
-                               pcm.data(), nullptr, cap, VPZ_OUT_INTERLEAVED, 0, &written);
+                               s16 ? static_cast<void *>(pcm16.data()) : static_cast<void *>(pcm.data()), nullptr, cap,
+                               s16 ? VPZ_OUT_INTERLEAVED_S16 : VPZ_OUT_INTERLEAVED, 0, &written);
         // a window mismatch (the reference's OverlapBuffers exception) costs only that packet; the
         // reference test harness never reads that far (AssetTest.cs:107-118), so keep going
         if (rc != VPZ_OK && rc != VPZ_E_WINDOW_MISMATCH) return fail(rc, vpz_context_last_error(ctx));
         packet_samples.resize((size_t)n);
         vpz_decoder_last_packet_samples(dec, packet_samples.data(), n);
-        pcm.resize((size_t)written * C);
+        if (s16) pcm16.resize((size_t)written * C);
+        else pcm.resize((size_t)written * C);
         return VPZ_OK;
     }
 
-    // StreamDecoder.Read core (:418-498)
-    int64_t read(float *buffer, int64_t buffer_len, int64_t samples_to_read, int64_t channel_stride, bool interleave,
+    // StreamDecoder.Read core (:418-498); T = float, or int16_t when the reader delivers 16-bit samples
+    template <typename T>
+    int64_t read(T *buffer, int64_t buffer_len, int64_t samples_to_read, int64_t channel_stride, bool interleave,
                  int *status)
     {
+        const std::vector<T> &pcm = batch_pcm(static_cast<T *>(nullptr));
         const int C = info.channels;
         *status = VPZ_OK;
         if (!opened || C < 1) { *status = fail(VPZ_E_INVALID_ARG, "the reader has no open stream"); return 0; }
@@ -175,9 +183,9 @@ struct vpzr_reader {
             }
             const int64_t copy_len = std::min<int64_t>(samples_to_read - idx, cur_remaining);
             if (copy_len <= 0) break;
-            const float *src = pcm.data() + (size_t)cur_offset * C;
+            const T *src = pcm.data() + (size_t)cur_offset * C;
             if (interleave) {
-                memcpy(buffer + idx * C, src, sizeof(float) * (size_t)(copy_len * C));
+                memcpy(buffer + idx * C, src, sizeof(T) * (size_t)(copy_len * C));
             } else {
                 for (int ch = 0; ch < C; ++ch)
                     for (int64_t i = 0; i < copy_len; ++i) buffer[ch * channel_stride + idx + i] = src[i * C + ch];
@@ -189,6 +197,8 @@ struct vpzr_reader {
         }
         return idx;
     }
+    const std::vector<float> &batch_pcm(float *) const { return pcm; }
+    const std::vector<int16_t> &batch_pcm(int16_t *) const { return pcm16; }
 };
 
 extern "C" {
@@ -281,6 +291,14 @@ int vpzr_set_clip_samples(vpzr_reader *r, int clip)
     return VPZ_OK;
 }
 
+int vpzr_set_sample_format(vpzr_reader *r, int format)
+{
+    if (!r || (format != VPZR_FORMAT_F32 && format != VPZR_FORMAT_S16)) return VPZ_E_INVALID_ARG;
+    if (r->dec) return VPZ_E_INVALID_ARG;  // fixed once decoding has started
+    r->s16 = format == VPZR_FORMAT_S16;
+    return VPZ_OK;
+}
+
 int vpzr_set_batch_packets(vpzr_reader *r, int packets)
 {
     if (!r || packets < 1) return VPZ_E_INVALID_ARG;
@@ -300,8 +318,22 @@ int64_t vpzr_read_samples(vpzr_reader *r, float *buffer, int64_t buffer_len, int
     int st = VPZ_OK;
     if (!r || (!buffer && buffer_len) || buffer_len < 0) { if (status) *status = VPZ_E_INVALID_ARG; return 0; }
     if (!r->opened) { if (status) *status = r->fail(VPZ_E_INVALID_ARG, "the reader has no open stream"); return 0; }
+    if (r->s16) { if (status) *status = r->fail(VPZ_E_INVALID_ARG, "the reader delivers 16-bit samples (vpzr_set_sample_format)"); return 0; }
     const int C = r->info.channels;
     const int64_t count = buffer_len - buffer_len % C;  // VorbisReader.cs:235
+    int64_t n = count == 0 ? 0 : r->read(buffer, count, count / C, 0, true, &st);
+    if (status) *status = st;
+    return n;
+}
+
+int64_t vpzr_read_samples_s16(vpzr_reader *r, int16_t *buffer, int64_t buffer_len, int *status)
+{
+    int st = VPZ_OK;
+    if (!r || (!buffer && buffer_len) || buffer_len < 0) { if (status) *status = VPZ_E_INVALID_ARG; return 0; }
+    if (!r->opened) { if (status) *status = r->fail(VPZ_E_INVALID_ARG, "the reader has no open stream"); return 0; }
+    if (!r->s16) { if (status) *status = r->fail(VPZ_E_INVALID_ARG, "the reader delivers float samples (vpzr_set_sample_format)"); return 0; }
+    const int C = r->info.channels;
+    const int64_t count = buffer_len - buffer_len % C;
     int64_t n = count == 0 ? 0 : r->read(buffer, count, count / C, 0, true, &st);
     if (status) *status = st;
     return n;
@@ -313,6 +345,7 @@ int64_t vpzr_read_samples_planar(vpzr_reader *r, float *buffer, int64_t buffer_l
     int st = VPZ_OK;
     if (!r || (!buffer && buffer_len) || buffer_len < 0) { if (status) *status = VPZ_E_INVALID_ARG; return 0; }
     if (!r->opened) { if (status) *status = r->fail(VPZ_E_INVALID_ARG, "the reader has no open stream"); return 0; }
+    if (r->s16) { if (status) *status = r->fail(VPZ_E_INVALID_ARG, "the reader delivers 16-bit samples (vpzr_set_sample_format)"); return 0; }
     const int C = r->info.channels;
     const int64_t count = buffer_len - buffer_len % C;  // VorbisReader.cs:246
     int64_t n = count == 0 ? 0 : r->read(buffer, count, samples_to_read, channel_stride, false, &st);
