@@ -1,0 +1,118 @@
+// The patch of Mapping / StreamDecoder that queues frames instead of synthesising them (SURVEY.md 8b "what calls it"):
+// the reference keeps Ogg paging, VorbisPacket bit reading and the entropy decode of floor / residue exactly where
+// they are; this class collects what they produce per packet and hands whole batches to vpz_decoder_synth.
+// To be added on the reference side (NVorbis/Native/GpuSynthesisBatch.cs) together with the call-site edits listed in
+// INTEGRATION.md section 2.  Pure glue: no sample arithmetic happens in C#.
+using System;
+using System.Buffers;
+
+namespace NVorbis.Native
+{
+    internal sealed unsafe class GpuSynthesisBatch : IDisposable
+    {
+        private readonly VorbisPizzaSynth.ContextHandle _ctx;
+        private readonly VorbisPizzaSynth.DecoderHandle _decoder;
+        private readonly int _channels, _halfSize1;
+        private VorbisPizzaSynth.Packet[] _packets;
+        private float[] _residue;       // batch buffer: packet p's residue at _packets[p].ResidueOffset
+        private short[] _posts;         // [record][64], record = packet * channels + channel
+        private byte[] _postCounts;     // Floor1.Data.PostCount per record (0 => ExecuteChannel false)
+        private int _count;
+        private long _residueUsed;
+
+        /// <summary>Called once from StreamDecoder.LoadBooks (StreamDecoder.cs:262-321) with the setup-header products.</summary>
+        public GpuSynthesisBatch(VorbisPizzaSynth.ContextHandle ctx, int channels, int blockSize0, int blockSize1,
+                                 ReadOnlySpan<VorbisPizzaSynth.Floor1Config> floors,
+                                 ReadOnlySpan<VorbisPizzaSynth.MappingConfig> mappings, bool clipSamples, int capacityPackets = 128)
+        {
+            _ctx = ctx;
+            _channels = channels;
+            _halfSize1 = blockSize1 / 2;
+            _packets = new VorbisPizzaSynth.Packet[capacityPackets];
+            _residue = new float[(long)capacityPackets * channels * _halfSize1];
+            _posts = new short[capacityPackets * channels * VorbisPizzaSynth.PostsStride];
+            _postCounts = new byte[capacityPackets * channels];
+            fixed (VorbisPizzaSynth.Floor1Config* pf = floors)
+            fixed (VorbisPizzaSynth.MappingConfig* pm = mappings)
+            {
+                var cfg = new VorbisPizzaSynth.StreamConfig
+                {
+                    Channels = channels, BlockSize0 = blockSize0, BlockSize1 = blockSize1,
+                    FloorCount = floors.Length, Floors = pf, MappingCount = mappings.Length, Mappings = pm,
+                    ClipSamples = clipSamples ? 1 : 0, FloorTypes = null, Floors0 = null,
+                };
+                VorbisPizzaSynth.ThrowOnError(VorbisPizzaSynth.vpz_decoder_create(ctx, &cfg, 1, out _decoder), ctx, "vpz_decoder_create");
+            }
+        }
+
+        public bool IsFull => _count == _packets.Length;
+        public int Count => _count;
+
+        /// <summary>The residue span Mapping.DecodePacket decodes into instead of its ChannelBuffer (Mapping.cs:136-163):
+        /// planar [channel][blockSize / 2], or the Residue2 vector [blockSize / 2][channels] with Interleaved set.</summary>
+        public Span<float> NextResidue(int blockSize) => _residue.AsSpan((int)_residueUsed, _channels * (blockSize / 2));
+
+        /// <summary>The posts row Floor1.Unpack fills for one channel (Floor1.cs:167-218).</summary>
+        public Span<short> NextPosts(int channel) => _posts.AsSpan((_count * _channels + channel) * VorbisPizzaSynth.PostsStride, VorbisPizzaSynth.PostsStride);
+
+        /// <summary>Appends the packet DecodeNextPacket has just entropy-decoded (StreamDecoder.cs:696-762).  A null decode is
+        /// appended with NotDecoded so that the EOS drain (:451-455) happens where the reference does it.</summary>
+        public void Append(VorbisPizzaSynth.PacketFlags flags, byte mappingIndex, long granulePosition, int blockSize,
+                           ReadOnlySpan<byte> postCountPerChannel)
+        {
+            ref VorbisPizzaSynth.Packet p = ref _packets[_count];
+            p.Stream = 0;
+            p.Flags = flags;
+            p.Mapping = mappingIndex;
+            p.Granule = granulePosition;
+            p.ResidueOffset = _residueUsed;
+            postCountPerChannel.CopyTo(_postCounts.AsSpan(_count * _channels, _channels));
+            if ((flags & VorbisPizzaSynth.PacketFlags.NotDecoded) == 0) _residueUsed += (long)_channels * (blockSize / 2);
+            _count++;
+        }
+
+        /// <summary>One vpz_decoder_synth call for everything queued: PCM straight into the caller's span, interleaved as
+        /// StreamDecoder.Read(Span&lt;float&gt;) returns it.  perPacketSamples receives what each packet contributed, so that
+        /// Read can keep handing out at most one packet's worth per call (`while (idx == 0)`, StreamDecoder.cs:436).</summary>
+        public long Flush(Span<float> pcm, Span<int> perPacketSamples)
+        {
+            if (_count == 0) return 0;
+            long written = 0;
+            int rc;
+            fixed (VorbisPizzaSynth.Packet* pk = _packets)
+            fixed (float* res = _residue)
+            fixed (short* po = _posts)
+            fixed (byte* pc = _postCounts)
+            fixed (float* dst = pcm)
+            fixed (int* per = perPacketSamples)
+            {
+                rc = VorbisPizzaSynth.vpz_decoder_synth(_decoder, _count, pk, res, po, pc, VorbisPizzaSynth.MemHost, dst, null,
+                                                        pcm.Length / _channels, VorbisPizzaSynth.OutInterleaved, 0, &written);
+                VorbisPizzaSynth.vpz_decoder_last_packet_samples(_decoder, per, Math.Min(perPacketSamples.Length, _count));
+            }
+            _count = 0;
+            _residueUsed = 0;
+            // a window mismatch costs only the offending packet, like the exception out of OverlapBuffers
+            if (rc != VorbisPizzaSynth.Ok && rc != VorbisPizzaSynth.EWindowMismatch)
+                VorbisPizzaSynth.ThrowOnError(rc, _ctx, "vpz_decoder_synth");
+            return written;
+        }
+
+        public void Reset()                                   // StreamDecoder.ResetDecoder (:357-369)
+        {
+            _count = 0;
+            _residueUsed = 0;
+            VorbisPizzaSynth.ThrowOnError(VorbisPizzaSynth.vpz_decoder_reset(_decoder, 0), _ctx, "vpz_decoder_reset");
+        }
+
+        public long Position
+        {
+            get { VorbisPizzaSynth.vpz_decoder_position(_decoder, 0, out long p); return p; }
+            set => VorbisPizzaSynth.ThrowOnError(VorbisPizzaSynth.vpz_decoder_set_position(_decoder, 0, value), _ctx, "vpz_decoder_set_position");
+        }
+
+        public bool HasClipped { get { VorbisPizzaSynth.vpz_decoder_has_clipped(_decoder, 0, out int c); return c != 0; } }
+
+        public void Dispose() => _decoder.Dispose();
+    }
+}
