@@ -20,6 +20,10 @@ namespace NVorbis.Native
         [DllImport(Host, CallingConvention = CallingConvention.Cdecl)] static extern int vpzr_open_memory(IntPtr ctx, byte* data, ulong size, out IntPtr reader);
         [DllImport(Host, CallingConvention = CallingConvention.Cdecl)] static extern void vpzr_close(IntPtr reader);
         [DllImport(Host, CallingConvention = CallingConvention.Cdecl)] static extern IntPtr vpzr_last_error(IntPtr reader);
+        [DllImport(Host, CallingConvention = CallingConvention.Cdecl)] static extern int vpzr_find_next_stream(IntPtr reader);
+        [DllImport(Host, CallingConvention = CallingConvention.Cdecl)] static extern int vpzr_stream_count(IntPtr reader);
+        [DllImport(Host, CallingConvention = CallingConvention.Cdecl)] static extern int vpzr_switch_streams(IntPtr reader, int index);
+        [DllImport(Host, CallingConvention = CallingConvention.Cdecl)] static extern int vpzr_stream_serial(IntPtr reader);
         [DllImport(Host, CallingConvention = CallingConvention.Cdecl)] static extern int vpzr_channels(IntPtr reader);
         [DllImport(Host, CallingConvention = CallingConvention.Cdecl)] static extern int vpzr_sample_rate(IntPtr reader);
         [DllImport(Host, CallingConvention = CallingConvention.Cdecl)] static extern long vpzr_sample_position(IntPtr reader);
@@ -48,6 +52,17 @@ namespace NVorbis.Native
             fixed (byte* p = data) rc = vpzr_open_memory(_ctx, p, (ulong)data.Length, out _reader);
             if (rc != 0) throw new ArgumentException("Could not load the specified container. " + LastError(), nameof(stream));
             if (sixteenBit) Check(vpzr_set_sample_format(_reader, 1), "vpzr_set_sample_format");
+        }
+
+        // chained / multiplexed containers: VorbisReader.Streams, FindNextStream, SwitchStreams (VorbisReader.cs:191-217)
+        public int StreamCount => vpzr_stream_count(_reader);
+        public int StreamSerial => vpzr_stream_serial(_reader);
+        public bool FindNextStream() => vpzr_find_next_stream(_reader) != 0;
+        public bool SwitchStreams(int index)
+        {
+            int rc = vpzr_switch_streams(_reader, index);
+            if (rc < 0) throw new ArgumentOutOfRangeException(nameof(index));
+            return rc != 0;      // true: channel count or sample rate changed
         }
 
         public int Channels => vpzr_channels(_reader);

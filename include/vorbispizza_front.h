@@ -24,11 +24,16 @@ extern "C" {
 #define VPZH_E_INVALID_DATA (-1)  /* InvalidDataException in the reference */
 #define VPZH_E_UNSUPPORTED  (-2)
 #define VPZH_E_ARG          (-3)
+#define VPZH_E_NO_STREAM    (-4)  /* the container has no logical stream of that index (FindNextStream() == false) */
 
 typedef struct vpzh_stream vpzh_stream;
 
 /* Parses the container and the three header packets of the first logical stream in `data`. */
 int  vpzh_open_memory(const uint8_t *data, uint64_t size, vpzh_stream **out);
+/* The same for the `stream_index`-th logical stream, counted by beginning-of-stream pages: chained files
+ * (VorbisReader.FindNextStream / SwitchStreams, VorbisReader.cs:191-217) are decoded stream by stream, each with its
+ * own setup headers.  VPZH_E_NO_STREAM when there is none. */
+int  vpzh_open_memory_stream(const uint8_t *data, uint64_t size, int32_t stream_index, vpzh_stream **out);
 void vpzh_close(vpzh_stream *s);
 const char *vpzh_last_error(vpzh_stream *s);
 
@@ -39,6 +44,8 @@ typedef struct vpzh_info {
     int64_t last_granule;       /* granule position of the last page == total samples per channel */
     int64_t residue_floats;     /* floats vpzh_decode_all writes to `residue` */
     int32_t pages, bad_crc_pages;
+    int32_t stream_serial;      /* IStreamDecoder.StreamSerial */
+    int32_t reserved;
 } vpzh_info;
 int vpzh_get_info(vpzh_stream *s, vpzh_info *info);
 
@@ -61,7 +68,9 @@ int vpzh_seek(vpzh_stream *s, int64_t sample_position, int64_t *first_packet, in
 /* Entropy-decodes every audio packet.  packets[audio_packets], residue[residue_floats],
  * posts[audio_packets*channels*64], post_counts[audio_packets*channels].  `stream_id` is written to
  * vpz_packet.stream, `residue_base` is added to every residue_offset.  Packets whose first bit is set
- * or that fail GetPacketInfo get VPZ_PKT_NOT_DECODED (StreamDecoder.cs:728, 750-761). */
+ * or that fail GetPacketInfo get VPZ_PKT_NOT_DECODED (StreamDecoder.cs:728, 750-761); packets completed on a page
+ * that was found after lost sync (bad checksum, garbage between pages) or out of sequence get VPZ_PKT_RESYNC
+ * (VorbisPacket.IsResync; StreamDecoder.cs:718-722 then picks the position up again). */
 int vpzh_decode_all(vpzh_stream *s, int32_t stream_id, int64_t residue_base, vpz_packet *packets,
                     float *residue, int16_t *posts, uint8_t *post_counts);
 

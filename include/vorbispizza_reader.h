@@ -20,6 +20,16 @@ int  vpzr_open_memory(vpz_context *ctx, const uint8_t *data, uint64_t size, vpzr
 void vpzr_close(vpzr_reader *r);
 const char *vpzr_last_error(vpzr_reader *r);
 
+/* Logical streams of the container (VorbisReader.Streams / FindNextStream / SwitchStreams, VorbisReader.cs:191-217):
+ * the reader opens the first one; vpzr_find_next_stream looks for one more (a chained file starts it after the
+ * previous stream's last page) and returns 1 when it added one; vpzr_switch_streams makes stream `index` the one
+ * every other call below talks to and returns 1 when its channel count or sample rate differ from the previous
+ * one's, 0 when they do not, VPZ_E_INVALID_ARG for a bad index.  Every stream keeps its own decoder and position. */
+int     vpzr_find_next_stream(vpzr_reader *r);
+int     vpzr_stream_count(vpzr_reader *r);
+int     vpzr_switch_streams(vpzr_reader *r, int index);
+int     vpzr_stream_serial(vpzr_reader *r);        /* IStreamDecoder.StreamSerial of the current stream */
+
 int     vpzr_channels(vpzr_reader *r);             /* IVorbisReader.Channels */
 int     vpzr_sample_rate(vpzr_reader *r);          /* IVorbisReader.SampleRate */
 int64_t vpzr_sample_position(vpzr_reader *r);      /* samples per channel handed out so far */

@@ -45,6 +45,9 @@ class Floor1(C.Structure):
                 ("sortidx", C.c_int * 65)]
 
 
+READ_NEXT_PACKET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)  # one ReadNextPacket of the caller's packet provider
+
+
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
@@ -92,6 +95,10 @@ def lib():
         L.orc_stream_destroy.restype = None
         L.orc_stream_reset.argtypes = [C.c_void_p]
         L.orc_stream_reset.restype = None
+        L.orc_stream_mark_resync.argtypes = [C.c_void_p]
+        L.orc_stream_mark_resync.restype = None
+        L.orc_stream_seek_to.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, READ_NEXT_PACKET_FN, C.c_void_p]
+        L.orc_stream_seek_to.restype = C.c_int
         L.orc_stream_next_buffer.argtypes = [C.c_void_p]
         L.orc_stream_next_buffer.restype = f32p
         L.orc_stream_read_next_packet.argtypes = [C.c_void_p, C.c_int, C.POINTER(PacketInfo),

@@ -878,6 +878,41 @@ void orc_stream_reset(orc_stream *s) /* :357-369 */
     s->has_position = 0;
 }
 
+void orc_stream_mark_resync(orc_stream *s) /* DecodeNextPacket :718-722: packet.IsResync */
+{
+    s->has_position = 0;
+}
+
+/* StreamDecoder.SeekTo(long samplePosition, SeekOrigin.Begin) :817-880, from the point where the packet provider has
+ * been positioned: provider_pos is what `_packetProvider.SeekTo(samplePosition, 1, this)` returned (the stream
+ * position at the start of the packet AFTER the pre-roll packet), read_next_packet performs one ReadNextPacket (the
+ * caller decodes the provider's next packet into orc_stream_next_buffer and calls orc_stream_read_next_packet; its
+ * result > 0 is ReadNextPacket's `true`).  Returns 0, -1 for SeekOutOfRangeException, -2 for PreRollPacketException. */
+int orc_stream_seek_to(orc_stream *s, int64_t sample_position, int64_t provider_pos, int64_t max_granule_count,
+                       orc_read_next_packet_fn read_next_packet, void *user)
+{
+    int roll_forward = (int)(sample_position - provider_pos); /* :848 */
+
+    orc_stream_reset(s);   /* :851 */
+    s->has_position = 1;   /* :852 */
+
+    if (read_next_packet(user) <= 0) { /* the pre-roll packet, :855-867 */
+        s->eos_found |= 8; /* EndOfStreamFlags.InvalidPreroll = 1 << 3 */
+        if (sample_position > max_granule_count) return -1;
+        s->prev_start = s->prev_stop;
+        s->current_position = sample_position;
+        return 0;
+    }
+    if (read_next_packet(user) <= 0) { /* the actual packet, :870-876 */
+        orc_stream_reset(s);
+        s->eos_found |= 1; /* EndOfStreamFlags.InvalidPacket = 1 << 0 */
+        return -2;
+    }
+    s->prev_start += roll_forward;          /* :879 */
+    s->current_position = sample_position;  /* :880 */
+    return 0;
+}
+
 float *orc_stream_next_buffer(orc_stream *s) /* _nextPacketBuf ??= GetBuffer() :738 */
 {
     if (!s->next_buf)
@@ -915,7 +950,7 @@ int orc_stream_read_next_packet(orc_stream *s, int decoded, const orc_packet_inf
     int64_t sample_position = decoded ? granule : -1; /* :758-761 */
     int packet_len, right_start;
 
-    s->eos_found |= eos_flag ? 1 : 0;
+    s->eos_found |= eos_flag ? 4 : 0; /* EndOfStreamFlags.PacketFlag = 1 << 2 */
     if (!cur) return 0;
 
     packet_len = s->prev_stop - s->prev_end;

@@ -115,6 +115,12 @@ typedef struct orc_stream orc_stream;
 orc_stream *orc_stream_create(int channels, int size0, int size1);
 void orc_stream_destroy(orc_stream *s);
 void orc_stream_reset(orc_stream *s);                     /* ResetDecoder :357-369 */
+/* packet.IsResync seen by DecodeNextPacket (:718-722): `_hasPosition = false` */
+void orc_stream_mark_resync(orc_stream *s);
+/* StreamDecoder.SeekTo (:817-880) once the packet provider is positioned; see the definition */
+typedef int (*orc_read_next_packet_fn)(void *user);
+int orc_stream_seek_to(orc_stream *s, int64_t sample_position, int64_t provider_pos, int64_t max_granule_count,
+                       orc_read_next_packet_fn read_next_packet, void *user);
 /* buffer the decoder should fill for the next packet (planar, stride = size1) */
 float *orc_stream_next_buffer(orc_stream *s);
 /* ReadNextPacket with an already decoded packet in orc_stream_next_buffer().

@@ -32,45 +32,55 @@ def gaussian_spectra(shape, seed, sigma=2.0 ** -8):
     return (np.random.default_rng(seed).standard_normal(shape) * sigma).astype(np.float32)
 
 
-def oracle_decode(orc, channels, size0, size1, packets, floors=(), mappings=(), clip=False,
-                  interleave=False, state=None, keep_state=False):
-    """Runs one stream through the oracle.  packets: list of dicts with keys
-    flags, granule (default -1), mapping (default 0), residue (np [channels*half] as laid out for the
-    ABI), posts (np [channels, <=64]), post_count (np [channels]).  Returns PCM [channels, T] or [T, channels]."""
-    L = orc.lib()
-    # `state`: continue on an oracle stream a previous call kept (keep_state=True returns it as a 4th value,
-    # e.g. to put an orc_stream_reset between two calls)
-    st = state if state is not None else L.orc_stream_create(channels, size0, size1)
-    ofl = [orc.floor1_init(*f) if not isinstance(f, dict) else None for f in floors]
-    chunks = []
-    mismatches = []
-    eos_seen = False
+PKT_RESYNC = 0x80
 
-    def take():
+
+class OracleStream:
+    """One reference StreamDecoder, restated: the oracle's stream state plus what Read()'s `while (idx == 0)` loop does
+    around ReadNextPacket (StreamDecoder.cs:418-498).  Packets are dicts with keys flags, granule (default -1), mapping
+    (default 0), residue (np [channels*half] as laid out for the ABI), posts (np [channels, <=64]), post_count
+    (np [channels]), for type-0 floors f0_amp / f0_coeff."""
+
+    def __init__(self, orc, channels, size0, size1, floors=(), mappings=(), clip=False, interleave=False, state=None):
+        self.orc, self.L = orc, orc.lib()
+        self.channels, self.size0, self.size1 = channels, size0, size1
+        self.floors, self.mappings, self.clip, self.interleave = floors, mappings, clip, interleave
+        self.st = state if state is not None else self.L.orc_stream_create(channels, size0, size1)
+        self.ofl = [orc.floor1_init(*f) if not isinstance(f, dict) else None for f in floors]
+        self.eos_seen = False
+        self.mismatches = 0
+
+    def close(self):
+        if self.st is not None:
+            self.L.orc_stream_destroy(self.st)
+            self.st = None
+
+    def take(self):
+        """Hands out everything readable, like repeated Read calls; returns [channels, n] or None."""
+        L, st, channels = self.L, self.st, self.channels
         n = L.orc_stream_available(st)
         if n <= 0:
-            return
-        if interleave:
+            return None
+        if self.interleave:
             buf = np.zeros((n, channels), dtype=np.float32)
-            L.orc_stream_store(st, buf.ctypes.data_as(C.POINTER(C.c_float)), 0, n, 0, 1, int(clip))
-            chunks.append(buf.T.copy())
-        else:
-            buf = np.zeros((channels, n), dtype=np.float32)
-            L.orc_stream_store(st, buf.ctypes.data_as(C.POINTER(C.c_float)), 0, n, n, 0, int(clip))
-            chunks.append(buf)
+            L.orc_stream_store(st, buf.ctypes.data_as(C.POINTER(C.c_float)), 0, n, 0, 1, int(self.clip))
+            return buf.T.copy()
+        buf = np.zeros((channels, n), dtype=np.float32)
+        L.orc_stream_store(st, buf.ctypes.data_as(C.POINTER(C.c_float)), 0, n, n, 0, int(self.clip))
+        return buf
 
-    for pk in packets:
-        if eos_seen and L.orc_stream_available(st) == 0:
-            break  # Read(): nothing more is read after EOS (StreamDecoder.cs:441-447)
+    def read_next_packet(self, pk):
+        """DecodeNextPacket + ReadNextPacket for one packet (StreamDecoder.cs:640-762); returns ReadNextPacket's result
+        (1 accepted, 0 no packet, -1 where OverlapBuffers throws)."""
+        orc, L, st = self.orc, self.L, self.st
+        channels, size0, size1, floors, mappings = self.channels, self.size0, self.size1, self.floors, self.mappings
         flags = pk["flags"]
         eos = 1 if flags & PKT_EOS else 0
+        if flags & PKT_RESYNC:
+            L.orc_stream_mark_resync(st)  # :718-722, before the packet's first bit is looked at
         if flags & PKT_NOT_DECODED:
             L.orc_stream_read_next_packet(st, 0, None, -1, eos)
-            if eos:
-                eos_seen = True
-                L.orc_stream_drain_eos(st)
-                take()
-            continue
+            return 0
         bf = 1 if flags & PKT_BLOCK_FLAG else 0
         n = size1 if bf else size0
         half = n // 2
@@ -104,29 +114,61 @@ def oracle_decode(orc, channels, size0, size1, packets, floors=(), mappings=(), 
                 pcm[c] = orc.mdct_reverse(spec[None, :], n)[0]
         else:
             m = mappings[pk.get("mapping", 0)]
-            pcm = orc.mapping_synth(channels, n, res, ofl, m.get("channel_floor", [0] * channels),
+            pcm = orc.mapping_synth(channels, n, res, self.ofl, m.get("channel_floor", [0] * channels),
                                     pk["posts"], pk["post_count"], m.get("coupling", []))
         p = L.orc_stream_next_buffer(st)
         view = np.ctypeslib.as_array(p, shape=(channels, size1))
         view[:] = 0
         view[:, :n] = pcm
-        rc = L.orc_stream_read_next_packet(st, 1, C.byref(info), int(pk.get("granule", -1)), eos)
+        return L.orc_stream_read_next_packet(st, 1, C.byref(info), int(pk.get("granule", -1)), eos)
+
+    def feed(self, pk):
+        """One iteration of Read()'s loop for a packet: returns the samples it made readable ([channels, n] or None)."""
+        if self.eos_seen and self.L.orc_stream_available(self.st) == 0:
+            return None  # Read(): nothing more is read after EOS (StreamDecoder.cs:441-447)
+        rc = self.read_next_packet(pk)
+        eos = bool(pk["flags"] & PKT_EOS)
+        if pk["flags"] & PKT_NOT_DECODED:
+            if eos:
+                self.eos_seen = True
+                self.L.orc_stream_drain_eos(self.st)
+                return self.take()
+            return None
+        if eos:
+            self.eos_seen = True
         if rc < 0:
             # OverlapBuffers would throw (StreamDecoder.cs:777-778): that Read fails, the packet is
             # consumed, the decoder state stays as it was
-            mismatches.append(len(chunks))
-            if eos:
-                eos_seen = True
-            continue
-        if eos:
-            eos_seen = True
-        take()
-    pos = L.orc_stream_position(st)
-    clipped = bool(L.orc_stream_has_clipped(st))
+            self.mismatches += 1
+            return None
+        return self.take()
+
+    @property
+    def position(self):
+        return self.L.orc_stream_position(self.st)
+
+    @property
+    def has_clipped(self):
+        return bool(self.L.orc_stream_has_clipped(self.st))
+
+
+def oracle_decode(orc, channels, size0, size1, packets, floors=(), mappings=(), clip=False,
+                  interleave=False, state=None, keep_state=False):
+    """Runs one stream through the oracle (see OracleStream for the packet dicts).  Returns PCM [channels, T] or
+    [T, channels], the position and the clip flag."""
+    # `state`: continue on an oracle stream a previous call kept (keep_state=True returns it as a 4th value,
+    # e.g. to put an orc_stream_reset between two calls)
+    s = OracleStream(orc, channels, size0, size1, floors, mappings, clip, interleave, state=state)
+    chunks = []
+    for pk in packets:
+        got = s.feed(pk)
+        if got is not None:
+            chunks.append(got)
+    pos, clipped, st = s.position, s.has_clipped, s.st
     if not keep_state:
-        L.orc_stream_destroy(st)
+        s.close()
     pcm = np.concatenate(chunks, axis=1) if chunks else np.zeros((channels, 0), dtype=np.float32)
-    oracle_decode.last_mismatches = len(mismatches)
+    oracle_decode.last_mismatches = s.mismatches
     if keep_state:
         return (pcm.T.copy() if interleave else pcm), pos, clipped, st
     return (pcm.T.copy() if interleave else pcm), pos, clipped

@@ -145,3 +145,63 @@ def test_seek_table_matches_the_packet_geometry(front, name):
         f.seek(int(cum[-1]) + 1)
     with pytest.raises(front.FrontError):
         f.seek(-1)
+
+
+# ---- chained streams and resync ----
+def _pages(ogg):
+    out, pos = [], 0
+    while pos < len(ogg):
+        assert ogg[pos:pos + 4] == b"OggS"
+        nseg = ogg[pos + 26]
+        body = sum(ogg[pos + 27: pos + 27 + nseg])
+        out.append((pos, 27 + nseg + body))
+        pos += 27 + nseg + body
+    return out
+
+
+def test_chained_container_opens_stream_by_stream(front):
+    """VorbisReader.FindNextStream / SwitchStreams (VorbisReader.cs:191-217): a chained file is a sequence of logical
+    streams, each with its own setup headers; stream i of the chain decodes exactly like the file it came from."""
+    a = open(os.path.join(GOLDEN, "3test.ogg"), "rb").read()
+    b = open(os.path.join(GOLDEN, "1test.ogg"), "rb").read()
+    chain = a + b + a
+    for idx, single in enumerate((a, b, a)):
+        want = front.OggVorbisFile(single)
+        got = front.OggVorbisFile(chain, stream_index=idx)
+        assert (got.channels, got.sample_rate, got.audio_packets, got.last_granule) == \
+               (want.channels, want.sample_rate, want.audio_packets, want.last_granule)
+        assert got.info.stream_serial == want.info.stream_serial
+        for x, y in zip(got.decode_packets(), want.decode_packets()):
+            assert np.array_equal(x, y)
+    with pytest.raises(front.FrontError):
+        front.OggVorbisFile(chain, stream_index=3)
+
+
+def test_a_dropped_page_marks_the_next_packet_as_resync(front):
+    """A page with a bad checksum is skipped (PageReaderBase.cs:286-361); the page found after it is a resync page and
+    its packets carry IsResync (StreamDecoder.cs:718-722 clears _hasPosition for them).  A gap in the page sequence
+    numbers does the same (StreamPageReader.cs:87-96)."""
+    from vorbispizza_amd import capi
+    ogg = bytearray(open(os.path.join(GOLDEN, "3test.ogg"), "rb").read())
+    clean = front.OggVorbisFile(bytes(ogg))
+    pk0 = clean.decode_packets()[0]
+    assert not (pk0["flags"] & capi.PKT_RESYNC).any()
+    pages = _pages(ogg)
+    victim = len(pages) // 2
+    pos, length = pages[victim]
+    ogg[pos + length - 1] ^= 0x55                      # body byte: the checksum no longer matches
+    f = front.OggVorbisFile(bytes(ogg))
+    assert f.info.bad_crc_pages >= 1 and f.audio_packets < clean.audio_packets
+    pk = f.decode_packets()[0]
+    marked = np.nonzero(pk["flags"] & capi.PKT_RESYNC)[0]
+    assert len(marked) >= 1
+    # every packet completed on the page after the dropped one is flagged, nothing else
+    nseg = ogg[pages[victim + 1][0] + 26]
+    segs = ogg[pages[victim + 1][0] + 27: pages[victim + 1][0] + 27 + nseg]
+    completed = sum(1 for v in segs if v < 255)
+    assert 1 <= len(marked) <= completed and (np.diff(marked) == 1).all()
+    # cutting the page out altogether leaves a sequence gap instead of skipped bytes: same flags
+    cut = bytes(ogg[:pos]) + bytes(ogg[pos + length:])
+    g = front.OggVorbisFile(cut)
+    assert g.info.bad_crc_pages == 0
+    assert np.array_equal(g.decode_packets()[0]["flags"], pk["flags"])

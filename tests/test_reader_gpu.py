@@ -235,3 +235,177 @@ def test_a_throwing_packet_surfaces_once_and_the_stream_goes_on(ctx, oracle):
         assert errors == 1, (batch, errors)
         assert got.shape[0] == ref.shape[0] and np.abs(got - ref[:, 0]).max() <= 1e-5
         rdr.Dispose()
+
+
+def _oracle_packets(path):
+    from vorbispizza_amd.front import OggVorbisFile
+    f = OggVorbisFile(path)
+    pk, res, posts, counts = f.decode_packets()
+    return f, pk, helpers.packets_for_oracle(f, pk, res, posts, counts)
+
+
+@pytest.mark.parametrize("name", ["1test.ogg", "3test.ogg"])
+def test_seek_matches_the_restated_streamdecoder_seekto(ctx, oracle, name):
+    """StreamDecoder.SeekTo restated in the oracle (orc_stream_seek_to, StreamDecoder.cs:817-880): ResetDecoder,
+    _hasPosition = true, the pre-roll packet and the target packet through ReadNextPacket, `_prevPacketStart +=
+    rollForward`.  The reader's seek must hand out the oracle's samples -- including a seek into the last packets,
+    where the EOS trim (:658-666) runs on the position the decoder held BEFORE the seek."""
+    import ctypes as C
+    from vorbispizza_amd.front import VorbisReader
+    path = os.path.join(GOLDEN, name)
+    f, pk, opk = _oracle_packets(path)
+    C_ = f.channels
+    # PacketProvider's view: samples every packet adds (PacketInfo.SampleCount; the first one only primes)
+    counts = []
+    for i in range(len(pk)):
+        fl = int(pk["flags"][i])
+        info = oracle.packet_info(f.block_size0, f.block_size1, fl & 1, bool(fl & 2), bool(fl & 4))
+        counts.append(0 if i == 0 else info.SampleCount)
+    cum = np.cumsum(counts)
+    total = min(int(cum[-1]), int(f.last_granule))
+    rdr = VorbisReader(ctx, path, batch_packets=16)
+    buf = np.zeros(C_ * 4096, dtype=np.float32)
+    # the reader has decoded a little already: the stale position is not zero
+    for _ in range(5):
+        rdr.ReadSamples(buf)
+    stale = rdr.SamplePosition
+    ostream = helpers.OracleStream(oracle, C_, f.block_size0, f.block_size1, f.floors, f.mappings, clip=True, interleave=True)
+    for i in range(len(pk)):        # bring the oracle's decoder to the same place (same stale _currentPosition)
+        if ostream.position >= stale:
+            break
+        ostream.feed(opk[i])
+    assert ostream.position == stale
+    rng = np.random.default_rng(7)
+    targets = [total - 1500, total - 200, 5000, total // 3] + [int(v) for v in rng.integers(1, total - 1, 6)]
+    for g in targets:
+        k = int(np.searchsorted(cum, g, side="right"))    # first packet whose span holds the position
+        k = min(k, len(pk) - 1)
+        provider_pos = int(cum[k - 1])
+        feed = iter(range(k - 1, len(pk)))
+        readable = []
+
+        def read_next_packet(_user):
+            return ostream.read_next_packet(opk[next(feed)])
+
+        cb = oracle.READ_NEXT_PACKET_FN(read_next_packet)
+        ostream.eos_seen = False
+        rc = oracle.lib().orc_stream_seek_to(ostream.st, g, provider_pos, int(cum[-1]), cb, None)
+        assert rc == 0
+        first = ostream.take()
+        if first is not None:
+            readable.append(first)
+        for i in feed:
+            got = ostream.feed(opk[i])
+            if got is not None:
+                readable.append(got)
+            if sum(c.shape[1] for c in readable) >= 3000:
+                break
+        want = np.concatenate(readable, axis=1).T if readable else np.zeros((0, C_), np.float32)
+        want_pos = ostream.position
+        # the library
+        rdr.SeekTo(g)
+        assert rdr.SamplePosition == g
+        chunks = []
+        while sum(len(c) for c in chunks) < len(want):
+            n = rdr.ReadSamples(buf)
+            if n == 0:
+                break
+            chunks.append(buf[: n * C_].reshape(n, C_).copy())
+        got = np.concatenate(chunks) if chunks else np.zeros((0, C_), np.float32)
+        assert got.shape == want.shape, (g, got.shape, want.shape)
+        if len(want):
+            assert np.abs(got - want).max() <= 1e-5 * max(1.0, float(np.abs(want).max())), g
+        assert rdr.SamplePosition == want_pos, (g, rdr.SamplePosition, want_pos)
+    ostream.close()
+    rdr.Dispose()
+
+
+def test_position_is_picked_up_again_after_a_resync(ctx, oracle, tmp_path):
+    """A dropped page: the front end flags the next packet VPZ_PKT_RESYNC, `_hasPosition` goes false and the position
+    comes from the next packet that carries a granule (StreamDecoder.cs:459-463, 718-722)."""
+    from vorbispizza_amd import capi
+    from vorbispizza_amd.front import OggVorbisFile, VorbisReader
+    ogg = bytearray(open(os.path.join(GOLDEN, "3test.ogg"), "rb").read())
+    pages, pos = [], 0
+    while pos < len(ogg):
+        nseg = ogg[pos + 26]
+        body = sum(ogg[pos + 27: pos + 27 + nseg])
+        pages.append((pos, 27 + nseg + body))
+        pos += 27 + nseg + body
+    p0, ln = pages[len(pages) // 2]
+    ogg[p0 + ln - 1] ^= 0x55
+    ogg = bytes(ogg)
+    f = OggVorbisFile(ogg)
+    pk, res, posts, counts = f.decode_packets()
+    assert (pk["flags"] & capi.PKT_RESYNC).any() and f.info.bad_crc_pages >= 1
+    ref, ref_pos, _ = helpers.oracle_decode(oracle, f.channels, f.block_size0, f.block_size1,
+                                            helpers.packets_for_oracle(f, pk, res, posts, counts), floors=f.floors,
+                                            mappings=f.mappings, clip=True, interleave=True)
+    for batch in (3, 128):
+        rdr = VorbisReader(ctx, ogg, batch_packets=batch)
+        buf = np.zeros(2 * 4096, dtype=np.float32)
+        chunks = []
+        while True:
+            n = rdr.ReadSamples(buf)
+            if n == 0:
+                break
+            chunks.append(buf[: 2 * n].reshape(n, 2).copy())
+        got = np.concatenate(chunks)
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+        rdr.Dispose()
+    # the decoder's own position (the reader counts handed-out samples; the decoder re-bases on the granule)
+    from vorbispizza_amd import Decoder
+    dec = Decoder(ctx, f.channels, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings, clip_samples=True)
+    dec.synth(pk, res, posts, counts)
+    assert dec.position(0) == ref_pos and ref_pos != ref.shape[0]   # samples were lost: position != count
+    dec.close()
+
+
+def test_chained_file_is_read_stream_by_stream(ctx, oracle):
+    """VorbisReader.FindNextStream / SwitchStreams (VorbisReader.cs:191-217) over a chain 3test | 1test | 3test."""
+    from vorbispizza_amd import SynthError
+    from vorbispizza_amd.front import VorbisReader
+    a = open(os.path.join(GOLDEN, "3test.ogg"), "rb").read()
+    b = open(os.path.join(GOLDEN, "1test.ogg"), "rb").read()
+    want = {}
+    for key, data in (("a", a), ("b", b)):
+        r = VorbisReader(ctx, data)
+        buf = np.zeros(r.Channels * 4096, dtype=np.float32)
+        chunks = []
+        while True:
+            n = r.ReadSamples(buf)
+            if n == 0:
+                break
+            chunks.append(buf[: n * r.Channels].reshape(n, r.Channels).copy())
+        want[key] = np.concatenate(chunks)
+        r.Dispose()
+    rdr = VorbisReader(ctx, a + b + a)
+    assert rdr.StreamCount == 1 and rdr.Channels == 2
+    outs = []
+    index = 0
+    while True:
+        buf = np.zeros(rdr.Channels * 4096, dtype=np.float32)
+        chunks = []
+        while True:
+            n = rdr.ReadSamples(buf)
+            if n == 0:
+                break
+            chunks.append(buf[: n * rdr.Channels].reshape(n, rdr.Channels).copy())
+        outs.append(np.concatenate(chunks))
+        if not rdr.FindNextStream():
+            break
+        index += 1
+        changed = rdr.SwitchStreams(index)
+        assert changed == (index in (1, 2))          # stereo -> mono -> stereo
+    assert rdr.StreamCount == 3 and len(outs) == 3
+    for got, key in zip(outs, "aba"):
+        assert got.shape == want[key].shape and np.array_equal(got, want[key])
+    # streams keep their own position; switching back does not rewind
+    assert rdr.SwitchStreams(0) is False           # 3test -> 3test: same channels and rate
+    assert rdr.IsEndOfStream and rdr.SamplePosition == len(want["a"])
+    assert rdr.SwitchStreams(1) is True and rdr.Channels == 1 and rdr.SwitchStreams(0) is True
+    rdr.SeekTo(1000)
+    assert rdr.SamplePosition == 1000
+    with pytest.raises(SynthError):
+        rdr.SwitchStreams(7)
+    rdr.Dispose()

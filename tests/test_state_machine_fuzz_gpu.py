@@ -1,12 +1,12 @@
 """Randomised differential test of the per-stream state machine (`ReadNextPacket` / `Read`, StreamDecoder.cs:418-498,
 640-694) between the library and the oracle: arbitrary block / window flag sequences (consistent or not: mismatches
-are part of the game), undecodable packets, EOS anywhere with or without a granule, granule position pick-up after a
+are part of the game), undecodable packets, resync packets (the position becomes unknown until the next granule), EOS anywhere with or without a granule, granule position pick-up after a
 reset, arbitrary batch splits, two block-size pairs.  PCM within 1e-5, everything integer exact."""
 import numpy as np
 import pytest
 
 import helpers
-from helpers import (PKT_BLOCK_FLAG, PKT_EOS, PKT_NEXT_FLAG, PKT_NO_FLOOR, PKT_NOT_DECODED, PKT_PREV_FLAG)
+from helpers import (PKT_BLOCK_FLAG, PKT_EOS, PKT_NEXT_FLAG, PKT_NO_FLOOR, PKT_NOT_DECODED, PKT_PREV_FLAG, PKT_RESYNC)
 
 pytestmark = pytest.mark.gpu
 
@@ -35,6 +35,8 @@ def random_stream(rng, frames, size0, size1):
         flags[f] = bf[f] * (PKT_BLOCK_FLAG | prev * PKT_PREV_FLAG | nxt * PKT_NEXT_FLAG)
         if rng.random() < 0.06:
             flags[f] |= PKT_NOT_DECODED
+        if rng.random() < 0.05:
+            flags[f] |= PKT_RESYNC      # lost sync in front of this packet: the position is picked up again (:718-722)
         if rng.random() < 0.15:
             gran[f] = int(rng.integers(0, frames * size1 // 2))
     if rng.random() < 0.7:  # an EOS somewhere in the second half, sometimes on an undecodable packet

@@ -18,7 +18,7 @@ class Info(C.Structure):
                 ("block_size1", C.c_int32), ("floor_count", C.c_int32), ("residue_count", C.c_int32),
                 ("mapping_count", C.c_int32), ("mode_count", C.c_int32), ("codebook_count", C.c_int32),
                 ("audio_packets", C.c_int64), ("last_granule", C.c_int64), ("residue_floats", C.c_int64),
-                ("pages", C.c_int32), ("bad_crc_pages", C.c_int32)]
+                ("pages", C.c_int32), ("bad_crc_pages", C.c_int32), ("stream_serial", C.c_int32), ("reserved", C.c_int32)]
 
 
 class FrontError(RuntimeError):
@@ -36,6 +36,8 @@ def lib():
         vp = C.c_void_p
         L.vpzh_open_memory.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
         L.vpzh_open_memory.restype = C.c_int
+        L.vpzh_open_memory_stream.argtypes = [vp, C.c_uint64, C.c_int32, C.POINTER(vp)]
+        L.vpzh_open_memory_stream.restype = C.c_int
         L.vpzh_close.argtypes = [vp]
         L.vpzh_close.restype = None
         L.vpzh_last_error.argtypes = [vp]
@@ -71,7 +73,10 @@ def lib():
         L.vpzr_close.restype = None
         L.vpzr_last_error.argtypes = [vp]
         L.vpzr_last_error.restype = C.c_char_p
-        for name in ("vpzr_channels", "vpzr_sample_rate", "vpzr_is_end_of_stream", "vpzr_has_clipped"):
+        L.vpzr_switch_streams.argtypes = [vp, C.c_int]
+        L.vpzr_switch_streams.restype = C.c_int
+        for name in ("vpzr_channels", "vpzr_sample_rate", "vpzr_is_end_of_stream", "vpzr_has_clipped",
+                     "vpzr_find_next_stream", "vpzr_stream_count", "vpzr_stream_serial"):
             getattr(L, name).argtypes = [vp]
             getattr(L, name).restype = C.c_int
         L.vpzr_sample_position.argtypes = [vp]
@@ -107,11 +112,11 @@ class OggVorbisFile:
     (StreamDecoder.cs:213-321): channels, sample_rate, block sizes, floors [(x_list, multiplier)],
     mappings [{"coupling": [(mag, ang)], "channel_floor": [...]}]."""
 
-    def __init__(self, path_or_bytes):
+    def __init__(self, path_or_bytes, stream_index=0):
         data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
         self._data = np.frombuffer(bytes(data), dtype=np.uint8)
         self._h = C.c_void_p()
-        rc = lib().vpzh_open_memory(self._data.ctypes.data, self._data.size, C.byref(self._h))
+        rc = lib().vpzh_open_memory_stream(self._data.ctypes.data, self._data.size, stream_index, C.byref(self._h))
         if rc != 0:
             msg = lib().vpzh_last_error(self._h).decode() if self._h else "open failed"
             self.close()
@@ -245,6 +250,19 @@ class VorbisReader:
     IsEndOfStream = property(lambda self: bool(lib().vpzr_is_end_of_stream(self._h)))
     HasClipped = property(lambda self: bool(lib().vpzr_has_clipped(self._h)))
     TotalSamples = property(lambda self: lib().vpzr_total_samples(self._h))
+    StreamSerial = property(lambda self: lib().vpzr_stream_serial(self._h))
+    StreamCount = property(lambda self: lib().vpzr_stream_count(self._h))
+
+    def FindNextStream(self):
+        """VorbisReader.FindNextStream (VorbisReader.cs:191-194)"""
+        return bool(lib().vpzr_find_next_stream(self._h))
+
+    def SwitchStreams(self, index):
+        """VorbisReader.SwitchStreams (VorbisReader.cs:197-217): True when channels or sample rate changed."""
+        rc = lib().vpzr_switch_streams(self._h, int(index))
+        if rc < 0:
+            raise capi.SynthError(rc, "SwitchStreams: index out of range")
+        return bool(rc)
 
     def SeekTo(self, samplePosition, seekOrigin=0):
         """StreamDecoder.SeekTo(long, SeekOrigin) (StreamDecoder.cs:815-881); seekOrigin 0 Begin, 1 Current, 2 End.

@@ -620,6 +620,7 @@ struct OggPacket {
     std::vector<uint8_t> data;
     int64_t granule = -1;
     bool eos = false;
+    bool resync = false;   // VorbisPacket.IsResync: the page that completes the packet was found after lost sync
 };
 
 // Ogg CRC (polynomial 0x04c11db7, no reflection), Ogg/Crc.cs
@@ -662,18 +663,27 @@ struct vpzh_stream {
     int64_t decode_failures = 0, first_failed_packet = -1;  // of the last vpzh_decode_range* call
 
     // ---- container: Ogg/PageReaderBase.cs:286-361 (sync, CRC), Ogg/PacketProvider.cs:427-560 (packets)
-    void demux(const uint8_t *d, size_t size, std::vector<OggPacket> &packets)
+    // `want`: which logical stream of the container, counted by beginning-of-stream pages (0 = the first one; a
+    // chained file starts its second stream after the first one's end-of-stream page, VorbisReader.FindNextStream).
+    // Returns false when the container holds no such stream.
+    bool demux(const uint8_t *d, size_t size, std::vector<OggPacket> &packets, int want = 0)
     {
         crc_init();
         size_t pos = 0;
-        bool have_serial = false;
+        bool have_serial = false, finished = false;
         uint32_t serial = 0;
+        int bos_seen = 0;
+        // IsResync (Ogg/PageReaderBase.cs:297-342, StreamPageReader.cs:87-96): a page is a resync page when bytes
+        // had to be skipped to find it, or when its sequence number does not follow the previous page of the stream
+        bool skipped_bytes = false, page_resync = false;
+        uint32_t last_seq = 0;
+        bool resync_carry = false;  // a resync page whose first piece was dropped: the next packet carries the flag
         std::vector<uint8_t> pending;  // packet continued from earlier pages
         bool pending_valid = false;
         OggPacket *last_granule_candidate = nullptr;
         (void)last_granule_candidate;
         while (pos + 27 <= size) {
-            if (memcmp(d + pos, "OggS", 4) != 0) { ++pos; continue; }
+            if (memcmp(d + pos, "OggS", 4) != 0) { ++pos; skipped_bytes = true; continue; }
             const uint8_t *h = d + pos;
             int nseg = h[26];
             if (pos + 27 + nseg > size) break;
@@ -685,8 +695,9 @@ struct vpzh_stream {
             static const uint8_t zero4[4] = {0, 0, 0, 0};
             crc = crc_update(crc, zero4, 4);
             crc = crc_update(crc, h + 26, 1 + nseg + body);
-            if (crc != stored) { ++bad_crc; ++pos; continue; }  // resync byte-wise
-            ++pages;
+            if (crc != stored) { ++bad_crc; ++pos; skipped_bytes = true; continue; }  // resync byte-wise
+            const bool found_after_skip = skipped_bytes;
+            skipped_bytes = false;
             uint32_t ser = (uint32_t)h[14] | ((uint32_t)h[15] << 8) | ((uint32_t)h[16] << 16) | ((uint32_t)h[17] << 24);
             uint8_t flags = h[5];
             int64_t granule = 0;
@@ -694,10 +705,16 @@ struct vpzh_stream {
             const size_t page_len = 27 + nseg + body;
             if (!have_serial) {
                 if (!(flags & 2)) { pos += page_len; continue; }  // wait for a beginning-of-stream page
+                if (bos_seen++ != want) { pos += page_len; continue; }
                 serial = ser;
                 have_serial = true;
             }
-            if (ser != serial) { pos += page_len; continue; }  // other logical streams are ignored
+            if (ser != serial || finished) { pos += page_len; continue; }  // pages of other logical streams
+            ++pages;
+            const uint32_t seq = (uint32_t)h[18] | ((uint32_t)h[19] << 8) | ((uint32_t)h[20] << 16) | ((uint32_t)h[21] << 24);
+            page_resync = found_after_skip || (last_seq != 0 && last_seq + 1 != seq);
+            last_seq = seq;
+            if (flags & 4) finished = true;  // end-of-stream page: a later stream may reuse the serial number
             const uint8_t *seg = h + 27;
             const uint8_t *data = h + 27 + nseg;
             const bool continuation = flags & 1;
@@ -706,10 +723,11 @@ struct vpzh_stream {
             for (int i = 0; i < nseg; ++i) if (seg[i] < 255) ++packet_count;
             const bool page_continued = nseg > 0 && seg[nseg - 1] == 255;
             if (page_continued) ++packet_count;
-            if (!continuation && pending_valid) {  // broken continuation: drop what we had
-                pending.clear();
+            if ((!continuation || page_resync) && pending_valid) {  // broken continuation (PacketProvider.cs:473-478
+                pending.clear();                                    // "can't merge across resync"): drop what we had
                 pending_valid = false;
             }
+            if (page_resync) resync_carry = true;
             int packet_idx = 0;
             size_t off = 0, cur = 0;
             bool first_is_continuation = continuation;
@@ -722,7 +740,9 @@ struct vpzh_stream {
                             pk.data = pending;
                             pk.data.insert(pk.data.end(), data + off, data + off + cur);
                         } else {
-                            // continuation of a packet we never saw: the reference drops it
+                            // The tail of a packet whose head was lost.  The reference's sequential reader hands this
+                            // piece to the decoder as a packet of its own (flagged IsResync); it is known garbage, so
+                            // it is dropped here and the flag moves to the next packet of the page.
                             off += cur; cur = 0; ++packet_idx;
                             continue;
                         }
@@ -733,6 +753,8 @@ struct vpzh_stream {
                     }
                     // GranulePosition only on the last packet of the page (PacketProvider.cs:515-530)
                     pk.granule = (packet_idx == packet_count - 1) ? granule : -1;
+                    pk.resync = resync_carry;
+                    resync_carry = false;
                     packets.push_back(std::move(pk));
                     off += cur; cur = 0; ++packet_idx;
                 }
@@ -750,7 +772,10 @@ struct vpzh_stream {
         }
         // IsEndOfStream: last packet completed in the last page (PacketProvider.cs:522-525)
         if (!packets.empty() && packets.back().granule != -1) packets.back().eos = true;
+        stream_serial = serial;
+        return have_serial;
     }
+    uint32_t stream_serial = 0;
 
     void load_headers(std::vector<OggPacket> &pk)
     {
@@ -874,6 +899,7 @@ struct vpzh_stream {
         out->granule = -1;
         out->residue_offset = residue_off;
         if (pk.eos) out->flags |= VPZ_PKT_EOS;
+        if (pk.resync) out->flags |= VPZ_PKT_RESYNC;
         for (int c = 0; c < channels; ++c) post_counts[c] = 0;
         memset(posts, 0, sizeof(int16_t) * 64 * (size_t)channels);
         BitReader p;
@@ -992,13 +1018,21 @@ extern "C" {
 
 int vpzh_open_memory(const uint8_t *data, uint64_t size, vpzh_stream **out)
 {
-    if (!data || !out) return VPZH_E_ARG;
+    return vpzh_open_memory_stream(data, size, 0, out);
+}
+
+int vpzh_open_memory_stream(const uint8_t *data, uint64_t size, int32_t stream_index, vpzh_stream **out)
+{
+    if (!data || !out || stream_index < 0) return VPZH_E_ARG;
     *out = nullptr;
     std::unique_ptr<vpzh_stream> s(new vpzh_stream());
     int rc = VPZH_OK;
     try {
         std::vector<OggPacket> packets;
-        s->demux(data, (size_t)size, packets);
+        if (!s->demux(data, (size_t)size, packets, stream_index)) {
+            if (stream_index > 0) return VPZH_E_NO_STREAM;  // FindNextStream() == false
+            throw InvalidData("no logical stream in the container");
+        }
         s->load_headers(packets);
         s->audio.assign(std::make_move_iterator(packets.begin() + 3), std::make_move_iterator(packets.end()));
         s->residue_floats = 0;
@@ -1039,6 +1073,7 @@ int vpzh_get_info(vpzh_stream *s, vpzh_info *info)
     info->residue_floats = s->residue_floats;
     info->pages = s->pages;
     info->bad_crc_pages = s->bad_crc;
+    info->stream_serial = (int32_t)s->stream_serial;
     return VPZH_OK;
 }
 

@@ -16,7 +16,8 @@
 #include "../../include/vorbispizza_front.h"
 #include "../../include/vorbispizza_reader.h"
 
-struct vpzr_reader {
+// One logical stream of the container: what a StreamDecoder is in the reference.
+struct Sub {
     vpz_context *ctx = nullptr;
     vpzh_stream *front = nullptr;
     vpz_decoder *dec = nullptr;
@@ -199,6 +200,38 @@ struct vpzr_reader {
     }
     const std::vector<float> &batch_pcm(float *) const { return pcm; }
     const std::vector<int16_t> &batch_pcm(int16_t *) const { return pcm16; }
+
+    ~Sub()
+    {
+        if (dec) vpz_decoder_destroy(dec);
+        if (front) vpzh_close(front);
+    }
+};
+
+// VorbisReader (VorbisReader.cs): the logical streams found so far (`Streams`), the one the convenience members
+// forward to (`_streamDecoder`), and the container bytes FindNextStream keeps scanning.
+struct vpzr_reader {
+    vpz_context *ctx = nullptr;
+    std::vector<uint8_t> data;
+    std::vector<std::unique_ptr<Sub>> subs;
+    Sub *cur = nullptr;
+    std::string open_error;
+
+    // opens logical stream number `index` of the container; VPZH_* status
+    int open_stream(int index, std::unique_ptr<Sub> &out)
+    {
+        std::unique_ptr<Sub> s(new Sub());
+        s->ctx = ctx;
+        const int rc = vpzh_open_memory_stream(data.data(), data.size(), index, &s->front);
+        if (rc != VPZH_OK) {
+            open_error = s->front ? vpzh_last_error(s->front) : "could not load the specified container";
+            return rc;
+        }
+        vpzh_get_info(s->front, &s->info);
+        s->opened = s->info.channels >= 1;
+        out = std::move(s);
+        return VPZH_OK;
+    }
 };
 
 extern "C" {
@@ -209,38 +242,64 @@ int vpzr_open_memory(vpz_context *ctx, const uint8_t *data, uint64_t size, vpzr_
     *out = nullptr;
     std::unique_ptr<vpzr_reader> r(new vpzr_reader());
     r->ctx = ctx;
-    int rc = vpzh_open_memory(data, size, &r->front);
+    r->data.assign(data, data + size);
+    std::unique_ptr<Sub> first;
+    const int rc = r->open_stream(0, first);
     if (rc != VPZH_OK) {
         // the handle only carries the error text; every other entry point refuses it
-        r->error = r->front ? vpzh_last_error(r->front) : "could not load the specified container";
         *out = r.release();
         return rc == VPZH_E_UNSUPPORTED ? VPZ_E_UNSUPPORTED : VPZ_E_INVALID_ARG;
     }
-    vpzh_get_info(r->front, &r->info);
-    r->opened = r->info.channels >= 1;
+    r->subs.push_back(std::move(first));
+    r->cur = r->subs[0].get();
     *out = r.release();
     return VPZ_OK;
 }
 
-void vpzr_close(vpzr_reader *r)
+void vpzr_close(vpzr_reader *r) { delete r; }
+
+// VorbisReader.FindNextStream (VorbisReader.cs:191-194): looks for one more logical stream in the container (a
+// chained file starts it after the previous stream's last page) and adds it to the list.  1: found, 0: none.
+int vpzr_find_next_stream(vpzr_reader *r)
 {
-    if (!r) return;
-    if (r->dec) vpz_decoder_destroy(r->dec);
-    if (r->front) vpzh_close(r->front);
-    delete r;
+    if (!r || !r->cur) return 0;
+    std::unique_ptr<Sub> next;
+    if (r->open_stream((int)r->subs.size(), next) != VPZH_OK) return 0;
+    next->clip = r->cur->clip;
+    next->batch = r->cur->batch;
+    next->s16 = r->cur->s16;
+    r->subs.push_back(std::move(next));
+    return 1;
 }
 
-const char *vpzr_last_error(vpzr_reader *r) { return r ? r->error.c_str() : ""; }
-int vpzr_channels(vpzr_reader *r) { return r && r->opened ? r->info.channels : 0; }
-int vpzr_sample_rate(vpzr_reader *r) { return r && r->opened ? r->info.sample_rate : 0; }
-int64_t vpzr_sample_position(vpzr_reader *r) { return r ? r->position : 0; }
-int vpzr_is_end_of_stream(vpzr_reader *r) { return r ? (r->ended && r->cur_remaining == 0 && r->cur_packet >= r->packet_samples.size()) : 1; }
+int vpzr_stream_count(vpzr_reader *r) { return r ? (int)r->subs.size() : 0; }
 
-int64_t vpzr_total_samples(vpzr_reader *r) { return r && r->opened ? vpzh_total_samples(r->front) : 0; }
+// VorbisReader.SwitchStreams (VorbisReader.cs:197-217): 1 when channels or sample rate differ from the stream that
+// was current (the caller has to re-open its output), 0 otherwise, VPZ_E_INVALID_ARG for a bad index.
+int vpzr_switch_streams(vpzr_reader *r, int index)
+{
+    if (!r || !r->cur || index < 0 || index >= (int)r->subs.size()) return VPZ_E_INVALID_ARG;
+    Sub *next = r->subs[(size_t)index].get(), *old = r->cur;
+    if (next == old) return 0;
+    if (!next->dec) next->clip = old->clip;  // "carry-through the clipping setting"
+    r->cur = next;
+    return (next->info.channels != old->info.channels || next->info.sample_rate != old->info.sample_rate) ? 1 : 0;
+}
+
+int vpzr_stream_serial(vpzr_reader *r) { return r && r->cur ? r->cur->info.stream_serial : 0; }
+
+const char *vpzr_last_error(vpzr_reader *R) { return !R ? "" : (R->cur ? R->cur->error.c_str() : R->open_error.c_str()); }
+int vpzr_channels(vpzr_reader *R) { Sub *r = R ? R->cur : nullptr; return r && r->opened ? r->info.channels : 0; }
+int vpzr_sample_rate(vpzr_reader *R) { Sub *r = R ? R->cur : nullptr; return r && r->opened ? r->info.sample_rate : 0; }
+int64_t vpzr_sample_position(vpzr_reader *R) { Sub *r = R ? R->cur : nullptr; return r ? r->position : 0; }
+int vpzr_is_end_of_stream(vpzr_reader *R) { Sub *r = R ? R->cur : nullptr; return r ? (r->ended && r->cur_remaining == 0 && r->cur_packet >= r->packet_samples.size()) : 1; }
+
+int64_t vpzr_total_samples(vpzr_reader *R) { Sub *r = R ? R->cur : nullptr; return r && r->opened ? vpzh_total_samples(r->front) : 0; }
 
 // StreamDecoder.SeekTo(long, SeekOrigin) (StreamDecoder.cs:815-881)
-int vpzr_seek_to(vpzr_reader *r, int64_t sample_position, int origin)
+int vpzr_seek_to(vpzr_reader *R, int64_t sample_position, int origin)
 {
+    Sub *r = R ? R->cur : nullptr;
     if (!r) return VPZ_E_INVALID_ARG;
     if (!r->opened) return r->fail(VPZ_E_INVALID_ARG, "the reader has no open stream");
     if (sample_position < 0) return r->fail(VPZ_E_INVALID_ARG, "samplePosition");  // ArgumentOutOfRangeException
@@ -283,38 +342,43 @@ int vpzr_seek_to(vpzr_reader *r, int64_t sample_position, int origin)
     return VPZ_OK;
 }
 
-int vpzr_set_clip_samples(vpzr_reader *r, int clip)
+int vpzr_set_clip_samples(vpzr_reader *R, int clip)
 {
+    Sub *r = R ? R->cur : nullptr;
     if (!r) return VPZ_E_INVALID_ARG;
     if (r->dec) return VPZ_E_INVALID_ARG;  // fixed once decoding has started
     r->clip = clip != 0;
     return VPZ_OK;
 }
 
-int vpzr_set_sample_format(vpzr_reader *r, int format)
+int vpzr_set_sample_format(vpzr_reader *R, int format)
 {
+    Sub *r = R ? R->cur : nullptr;
     if (!r || (format != VPZR_FORMAT_F32 && format != VPZR_FORMAT_S16)) return VPZ_E_INVALID_ARG;
     if (r->dec) return VPZ_E_INVALID_ARG;  // fixed once decoding has started
     r->s16 = format == VPZR_FORMAT_S16;
     return VPZ_OK;
 }
 
-int vpzr_set_batch_packets(vpzr_reader *r, int packets)
+int vpzr_set_batch_packets(vpzr_reader *R, int packets)
 {
+    Sub *r = R ? R->cur : nullptr;
     if (!r || packets < 1) return VPZ_E_INVALID_ARG;
     r->batch = packets;
     return VPZ_OK;
 }
 
-int vpzr_has_clipped(vpzr_reader *r)
+int vpzr_has_clipped(vpzr_reader *R)
 {
+    Sub *r = R ? R->cur : nullptr;
     int32_t v = 0;
     if (r && r->dec) vpz_decoder_has_clipped(r->dec, 0, &v);
     return v;
 }
 
-int64_t vpzr_read_samples(vpzr_reader *r, float *buffer, int64_t buffer_len, int *status)
+int64_t vpzr_read_samples(vpzr_reader *R, float *buffer, int64_t buffer_len, int *status)
 {
+    Sub *r = R ? R->cur : nullptr;
     int st = VPZ_OK;
     if (!r || (!buffer && buffer_len) || buffer_len < 0) { if (status) *status = VPZ_E_INVALID_ARG; return 0; }
     if (!r->opened) { if (status) *status = r->fail(VPZ_E_INVALID_ARG, "the reader has no open stream"); return 0; }
@@ -326,8 +390,9 @@ int64_t vpzr_read_samples(vpzr_reader *r, float *buffer, int64_t buffer_len, int
     return n;
 }
 
-int64_t vpzr_read_samples_s16(vpzr_reader *r, int16_t *buffer, int64_t buffer_len, int *status)
+int64_t vpzr_read_samples_s16(vpzr_reader *R, int16_t *buffer, int64_t buffer_len, int *status)
 {
+    Sub *r = R ? R->cur : nullptr;
     int st = VPZ_OK;
     if (!r || (!buffer && buffer_len) || buffer_len < 0) { if (status) *status = VPZ_E_INVALID_ARG; return 0; }
     if (!r->opened) { if (status) *status = r->fail(VPZ_E_INVALID_ARG, "the reader has no open stream"); return 0; }
@@ -339,9 +404,10 @@ int64_t vpzr_read_samples_s16(vpzr_reader *r, int16_t *buffer, int64_t buffer_le
     return n;
 }
 
-int64_t vpzr_read_samples_planar(vpzr_reader *r, float *buffer, int64_t buffer_len, int64_t samples_to_read,
+int64_t vpzr_read_samples_planar(vpzr_reader *R, float *buffer, int64_t buffer_len, int64_t samples_to_read,
                                  int64_t channel_stride, int *status)
 {
+    Sub *r = R ? R->cur : nullptr;
     int st = VPZ_OK;
     if (!r || (!buffer && buffer_len) || buffer_len < 0) { if (status) *status = VPZ_E_INVALID_ARG; return 0; }
     if (!r->opened) { if (status) *status = r->fail(VPZ_E_INVALID_ARG, "the reader has no open stream"); return 0; }
