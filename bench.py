@@ -40,17 +40,22 @@ N = 2048
 
 
 def pmc_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 FETCH_SIZE x2 correction): counters cannot be
-    collected inside this process, so the figure is read from profiles/ and null if absent."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.txt")
+    """HBM bytes per launch of the dominant kernel as measured with the PMC counters (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate passes, gfx950 corrections): counters cannot be collected inside this process, so the figure
+    comes from profiles/traffic_stamp.json, written on the GPU box by tools/stamp_traffic.py together with the SHA-256
+    of the kernel's sources.  Null when there is no stamp or when the sources have changed since it was taken."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "traffic_stamp.json")
     try:
-        for line in open(path):
-            if line.startswith("corrected HBM traffic per launch:"):
-                return int(float(line.split(":")[1].split("MB")[0]) * 1e6)
-    except OSError:
-        pass
-    return None
+        stamp = json.load(open(path))
+        h = hashlib.sha256()
+        for rel in stamp["kernel_sources"]:
+            h.update(open(os.path.join(ROOT, rel), "rb").read())
+        if h.hexdigest() != stamp["kernel_sources_sha256"]:
+            return None
+        return int(stamp["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def host_threads(cap=16):
