@@ -55,15 +55,41 @@ constexpr int32_t kPreNone = 0;     // the stream has no previous block (first p
 constexpr int32_t kPreState = 1;    // previous block's h is in the decoder's device state
 constexpr int32_t kPreRecompute = 2;// previous block is frame first-1 of this batch: recompute it
 constexpr uint32_t kRunSaveState = 1u;  // run ends the stream's batch: save h of its last block
+// COMPACT runs: the host uploads two bytes per frame (the packet's window flags and its mapping index) instead of a
+// 32-byte FrameDesc; the wave that owns the run derives its descriptors -- window geometry from the flag pairs,
+// residue / output offsets by a prefix sum over the run -- into the LDS area explicit descriptors are staged in.
+// Possible when the batch is what real hosts produce (see run_state_machine_parallel) and the packets' residues
+// lie back to back.
+constexpr uint32_t kRunCompact = 2u;
+constexpr uint32_t kRunLastTrimmed = 4u;  // the run's last frame: out_count / left_start as given (EOS trim, :658-666)
+// compact frame byte
+constexpr uint32_t kCfNoFloor = 8u;       // bits 0..2: vpz_packet.flags & 7
+constexpr uint32_t kCfInterleaved = 16u;  // residue is the Residue2 vector AND the batch runs in group mode
+constexpr uint32_t kCfSkip = 128u;        // the packet was skipped (window mismatch): a frame that does nothing
 
-struct RunDesc {
-    int32_t first;       // index of the first FrameDesc
+struct RunDesc {         // 64 bytes
+    int32_t first;       // index of the first frame (FrameDesc index, or packet index for a compact run)
     int32_t count;       // frames in the run
     int32_t stream;
     int32_t pre_kind;
     uint32_t flags;
     int32_t prev_long;   // kPreState: 1 if the saved block was a size1 block
-    int32_t reserved0, reserved1;
+    // ---- compact runs only; "first staged frame" = frame `first`, or `first - 1` when that block is recomputed
+    int32_t rec_base;    // channel record of the first staged frame; consecutive frames are consecutive packets
+    uint16_t prev_end0, prev_stop0;  // window of the block in front of the first staged frame (has_prev0)
+    int64_t spec_base;   // residue offset of the first staged frame
+    int64_t out_base;    // output offset (samples per channel, inside the stream) of frame `first`
+    uint16_t last_out_count, last_left_start;  // kRunLastTrimmed
+    uint8_t has_prev0;
+    uint8_t pad[3];
+    int32_t clip_epoch;  // what the run stores into clipped[stream] when a sample was clipped (see vpz_decoder_reset)
+    int32_t reserved;
+};
+static_assert(sizeof(RunDesc) == 64, "RunDesc layout");
+
+// Mode.GetPacketInfo by (block | prev << 1 | next << 2), what the compact path needs of it
+struct PacketGeom {
+    uint16_t left_start, right_start, right_end, left_use_size1;
 };
 
 // Floor1 static tables on the device (Floor1.cs:30-31), one per vpz_floor1_config
@@ -79,7 +105,11 @@ struct FloorDev {
 };
 
 struct SynthArgs {
-    const FrameDesc *frames;
+    const FrameDesc *frames;    // explicit descriptors (nullptr when every run is compact)
+    const uint8_t *cflags;      // compact runs: [frame] flag byte, [frame] mapping index,
+    const uint8_t *cmap;
+    const uint32_t *map_bits;   // [mapping] group-mode flag bits of a floored frame of that mapping (stage / steps)
+    PacketGeom geom[8];
     const RunDesc *runs;
     int32_t n_runs;
     int32_t channels;

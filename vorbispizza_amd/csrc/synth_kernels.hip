@@ -647,6 +647,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     __shared__ float s_slope0[kGeneral ? 512 : 128];
     __shared__ float s_db[kHasFloor ? 256 : 1];
     __shared__ uint8_t s_steps[kGroup ? 2 * kGroupMaxStepPairs : 4];
+    __shared__ PacketGeom s_geom[8];
     __shared__ float s_work[kSynthWaves][kWaveBufFloats];   // h of the block being built
     __shared__ float s_tail[kSynthWaves][kWaveTailFloats];  // upper half of the previous block's h
     __shared__ uint4 s_desc[kSynthWaves][(kRunMax + 1) * 2];  // the run's frame descriptors
@@ -676,6 +677,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     for (int i = threadIdx.x; i < a.size1 / 2; i += kSynthThreads) s_slope1[i] = a.slope1[i];
     for (int i = threadIdx.x; i < a.size0 / 2 && i < (kGeneral ? 512 : 128); i += kSynthThreads) s_slope0[i] = a.slope0[i];
     if (kHasFloor && threadIdx.x < 256) s_db[threadIdx.x] = a.inv_db[threadIdx.x];
+    if (threadIdx.x < 8) s_geom[threadIdx.x] = a.geom[threadIdx.x];
     if (kGroup)
         for (int i = threadIdx.x; i < 2 * a.n_step_pairs && i < 2 * kGroupMaxStepPairs; i += kSynthThreads)
             s_steps[i] = a.steps[i];
@@ -759,9 +761,50 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         __syncthreads();
         iters = s_iters;
     }
-    // Stage the run's descriptors in LDS with one coalesced read: per-frame scalar loads from
-    // global memory put an L2 round trip on every frame's critical path.
-    {
+    // Stage the run's descriptors in LDS: per-frame scalar loads from global memory would put an L2 round trip on
+    // every frame's critical path.  Explicit descriptors come with one coalesced read; a compact run builds them here.
+    if (run.flags & kRunCompact) {
+        const int n = run.count - fi0;  // staged frames (<= kRunMax + 1 <= 64), one lane each
+        const int f0 = run.first + fi0;
+        uint32_t cf = 0, mp = 0;
+        if (lane < n) { cf = a.cflags[f0 + lane]; mp = a.cmap[f0 + lane]; }
+        const uint32_t pcf = __shfl_up(cf, 1);
+        const PacketGeom g = s_geom[cf & 7], pg = s_geom[pcf & 7];
+        const bool has_prev = lane > 0 || run.has_prev0;
+        const int prev_end = lane > 0 ? pg.right_start : run.prev_end0;
+        const int prev_stop = lane > 0 ? pg.right_end : run.prev_stop0;
+        int left_start = has_prev ? g.left_start : g.right_start;  // StreamDecoder.cs:674 / :679
+        int out_count = has_prev ? max(0, (int)g.right_start - (int)g.left_start) : 0;
+        uint32_t fl = ((cf & 1) ? kFrameLong : 0u) | (g.left_use_size1 ? kFrameSlope1 : 0u) |
+                      ((cf & kCfNoFloor) ? kFrameNoFloor : 0u);
+        if (cf & kCfInterleaved) fl |= kFrameInterleaved | kFrameStage;
+        if (!(cf & kCfNoFloor)) fl |= a.map_bits[mp];
+        if (cf & kCfSkip) { fl = kFrameDrain; out_count = 0; }
+        if ((run.flags & kRunLastTrimmed) && lane == n - 1) { out_count = run.last_out_count; left_start = run.last_left_start; }
+        // residue and output offsets: exclusive prefix sums over the run's frames
+        const int half = (cf & 1) ? (a.size1 >> 1) : (a.size0 >> 1);
+        int spec_sz = lane < n ? C * half : 0;
+        int out_sz = (lane < n && lane >= -fi0) ? out_count : 0;
+        int spec_incl = spec_sz, out_incl = out_sz;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t0 = __shfl_up(spec_incl, d), t1 = __shfl_up(out_incl, d);
+            if (lane >= d) { spec_incl += t0; out_incl += t1; }
+        }
+        if (lane < n) {
+            const int64_t spec_off = run.spec_base + (spec_incl - spec_sz);
+            const int64_t out_off = run.out_base + (out_incl - out_sz);
+            uint4 lo, hi;
+            lo.x = (uint32_t)spec_off; lo.y = (uint32_t)((uint64_t)spec_off >> 32);
+            lo.z = (uint32_t)out_off; lo.w = (uint32_t)((uint64_t)out_off >> 32);
+            hi.x = (uint32_t)(run.rec_base + lane * C);
+            hi.y = (uint32_t)left_start | ((uint32_t)(has_prev && !(cf & kCfSkip) ? prev_stop - prev_end : 0) << 16);
+            hi.z = (uint32_t)((has_prev && !(cf & kCfSkip)) ? prev_end : 0) | ((uint32_t)out_count << 16);
+            hi.w = fl;
+            s_desc[wave][2 * lane] = lo;
+            s_desc[wave][2 * lane + 1] = hi;
+        }
+    } else {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.frames + (run.first + fi0));
         const int n16 = (run.count - fi0) * 2;
         for (int i = lane; i < n16; i += 64) s_desc[wave][i] = src[i];
@@ -1185,7 +1228,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         float *st = a.state_h + ((size_t)run.stream * a.channels + ch) * half1;
         for (int i = lane; i < prev_n4; i += 64) st[i] = tail[i];
     }
-    if (a.clip && __any(clipped_any) && lane == 0) atomicOr(&a.clipped[run.stream], 1);
+    // HasClipped is sticky until ResetDecoder: the flag holds the stream's reset epoch, so a reset costs no device work
+    if (a.clip && __any(clipped_any) && lane == 0) atomicMax(&a.clipped[run.stream], run.clip_epoch);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -62,6 +62,7 @@ struct StreamState {
     bool has_position = true;   // ProcessHeaderPackets: _currentPosition = 0; _hasPosition = true (:165-168)
     bool eos_found = false;
     bool has_clipped = false;
+    int32_t clip_epoch = 1;     // resets so far + 1: clipped[stream] == clip_epoch <=> HasClipped
 };
 
 struct DevBuf {
@@ -73,6 +74,7 @@ struct DevBuf {
 // and the next call waits (on an event) only for the previous call's uploads before reusing it.
 struct PinnedArena {
     char *base = nullptr;
+    char *mapped = nullptr;   // the same memory as the GPU addresses it (hipHostGetDevicePointer)
     size_t cap = 0, used = 0;
     hipEvent_t uploaded = nullptr;   // the arena is in its device mirror
     bool pending = false;
@@ -99,6 +101,12 @@ struct Decoder {
     int32_t *d_clipped = nullptr;
     uint8_t *d_steps = nullptr;              // coupling steps of all mappings, pairs (mag, ang)
     uint8_t *d_steps_lvl = nullptr;          // the same with bit 7 of `mag` set where a level of disjoint steps starts
+    uint32_t *d_map_bits = nullptr;          // per mapping: group-mode frame flag bits (stage / steps) of a floored frame
+    std::vector<uint8_t> mapping_uses_floor0;
+    std::vector<int64_t> out_off_scratch;    // compact batches: output offset of every frame (host only)
+    std::vector<int32_t> trim_out_count, trim_left_start;  // per stream: EOS-trimmed last frame of the batch, -1: none
+    bool no_compact = false;                 // VPZ_NO_COMPACT=1: always upload explicit frame descriptors (A/B tests)
+    size_t zero_copy_max = 1u << 20;         // arenas up to this size are read in place by the kernels (VPZ_ZERO_COPY_MAX)
     std::vector<int32_t> mapping_steps_off;  // per mapping: offset into d_steps (pairs*2), -1 none
     DevBuf b_curve, b_temp, b_cposts, b_ccount;
     // group mode of synth_kernel (channels of a packet share a workgroup; de-interleave + coupling in LDS)
@@ -138,11 +146,15 @@ static int arena_begin(Context *ctx, PinnedArena &A, size_t need)
     if (A.cap < need) {
         if (A.base) VPZ_HIP_TRY(ctx, hipHostFree(A.base));
         A.base = nullptr;
+        A.mapped = nullptr;
         A.cap = 0;
         const size_t want = need + need / 2 + 4096;
-        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&A.base), want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&A.base), want, hipHostMallocMapped);
         if (e != hipSuccess) return set_error(ctx, VPZ_E_NOMEM, "hipHostMalloc(descriptor arena)", e);
         A.cap = want;
+        void *m = nullptr;
+        A.mapped = hipHostGetDevicePointer(&m, A.base, 0) == hipSuccess ? static_cast<char *>(m) : nullptr;
+        if (!A.mapped) (void)hipGetLastError();
     }
     A.used = 0;
     return VPZ_OK;
@@ -325,6 +337,19 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         D.group_ok = synth_group_supported(D.channels) && !D.generic && !has_floor0 && D.max_steps <= 255 &&
                      D.n_step_pairs <= kGroupMaxStepPairs && !(no_group && atoi(no_group));
         D.max_steps = max_levels;  // from here on: the barriers a frame's coupling needs in group mode
+        const char *nc = getenv("VPZ_NO_COMPACT");
+        D.no_compact = nc && atoi(nc);
+        if (const char *z = getenv("VPZ_ZERO_COPY_MAX")) D.zero_copy_max = (size_t)atoll(z);
+    }
+    std::vector<uint32_t> map_bits(std::max<size_t>(1, D.mappings.size()), 0u);
+    D.mapping_uses_floor0.assign(D.mappings.size(), 0);
+    for (size_t m = 0; m < D.mappings.size(); ++m) {
+        const int n = D.mappings[m].coupling_steps;
+        if (D.group_ok && n > 0)
+            map_bits[m] = kFrameStage | ((uint32_t)n << kFrameStepsShift) |
+                          ((uint32_t)(D.mapping_steps_off[m] / 2) << kFrameStepsOffShift);
+        for (int ch = 0; ch < D.channels; ++ch)
+            if (!D.floor_types.empty() && D.floor_types[D.mappings[m].channel_floor[ch]] == 0) D.mapping_uses_floor0[m] = 1;
     }
     if (rc != VPZ_OK) {
         delete d;
@@ -349,6 +374,8 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     if (e == hipSuccess) e = hipMemset(D.d_clipped, 0, sizeof(int32_t) * (size_t)n_streams);
     if (e == hipSuccess) e = hipMalloc((void **)&D.d_steps, steps.size() ? steps.size() : 1);
     if (e == hipSuccess && !steps.empty()) e = hipMemcpy(D.d_steps, steps.data(), steps.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&D.d_map_bits, sizeof(uint32_t) * map_bits.size());
+    if (e == hipSuccess) e = hipMemcpy(D.d_map_bits, map_bits.data(), sizeof(uint32_t) * map_bits.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&D.d_steps_lvl, steps_lvl.size() ? steps_lvl.size() : 1);
     if (e == hipSuccess && !steps_lvl.empty())
         e = hipMemcpy(D.d_steps_lvl, steps_lvl.data(), steps_lvl.size(), hipMemcpyHostToDevice);
@@ -412,6 +439,7 @@ void vpz_decoder_destroy(vpz_decoder *d)
     if (D.d_clipped) (void)hipFree(D.d_clipped);
     if (D.d_steps) (void)hipFree(D.d_steps);
     if (D.d_steps_lvl) (void)hipFree(D.d_steps_lvl);
+    if (D.d_map_bits) (void)hipFree(D.d_map_bits);
     if (D.d_floors0) (void)hipFree(D.d_floors0);
     if (D.d_bark_maps) (void)hipFree(D.d_bark_maps);
     for (PinnedArena &A : D.arenas) {
@@ -430,11 +458,16 @@ int vpz_decoder_reset(vpz_decoder *d, int32_t stream)
     const int lo = stream < 0 ? 0 : stream, hi = stream < 0 ? D.n_streams : stream + 1;
     for (int s = lo; s < hi; ++s) {  // StreamDecoder.cs:357-369: the position value itself is kept
         const int64_t pos = D.states[s].current_position;
+        const int32_t epoch = D.states[s].clip_epoch;
         D.states[s] = StreamState();
         D.states[s].current_position = pos;
         D.states[s].has_position = false;
+        // `_hasClipped = false`: the fused kernels record clipping as "the stream's epoch", so moving on to the next
+        // epoch clears the flag without any device work; the any-block-size path sets a plain 1 and is cleared below
+        D.states[s].clip_epoch = D.generic ? 1 : epoch + 1;
     }
-    VPZ_HIP_TRY(D.ctx, hipMemsetAsync(D.d_clipped + lo, 0, sizeof(int32_t) * (size_t)(hi - lo), D.ctx->stream));
+    if (D.generic)
+        VPZ_HIP_TRY(D.ctx, hipMemsetAsync(D.d_clipped + lo, 0, sizeof(int32_t) * (size_t)(hi - lo), D.ctx->stream));
     return VPZ_OK;
 }
 
@@ -473,6 +506,8 @@ struct SynthCall {
     bool any_floor = false, any_floor0 = false, need_coupling = false;
     bool group_align_ok = true;   // every interleaved packet starts on a 16-byte boundary (group mode loads 16 bytes)
     bool use_group = false;       // decided after pass 1: synth_kernel's group mode instead of the coupling pass
+    bool compact = false;         // every run compact: two bytes per frame instead of a FrameDesc (parallel pass only)
+    uint8_t *cflags = nullptr, *cmap = nullptr;
     int64_t mismatches = 0, res_extent = 0;
     // ---- descriptor tables (pinned arena; dev() gives the device mirror's address)
     RunDesc *runs = nullptr;
@@ -506,10 +541,15 @@ struct SynthCall {
     {
     }
 
+    // device view of a table carved out of the arena: its copy in the device mirror, or -- for small arenas --
+    // the pinned host memory itself, which the GPU reads over the link (see stage_inputs)
     void *dev(const void *host_ptr) const
     {
-        return host_ptr ? static_cast<char *>(A->dev.p) + (static_cast<const char *>(host_ptr) - A->base) : nullptr;
+        if (!host_ptr) return nullptr;
+        char *base = zero_copy ? A->mapped : static_cast<char *>(A->dev.p);
+        return base + (static_cast<const char *>(host_ptr) - A->base);
     }
+    bool zero_copy = false;
 
     // Every per-call table (frame / run descriptors, coupling packets, per-record floor info, output
     // offsets, ...) is carved out of ONE pinned arena that goes to its device mirror in a single copy;
@@ -519,7 +559,9 @@ struct SynthCall {
         bool has_floor0_type = false;
         for (uint8_t t : D.floor_types) has_floor0_type |= (t == 0);
         const size_t np = (size_t)n_packets;
-        size_t need = (sizeof(FrameDesc) + sizeof(RunDesc) + coupling_packet_size()) * np +
+        // (runs hold >= 4 frames unless VPZ_RUN_LENGTH says otherwise)
+        size_t need = (sizeof(FrameDesc) + (D.run_length_override > 0 ? sizeof(RunDesc) : sizeof(RunDesc) / 4) + 2 +
+                       coupling_packet_size()) * np +
                       sizeof(RunDesc) * ((size_t)D.n_streams + 1) + (have_posts ? (size_t)n_rec : 0) +
                       sizeof(int64_t) * (size_t)D.n_streams + 4096;
         if (has_floor0_type) need += floor0_rec_size() * (size_t)n_rec + 64;
@@ -585,6 +627,7 @@ struct SynthCall {
             int64_t base = 0;         // filled between the sweeps: samples of the leading stream before this chunk
             int64_t res_extent = 0;
             bool any_floor = false, any_floor0 = false, need_coupling = false, align_ok = true;
+            bool dense = true;        // every packet's residue starts where its predecessor's (same stream) ends
             char pad[64];
         };
         std::vector<Chunk> chunks((size_t)parties);
@@ -672,10 +715,16 @@ struct SynthCall {
                 if (!no_floor) {
                     K.any_floor = true;
                     if (D.mappings[pk.mapping].coupling_steps > 0) K.need_coupling = true;
+                    if (D.mapping_uses_floor0[pk.mapping]) K.any_floor0 = true;
                 }
                 if (pk.flags & VPZ_PKT_INTERLEAVED) {
                     K.need_coupling = true;
                     if (pk.residue_offset & 3) K.align_ok = false;
+                }
+                if (!new_stream) {
+                    const vpz_packet &pp = packets[p - 1];
+                    const int64_t prev_floats = (int64_t)C * ((pp.flags & VPZ_PKT_BLOCK_FLAG) ? half1 : half0);
+                    if (pk.residue_offset != pp.residue_offset + prev_floats) K.dense = false;
                 }
             }
             if (leading) { K.lead_sum = run; K.lead_end = K.hi; }
@@ -686,9 +735,29 @@ struct SynthCall {
                 std::fill(D.packet_samples.begin(), D.packet_samples.end(), 0);
                 return 0;
             }
-        frames = arena_alloc<FrameDesc>(*A, (size_t)n_packets);
+        bool all_dense = true;
+        for (const Chunk &K : chunks) {
+            all_dense &= K.dense;
+            any_floor0 |= K.any_floor0;
+            need_coupling |= K.need_coupling;
+            group_align_ok &= K.align_ok;
+        }
+        // Compact runs (two bytes per frame, descriptors built on the device) need consecutive packets with back to
+        // back residues and a batch the fused kernel takes as it is (no planar temp, no type-0 floor pass)
+        const bool group_usable = D.group_ok && group_align_ok &&
+                                  (mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
+        compact = all_dense && !D.generic && !any_floor0 && !D.no_compact && (!need_coupling || group_usable);
+        if (compact) {
+            cflags = arena_alloc<uint8_t>(*A, (size_t)n_packets);
+            cmap = arena_alloc<uint8_t>(*A, (size_t)n_packets);
+            D.out_off_scratch.resize((size_t)n_packets);
+        } else {
+            frames = arena_alloc<FrameDesc>(*A, (size_t)n_packets);
+        }
         rec_floor = have_posts ? arena_alloc<uint8_t>(*A, (size_t)n_rec) : nullptr;
         st = D.states;
+        D.trim_out_count.assign((size_t)D.n_streams, -1);
+        D.trim_left_start.assign((size_t)D.n_streams, 0);
         started_with_prev.resize(D.n_streams);
         started_prev_long.resize(D.n_streams);
         for (int s = 0; s < D.n_streams; ++s) {
@@ -710,11 +779,10 @@ struct SynthCall {
                 cur_stream = last;
                 res_extent = std::max(res_extent, K.res_extent);
                 any_floor |= K.any_floor;
-                need_coupling |= K.need_coupling;
-                group_align_ok &= K.align_ok;
             }
         }
         if (D.generic) need_coupling = true;
+        const bool group_bits = D.group_ok;  // (frame_flags' rule: group-mode bits only when the decoder can use them)
         // sweep B: the descriptors, the per-record floor info, where each stream's packets begin and end
         pool.run([&](int c) {
             Chunk &K = chunks[c];
@@ -728,25 +796,36 @@ struct SynthCall {
                 prev_of(p, has_prev, prev_end, prev_stop);
                 const PacketInfo &pi = D.packet_info[pk.flags & 7];
                 const bool last = is_last_of_stream(p);
-                FrameDesc fd{};
-                fd.rec = (int32_t)(p * C);
-                if (last && has_prev && prev_stop - prev_end > (pi.left_use_size1 ? half1 : half0)) {
-                    fd.flags = kFrameDrain;  // skipped packet (window mismatch): a frame that does nothing
+                const bool skipped = last && has_prev && prev_stop - prev_end > (pi.left_use_size1 ? half1 : half0);
+                if (compact) {
+                    uint8_t cf = (uint8_t)(pk.flags & 7);
+                    if (pk.flags & VPZ_PKT_NO_FLOOR) cf |= kCfNoFloor;
+                    if ((pk.flags & VPZ_PKT_INTERLEAVED) && group_bits) cf |= kCfInterleaved;
+                    if (skipped) cf |= kCfSkip;  // window mismatch: a frame that does nothing
+                    cflags[p] = cf;
+                    cmap[p] = pk.mapping;
+                    D.out_off_scratch[(size_t)p] = run;
                 } else {
-                    fd.flags = frame_flags(pk, pi);
-                    if (has_prev) {
-                        fd.packet_len = (uint16_t)(prev_stop - prev_end);
-                        fd.prev_end = (uint16_t)prev_end;
-                        fd.left_start = (uint16_t)pi.left_start;
+                    FrameDesc fd{};
+                    fd.rec = (int32_t)(p * C);
+                    if (skipped) {
+                        fd.flags = kFrameDrain;  // skipped packet (window mismatch): a frame that does nothing
                     } else {
-                        fd.left_start = (uint16_t)pi.right_start;  // StreamDecoder.cs:679
+                        fd.flags = frame_flags(pk, pi);
+                        if (has_prev) {
+                            fd.packet_len = (uint16_t)(prev_stop - prev_end);
+                            fd.prev_end = (uint16_t)prev_end;
+                            fd.left_start = (uint16_t)pi.left_start;
+                        } else {
+                            fd.left_start = (uint16_t)pi.right_start;  // StreamDecoder.cs:679
+                        }
+                        fd.out_count = (uint16_t)psamples[p];
+                        fd.spec_off = pk.residue_offset;
                     }
-                    fd.out_count = (uint16_t)psamples[p];
-                    fd.spec_off = pk.residue_offset;
+                    fd.out_off = run;
+                    frames[p] = fd;
                 }
-                fd.out_off = run;
                 run += psamples[p];
-                frames[p] = fd;
                 if (rec_floor) {
                     if (pk.flags & VPZ_PKT_NO_FLOOR) {
                         for (int ch = 0; ch < C; ++ch) rec_floor[(size_t)(p * C + ch)] = 0;
@@ -756,7 +835,6 @@ struct SynthCall {
                         for (int ch = 0; ch < C; ++ch) {
                             const uint8_t fl = mc.channel_floor[ch];
                             const bool f0 = D.floor_types[fl] == 0;
-                            K.any_floor0 |= f0;
                             rec_floor[(size_t)(p * C + ch)] = (uint8_t)(fl | long_bit | (f0 ? 0x40 : 0));
                         }
                     }
@@ -782,14 +860,15 @@ struct SynthCall {
             bool has_prev;
             int prev_end, prev_stop;
             prev_of(L, has_prev, prev_end, prev_stop);
-            const bool skipped = frames[L].flags == kFrameDrain && frames[L].out_count == 0 && mismatch_at(L);
+            const bool skipped = mismatch_at(L);
+            auto out_off_of = [&](int64_t q) { return compact ? D.out_off_scratch[(size_t)q] : frames[q].out_off; };
             // position in front of the last packet: the stream's own count, re-based where a granule was picked up
             int64_t pos_base = S.current_position;
             bool has_pos = S.has_position;
             const int64_t anchor = D.anchor_pkt[s];
             if (!has_pos && anchor != kNone && anchor < L) {
                 has_pos = true;
-                pos_base = packets[anchor].granule - (frames[anchor].out_off + psamples[anchor]);
+                pos_base = packets[anchor].granule - (out_off_of(anchor) + psamples[anchor]);
             }
             if (skipped) {
                 ++mismatches;
@@ -805,7 +884,7 @@ struct SynthCall {
             } else {
                 int right_start = pi.right_start;
                 if (pk.granule != -1 && eos) {  // :658-666
-                    const int64_t actual_end = pos_base + frames[L].out_off + (has_prev ? prev_stop - prev_end : 0);
+                    const int64_t actual_end = pos_base + out_off_of(L) + (has_prev ? prev_stop - prev_end : 0);
                     const int diff = (int)(actual_end - pk.granule);
                     if (diff > 0) right_start = std::max(right_start - diff, 0);
                 }
@@ -815,12 +894,16 @@ struct SynthCall {
                 if (right_start != pi.right_start) {  // trimmed: the last frame, the stream's total
                     out_count[s] += cnt - psamples[L];
                     psamples[L] = cnt;
-                    frames[L].out_count = (uint16_t)cnt;
-                    frames[L].left_start = (uint16_t)start;
+                    D.trim_out_count[s] = cnt;
+                    D.trim_left_start[s] = start;
+                    if (!compact) {
+                        frames[L].out_count = (uint16_t)cnt;
+                        frames[L].left_start = (uint16_t)start;
+                    }
                 }
                 if (pk.granule != -1 && !has_pos) {  // :459-463 at the last packet itself
                     has_pos = true;
-                    pos_base = pk.granule - d - frames[L].out_off;
+                    pos_base = pk.granule - d - out_off_of(L);
                 }
                 S.has_prev = true;
                 S.prev_long = pk.flags & VPZ_PKT_BLOCK_FLAG;
@@ -835,7 +918,6 @@ struct SynthCall {
             if (out_count[s] > stream_out_capacity)
                 return set_error(ctx, VPZ_E_CAPACITY, "vpz_decoder_synth: stream_out_capacity too small");
         n_frames = (size_t)n_packets;
-        for (const Chunk &K : chunks) any_floor0 |= K.any_floor0;
         for (int s = 0; s < D.n_streams; ++s) samples_written[s] = out_count[s];
         if (any_floor0) need_coupling = true;  // type-0 floors are applied in place on the planar temp
         return 1;
@@ -1024,6 +1106,30 @@ struct SynthCall {
                     r.pre_kind = kPreRecompute;
                 }
                 if (f0 + R >= cnt) r.flags |= kRunSaveState;
+                r.clip_epoch = D.states[s].clip_epoch;
+                if (compact) {
+                    r.flags |= kRunCompact;
+                    const int64_t q = (int64_t)r.first + (r.pre_kind == kPreRecompute ? -1 : 0);  // first staged frame
+                    r.rec_base = (int32_t)(q * C);
+                    r.spec_base = packets[q].residue_offset;
+                    r.out_base = D.out_off_scratch[(size_t)r.first];
+                    if (q > 0 && packets[q - 1].stream == s) {
+                        const PacketInfo &ppi = D.packet_info[packets[q - 1].flags & 7];
+                        r.has_prev0 = 1;
+                        r.prev_end0 = (uint16_t)ppi.right_start;
+                        r.prev_stop0 = (uint16_t)ppi.right_end;
+                    } else {
+                        const StreamState &S0 = D.states[s];
+                        r.has_prev0 = S0.has_prev ? 1 : 0;
+                        r.prev_end0 = (uint16_t)S0.prev_end;
+                        r.prev_stop0 = (uint16_t)S0.prev_stop;
+                    }
+                    if (f0 + R >= cnt && D.trim_out_count[s] >= 0) {  // the stream's last frame was cut by the EOS trim
+                        r.flags |= kRunLastTrimmed;
+                        r.last_out_count = (uint16_t)D.trim_out_count[s];
+                        r.last_left_start = (uint16_t)D.trim_left_start[s];
+                    }
+                }
                 runs[n_runs++] = r;
             }
         }
@@ -1193,9 +1299,16 @@ struct SynthCall {
             return rc;
         // (A second stream for this upload, ordered with events so that it overlaps the previous call's kernels, was
         // measured 2-3x SLOWER per call on MI355X / ROCm 7.2: cross-stream event waits cost more than the copy.)
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(A->dev.p, A->base, A->used, hipMemcpyHostToDevice, ctx->stream));
-        VPZ_HIP_TRY(ctx, hipEventRecord(A->uploaded, ctx->stream));
-        A->pending = true;
+        // A small arena is not copied at all: the kernels read the few hundred KiB of descriptors straight from the
+        // pinned host memory (each wave fetches its 64-byte run record and two bytes per frame once, at its start).
+        // That takes a DMA command and its two command-processor gaps (~25 us) off every call; the arena stays
+        // untouched until the kernels are done (`uploaded` is recorded after the launches in that case).
+        zero_copy = A->mapped != nullptr && A->used <= D.zero_copy_max && !D.generic;
+        if (!zero_copy) {
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(A->dev.p, A->base, A->used, hipMemcpyHostToDevice, ctx->stream));
+            VPZ_HIP_TRY(ctx, hipEventRecord(A->uploaded, ctx->stream));
+            A->pending = true;
+        }
         return VPZ_OK;
     }
 
@@ -1270,6 +1383,14 @@ struct SynthCall {
         }
         SynthArgs a{};
         a.frames = static_cast<const FrameDesc *>(dev(frames));
+        a.cflags = static_cast<const uint8_t *>(dev(cflags));
+        a.cmap = static_cast<const uint8_t *>(dev(cmap));
+        a.map_bits = D.d_map_bits;
+        for (int f = 0; f < 8; ++f) {
+            const PacketInfo &pi = D.packet_info[f];
+            a.geom[f] = PacketGeom{(uint16_t)pi.left_start, (uint16_t)pi.right_start, (uint16_t)pi.right_end,
+                                   (uint16_t)pi.left_use_size1};
+        }
         a.runs = static_cast<const RunDesc *>(dev(runs));
         a.n_runs = (int32_t)n_runs;
         a.channels = C;
@@ -1381,6 +1502,10 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     const auto t_pass2 = tick();
     if ((rc = call.stage_inputs()) != VPZ_OK) return rc;
     if ((rc = call.launch()) != VPZ_OK) return rc;
+    if (call.zero_copy) {  // the kernels read the arena itself: it is free again when they are done
+        VPZ_HIP_TRY(ctx, hipEventRecord(call.A->uploaded, ctx->stream));
+        call.A->pending = true;
+    }
     if ((rc = call.copy_back()) != VPZ_OK) return rc;
     D.states = call.st;
     if (host_profile) {
@@ -1471,7 +1596,7 @@ int vpz_decoder_has_clipped(vpz_decoder *d, int32_t stream, int32_t *has_clipped
     int32_t v = 0;
     VPZ_HIP_TRY(D.ctx, hipMemcpyAsync(&v, D.d_clipped + stream, sizeof v, hipMemcpyDeviceToHost, D.ctx->stream));
     VPZ_HIP_TRY(D.ctx, hipStreamSynchronize(D.ctx->stream));
-    *has_clipped = v != 0;
+    *has_clipped = D.generic ? v != 0 : v == D.states[stream].clip_epoch;
     return VPZ_OK;
 }
 
