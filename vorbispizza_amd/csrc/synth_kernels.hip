@@ -34,17 +34,6 @@ constexpr int kWaveTailFloats = 512;  // upper half of the previous block's h: a
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int iabs(int x) { int s = x >> 31; return (x ^ s) - s; }
 
-__device__ __forceinline__ int render_point(int x0, int y0, int x1, int y1, int X)
-{
-    int dy = y1 - y0;
-    int adx = x1 - x0;
-    int ady = iabs(dy);
-    int err = ady * (X - x0);
-    int off = err / adx;
-    return dy < 0 ? y0 - off : y0 + off;
-}
-
-// (the kernel itself, floor1_prepare_kernel, follows the render helpers below)
 
 // ---------------------------------------------------------------------------------------------
 // De-interleave + inverse coupling into a planar temp.  One thread per (packet, bin).
@@ -163,12 +152,25 @@ __global__ __launch_bounds__(256) void coupling_kernel(const CouplingPacket *__r
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int div_floor_small(int a, int b)
 {
-    // exact floor(a/b) for 0 <= a < 2^23, 0 < b <= 8192
+    // exact floor(a / b) for 0 <= a < 2^31, 0 < b <= 32768 as long as the quotient stays below ~10^5 (it is at most
+    // the y range here): the float quotient is off by less than 1 (relative error ~2^-22), the remainder -- in
+    // integers -- says which way
     int q = (int)((float)a * __frcp_rn((float)b));
     int r = a - q * b;
     if (r < 0) { --q; }
     else if (r >= b) { ++q; }
     return q;
+}
+
+// Floor1.RenderPoint (Floor1.cs:355-370)
+__device__ __forceinline__ int render_point(int x0, int y0, int x1, int y1, int X)
+{
+    int dy = y1 - y0;
+    int adx = x1 - x0;
+    int ady = iabs(dy);
+    int err = ady * (X - x0);
+    int off = div_floor_small(err, adx);  // err >= 0, adx > 0: C#'s truncating division
+    return dy < 0 ? y0 - off : y0 + off;
 }
 
 // One rendered segment between two active posts, packed for LDS:
@@ -319,11 +321,11 @@ __global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int1
                                                           int32_t *__restrict__ cposts, uint8_t *__restrict__ ccount,
                                                           int16_t *__restrict__ dbg_y, uint8_t *__restrict__ dbg_f)
 {
-    __shared__ int s_y[64][65];          // [post][record], padded
-    __shared__ uint8_t s_f[64][68];
+    // finalY of the 64 records, [post][record]; 16 bits hold every value a valid packet can produce (below 2 * range)
+    // -- beyond that the reference indexes outside its dB table anyway -- and keep the kernel at 20 KB of LDS, i.e.
+    // every wavefront of a large batch resident at once (the walk below is a chain of dependent LDS round trips)
+    __shared__ int16_t s_y[64][66];
     __shared__ int16_t s_posts[64][66];  // raw posts of the 64 records, staged with coalesced loads
-    __shared__ int s_out[64][65];        // [record][slot]
-    __shared__ uint8_t s_cnt[64];
     __shared__ FloorDev s_floors[kPrepFloorsInLds];
     const int lane = threadIdx.x;
     const int first = blockIdx.x * 64;
@@ -354,16 +356,16 @@ __global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int1
     int count = 0;
     if (rec < n_rec && post_counts[rec] != 0) {
         const uint8_t info = rec_info[rec];
+        int32_t *row = cposts + (size_t)rec * 64;  // this lane's record: one 256-byte row, written front to back
         if (info & 0x40) {  // type-0 floor: already applied, the curve is 1.0
-            s_out[lane][0] = 255 << 16;
+            row[0] = 255 << 16;
             count = 1;
         } else {
             const FloorDev &f = floors[info & 0x3F];
             const int pc = f.x_count;  // Unpack leaves PostCount == xList.Length or 0 (Floor1.cs:173-218)
             const int16_t *p = s_posts[lane];
-            for (int i = 0; i < 64; ++i) s_f[i][lane] = 0;
-            s_f[0][lane] = 1;
-            s_f[1][lane] = 1;
+            auto clamp16 = [](int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); };
+            unsigned long long flags = 3ull;  // stepFlags, one bit per post: posts 0 and 1 are always set (:283-284)
             s_y[0][lane] = p[0];
             s_y[1][lane] = p[1];
             for (int i = 2; i < pc; ++i) {
@@ -375,45 +377,32 @@ __global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int1
                 const int room = (highroom < lowroom ? highroom : lowroom) * 2;
                 int result;
                 if (val != 0) {
-                    s_f[lo][lane] = 1;
-                    s_f[hi][lane] = 1;
-                    s_f[i][lane] = 1;
+                    flags |= (1ull << lo) | (1ull << hi) | (1ull << i);
                     if (val >= room) {
                         result = (highroom > lowroom) ? val - lowroom + predicted : predicted - val + highroom - 1;
                     } else {
                         result = ((val % 2) == 1) ? predicted - ((val + 1) / 2) : predicted + (val / 2);
                     }
                 } else {
-                    s_f[i][lane] = 0;
-                    result = predicted;
+                    result = predicted;  // (its flag stays clear, :344-347)
                 }
-                s_y[i][lane] = result;
+                s_y[i][lane] = (int16_t)clamp16(result);
             }
-            for (int i = 0; i < pc; ++i) {  // Apply multiplies by _multiplier (Floor1.cs:237,245)
-                const int v = s_y[i][lane] * f.multiplier;
-                s_y[i][lane] = v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
-            }
-            // Floor1.cs:236-252: post 0, then every flagged post in X order
+            // Floor1.cs:236-252: post 0, then every flagged post in X order; Apply multiplies by _multiplier (:237,245)
             for (int i = 0; i < pc; ++i) {
                 const int idx = f.sort_idx[i];
-                if (i == 0 || s_f[idx][lane]) s_out[lane][count++] = (f.x_list[idx] & 0xFFFF) | (s_y[idx][lane] << 16);
+                if (i == 0 || ((flags >> idx) & 1ull))
+                    row[count++] = (f.x_list[idx] & 0xFFFF) | (clamp16(s_y[idx][lane] * f.multiplier) << 16);
             }
             if (dbg_y) {
                 for (int i = 0; i < 64; ++i) {
-                    dbg_y[(size_t)rec * 64 + i] = i < pc ? (int16_t)s_y[i][lane] : (int16_t)0;
-                    dbg_f[(size_t)rec * 64 + i] = i < pc ? s_f[i][lane] : (uint8_t)0;
+                    dbg_y[(size_t)rec * 64 + i] = i < pc ? (int16_t)clamp16(s_y[i][lane] * f.multiplier) : (int16_t)0;
+                    dbg_f[(size_t)rec * 64 + i] = i < pc ? (uint8_t)((flags >> i) & 1ull) : (uint8_t)0;
                 }
             }
         }
     }
-    s_cnt[lane] = (uint8_t)count;
     if (rec < n_rec) ccount[rec] = (uint8_t)count;
-    __syncthreads();
-    // coalesced write of the 64 records' posts (whole halves of 32 slots: full 128-byte lines)
-    for (int it = 0; it < 64; ++it) {
-        const int cnt = s_cnt[it];
-        if (first + it < n_rec && lane < ((cnt + 31) & ~31)) cposts[(size_t)(first + it) * 64 + lane] = lane < cnt ? s_out[it][lane] : 0;
-    }
 }
 
 // floor1_render_kernel: the curve of every record as one table index per bin in memory, curve_y[rec][half1] -- for
