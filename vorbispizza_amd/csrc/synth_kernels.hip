@@ -203,8 +203,10 @@ __device__ __forceinline__ Seg unpack_segment(int A, int B, int C)
 // term (|dy|*k mod adx) - adx), then the reference's DDA (Floor1.cs:386-396) step by step.
 constexpr int render_aux_ints(int words) { return 2 * words + 3 * 65; }
 
+// n_render <= n: bins [n_render, n) are not needed (the spectrum is zero there: whatever index they get multiplies a
+// zero) -- the lanes share the first n_render bins among themselves and the rest of the row is left as it is.
 template <int kWords>
-__device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int n, int cp, int m, int lane)
+__device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int n, int n_render, int cp, int m, int lane)
 {
     int *bitmap = aux, *prefix = aux + kWords;
     int *segA = aux + 2 * kWords, *segB = segA + 65, *segC = segB + 65;
@@ -257,9 +259,9 @@ __device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int
         for (int i = 0; i < per; ++i) { prefix[lane * per + i] = run; run += c[i]; }
     }
     __builtin_amdgcn_wave_barrier();
-    const int per_lane = n >= 256 ? (n >> 6) : 4;  // bins per lane, a multiple of 4
+    const int per_lane = n_render >= 256 ? (((n_render + 63) >> 6) + 3) & ~3 : 4;  // bins per lane, a multiple of 4
     int xx = lane * per_lane;
-    if (xx >= n) return;
+    if (xx >= n_render) return;
     const unsigned w = (unsigned)bitmap[xx >> 5];
     int j = prefix[xx >> 5] + __popc(w & ((2u << (xx & 31)) - 1u)) - 1;
     Seg s = unpack_segment(segA[j], segB[j], segC[j]);
@@ -424,8 +426,8 @@ __global__ __launch_bounds__(64 * kRenderWaves) void floor1_render_kernel(int n_
     const int cp = lane < m ? cposts[(size_t)rec * 64 + lane] : 0;
     const int n = (rec_info[rec] & 0x80) ? half1 : half0;
     uint8_t *row = curve_y + (size_t)rec * half1;
-    if (n <= 1024) render_floor_indices<32>(row, s_aux[wave], n, cp, m, lane);
-    else render_floor_indices<128>(row, s_aux[wave], n, cp, m, lane);
+    if (n <= 1024) render_floor_indices<32>(row, s_aux[wave], n, n, cp, m, lane);
+    else render_floor_indices<128>(row, s_aux[wave], n, n, cp, m, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -836,21 +838,32 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     bool excur = false;
     FrameDesc fd_next = frame_at(fi0);
     if (run.count > 0 && !(fd_next.flags & kFrameDrain)) prefetch(fd_next, xcur, cpcur, excur);
-    // Floor1 curve of a frame's channel: table indices rendered into this wave's LDS row (it must be free), the
-    // lane's 16 indices into fy.  Group mode renders the NEXT frame's curve at the end of an iteration -- the row is
-    // free then, and the work overlaps the drain of the frame's PCM stores instead of sitting on the barrier chain.
-    auto render_curve = [&](const FrameDesc &f, int cp, uint32_t (&fy)[4]) {
+    // Floor1 curve of a frame's channel: table indices rendered into this wave's LDS row (free until the transform
+    // needs it: in group mode the wave has just taken its spectrum out of it), the lane's 16 indices into fy.  Only the
+    // bins below the spectrum's last non-zero one are rendered: real streams leave the top of the spectrum empty (the
+    // residue ends below N/2; low-bitrate streams use a small part of it), and a zero times any table entry is zero.
+    auto render_curve = [&](const FrameDesc &f, int cp, const float2 (&x)[8], uint32_t (&fy)[4]) {
+        const int lpb = lpb_of(f.flags);
+        const unsigned long long group0 = lpb >= 64 ? ~0ull : ((1ull << lpb) - 1ull);  // lanes that hold distinct points
+        int top = -1;  // highest point k = k0 + lpb * m with a non-zero bin (wave-uniform)
+#pragma unroll
+        for (int m = 7; m >= 0; --m) {
+            const unsigned long long b = __ballot(x[m].x != 0.0f || x[m].y != 0.0f) & group0;
+            if (top < 0 && b != 0) top = lpb * m + 63 - __clzll(b);
+        }
+        const int n = size_of(f.flags) >> 1;
+        int n_render = 2 * (top + 1);
+        if (a.ablate & 64) n_render = n;
         // lanes below the record's post count hold a post; only post 0 (x = 0) can be all zero bits
         const int m = __builtin_amdgcn_readfirstlane(__popcll(__ballot(cp != 0 || lane == 0)));
-        render_floor_indices<32>(reinterpret_cast<uint8_t *>(hcur), reinterpret_cast<int *>(hcur) + 256,
-                                 size_of(f.flags) >> 1, cp, m, lane);
+        if (n_render > 0)
+            render_floor_indices<32>(reinterpret_cast<uint8_t *>(hcur), reinterpret_cast<int *>(hcur) + 256, n, n_render, cp,
+                                     m, lane);
         __builtin_amdgcn_wave_barrier();
-        load_floor_indices(fy, reinterpret_cast<const uint8_t *>(hcur), lpb_of(f.flags), lane);
+        load_floor_indices(fy, reinterpret_cast<const uint8_t *>(hcur), lpb, lane);
         __builtin_amdgcn_wave_barrier();
     };
     uint32_t fycur[4];
-    if (kHasFloor && kGroup && run.count > 0 && !(fd_next.flags & (kFrameDrain | kFrameNoFloor)) && excur && !(a.ablate & 8))
-        render_curve(fd_next, cpcur, fycur);
     for (int it = 0; it < iters; ++it) {
         const int fi = fi0 + it;
         const bool live = !kSync || fi < run.count;  // wave-uniform; idle iterations only keep the barriers matched
@@ -913,8 +926,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             }
             if (stage && exec) load_spectrum(xcur, hcur, lpb_of(fd.flags), lane);
         }
-        // ---- free-running waves render the curve here, right before the row is needed for the transform
-        if (kHasFloor && !kGroup && exec && !(fd.flags & kFrameNoFloor) && !(a.ablate & 8)) render_curve(fd, cpcur, fycur);
+        // ---- the curve, right before the row is needed for the transform
+        if (kHasFloor && exec && !(fd.flags & kFrameNoFloor) && !(a.ablate & 8)) render_curve(fd, cpcur, xcur, fycur);
         if (build) {
             // The transforms address LDS by lane-derived indices that do not depend on the frame: computed ahead of the
             // frame loop they would all stay live across it (and spill in the variants that are short of registers);
@@ -1207,9 +1220,6 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         for (int m = 0; m < 8; ++m) xcur[m] = xnext[m];
         cpcur = cpnext;
         excur = exnext;
-        if (kHasFloor && kGroup && fi + 1 < run.count && !(fd_next.flags & (kFrameDrain | kFrameNoFloor)) && excur &&
-            !(a.ablate & 8))
-            render_curve(fd_next, cpcur, fycur);
     }
 
     // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
