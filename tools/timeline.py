@@ -12,6 +12,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
     ap.add_argument("--last", type=int, default=24)
+    ap.add_argument("--ours", action="store_true", help="only the library's kernels and the memory copies")
     args = ap.parse_args()
     rows = []
     for f in glob.glob(os.path.join(args.dir, "**", "*kernel_trace.csv"), recursive=True):
@@ -21,6 +22,8 @@ def main():
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "")))
     rows.sort()
+    if args.ours:
+        rows = [r for r in rows if "vpz::" in r[2] or r[2].startswith("COPY") or "fillBuffer" in r[2]]
     rows = rows[-args.last:]
     prev_end = rows[0][0]
     for s, e, name in rows:
