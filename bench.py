@@ -190,7 +190,8 @@ REAL_FIXTURES = (("3test.ogg", 288094), ("issue6test.ogg", 548160))  # (file, de
 TOTAL_REAL_STREAMS = 1024  # BASELINE configs[4]; global stream s plays fixture s % 2
 
 
-def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, before_timing=None, reduce_time=None):
+def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, before_timing=None, reduce_time=None,
+                      repeats=3):
     """GPU-stage rate over real stereo streams, interleaved output, decoded spectra device-resident.
     `copies` streams of each fixture, or `plan` = [global ids playing fixture 0, global ids playing fixture 1]
     (one decoder group per fixture: streams of a group share a setup header).  Returns (seconds per step, samples,
@@ -229,15 +230,18 @@ def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, 
     for _ in range(warmup):
         step()
     ctx.synchronize()
-    if before_timing:
-        before_timing()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    ctx.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    if reduce_time:
-        dt = reduce_time(dt)
+    dt = None
+    for _ in range(repeats):  # best of `repeats` loops; with several ranks each loop starts at a barrier and counts
+        if before_timing:     # with the slowest rank's time
+            before_timing()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ctx.synchronize()
+        t = (time.perf_counter() - t0) / steps
+        if reduce_time:
+            t = reduce_time(t)
+        dt = t if dt is None else min(dt, t)
     # per-stream PCM checksum: the sum of the stream's float32 bit patterns as integers (exact, order independent)
     results = {}
     for dec, pk, res, posts, counts, out, offs, cap, samples, ch, ids in groups:
@@ -358,7 +362,10 @@ def cpu_plumbing_2test():
             "note": "CPU only: C++ front end + C oracle driven packet by packet from Python"}
 
 
-def time_decoder(ctx, dec, torch, pk, residue, posts, counts, samples, channels, steps, warmup):
+def time_decoder(ctx, dec, torch, pk, residue, posts, counts, samples, channels, steps, warmup, repeats=3):
+    """Seconds per vpz_decoder_synth call: `repeats` timed loops of `steps` calls each, the best loop counts (the
+    side workloads share the box's host cores with other tenants; one disturbed loop must not decide the figure).
+    The contract line in main() is NOT measured this way: it times exactly --steps steps once."""
     from vorbispizza_amd import capi
     out = torch.empty(channels * (samples + 1024), device=residue.device, dtype=torch.float32)
     cap = samples + 1024
@@ -371,12 +378,15 @@ def time_decoder(ctx, dec, torch, pk, residue, posts, counts, samples, channels,
     for _ in range(warmup):
         step()
     ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    ctx.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return dt, out
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        best = dt if best is None else min(best, dt)
+    return best, out
 
 
 def main():
@@ -484,7 +494,7 @@ def main():
             # north_star's literal line: batched stereo N=2048 IMDCT + window + OLA through the fused kernel
             pk, residue, samples, res_floats = build_synth_ola(torch, device, args.extras_frames, all_long=True)
             dec = Decoder(ctx, CHANNELS, 256, 2048)
-            dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 20, 3)
+            dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 10, 3)
             byt = 4 * res_floats + 4 * samples * CHANNELS
             extras["north_star line: all-long N=2048 stereo IMDCT + window + OLA (fused synth kernel), %d frames, planar out"
                    % args.extras_frames] = {
@@ -492,36 +502,37 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": round(byt / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": byt,
                              "bytes_per_sample": round(byt / (samples * CHANNELS), 3)},
-                "note": "whole vpz_decoder_synth call incl. host state machine + descriptor upload; 8 B per sample"}
+                "note": "whole vpz_decoder_synth call incl. the host state machine; 8 B per sample; best of 3 loops of 10 calls"}
             dec.close()
             del residue
             torch.cuda.empty_cache()
             # configs[2]
             pk, residue, samples, res_floats = build_synth_ola(torch, device, args.extras_frames)
             dec = Decoder(ctx, CHANNELS, 256, 2048)
-            dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 20, 3)
+            dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 10, 3)
             byt = 4 * res_floats + 4 * samples * CHANNELS
             extras["configs[2] mixed 256/2048 + window + OLA, stereo, %d frames, planar out" % args.extras_frames] = {
                 "Msamples_per_s": round(samples * CHANNELS / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "whole vpz_decoder_synth call incl. host state machine + descriptor upload"}
+                "note": "whole vpz_decoder_synth call incl. the host state machine; best of 3 loops of 10 calls"}
             dec.close()
             del residue
             torch.cuda.empty_cache()
             # configs[3]
             pk, res6, posts, counts, floors, mappings, samples6 = build_floor6(torch, device, args.extras_frames6)
             dec = Decoder(ctx, 6, 256, 2048, floors=floors, mappings=mappings)
-            dt, _ = time_decoder(ctx, dec, torch, pk, res6, posts, counts, samples6, 6, 20, 3)
+            dt, _ = time_decoder(ctx, dec, torch, pk, res6, posts, counts, samples6, 6, 10, 3)
             byt = 4 * res6.numel() + 4 * samples6 * 6 + posts.numel() * 2
             extras["configs[3] 6ch Residue2-interleaved + coupling + Floor1 on GPU, N=2048, %d frames" % args.extras_frames6] = {
                 "Msamples_per_s": round(samples6 * 6 / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "2 kernels (Floor1 unwrap; fused de-interleave + coupling + floor + IMDCT + OLA); whole call"}
+                "note": "2 kernels (Floor1 unwrap; fused de-interleave + coupling + floor + IMDCT + OLA); whole call; "
+                        "best of 3 loops of 10 calls"}
             dec.close()
             del res6, posts, counts
             torch.cuda.empty_cache()
             # configs[4], one GPU's share: 128 stereo streams (64 x 3test.ogg + 64 x issue6test.ogg)
-            dt, tot, t_front, _ = time_real_streams(ctx, torch, device, 64, steps=20, warmup=3)
+            dt, tot, t_front, _ = time_real_streams(ctx, torch, device, 64, steps=10, warmup=3)
             extras["configs[4] share of one GPU: 128 real stereo streams (64x 3test.ogg + 64x issue6test.ogg), "
                    "interleaved out, decoded spectra device-resident"] = {
                 "Msamples_per_s": round(tot / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
@@ -550,7 +561,7 @@ def main():
                                                     before_timing=sync, reduce_time=reduce_t)
         samples, sums = sharding.merge_stream_results(TOTAL_REAL_STREAMS, local, red_device)
         # the same two fixtures decoded alone (one stream, one call): what a single-GPU run of the job produces
-        _, _, _, solo = time_real_streams(ctx, torch, device, 1, steps=1, warmup=0)
+        _, _, _, solo = time_real_streams(ctx, torch, device, 1, steps=1, warmup=0, repeats=1)
         expect = sharding.combine_stream_checksums([solo[s % 2][1] for s in range(TOTAL_REAL_STREAMS)])
         job_sum = sharding.combine_stream_checksums(sums)
         tot = sum(samples) * 2
@@ -571,7 +582,7 @@ def main():
                                  sharding.shard_range(TOTAL_REAL_STREAMS, world, r)[0] for r in range(world)],
             "pcm_checksum": "%016x" % job_sum, "checksum_equals_single_stream_decode": job_sum == expect,
             "scaling": "strong (1024 streams in total)", "collectives_on_the_data_path": 0,
-            "note": "GPU stage: decoded spectra device-resident, 5 steps, barrier + max over ranks; end to end: container "
+            "note": "GPU stage: decoded spectra device-resident, best of 3 loops of 5 steps (barrier before, max over ranks after each); end to end: container "
                     "bytes in host memory -> PCM in host memory incl. CPU entropy decode, best of 3 per rank, max over ranks"}
     if rank == 0 and extras:
         result["extra_workloads"] = extras

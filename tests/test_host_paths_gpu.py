@@ -286,3 +286,79 @@ def test_real_streams_take_the_parallel_pass_and_match_the_serial_one(ctx, name)
         if not reset_first and name != "issue6test.ogg":
             assert (a[1] == f.last_granule).all() and a[3] == [f.last_granule] * copies
         assert a[4] == (capi.E_WINDOW_MISMATCH if name == "issue6test.ogg" else 0)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_multi_stream_batches_parallel_compact_vs_serial(ctx, seed):
+    """Randomised differential run of the three host routes -- serial; parallel with explicit descriptors
+    (VPZ_NO_COMPACT=1); parallel with compact runs -- over the cases the parallel pass settles per stream: EOS on a stream's
+    last packet with and without a trimming granule, granules anywhere (position pick-up after a reset), a window
+    mismatch on the last packet, several calls with resets in between, 1-3 channels, floors on or off."""
+    from vorbispizza_amd import Decoder, SynthError, capi, make_packets
+    rng = np.random.default_rng(9000 + seed)
+    channels = int(rng.integers(1, 4))
+    n_streams = int(rng.integers(1, 7))
+    use_floor = bool(rng.integers(0, 2))
+    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)] if use_floor else []
+    steps = [(0, 1)] if (use_floor and channels >= 2 and rng.random() < 0.7) else []
+    mappings = [{"coupling": steps, "channel_floor": [0] * channels}, {"coupling": steps, "channel_floor": [1] * channels}] \
+        if use_floor else []
+    calls = []
+    for _ in range(int(rng.integers(2, 5))):
+        pks, res_parts, posts_parts, counts_parts = [], [], [], []
+        off = 0
+        for s in range(n_streams):
+            frames = int(rng.integers(1, 40))
+            flags = helpers.markov_block_flags(frames, seed=int(rng.integers(1 << 30)), start_long=bool(rng.integers(0, 2)))
+            if rng.random() < 0.3:                      # contradict the window of the last packet: it gets skipped
+                flags[-1] = PKT_BLOCK_FLAG | PKT_NEXT_FLAG if not (flags[-1] & PKT_BLOCK_FLAG) else PKT_BLOCK_FLAG
+            gran = np.full(frames, -1, dtype=np.int64)
+            gran[rng.random(frames) < 0.2] = rng.integers(0, 40000)
+            eos = rng.random() < 0.5
+            if eos and rng.random() < 0.7:
+                gran[-1] = int(rng.integers(0, 30000))
+            for f in range(frames):
+                half = 1024 if flags[f] & 1 else 128
+                pk = np.zeros(1, dtype=capi.PACKET_DTYPE)
+                pk["stream"], pk["granule"], pk["residue_offset"] = s, gran[f], off
+                pk["flags"] = int(flags[f]) | (0 if use_floor else PKT_NO_FLOOR) | (PKT_EOS if eos and f == frames - 1 else 0)
+                pk["mapping"] = int(flags[f] & 1) if use_floor else 0
+                x = rng.standard_normal(channels * half).astype(np.float32) * (3.0 if use_floor else 2.0 ** -8)
+                res_parts.append(np.round(x) if use_floor else x)
+                off += channels * half
+                pks.append(pk)
+                if use_floor:
+                    p, c = helpers.random_posts(rng, helpers.LONG_XLIST if flags[f] & 1 else helpers.SHORT_XLIST, 2, channels, 0.15)
+                    posts_parts.append(p)
+                    counts_parts.append(c)
+        calls.append((np.concatenate(pks), np.concatenate(res_parts),
+                      np.concatenate(posts_parts) if use_floor else None, np.concatenate(counts_parts) if use_floor else None,
+                      [s for s in range(n_streams) if rng.random() < 0.3]))
+    results = []
+    for kv in (dict(VPZ_PAR_MIN_PACKETS=1 << 40), dict(VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=3, VPZ_NO_COMPACT=1),
+               dict(VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=5, VPZ_NO_COMPACT=None)):
+        with env(**kv):
+            dec = Decoder(ctx, channels, 256, 2048, floors=floors, mappings=mappings, n_streams=n_streams, clip_samples=True)
+            trace = []
+            for pk, res, posts, counts, resets in calls:
+                cap = len(pk) * 1472 + 64
+                out = np.zeros(n_streams * channels * cap, dtype=np.float32)
+                offs = np.arange(n_streams, dtype=np.int64) * channels * cap
+                status = 0
+                try:
+                    w = dec.synth_raw(pk, res, posts, counts, out, offs, cap, capi.OUT_INTERLEAVED, 0, capi.MEM_HOST)
+                except SynthError as e:
+                    assert e.status == capi.E_WINDOW_MISMATCH
+                    status, w = e.status, None
+                trace.append((out, None if w is None else w.copy(), dec.last_packet_samples(len(pk)), status,
+                              [dec.position(s) for s in range(n_streams)], [dec.has_clipped(s) for s in range(n_streams)]))
+                for s in resets:
+                    dec.reset(s)
+            dec.close()
+        results.append(trace)
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert a[3] == b[3] and a[4] == b[4] and a[5] == b[5]
+            assert np.array_equal(a[2], b[2])
+            assert (a[1] is None) == (b[1] is None) and (a[1] is None or np.array_equal(a[1], b[1]))
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
