@@ -494,7 +494,7 @@ def main():
             # north_star's literal line: batched stereo N=2048 IMDCT + window + OLA through the fused kernel
             pk, residue, samples, res_floats = build_synth_ola(torch, device, args.extras_frames, all_long=True)
             dec = Decoder(ctx, CHANNELS, 256, 2048)
-            dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 10, 3)
+            dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 40, 3)
             byt = 4 * res_floats + 4 * samples * CHANNELS
             extras["north_star line: all-long N=2048 stereo IMDCT + window + OLA (fused synth kernel), %d frames, planar out"
                    % args.extras_frames] = {
@@ -502,37 +502,37 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": round(byt / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": byt,
                              "bytes_per_sample": round(byt / (samples * CHANNELS), 3)},
-                "note": "whole vpz_decoder_synth call incl. the host state machine; 8 B per sample; best of 3 loops of 10 calls"}
+                "note": "whole vpz_decoder_synth call incl. the host state machine; 8 B per sample; best of 3 loops of 40 calls"}
             dec.close()
             del residue
             torch.cuda.empty_cache()
             # configs[2]
             pk, residue, samples, res_floats = build_synth_ola(torch, device, args.extras_frames)
             dec = Decoder(ctx, CHANNELS, 256, 2048)
-            dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 10, 3)
+            dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 40, 3)
             byt = 4 * res_floats + 4 * samples * CHANNELS
             extras["configs[2] mixed 256/2048 + window + OLA, stereo, %d frames, planar out" % args.extras_frames] = {
                 "Msamples_per_s": round(samples * CHANNELS / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "whole vpz_decoder_synth call incl. the host state machine; best of 3 loops of 10 calls"}
+                "note": "whole vpz_decoder_synth call incl. the host state machine; best of 3 loops of 40 calls"}
             dec.close()
             del residue
             torch.cuda.empty_cache()
             # configs[3]
             pk, res6, posts, counts, floors, mappings, samples6 = build_floor6(torch, device, args.extras_frames6)
             dec = Decoder(ctx, 6, 256, 2048, floors=floors, mappings=mappings)
-            dt, _ = time_decoder(ctx, dec, torch, pk, res6, posts, counts, samples6, 6, 10, 3)
+            dt, _ = time_decoder(ctx, dec, torch, pk, res6, posts, counts, samples6, 6, 40, 3)
             byt = 4 * res6.numel() + 4 * samples6 * 6 + posts.numel() * 2
             extras["configs[3] 6ch Residue2-interleaved + coupling + Floor1 on GPU, N=2048, %d frames" % args.extras_frames6] = {
                 "Msamples_per_s": round(samples6 * 6 / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "2 kernels (Floor1 unwrap; fused de-interleave + coupling + floor + IMDCT + OLA); whole call; "
-                        "best of 3 loops of 10 calls"}
+                        "best of 3 loops of 40 calls"}
             dec.close()
             del res6, posts, counts
             torch.cuda.empty_cache()
             # configs[4], one GPU's share: 128 stereo streams (64 x 3test.ogg + 64 x issue6test.ogg)
-            dt, tot, t_front, _ = time_real_streams(ctx, torch, device, 64, steps=10, warmup=3)
+            dt, tot, t_front, _ = time_real_streams(ctx, torch, device, 64, steps=40, warmup=3)
             extras["configs[4] share of one GPU: 128 real stereo streams (64x 3test.ogg + 64x issue6test.ogg), "
                    "interleaved out, decoded spectra device-resident"] = {
                 "Msamples_per_s": round(tot / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
