@@ -47,7 +47,11 @@ class env:
                 os.environ[k] = v
 
 
-def stream_major_batch(n_streams, frames, channels, seed, floor=False, interleaved=False):
+def random_xlist(rng, half, count):
+    return [0, half] + [int(v) for v in rng.choice(np.arange(1, half), size=count - 2, replace=False)]
+
+
+def stream_major_batch(n_streams, frames, channels, seed, floor=False, interleaved=False, size0=256, size1=2048, xlists=None):
     from vorbispizza_amd import make_packets
     rng = np.random.default_rng(seed)
     pk = make_packets(n_streams * frames)
@@ -56,7 +60,7 @@ def stream_major_batch(n_streams, frames, channels, seed, floor=False, interleav
     for s in range(n_streams):
         flags = helpers.markov_block_flags(frames, seed=seed * 1000 + s, start_long=bool(s & 1))
         for f in range(frames):
-            half = 1024 if flags[f] & 1 else 128
+            half = (size1 if flags[f] & 1 else size0) // 2
             r = (rng.standard_normal((channels, half)) * (4.0 if floor else 2.0 ** -8)).astype(np.float32)
             if floor:
                 r = np.round(r)
@@ -67,7 +71,8 @@ def stream_major_batch(n_streams, frames, channels, seed, floor=False, interleav
             res.append(r.T.reshape(-1) if interleaved else r.reshape(-1))
             off += channels * half
             if floor:
-                xl = helpers.LONG_XLIST if flags[f] & 1 else helpers.SHORT_XLIST
+                xl = (xlists[1] if flags[f] & 1 else xlists[0]) if xlists else \
+                    (helpers.LONG_XLIST if flags[f] & 1 else helpers.SHORT_XLIST)
                 p, c = helpers.random_posts(rng, xl, 2, channels, silent_prob=0.1)
                 posts.append(p)
                 counts.append(c)
@@ -78,13 +83,15 @@ def stream_major_batch(n_streams, frames, channels, seed, floor=False, interleav
     return pk, res, None, None
 
 
-def run(ctx, pk, res, posts, counts, n_streams, channels, floors=(), mappings=(), layout=None, splits=1):
+def run(ctx, pk, res, posts, counts, n_streams, channels, floors=(), mappings=(), layout=None, splits=1, size0=256,
+        size1=2048):
     from vorbispizza_amd import Decoder, capi
     layout = capi.OUT_PLANAR if layout is None else layout
-    dec = Decoder(ctx, channels, 256, 2048, floors=floors, mappings=mappings, n_streams=n_streams)
+    dec = Decoder(ctx, channels, size0, size1, floors=floors, mappings=mappings, n_streams=n_streams)
     per_stream = len(pk) // n_streams
     cap = per_stream * 1024 + 64
-    out = np.zeros(n_streams * channels * cap, dtype=np.float32)
+    s16 = layout in (capi.OUT_INTERLEAVED_S16, capi.OUT_PLANAR_S16)
+    out = np.zeros(n_streams * channels * cap, dtype=np.int16 if s16 else np.float32)
     offs = np.arange(n_streams, dtype=np.int64) * channels * cap
     total = np.zeros(n_streams, dtype=np.int64)
     samples = []
@@ -96,7 +103,7 @@ def run(ctx, pk, res, posts, counts, n_streams, channels, floors=(), mappings=()
         sub = pk[sel].copy()
         sub_posts = None if posts is None else np.ascontiguousarray(posts.reshape(len(pk), channels, 64)[sel].reshape(-1, 64))
         sub_counts = None if counts is None else np.ascontiguousarray(counts.reshape(len(pk), channels)[sel].reshape(-1))
-        step_offs = offs + total * (channels if layout == capi.OUT_INTERLEAVED else 1)
+        step_offs = offs + total * (channels if layout in (capi.OUT_INTERLEAVED, capi.OUT_INTERLEAVED_S16) else 1)
         w = dec.synth_raw(sub, res, sub_posts, sub_counts, out, step_offs, cap - int(total.max()), layout, cap, capi.MEM_HOST)
         samples.append(dec.last_packet_samples(len(sub)))
         total += w
@@ -362,3 +369,53 @@ def test_random_multi_stream_batches_parallel_compact_vs_serial(ctx, seed):
             assert np.array_equal(a[2], b[2])
             assert (a[1] is None) == (b[1] is None) and (a[1] is None or np.array_equal(a[1], b[1]))
             assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+
+
+@pytest.mark.parametrize("size0,size1", [(512, 1024), (256, 1024), (1024, 2048), (512, 512)])
+@pytest.mark.parametrize("channels,steps", [(2, [(0, 1)]), (5, [(0, 1), (3, 1), (2, 4)])])
+def test_group_mode_with_the_other_block_sizes_and_16_bit_output(ctx, oracle, size0, size1, channels, steps):
+    """The general-size instantiations of the fused kernel in group mode (512 / 1024 blocks are what speech-rate and
+    low-bitrate streams use), float and 16-bit output, compact runs: bit-equal to the separate coupling pass, and
+    within tolerance of the oracle."""
+    from vorbispizza_amd import capi
+    rng = np.random.default_rng(size0 + size1 + channels)
+    xlists = [random_xlist(rng, size0 // 2, 12), random_xlist(rng, size1 // 2, 25)]
+    if size0 == size1:
+        xlists[1] = xlists[0]             # one block size: every frame uses mapping 0 and its floor
+    floors = [(xlists[0], 2), (xlists[1], 2)]
+    n_streams, frames = 4, 24
+    pk, res, posts, counts = stream_major_batch(n_streams, frames, channels, seed=size0 + channels, floor=True, interleaved=True,
+                                                size0=size0, size1=size1, xlists=xlists)
+    if size0 == size1:
+        pk["flags"] &= ~np.uint8(7)       # equal block sizes: every block is a "short" one
+    pk["mapping"] = pk["flags"] & 1
+    mappings = [{"coupling": steps, "channel_floor": [0] * channels}, {"coupling": steps, "channel_floor": [1] * channels}]
+    outs = {}
+    for layout in (capi.OUT_PLANAR, capi.OUT_INTERLEAVED, capi.OUT_INTERLEAVED_S16):
+        with env(VPZ_NO_GROUP=None, VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=4):
+            g = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2, size0=size0,
+                    size1=size1)
+        with env(VPZ_NO_GROUP=1, VPZ_PAR_MIN_PACKETS=1 << 40):
+            l = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2, size0=size0,
+                    size1=size1)
+        assert np.array_equal(g[1], l[1]) and np.array_equal(g[2], l[2]) and g[3] == l[3]
+        assert np.array_equal(g[0], l[0]) if g[0].dtype == np.int16 else np.array_equal(g[0].view(np.uint32), l[0].view(np.uint32))
+        outs[layout] = g
+    s, per = 2, frames
+    opk = []
+    for i in range(s * per, (s + 1) * per):
+        half = (size1 if pk["flags"][i] & 1 else size0) // 2
+        off = int(pk["residue_offset"][i])
+        opk.append({"flags": int(pk["flags"][i]), "granule": -1, "mapping": int(pk["mapping"][i]),
+                    "residue": res[off: off + channels * half], "posts": posts[i * channels:(i + 1) * channels],
+                    "post_count": counts[i * channels:(i + 1) * channels]})
+    ref, _, _ = helpers.oracle_decode(oracle, channels, size0, size1, opk, floors=floors, mappings=mappings)
+    cap = per * 1024 + 64
+    got = outs[capi.OUT_PLANAR][0][s * channels * cap:(s + 1) * channels * cap].reshape(channels, cap)[:, :ref.shape[1]]
+    assert outs[capi.OUT_PLANAR][1][s] == ref.shape[1] and ref.shape[1] > 0
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+    # the 16-bit samples are the reference conversion of the float ones
+    f32 = outs[capi.OUT_INTERLEAVED][0][s * channels * cap: s * channels * cap + ref.size]
+    s16 = outs[capi.OUT_INTERLEAVED_S16][0][s * channels * cap: s * channels * cap + ref.size]
+    want = np.clip((f32 * np.float32(32768.0)).astype(np.int64), -32768, 32767).astype(np.int16)
+    assert np.array_equal(s16, want)
