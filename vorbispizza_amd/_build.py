@@ -80,7 +80,7 @@ def build(force=False, verbose=False):
         stale = force or not os.path.exists(obj) or any(
             os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src))
         if stale:
-            cmd = [hipcc] + COMMON + extra + ["-c", src, "-o", obj]
+            cmd = [hipcc] + COMMON + extra + os.environ.get("VPZ_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -135,6 +135,7 @@ struct SynthArgs {
     int32_t clip;
     int32_t *clipped;           // [stream] sticky HasClipped
     int32_t ablate;             // tuning only (VPZ_SYNTH_ABLATE): 1 skip PCM stores, 2 skip IMDCT, 4 skip loads
+    unsigned long long *stamps; // diagnostic builds only (-DVPZ_STAMPS): [16] cycles per phase, summed over the waves
 };
 
 }  // namespace vpz

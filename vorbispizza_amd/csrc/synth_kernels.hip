@@ -556,23 +556,25 @@ __device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base,
     for (int m = 0; m < 8; ++m) x[m] = s[k0 + st * m];
 }
 
-// Group mode, Residue2-interleaved packet ([half][C] floats, Residue2.cs:31-34): the C waves of the packet's channels
-// split the vector into 16-byte pieces, piece q = lane + 64*w + 64*C*j (w: wave in the group) -- every wave-load is
-// one contiguous 1 KiB span -- and keep them in the registers a planar spectrum would occupy (x[2j], x[2j+1]).
-__device__ __forceinline__ void load_interleaved_share(float2 (&x)[8], const float *packet, int C, int half, int w,
-                                                       int lane)
+// Group mode: every packet goes through the group's LDS rows, so the way it comes out of HBM is free to choose --
+// 16-byte pieces, four per lane, kept in the registers a spectrum would occupy (x[2j], x[2j+1]):
+//   Residue2-interleaved packet ([half][C] floats, Residue2.cs:31-34): the C waves split the vector, piece
+//     q = lane + 64*w + 64*C*j (w: wave in the group) -- every wave-load is one contiguous 1 KiB span;
+//   planar packet: the wave takes its own channel's row, piece q = lane + 64*j.
+// The loads are UNCONDITIONAL (pieces past the end re-read the last one; staging drops them): a load under a lane
+// condition needs a select on its result, and that select would make the wave wait for the data right here --
+// which is the one place where it must not.
+__device__ __forceinline__ void load_group_share(float2 (&x)[8], const float *src, int first, int step, int limit,
+                                                 int lane)
 {
-    const float4 *s4 = reinterpret_cast<const float4 *>(packet);
-    const int total4 = (C * half) >> 2;
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
     asm volatile("" : "+v"(lane));  // the piece numbers are frame-invariant: keep them out of long-lived registers
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int q = lane + 64 * w + 64 * C * j;
-        if (q < total4) {
-            const float4 v = s4[q];
-            x[2 * j] = make_float2(v.x, v.y);
-            x[2 * j + 1] = make_float2(v.z, v.w);
-        }
+        const int q = min(lane + first + step * j, limit - 1);
+        const float4 v = s4[q];
+        x[2 * j] = make_float2(v.x, v.y);
+        x[2 * j + 1] = make_float2(v.z, v.w);
     }
 }
 
@@ -606,6 +608,17 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
     }
 }
 
+// ... or, for a planar packet, the wave's own channel straight into its row
+__device__ __forceinline__ void stage_planar(const float2 (&x)[8], float *row, int half, int lane)
+{
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = lane + 64 * j;
+        if (q < (half >> 2)) reinterpret_cast<float4 *>(row)[q] = make_float4(x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y);
+    }
+}
+
 // kOut: 0 planar output, 1 interleaved (any channel count: every wave scatters its own channel),
 //       2 interleaved stereo: the two waves of a stream (channels 0 / 1, adjacent in the workgroup) build
 //         their blocks, meet at a workgroup barrier, and each writes HALF of the packet's samples for BOTH
@@ -619,6 +632,19 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
 // Floor: the wave renders its channel's curve (Floor1.cs:236-262, 372-397) from the record's active posts into its
 //       LDS row as one table index per bin, right before the row is needed for anything else.
 // kS16: PCM leaves as 16-bit samples (to_s16) instead of float32; offsets and strides count samples either way.
+// Diagnostic builds (VPZ_EXTRA_HIPCC_FLAGS=-DVPZ_STAMPS): shader-clock stamps between the phases of a frame, summed per
+// phase over all waves into a.stamps.  Compiled out otherwise.
+#ifdef VPZ_STAMPS
+#define VPZ_STAMP(k)                                                              \
+    do {                                                                          \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();            \
+        t_acc[k] += (unsigned)(t_now - t_last);                                   \
+        t_last = t_now;                                                           \
+    } while (0)
+#else
+#define VPZ_STAMP(k) do { } while (0)
+#endif
+
 template <bool kHasFloor, int kOut, bool kGeneral, bool kGroup, bool kS16>
 __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 {
@@ -714,9 +740,6 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     float *tail = s_tail[wave];
     int prev_n4 = 0;  // n/4 of the previous block (0: none yet)
 
-    auto exec_of = [&](uint32_t flags, int rec) -> bool {
-        return a.ccount == nullptr || (flags & kFrameNoFloor) || a.ccount[rec + ch] != 0;
-    };
     // which transform a frame takes depends on its block SIZE, not on its flag (size0 may be 2048 too)
     auto size_of = [&](uint32_t flags) -> int { return (flags & kFrameLong) ? a.size1 : a.size0; };
     // lanes per block of a frame; the plain variant only knows 2048 (64) and 256 (8)
@@ -727,19 +750,29 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     };
     // the raw input of a frame into registers: this wave's channel, or -- for an interleaved packet in group mode --
     // this wave's share of the packet.  cp: this lane's active floor post (lane < count).
-    auto prefetch = [&](const FrameDesc &fd, float2 (&x)[8], int &cp, bool &ex) {
-        const bool shared_input = kGroup && (fd.flags & kFrameInterleaved);
-        ex = exec_of(fd.flags, fd.rec);
-        if (shared_input) {
-            load_interleaved_share(x, a.spec + fd.spec_off, C, size_of(fd.flags) >> 1, ch, lane);
-        } else if (ex || (kGroup && (fd.flags & kFrameStage))) {
-            load_spectrum(x, spectrum_of(fd), lpb_of(fd.flags), lane);
+    int cc_run = 0;  // lane i: active floor posts of this wave's channel in the run's i-th staged frame
+    // Everything below is UNCONDITIONAL -- a frame that needs no input (none follows, a drain, a silent channel) reads
+    // a few bytes from the start of the residue instead: a load under a condition leaves the compiler with a merge of
+    // "loaded" and "not loaded" registers, which it resolves with copies right behind the loads, and the copies wait
+    // for the data.  That put the full memory latency in front of every frame of every variant with a floor.
+    auto prefetch = [&](const FrameDesc &fd, int slot, bool valid, float2 (&x)[8], int &cp, int &cnt, bool &ex) {
+        cnt = valid ? __builtin_amdgcn_readlane(cc_run, slot) : 0;  // active posts of this wave's channel (0: silent)
+        ex = valid && (a.ccount == nullptr || (fd.flags & kFrameNoFloor) || cnt != 0);
+        if (kGroup) {
+            const int hh = size_of(fd.flags) >> 1;
+            const bool shared_input = fd.flags & kFrameInterleaved;
+            const float *src = a.spec + fd.spec_off + (shared_input ? 0 : (int64_t)ch * hh);
+            load_group_share(x, valid ? src : a.spec, shared_input ? 64 * ch : 0, shared_input ? 64 * C : 64,
+                             valid ? ((shared_input ? C * hh : hh) >> 2) : 1, lane);
+        } else {
+            load_spectrum(x, ex ? spectrum_of(fd) : a.spec, ex ? lpb_of(fd.flags) : 1, lane);
         }
-        if (kHasFloor && ex && !(fd.flags & kFrameNoFloor)) {
-            const int m = a.ccount[fd.rec + ch];
+        if (kHasFloor) {
+            // all 64 entries of the record's row (the ones past `cnt` are dropped where the curve is rendered)
+            const bool floored = ex && !(fd.flags & kFrameNoFloor);
             int l = lane;
             asm volatile("" : "+v"(l));  // keeps `cposts + lane` out of the registers that live across the frame loop
-            cp = l < m ? a.cposts[(size_t)(fd.rec + ch) * 64 + l] : 0;
+            cp = a.cposts[(size_t)(floored ? fd.rec + ch : 0) * 64 + l];
         }
     };
     const int fi0 = (run.pre_kind == kPreRecompute && run.count > 0) ? -1 : 0;
@@ -800,6 +833,13 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         const int n16 = (run.count - fi0) * 2;
         for (int i = lane; i < n16; i += 64) s_desc[wave][i] = src[i];
     }
+    // The run's post counts (ExecuteChannel of every frame for this wave's channel), one lane per frame, with ONE load
+    // ahead of the loop: read per frame, the count would put a dependent global load -- and, vmcnt being in order, the
+    // drain of the previous frame's PCM stores -- in front of every prefetch.
+    if (kHasFloor && a.ccount != nullptr) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < run.count - fi0) cc_run = a.ccount[(int)s_desc[wave][2 * lane + 1].x + ch];
+    }
     auto frame_at = [&](int fi) -> FrameDesc {  // broadcast LDS read, then into SGPRs
         const uint4 lo = s_desc[wave][(fi - fi0) * 2], hi = s_desc[wave][(fi - fi0) * 2 + 1];
         FrameDesc fd;
@@ -834,15 +874,21 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 
     // ---- software pipeline: the input of frame i+1 is in flight while frame i is synthesised
     float2 xcur[8];
-    int cpcur = 0;
+    int cpcur = 0, cntcur = 0;
     bool excur = false;
     FrameDesc fd_next = frame_at(fi0);
-    if (run.count > 0 && !(fd_next.flags & kFrameDrain)) prefetch(fd_next, xcur, cpcur, excur);
+    prefetch(fd_next, 0, run.count > 0 && !(fd_next.flags & kFrameDrain), xcur, cpcur, cntcur, excur);
+    // the first frame's input has to be there before the loop is entered: with loads pending at the loop header the
+    // compiler's wait-count bookkeeping falls back to "wait for everything" at the first use inside the loop -- after
+    // the next frame's loads have been issued, i.e. it would wait for those too
+#pragma unroll
+    for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(xcur[m].x), "v"(xcur[m].y));
+    if (kHasFloor) asm volatile("" ::"v"(cpcur));
     // Floor1 curve of a frame's channel: table indices rendered into this wave's LDS row (free until the transform
     // needs it: in group mode the wave has just taken its spectrum out of it), the lane's 16 indices into fy.  Only the
     // bins below the spectrum's last non-zero one are rendered: real streams leave the top of the spectrum empty (the
     // residue ends below N/2; low-bitrate streams use a small part of it), and a zero times any table entry is zero.
-    auto render_curve = [&](const FrameDesc &f, int cp, const float2 (&x)[8], uint32_t (&fy)[4]) {
+    auto render_curve = [&](const FrameDesc &f, int cp, int m, const float2 (&x)[8], uint32_t (&fy)[4]) {
         const int lpb = lpb_of(f.flags);
         const unsigned long long group0 = lpb >= 64 ? ~0ull : ((1ull << lpb) - 1ull);  // lanes that hold distinct points
         int top = -1;  // highest point k = k0 + lpb * m with a non-zero bin (wave-uniform)
@@ -854,8 +900,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         const int n = size_of(f.flags) >> 1;
         int n_render = 2 * (top + 1);
         if (a.ablate & 64) n_render = n;
-        // lanes below the record's post count hold a post; only post 0 (x = 0) can be all zero bits
-        const int m = __builtin_amdgcn_readfirstlane(__popcll(__ballot(cp != 0 || lane == 0)));
+        cp = lane < m ? cp : 0;  // lanes below the record's post count hold a post
         if (n_render > 0)
             render_floor_indices<32>(reinterpret_cast<uint8_t *>(hcur), reinterpret_cast<int *>(hcur) + 256, n, n_render, cp,
                                      m, lane);
@@ -864,16 +909,22 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         __builtin_amdgcn_wave_barrier();
     };
     uint32_t fycur[4];
+#ifdef VPZ_STAMPS
+    unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int it = 0; it < iters; ++it) {
         const int fi = fi0 + it;
         const bool live = !kSync || fi < run.count;  // wave-uniform; idle iterations only keep the barriers matched
         const FrameDesc fd = fd_next;
         float2 xnext[8];
-        int cpnext = 0;
+        int cpnext = 0, cntnext = 0;
         bool exnext = false;
-        if (fi + 1 < run.count) {
-            fd_next = frame_at(fi + 1);
-            if (!(fd_next.flags & kFrameDrain) && !(a.ablate & 4)) prefetch(fd_next, xnext, cpnext, exnext);
+        {
+            const bool has_next = fi + 1 < run.count;  // (a wave that idles reads a stale descriptor; nothing of it is used)
+            fd_next = frame_at(has_next ? fi + 1 : fi);
+            prefetch(fd_next, fi + 1 - fi0, has_next && !(fd_next.flags & kFrameDrain) && !(a.ablate & 4), xnext, cpnext, cntnext,
+                     exnext);
         }
         const bool drain = fd.flags & kFrameDrain;
         const int nblk = size_of(fd.flags);
@@ -881,30 +932,28 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         const int n4 = kGeneral ? (nblk >> 2) : (is_long ? 512 : 64);
         const bool build = live && !drain;
         const bool exec = build && excur;
+        VPZ_STAMP(0);  // descriptor + prefetch issue
         // ---- group mode: the packet goes through the group's LDS rows (de-interleave, inverse coupling)
         if (kGroup) {
-            const bool stage = build && (fd.flags & kFrameStage);
+            const bool stage = build;  // every packet goes through the rows (see load_group_share)
             __syncthreads();  // every wave of the group is done with its row (previous block emitted)
-            if (stage) {
+            VPZ_STAMP(1);  // first barrier
+            if (stage && !(a.ablate & 32)) {
                 if (fd.flags & kFrameInterleaved) {
                     stage_interleaved(xcur, s_work[gw0], C, div_magic, nblk >> 1, ch, lane);
                 } else {
-                    float2 *row2 = reinterpret_cast<float2 *>(hcur);
-                    const int lpb = lpb_of(fd.flags);
-                    if (lane < lpb) {
-#pragma unroll
-                        for (int m = 0; m < 8; ++m) row2[lane + lpb * m] = xcur[m];
-                    }
+                    stage_planar(xcur, hcur, nblk >> 1, lane);
                 }
             }
             __syncthreads();
+            VPZ_STAMP(2);  // staging + barrier
             // inverse coupling, steps in reverse order (Mapping.cs:166); the host has cut each mapping's steps into
             // LEVELS of steps that touch disjoint channels (bit 7 of a step's first byte: a new level starts here), so
             // that a workgroup barrier is needed between levels only -- (0,1),(2,3) of a 5.1 mapping run together
             int sidx = (int)((fd.flags >> kFrameStepsShift) & 0xFF) - 1;
             const uint8_t *st = s_steps + 2 * (fd.flags >> kFrameStepsOffShift);
             for (int lvl = 0; lvl < a.max_steps; ++lvl) {
-                if (stage) {
+                if (stage && !(a.ablate & 16)) {
                     bool first = true;
                     while (sidx >= 0 && (first || !(st[2 * sidx] & 0x80))) {
                         float4 *pm = reinterpret_cast<float4 *>(s_work[gw0 + (st[2 * sidx] & 0x7F)]);
@@ -924,10 +973,12 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 }
                 __syncthreads();
             }
+            VPZ_STAMP(3);  // coupling levels + barriers
             if (stage && exec) load_spectrum(xcur, hcur, lpb_of(fd.flags), lane);
         }
         // ---- the curve, right before the row is needed for the transform
-        if (kHasFloor && exec && !(fd.flags & kFrameNoFloor) && !(a.ablate & 8)) render_curve(fd, cpcur, xcur, fycur);
+        if (kHasFloor && exec && !(fd.flags & kFrameNoFloor) && !(a.ablate & 8)) render_curve(fd, cpcur, cntcur, xcur, fycur);
+        VPZ_STAMP(4);  // channel pick-up + curve
         if (build) {
             // The transforms address LDS by lane-derived indices that do not depend on the frame: computed ahead of the
             // frame loop they would all stay live across it (and spill in the variants that are short of registers);
@@ -960,12 +1011,14 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             }
         }
 
+        VPZ_STAMP(5);  // floor multiply + transform
         // gfx950's vmcnt counts stores as well as loads, in issue order, and the number of stores below
         // is data dependent -- so the wait for the prefetched input is forced HERE, before this
         // frame's stores are issued; otherwise it would also wait for them (HBM write latency).
 #pragma unroll
         for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(xnext[m].x), "v"(xnext[m].y));
         if (kHasFloor) asm volatile("" ::"v"(cpnext));
+        VPZ_STAMP(6);  // wait for the next frame's input
 
         if (kPair) __syncthreads();  // both channels' blocks (and tails) are in LDS
         if (live && fi >= 0 && fd.out_count > 0 && !(a.ablate & 1)) {
@@ -1200,6 +1253,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 }
             }
         }
+        VPZ_STAMP(7);  // window + overlap-add + stores
         if (kPair) __syncthreads();  // the partner is done reading this wave's block and tail
         if (live && !drain) {
             // keep what a later block can overlap with: y[N/2 .. N) lives in the upper half of h
@@ -1219,8 +1273,16 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 #pragma unroll
         for (int m = 0; m < 8; ++m) xcur[m] = xnext[m];
         cpcur = cpnext;
+        cntcur = cntnext;
         excur = exnext;
+        VPZ_STAMP(8);  // tail
     }
+#ifdef VPZ_STAMPS
+    if (a.stamps && active && lane == 0) {
+        for (int k = 0; k < 9; ++k) atomicAdd(&a.stamps[k], t_acc[k]);
+        atomicAdd(&a.stamps[15], 1ull);
+    }
+#endif
 
     // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
     if ((run.flags & kRunSaveState) && prev_n4 > 0) {

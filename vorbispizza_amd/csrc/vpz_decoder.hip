@@ -717,10 +717,8 @@ struct SynthCall {
                     if (D.mappings[pk.mapping].coupling_steps > 0) K.need_coupling = true;
                     if (D.mapping_uses_floor0[pk.mapping]) K.any_floor0 = true;
                 }
-                if (pk.flags & VPZ_PKT_INTERLEAVED) {
-                    K.need_coupling = true;
-                    if (pk.residue_offset & 3) K.align_ok = false;
-                }
+                if (pk.flags & VPZ_PKT_INTERLEAVED) K.need_coupling = true;
+                if (pk.residue_offset & 3) K.align_ok = false;  // group mode reads every packet in 16-byte pieces
                 if (!new_stream) {
                     const vpz_packet &pp = packets[p - 1];
                     const int64_t prev_floats = (int64_t)C * ((pp.flags & VPZ_PKT_BLOCK_FLAG) ? half1 : half0);
@@ -1048,10 +1046,8 @@ struct SynthCall {
                     rec_floor[(size_t)(p * C + ch)] = (uint8_t)(fl | long_bit | (f0 ? 0x40 : 0));
                 }
             }
-            if (pk.flags & VPZ_PKT_INTERLEAVED) {
-                need_coupling = true;
-                if (pk.residue_offset & 3) group_align_ok = false;
-            }
+            if (pk.flags & VPZ_PKT_INTERLEAVED) need_coupling = true;
+            if (pk.residue_offset & 3) group_align_ok = false;  // group mode reads every packet in 16-byte pieces
             frames[s_base[pk.stream] + s_cnt[pk.stream]++] = fd;
         }
         for (int s = 0; s < D.n_streams; ++s)
@@ -1417,8 +1413,29 @@ struct SynthCall {
         a.clip = D.clip;
         a.clipped = D.d_clipped;
         a.ablate = D.ablate;
+        a.stamps = nullptr;
+#ifdef VPZ_STAMPS
+        static unsigned long long *d_stamps = nullptr;
+        if (!d_stamps) (void)hipMalloc(&d_stamps, 16 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(d_stamps, 0, 16 * sizeof(unsigned long long), ctx->stream);
+        a.stamps = d_stamps;
+#endif
         hipError_t e = launch_synth(a, any_floor, ctx->stream);
         if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "synth kernel launch", e);
+#ifdef VPZ_STAMPS
+        {
+            unsigned long long h[16];
+            (void)hipMemcpyAsync(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+            static const char *names[9] = {"desc+prefetch", "barrier0", "stage+barrier", "coupling", "pickup+curve",
+                                           "floor*+imdct", "wait next", "ola+stores", "tail"};
+            unsigned long long tot = 0;
+            for (int k = 0; k < 9; ++k) tot += h[k];
+            fprintf(stderr, "[stamps] %llu waves, %.0f cycles per wave:", h[15], h[15] ? (double)tot / h[15] : 0.0);
+            for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %.1f%%", names[k], tot ? 100.0 * h[k] / tot : 0.0);
+            fprintf(stderr, "\n");
+        }
+#endif
         return VPZ_OK;
     }
 
@@ -1483,7 +1500,7 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     const bool was_parallel = rc == 1;
     if (rc == 0 && (rc = call.run_state_machine(samples_written)) != VPZ_OK) return rc;
     // group mode of the fused kernel (de-interleave and inverse coupling in LDS) when the batch needs either and
-    // its interleaved packets can be read in 16-byte pieces; otherwise the separate pass through a planar temp
+    // its packets can be read in 16-byte pieces; otherwise the separate pass through a planar temp
     call.use_group = D.group_ok && call.need_coupling && !call.any_floor0 && call.group_align_ok &&
                      (mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
     const auto t_pass1 = tick();
