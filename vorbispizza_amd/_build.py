@@ -71,6 +71,13 @@ def build(force=False, verbose=False):
     C++ host library that sits above it."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
+    # (diagnostic builds: VPZ_EXTRA_HIPCC_FLAGS=-DVPZ_STAMPS; a change of flags rebuilds everything)
+    extra_env = os.environ.get("VPZ_EXTRA_HIPCC_FLAGS", "")
+    flags_file = os.path.join(OBJ_DIR, "flags.txt")
+    if (open(flags_file).read() if os.path.exists(flags_file) else "") != extra_env:
+        force = True
+        with open(flags_file, "w") as f:
+            f.write(extra_env)
     objs, relink = [], force or not os.path.exists(LIB_PATH)
     for name, extra in SOURCES.items():
         src = os.path.join(CSRC, name)
@@ -80,7 +87,7 @@ def build(force=False, verbose=False):
         stale = force or not os.path.exists(obj) or any(
             os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src))
         if stale:
-            cmd = [hipcc] + COMMON + extra + os.environ.get("VPZ_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
+            cmd = [hipcc] + COMMON + extra + extra_env.split() + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

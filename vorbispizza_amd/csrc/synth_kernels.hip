@@ -584,26 +584,33 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
                                                   int w, int lane)
 {
     const int total4 = (C * half) >> 2;
-    // The 16 LDS addresses below do not depend on the frame: left alone, the compiler computes them once before the
+    // The LDS addresses below do not depend on the frame: left alone, the compiler computes them once before the
     // frame loop and then has to park them in scratch memory.  An opaque lane id keeps them inside the loop.
     asm volatile("" : "+v"(lane));
+    const int q0 = lane + 64 * w;
+    if (C == 2) {  // (L R L R): two bins of each channel, 8-byte stores
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = lane + 64 * w + 64 * C * j;
-        if (q < total4) {
-            const float v[4] = {x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y};
-            if (C == 2) {  // (L R L R): two bins of each channel, 8-byte stores
-                reinterpret_cast<float2 *>(rows)[q] = make_float2(v[0], v[2]);
-                reinterpret_cast<float2 *>(rows + kWaveBufFloats)[q] = make_float2(v[1], v[3]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t e = 4u * (uint32_t)q + (uint32_t)i;
-                    const uint32_t bin = (e * magic) >> 18;
-                    const uint32_t c = e - bin * (uint32_t)C;
-                    rows[c * kWaveBufFloats + bin] = v[i];
-                }
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + 128 * j;
+            if (q < total4) {
+                reinterpret_cast<float2 *>(rows)[q] = make_float2(x[2 * j].x, x[2 * j + 1].x);
+                reinterpret_cast<float2 *>(rows + kWaveBufFloats)[q] = make_float2(x[2 * j].y, x[2 * j + 1].y);
             }
+        }
+        return;
+    }
+    // piece j holds elements 4*q0 + 256*C*j + i: the SAME channel as element 4*q0 + i, 256*j bins further on -- one
+    // division per i, and the four pieces differ by a constant offset
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t e = 4u * (uint32_t)q0 + (uint32_t)i;
+        const uint32_t bin = (e * magic) >> 18;
+        const uint32_t c = e - bin * (uint32_t)C;
+        float *dst = rows + c * kWaveBufFloats + bin;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = (i & 2) ? ((i & 1) ? x[2 * j + 1].y : x[2 * j + 1].x) : ((i & 1) ? x[2 * j].y : x[2 * j].x);
+            if (q0 + 64 * C * j < total4) dst[256 * j] = v;
         }
     }
 }
