@@ -303,6 +303,98 @@ __device__ __forceinline__ void render_floor_indices(uint8_t *out, int *aux, int
     }
 }
 
+// The same curve without a serial walk, for blocks of up to 2048 samples (n <= 1024 bins): the DDA of Floor1.cs:386-396
+// draws y(x) = y0 + sign(dy) * floor(|dy| * (x - x0) / adx), and that quotient is computed per bin in float32 --
+//     trunc((dy * k +- 0.5) * rcp(adx)),  k = x - x0
+// is exact as long as |dy| * adx <= 2^21: dy * k +- 0.5 is a float, the true value of (|dy| k + 0.5) / adx is at least
+// 0.5 / adx away from an integer, and the two roundings (v_rcp_f32: 1 ulp, the product: 1/2 ulp) move it by less than
+// |dy| k * 1.5 * 2^-23 / adx.  Valid streams have |dy| <= 255; a record that breaks the bound (only a corrupt one can)
+// makes the function return false, nothing written, and the caller takes the integer walk above.
+// Every lane owns the 4 bins of one output word per round (64 consecutive words per round: no bank conflicts), looks
+// the segment of its FIRST bin up (bitmap of the post positions + prefix popcounts) and evaluates all four bins on that
+// segment's line; the bins of a word that lie behind a post inside it are then rewritten by the lane that owns that
+// post's segment (at most 3 bins each) -- no loop over segments, no divergence, 5 instructions per bin.
+// aux (ints, wave-private LDS, 16-byte aligned): [0..32) bitmap, [32..64) prefix popcounts, then one float4 per
+// segment: x0, y0, dy, 1 / adx.
+constexpr int kRenderFastAuxInts = 64 + 4 * 65;
+
+// inclusive prefix sum over lanes 0..31 (and, separately, 32..63) in the cross-lane data path of the vector ALU: no LDS
+// round trips (a ds_bpermute chain is five dependent ones), no lane masks for the compiler to hoist and spill
+__device__ __forceinline__ int wave_scan32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
+__device__ __forceinline__ bool render_floor_indices_fast(uint8_t *out, int *aux, int n, int n_render, int cp, int m, int lane)
+{
+    int *bitmap = aux, *prefix = aux + 32;
+    float4 *seg = reinterpret_cast<float4 *>(aux + 64);
+    const int p1 = __shfl_down(cp, 1);
+    const int x0 = cp & 0xFFFF, y0 = cp >> 16;
+    int x1raw = n, y1 = y0;  // flat tail after the last active post (Floor1.cs:259-262)
+    if (lane + 1 < m) { x1raw = p1 & 0xFFFF; y1 = p1 >> 16; }
+    const int x1 = x1raw < n ? x1raw : n;  // Math.Min(hx, n) enters the slope: quirk q2 (Floor1.cs:248)
+    const int adx = x1 - x0;
+    const int dy = y1 - y0;
+    const bool mine = lane < m && adx > 0;  // this lane's segment has bins
+    if (__any(mine && iabs(dy) * adx > (1 << 21))) return false;
+    const float x0f = (float)x0, y0f = (float)y0, dyf = (float)dy;
+    const float rinv = __builtin_amdgcn_rcpf((float)(adx > 0 ? adx : 1));  // v_rcp_f32: 1 ulp, which the bound allows for
+    if (lane < 32) bitmap[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (mine) {
+        atomicOr(reinterpret_cast<unsigned int *>(&bitmap[x0 >> 5]), 1u << (x0 & 31));
+        seg[lane] = make_float4(x0f, y0f, dyf, rinv);
+    }
+    __builtin_amdgcn_wave_barrier();
+    {   // exclusive prefix popcount over the bitmap words (lanes 0..31; the upper half scans zeros)
+        const int c = (lane < 32) ? __popc((unsigned)bitmap[lane]) : 0;
+        const int incl = wave_scan32(c);
+        if (lane < 32) prefix[lane] = incl - c;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // posts are counted, segments are stored by lane: a post at or beyond n has no bit and no bins, and only the
+    // posts at the END of the X order can be there -- so "posts at or below x, minus one" is the segment's lane
+    uint32_t *out4 = reinterpret_cast<uint32_t *>(out);
+    const int rounds = (n_render + 255) >> 8;
+    for (int r = 0; r < rounds; ++r) {
+        const int w = lane + 64 * r, x = 4 * w;
+        if (x < n_render) {
+            const unsigned bw = (unsigned)bitmap[x >> 5];
+            const int j = prefix[x >> 5] + __popc(bw & ((2u << (x & 31)) - 1u)) - 1;
+            const float4 sg = seg[j];
+            float t = fmaf((float)x - sg.x, sg.z, copysignf(0.5f, sg.z));
+            uint32_t pk = 0;
+            pk = __builtin_amdgcn_cvt_pk_u8_f32(sg.y + truncf(t * sg.w), 0, pk);
+            t += sg.z;
+            pk = __builtin_amdgcn_cvt_pk_u8_f32(sg.y + truncf(t * sg.w), 1, pk);
+            t += sg.z;
+            pk = __builtin_amdgcn_cvt_pk_u8_f32(sg.y + truncf(t * sg.w), 2, pk);
+            t += sg.z;
+            pk = __builtin_amdgcn_cvt_pk_u8_f32(sg.y + truncf(t * sg.w), 3, pk);
+            out4[w] = pk;
+        }
+    }
+    // a post inside a word: its bins up to the end of that word (or of its segment) belong to its own line
+    const int xe = x1 < n_render ? x1 : n_render;
+    const int a = x0 & 3;
+    if (mine && a != 0 && x0 < xe) {
+        const int cnt = min(4 - a, xe - x0);
+        float t = copysignf(0.5f, dyf);
+        out[x0] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(y0f + truncf(t * rinv), 0, 0u);
+        t += dyf;
+        if (cnt > 1) out[x0 + 1] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(y0f + truncf(t * rinv), 0, 0u);
+        t += dyf;
+        if (cnt > 2) out[x0 + 2] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(y0f + truncf(t * rinv), 0, 0u);
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // floor1_unwrap_kernel: everything serial about Floor1, one LANE per channel-record (64 records per wavefront):
 // Floor1.UnwrapPosts (Floor1.cs:270-353) and the walk over the posts in X order that picks the ones a line is drawn
@@ -417,7 +509,9 @@ __global__ __launch_bounds__(64 * kRenderWaves) void floor1_render_kernel(int n_
                                                                          int half0, int half1,
                                                                          uint8_t *__restrict__ curve_y)
 {
-    __shared__ int s_aux[kRenderWaves][render_aux_ints(128)];
+    // (the closed-form render works in LDS: 256 ints of curve, then its tables; the walk writes to memory directly)
+    constexpr int kAuxInts = (render_aux_ints(128) > 256 + kRenderFastAuxInts ? render_aux_ints(128) : 256 + kRenderFastAuxInts) + 3 & ~3;
+    __shared__ __attribute__((aligned(16))) int s_aux[kRenderWaves][kAuxInts];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rec = blockIdx.x * kRenderWaves + wave;
     if (rec >= n_rec) return;
@@ -426,8 +520,16 @@ __global__ __launch_bounds__(64 * kRenderWaves) void floor1_render_kernel(int n_
     const int cp = lane < m ? cposts[(size_t)rec * 64 + lane] : 0;
     const int n = (rec_info[rec] & 0x80) ? half1 : half0;
     uint8_t *row = curve_y + (size_t)rec * half1;
-    if (n <= 1024) render_floor_indices<32>(row, s_aux[wave], n, n, cp, m, lane);
-    else render_floor_indices<128>(row, s_aux[wave], n, n, cp, m, lane);
+    if (n <= 1024) {
+        if (render_floor_indices_fast(reinterpret_cast<uint8_t *>(s_aux[wave]), s_aux[wave] + 256, n, n, cp, m, lane)) {
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < (n >> 2); i += 64) reinterpret_cast<uint32_t *>(row)[i] = (uint32_t)s_aux[wave][i];
+        } else {
+            render_floor_indices<32>(row, s_aux[wave], n, n, cp, m, lane);
+        }
+    } else {
+        render_floor_indices<128>(row, s_aux[wave], n, n, cp, m, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -908,7 +1010,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         int n_render = 2 * (top + 1);
         if (a.ablate & 64) n_render = n;
         cp = lane < m ? cp : 0;  // lanes below the record's post count hold a post
-        if (n_render > 0)
+        if (n_render > 0 &&
+            !render_floor_indices_fast(reinterpret_cast<uint8_t *>(hcur), reinterpret_cast<int *>(hcur) + 256, n, n_render, cp, m, lane))
             render_floor_indices<32>(reinterpret_cast<uint8_t *>(hcur), reinterpret_cast<int *>(hcur) + 256, n, n_render, cp,
                                      m, lane);
         __builtin_amdgcn_wave_barrier();
