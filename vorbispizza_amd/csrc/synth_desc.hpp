@@ -92,16 +92,19 @@ struct PacketGeom {
     uint16_t left_start, right_start, right_end, left_use_size1;
 };
 
-// Floor1 static tables on the device (Floor1.cs:30-31), one per vpz_floor1_config
+// Floor1 static tables on the device (Floor1.cs:30-31, 108-149), one per vpz_floor1_config, laid out for the walk of
+// floor1_unwrap_kernel: everything a step needs that does not depend on the packet comes with ONE 8-byte read, which
+// can be issued a step ahead.
 struct FloorDev {
     int32_t x_count;
     int32_t multiplier;
     int32_t range;
     int32_t reserved;
-    int16_t x_list[64];
-    uint8_t l_neigh[64];
-    uint8_t h_neigh[64];
-    uint8_t sort_idx[64];
+    // UnwrapPosts step i >= 2 (Floor1.cs:286-352): .x = low neighbour | high neighbour << 8 | (x[i] - x[low]) << 16,
+    //                                             .y = x[high] - x[low]   (RenderPoint's adx)
+    uint32_t step[64][2];
+    // the posts in X order (Floor1.cs:129-149): post index | x << 16
+    uint32_t sorted[64];
 };
 
 struct SynthArgs {

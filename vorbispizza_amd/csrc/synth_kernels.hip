@@ -155,7 +155,7 @@ __device__ __forceinline__ int div_floor_small(int a, int b)
     // exact floor(a / b) for 0 <= a < 2^31, 0 < b <= 32768 as long as the quotient stays below ~10^5 (it is at most
     // the y range here): the float quotient is off by less than 1 (relative error ~2^-22), the remainder -- in
     // integers -- says which way
-    int q = (int)((float)a * __frcp_rn((float)b));
+    int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
     int r = a - q * b;
     if (r < 0) { --q; }
     else if (r >= b) { ++q; }
@@ -406,67 +406,121 @@ __device__ __forceinline__ bool render_floor_indices_fast(uint8_t *out, int *aux
 // one-post curve "index 255 everywhere" (table[255] == 1.0): floor0_apply_kernel has multiplied its spectrum already.
 // dbg_y / dbg_f (test entry only): finalY * multiplier and the step flags per post, [rec][64].
 // ---------------------------------------------------------------------------------------------
-constexpr int kPrepFloorsInLds = 8;
+constexpr int kPrepFloorsInLds = 4;
 
+// Diagnostic builds (VPZ_EXTRA_HIPCC_FLAGS=-DVPZ_STAMPS): shader-clock stamps between the phases of a frame, summed per
+// phase over all waves into a.stamps.  Compiled out otherwise.
+#ifdef VPZ_STAMPS
+#define VPZ_STAMP(k)                                                              \
+    do {                                                                          \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();            \
+        t_acc[k] += (unsigned)(t_now - t_last);                                   \
+        t_last = t_now;                                                           \
+    } while (0)
+#else
+#define VPZ_STAMP(k) do { } while (0)
+#endif
+
+// kFloorsInLds: the decoder's floors all fit the LDS copy (the usual case: a stream has one or two); otherwise they are
+// read from memory.  Two instantiations rather than one pointer that may point either way: that would be a FLAT
+// access, slow and -- in a chain of dependent steps -- waited for at every step.
+template <bool kFloorsInLds>
 __global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int16_t *__restrict__ posts,
                                                           const uint8_t *__restrict__ post_counts,
                                                           const uint8_t *__restrict__ rec_info,
                                                           const FloorDev *__restrict__ g_floors, int n_floors,
                                                           int32_t *__restrict__ cposts, uint8_t *__restrict__ ccount,
-                                                          int16_t *__restrict__ dbg_y, uint8_t *__restrict__ dbg_f)
+                                                          int16_t *__restrict__ dbg_y, uint8_t *__restrict__ dbg_f,
+                                                          unsigned long long *stamps)
 {
+#ifdef VPZ_STAMPS
+    unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
     // finalY of the 64 records, [post][record]; 16 bits hold every value a valid packet can produce (below 2 * range)
     // -- beyond that the reference indexes outside its dB table anyway -- and keep the kernel at 20 KB of LDS, i.e.
     // every wavefront of a large batch resident at once (the walk below is a chain of dependent LDS round trips)
     __shared__ int16_t s_y[64][66];
     __shared__ int16_t s_posts[64][66];  // raw posts of the 64 records, staged with coalesced loads
-    __shared__ FloorDev s_floors[kPrepFloorsInLds];
+    __shared__ FloorDev s_floors[kFloorsInLds ? kPrepFloorsInLds : 1];
     const int lane = threadIdx.x;
     const int first = blockIdx.x * 64;
-    // stage the inputs: a per-lane walk over global memory would put one DRAM round trip on every post
+    const int rec = first + lane;
+    // (asked for up front: read after the staging they would be two more memory round trips in a row)
+    const int my_count = rec < n_rec ? post_counts[rec] : 0;
+    const uint8_t info = rec < n_rec ? rec_info[rec] : 0;
+    // stage the inputs: a per-lane walk over global memory would put one DRAM round trip on every post.  Every load
+    // -- the floors' tables included -- is in flight before the first LDS store.
     {
+        constexpr int kFloorWords = (int)(sizeof(FloorDev) / 4);
+        constexpr int kFloorLoads = kFloorsInLds ? (kPrepFloorsInLds * kFloorWords + 63) / 64 : 1;
+        uint32_t fw[kFloorLoads];
+        const int words = kFloorsInLds ? n_floors * kFloorWords : 0;
+#pragma unroll
+        for (int j = 0; j < kFloorLoads; ++j) {
+            const int i = lane + 64 * j;
+            fw[j] = i < words ? reinterpret_cast<const uint32_t *>(g_floors)[i] : 0u;
+        }
         uint32_t v[32];
 #pragma unroll
-        for (int it = 0; it < 32; ++it) {  // all loads in flight before the first LDS store
+        for (int it = 0; it < 32; ++it) {
             const int i = lane + it * 64;
             const int r = i >> 5, w = i & 31;
-            v[it] = (first + r < n_rec) ? reinterpret_cast<const uint32_t *>(posts + (size_t)(first + r) * 64)[w] : 0u;
+            const int rr = first + r < n_rec ? first + r : n_rec - 1;  // (the last tile re-reads its last record)
+            v[it] = reinterpret_cast<const uint32_t *>(posts + (size_t)rr * 64)[w];
+        }
+#pragma unroll
+        for (int j = 0; j < kFloorLoads; ++j) {
+            const int i = lane + 64 * j;
+            if (i < words) reinterpret_cast<uint32_t *>(s_floors)[i] = fw[j];
         }
 #pragma unroll
         for (int it = 0; it < 32; ++it) {
             const int i = lane + it * 64;
             const int r = i >> 5, w = i & 31;
-            s_posts[r][2 * w] = (int16_t)(v[it] & 0xFFFF);
-            s_posts[r][2 * w + 1] = (int16_t)(v[it] >> 16);
+            reinterpret_cast<uint32_t *>(&s_posts[r][0])[w] = v[it];  // (a row is 33 words)
         }
-        const int nf = n_floors < kPrepFloorsInLds ? n_floors : kPrepFloorsInLds;
-        const int words = nf * (int)(sizeof(FloorDev) / 4);
-        for (int i = lane; i < words; i += 64)
-            reinterpret_cast<uint32_t *>(s_floors)[i] = reinterpret_cast<const uint32_t *>(g_floors)[i];
     }
     __syncthreads();
-    const FloorDev *floors = (n_floors <= kPrepFloorsInLds) ? s_floors : g_floors;
-    const int rec = first + lane;
+    VPZ_STAMP(0);
+    // The active posts leave through LDS (the raw posts' area, free once the walk is done; 33 words per record, the first
+    // 32 staged): written by their lane one at a time straight to memory they are 64 scattered 4-byte stores per
+    // instruction, and the address unit takes them one lane per cycle -- that was a third of this kernel's time.
+    int32_t *s_out = reinterpret_cast<int32_t *>(&s_posts[0][0]) + lane * 33;
     int count = 0;
-    if (rec < n_rec && post_counts[rec] != 0) {
-        const uint8_t info = rec_info[rec];
-        int32_t *row = cposts + (size_t)rec * 64;  // this lane's record: one 256-byte row, written front to back
+    if (my_count != 0) {
+        int32_t *row = cposts + (size_t)rec * 64;  // this lane's record: one 256-byte row, front to back
         if (info & 0x40) {  // type-0 floor: already applied, the curve is 1.0
-            row[0] = 255 << 16;
+            s_out[0] = 255 << 16;
             count = 1;
         } else {
-            const FloorDev &f = floors[info & 0x3F];
+            const int fi = info & 0x3F;
+            const FloorDev &f = kFloorsInLds ? s_floors[fi] : g_floors[fi];  // (folds to one address space)
             const int pc = f.x_count;  // Unpack leaves PostCount == xList.Length or 0 (Floor1.cs:173-218)
+            const int range = f.range, mult = f.multiplier;
             const int16_t *p = s_posts[lane];
             auto clamp16 = [](int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); };
             unsigned long long flags = 3ull;  // stepFlags, one bit per post: posts 0 and 1 are always set (:283-284)
             s_y[0][lane] = p[0];
             s_y[1][lane] = p[1];
+            // the walk is a chain of dependent LDS round trips (a step reads what earlier steps wrote): everything
+            // that does not depend on the packet -- neighbours, distances -- and the raw post are fetched a step ahead
+            uint32_t st0 = f.step[2][0], st1 = f.step[2][1];
+            int val_next = p[2];
             for (int i = 2; i < pc; ++i) {
-                const int lo = f.l_neigh[i], hi = f.h_neigh[i];
-                const int predicted = render_point(f.x_list[lo], s_y[lo][lane], f.x_list[hi], s_y[hi][lane], f.x_list[i]);
-                const int val = p[i];
-                const int highroom = f.range - predicted;
+                const uint32_t c0 = st0, c1 = st1;
+                const int val = val_next;
+                const int nx = i + 1 < pc ? i + 1 : i;
+                st0 = f.step[nx][0];
+                st1 = f.step[nx][1];
+                val_next = p[nx];
+                const int lo = c0 & 0xFF, hi = (c0 >> 8) & 0xFF;
+                // Floor1.RenderPoint (Floor1.cs:355-370) with its two x differences tabulated
+                const int y0 = s_y[lo][lane], y1 = s_y[hi][lane];
+                const int dy = y1 - y0;
+                const int off = div_floor_small(iabs(dy) * (int)(c0 >> 16), (int)(int16_t)(c1 & 0xFFFF));
+                const int predicted = dy < 0 ? y0 - off : y0 + off;
+                const int highroom = range - predicted;
                 const int lowroom = predicted;
                 const int room = (highroom < lowroom ? highroom : lowroom) * 2;
                 int result;
@@ -482,21 +536,59 @@ __global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int1
                 }
                 s_y[i][lane] = (int16_t)clamp16(result);
             }
-            // Floor1.cs:236-252: post 0, then every flagged post in X order; Apply multiplies by _multiplier (:237,245)
+            VPZ_STAMP(1);
+            // Floor1.cs:236-252: post 0, then every flagged post in X order; Apply multiplies by _multiplier (:237,245).
+            // Without a branch: a post that is not drawn to is written to where the next one goes (slot 32 of the 33:
+            // nobody reads it), so the LDS reads of several posts can be in flight together.
+#pragma unroll 8
             for (int i = 0; i < pc; ++i) {
-                const int idx = f.sort_idx[i];
-                if (i == 0 || ((flags >> idx) & 1ull))
-                    row[count++] = (f.x_list[idx] & 0xFFFF) | (clamp16(s_y[idx][lane] * f.multiplier) << 16);
+                const uint32_t so = f.sorted[i];
+                const int idx = so & 0xFF;
+                const bool active = i == 0 || ((flags >> idx) & 1ull);
+                const int v = (int)(so >> 16) | (clamp16(s_y[idx][lane] * mult) << 16);
+                s_out[count < 32 ? count : 32] = v;
+                if (active && count >= 32) row[count] = v;  // (more than 32 active posts: the rest goes out directly)
+                count += active ? 1 : 0;
             }
             if (dbg_y) {
                 for (int i = 0; i < 64; ++i) {
-                    dbg_y[(size_t)rec * 64 + i] = i < pc ? (int16_t)clamp16(s_y[i][lane] * f.multiplier) : (int16_t)0;
+                    dbg_y[(size_t)rec * 64 + i] = i < pc ? (int16_t)clamp16(s_y[i][lane] * mult) : (int16_t)0;
                     dbg_f[(size_t)rec * 64 + i] = i < pc ? (uint8_t)((flags >> i) & 1ull) : (uint8_t)0;
                 }
             }
         }
     }
+    VPZ_STAMP(2);
     if (rec < n_rec) ccount[rec] = (uint8_t)count;
+    // two records per pass: lanes 0..31 write the staged posts of one, lanes 32..63 of the next -- 128 contiguous bytes
+    // each; the LDS reads of eight passes are issued together
+    uint8_t *s_cnt = reinterpret_cast<uint8_t *>(&s_y[0][0]);  // (the walk's area is free now)
+    __builtin_amdgcn_wave_barrier();
+    s_cnt[lane] = (uint8_t)(count < 32 ? count : 32);
+    __builtin_amdgcn_wave_barrier();
+    const int half = lane >> 5, c = lane & 31;
+    for (int it0 = 0; it0 < 32; it0 += 8) {
+        int32_t v[8];
+        int cn[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = 2 * (it0 + u) + half;
+            v[u] = reinterpret_cast<const int32_t *>(&s_posts[0][0])[r * 33 + c];
+            cn[u] = s_cnt[r];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = 2 * (it0 + u) + half;
+            if (c < cn[u]) cposts[(size_t)(first + r) * 64 + c] = v[u];
+        }
+    }
+    VPZ_STAMP(3);
+#ifdef VPZ_STAMPS
+    if (stamps && lane == 0) {
+        for (int k = 0; k < 4; ++k) atomicAdd(&stamps[k], t_acc[k]);
+        atomicAdd(&stamps[15], 1ull);
+    }
+#endif
 }
 
 // floor1_render_kernel: the curve of every record as one table index per bin in memory, curve_y[rec][half1] -- for
@@ -741,19 +833,6 @@ __device__ __forceinline__ void stage_planar(const float2 (&x)[8], float *row, i
 // Floor: the wave renders its channel's curve (Floor1.cs:236-262, 372-397) from the record's active posts into its
 //       LDS row as one table index per bin, right before the row is needed for anything else.
 // kS16: PCM leaves as 16-bit samples (to_s16) instead of float32; offsets and strides count samples either way.
-// Diagnostic builds (VPZ_EXTRA_HIPCC_FLAGS=-DVPZ_STAMPS): shader-clock stamps between the phases of a frame, summed per
-// phase over all waves into a.stamps.  Compiled out otherwise.
-#ifdef VPZ_STAMPS
-#define VPZ_STAMP(k)                                                              \
-    do {                                                                          \
-        const unsigned long long t_now = __builtin_amdgcn_s_memtime();            \
-        t_acc[k] += (unsigned)(t_now - t_last);                                   \
-        t_last = t_now;                                                           \
-    } while (0)
-#else
-#define VPZ_STAMP(k) do { } while (0)
-#endif
-
 template <bool kHasFloor, int kOut, bool kGeneral, bool kGroup, bool kS16>
 __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 {
@@ -1046,7 +1125,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         // ---- group mode: the packet goes through the group's LDS rows (de-interleave, inverse coupling)
         if (kGroup) {
             const bool stage = build;  // every packet goes through the rows (see load_group_share)
-            __syncthreads();  // every wave of the group is done with its row (previous block emitted)
+            if (!(a.ablate & 256)) __syncthreads();  // every wave of the group is done with its row (previous block emitted)
             VPZ_STAMP(1);  // first barrier
             if (stage && !(a.ablate & 32)) {
                 if (fd.flags & kFrameInterleaved) {
@@ -1055,7 +1134,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     stage_planar(xcur, hcur, nblk >> 1, lane);
                 }
             }
-            __syncthreads();
+            if (!(a.ablate & 256)) __syncthreads();
             VPZ_STAMP(2);  // staging + barrier
             // inverse coupling, steps in reverse order (Mapping.cs:166); the host has cut each mapping's steps into
             // LEVELS of steps that touch disjoint channels (bit 7 of a step's first byte: a new level starts here), so
@@ -1081,7 +1160,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         first = false;
                     }
                 }
-                __syncthreads();
+                if (!(a.ablate & 256)) __syncthreads();
             }
             VPZ_STAMP(3);  // coupling levels + barriers
             if (stage && exec) load_spectrum(xcur, hcur, lpb_of(fd.flags), lane);
@@ -1506,8 +1585,29 @@ hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *
                                 uint8_t *dbg_f, hipStream_t stream)
 {
     if (n_rec <= 0) return hipSuccess;
-    hipLaunchKernelGGL(floor1_unwrap_kernel, dim3((n_rec + 63) / 64), dim3(64), 0, stream, n_rec, posts, post_counts,
-                       rec_info, floors, n_floors, cposts, ccount, dbg_y, dbg_f);
+    unsigned long long *stamps = nullptr;
+#ifdef VPZ_STAMPS
+    static unsigned long long *d_stamps = nullptr;
+    if (!d_stamps) (void)hipMalloc(&d_stamps, 16 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(d_stamps, 0, 16 * sizeof(unsigned long long), stream);
+    stamps = d_stamps;
+#endif
+    if (n_floors <= kPrepFloorsInLds)
+        hipLaunchKernelGGL(floor1_unwrap_kernel<true>, dim3((n_rec + 63) / 64), dim3(64), 0, stream, n_rec, posts,
+                           post_counts, rec_info, floors, n_floors, cposts, ccount, dbg_y, dbg_f, stamps);
+    else
+        hipLaunchKernelGGL(floor1_unwrap_kernel<false>, dim3((n_rec + 63) / 64), dim3(64), 0, stream, n_rec, posts,
+                           post_counts, rec_info, floors, n_floors, cposts, ccount, dbg_y, dbg_f, stamps);
+#ifdef VPZ_STAMPS
+    {
+        unsigned long long h[16];
+        (void)hipMemcpyAsync(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost, stream);
+        (void)hipStreamSynchronize(stream);
+        fprintf(stderr, "[unwrap stamps] %llu waves, cycles per wave: staging %.0f, walk %.0f, selection %.0f, copy-out %.0f\n", h[15],
+                h[15] ? (double)h[0] / h[15] : 0.0, h[15] ? (double)h[1] / h[15] : 0.0, h[15] ? (double)h[2] / h[15] : 0.0,
+                h[15] ? (double)h[3] / h[15] : 0.0);
+    }
+#endif
     return hipGetLastError();
 }
 

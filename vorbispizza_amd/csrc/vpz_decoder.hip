@@ -196,10 +196,8 @@ static int build_floor(const vpz_floor1_config &c, FloorDev *f)
     f->x_count = c.x_count;
     f->multiplier = c.multiplier;
     f->range = range_lookup[c.multiplier - 1] * 2;
-    for (int i = 0; i < c.x_count; ++i) {
+    for (int i = 0; i < c.x_count; ++i)
         if (c.x_list[i] < 0 || c.x_list[i] > 32767) return VPZ_E_INVALID_ARG;
-        f->x_list[i] = (int16_t)c.x_list[i];
-    }
     // Floor1.cs:96-97: `_xList[0] = 0; _xList[1] = 1 << rangeBits`.  The render starts its first segment at the
     // post with x == 0 (bin 0 looks its segment up by counting the posts at or below it)
     if (c.x_list[0] != 0 || c.x_list[1] <= 0) return VPZ_E_INVALID_ARG;
@@ -211,7 +209,7 @@ static int build_floor(const vpz_floor1_config &c, FloorDev *f)
             if (c.x_list[i] == c.x_list[j]) return VPZ_E_INVALID_ARG;  // InvalidDataException :141
             if (c.x_list[order[i]] > c.x_list[order[j]]) std::swap(order[i], order[j]);
         }
-    for (int i = 0; i < c.x_count; ++i) f->sort_idx[i] = (uint8_t)order[i];
+    for (int i = 0; i < c.x_count; ++i) f->sorted[i] = (uint32_t)order[i] | ((uint32_t)c.x_list[order[i]] << 16);
     for (int i = 2; i < c.x_count; ++i) {
         int lo = 0, hi = 1;
         for (int j = 2; j < i; ++j) {
@@ -219,8 +217,10 @@ static int build_floor(const vpz_floor1_config &c, FloorDev *f)
             if (t < c.x_list[i]) { if (t > c.x_list[lo]) lo = j; }
             else                 { if (t < c.x_list[hi]) hi = j; }
         }
-        f->l_neigh[i] = (uint8_t)lo;
-        f->h_neigh[i] = (uint8_t)hi;
+        // (a post below x[0] = 0 cannot exist; one above x[1] keeps hi = 1 and the reference extrapolates: the
+        // differences below are what RenderPoint computes, whatever their sign)
+        f->step[i][0] = (uint32_t)lo | ((uint32_t)hi << 8) | ((uint32_t)((c.x_list[i] - c.x_list[lo]) & 0xFFFF) << 16);
+        f->step[i][1] = (uint32_t)((c.x_list[hi] - c.x_list[lo]) & 0xFFFF);
     }
     return VPZ_OK;
 }
