@@ -21,10 +21,37 @@ namespace vpz {
 
 constexpr float kSqrtHalf = 0.70710678118654752440f;
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+// Complex arithmetic on (re, im) register pairs with the PACKED float32 instructions of gfx950 (two lanes of a 64-bit
+// register pair per instruction, full rate): a complex add is one instruction, a complex multiply two -- the
+// instructions' operand selectors (which half of a source feeds which half of the result) and sign modifiers do the
+// swaps and negations a multiplication by i or a complex product needs, so none of them costs a move.  The compiler
+// finds only part of this by itself (it packed 40 % of the transform), hence the explicit forms.
+typedef float vpz_c2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vpz_c2 c2(float2 a) { return vpz_c2{a.x, a.y}; }
+__device__ __forceinline__ float2 f2(vpz_c2 a) { return make_float2(a.x, a.y); }
+// a + i*d = (a.x - d.y, a.y + d.x)
+__device__ __forceinline__ vpz_c2 cadd_i(vpz_c2 a, vpz_c2 d)
 {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    vpz_c2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
 }
+// a - i*d = (a.x + d.y, a.y - d.x)
+__device__ __forceinline__ vpz_c2 csub_i(vpz_c2 a, vpz_c2 d)
+{
+    vpz_c2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+// a * b = a.x * (b.x, b.y) + a.y * (-b.y, b.x)
+__device__ __forceinline__ vpz_c2 cmul2(vpz_c2 a, vpz_c2 b)
+{
+    vpz_c2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return f2(cmul2(c2(a), c2(b))); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 // multiply by +i
@@ -50,27 +77,30 @@ __device__ __forceinline__ void store_nt(float4 *p, float4 v)
 }
 __device__ __forceinline__ void store_nt(float *p, float v) { __builtin_nontemporal_store(v, p); }
 
-// In-register 8-point inverse DFT: v[p] <- sum_m v[m] * exp(+2*pi*i*p*m/8)
-__device__ __forceinline__ void radix8_inverse(float2 (&v)[8])
+// In-register 8-point inverse DFT: v[p] <- sum_m v[m] * exp(+2*pi*i*p*m/8); 28 packed instructions
+__device__ __forceinline__ void radix8_inverse(float2 (&vv)[8])
 {
-    float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
-    float2 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
-    float2 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
-    float2 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
-    // odd branch twiddles exp(+i*pi*m/4), m = 1, 2, 3
-    a5 = make_float2((a5.x - a5.y) * kSqrtHalf, (a5.x + a5.y) * kSqrtHalf);
-    a6 = cmul_i(a6);
-    a7 = make_float2((-a7.x - a7.y) * kSqrtHalf, (a7.x - a7.y) * kSqrtHalf);
+    vpz_c2 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = c2(vv[i]);
+    const vpz_c2 a0 = v[0] + v[4], a4 = v[0] - v[4];
+    const vpz_c2 a1 = v[1] + v[5], d5 = v[1] - v[5];
+    const vpz_c2 a2 = v[2] + v[6], a6 = v[2] - v[6];
+    const vpz_c2 a3 = v[3] + v[7], d7 = v[3] - v[7];
+    // odd branch twiddles exp(+i*pi*m/4), m = 1, 2, 3:
+    //   d5 * (1 + i) / sqrt2 = (d5 + i*d5) / sqrt2;  d7 * (-1 + i) / sqrt2 = -(d7 - i*d7) / sqrt2;  a6 * i folded below
+    const vpz_c2 a5 = cadd_i(d5, d5) * kSqrtHalf;
+    const vpz_c2 a7 = csub_i(d7, d7) * -kSqrtHalf;
 
-    float2 b0 = cadd(a0, a2), b2 = csub(a0, a2);
-    float2 b1 = cadd(a1, a3), b3 = cmul_i(csub(a1, a3));
-    float2 c0 = cadd(a4, a6), c2 = csub(a4, a6);
-    float2 c1 = cadd(a5, a7), c3 = cmul_i(csub(a5, a7));
+    const vpz_c2 b0 = a0 + a2, b2 = a0 - a2;
+    const vpz_c2 b1 = a1 + a3, e3 = a1 - a3;
+    const vpz_c2 c0 = cadd_i(a4, a6), c2_ = csub_i(a4, a6);
+    const vpz_c2 c1 = a5 + a7, e7 = a5 - a7;
 
-    v[0] = cadd(b0, b1); v[4] = csub(b0, b1);
-    v[2] = cadd(b2, b3); v[6] = csub(b2, b3);
-    v[1] = cadd(c0, c1); v[5] = csub(c0, c1);
-    v[3] = cadd(c2, c3); v[7] = csub(c2, c3);
+    vv[0] = f2(b0 + b1); vv[4] = f2(b0 - b1);
+    vv[2] = f2(cadd_i(b2, e3)); vv[6] = f2(csub_i(b2, e3));
+    vv[1] = f2(c0 + c1); vv[5] = f2(c0 - c1);
+    vv[3] = f2(cadd_i(c2_, e7)); vv[7] = f2(csub_i(c2_, e7));
 }
 
 // LDS floats a wavefront needs for the transposes / the h staging area.
