@@ -656,18 +656,29 @@ __device__ __forceinline__ uint32_t pack_s16(float lo, float hi)
 {
     return ((uint32_t)to_s16(lo) & 0xFFFFu) | ((uint32_t)to_s16(hi) << 16);
 }
+// PCM leaves through pointers that are GLOBAL by construction.  The output base travels through scalar registers as two
+// integers (see out_base), which costs the compiler its knowledge of the address space: it would emit FLAT stores --
+// slower, and counted by the LDS wait counter as well.  Every PCM store goes through one of these.
+#define VPZ_GLOBAL __attribute__((address_space(1)))
 typedef uint32_t vpz_u4v __attribute__((ext_vector_type(4)));
 typedef uint32_t vpz_u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_nt(uint2 *p, uint32_t a, uint32_t b)
 {
     vpz_u2v t = {a, b};
-    __builtin_nontemporal_store(t, reinterpret_cast<vpz_u2v *>(p));
+    __builtin_nontemporal_store(t, (VPZ_GLOBAL vpz_u2v *)reinterpret_cast<vpz_u2v *>(p));
 }
 __device__ __forceinline__ void store_nt(uint4 *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
     vpz_u4v t = {a, b, c, d};
-    __builtin_nontemporal_store(t, reinterpret_cast<vpz_u4v *>(p));
+    __builtin_nontemporal_store(t, (VPZ_GLOBAL vpz_u4v *)reinterpret_cast<vpz_u4v *>(p));
 }
+__device__ __forceinline__ void store_pcm4(float4 *p, float4 v)
+{
+    vpz_f4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (VPZ_GLOBAL vpz_f4v *)reinterpret_cast<vpz_f4v *>(p));
+}
+template <class T>
+__device__ __forceinline__ void store_pcm(T *p, T v) { *(VPZ_GLOBAL T *)p = v; }
 
 // Branch-free addressing of the IMDCT output through its mirror symmetries (Mdct.cs:378-381).
 // y[pos..pos+3] (pos, n4 multiples of 4) = h4[idx] possibly reversed / negated.
@@ -1228,20 +1239,20 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 if (kInterleaved) {
                     out_t *d = dst + (int64_t)(4 * g) * ostep;
                     if (kS16) {
-                        d[0] = (out_t)to_s16(o0);
-                        d[ostep] = (out_t)to_s16(o1);
-                        d[2 * ostep] = (out_t)to_s16(o2);
-                        d[3 * ostep] = (out_t)to_s16(o3);
+                        store_pcm(d, (out_t)to_s16(o0));
+                        store_pcm(d + ostep, (out_t)to_s16(o1));
+                        store_pcm(d + 2 * ostep, (out_t)to_s16(o2));
+                        store_pcm(d + 3 * ostep, (out_t)to_s16(o3));
                     } else {
-                        d[0] = (out_t)o0;
-                        d[ostep] = (out_t)o1;
-                        d[2 * ostep] = (out_t)o2;
-                        d[3 * ostep] = (out_t)o3;
+                        store_pcm(d, (out_t)o0);
+                        store_pcm(d + ostep, (out_t)o1);
+                        store_pcm(d + 2 * ostep, (out_t)o2);
+                        store_pcm(d + 3 * ostep, (out_t)o3);
                     }
                 } else if (kS16) {
                     store_nt(reinterpret_cast<uint2 *>(dst) + g, pack_s16(o0, o1), pack_s16(o2, o3));
                 } else {
-                    store_nt(reinterpret_cast<float4 *>(dst) + g, make_float4(o0, o1, o2, o3));
+                    store_pcm4(reinterpret_cast<float4 *>(dst) + g, make_float4(o0, o1, o2, o3));
                 }
             };
             // stereo pair: L / R blocks and tails of this stream sit in the two adjacent wave buffers
@@ -1264,8 +1275,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                              pack_s16(l3, r3));
                 } else {
                     float4 *d = reinterpret_cast<float4 *>(pair_row) + 2 * g;
-                    store_nt(d, make_float4(l0, r0, l1, r1));
-                    store_nt(d + 1, make_float4(l2, r2, l3, r3));
+                    store_pcm4(d, make_float4(l0, r0, l1, r1));
+                    store_pcm4(d + 1, make_float4(l2, r2, l3, r3));
                 }
             };
             if (vec_pair && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 &&
@@ -1438,7 +1449,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         clipped_any |= was_clipped(v);
                         v = clip_value(v);
                     }
-                    dst[i * ostep] = kS16 ? (out_t)to_s16(v) : (out_t)v;
+                    store_pcm(dst + i * ostep, kS16 ? (out_t)to_s16(v) : (out_t)v);
                 }
             }
         }
