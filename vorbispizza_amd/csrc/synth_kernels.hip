@@ -633,6 +633,13 @@ __device__ __forceinline__ float clip_value(float v)
     return v > 0.99999994f ? 0.99999994f : (v < -0.99999994f ? -0.99999994f : v);
 }
 __device__ __forceinline__ bool was_clipped(float v) { return v > 0.99999994f || v < -0.99999994f; }
+// HasClipped in the fused kernel: the lane keeps the largest magnitude it has emitted (one instruction per sample; a NaN
+// leaves it alone, as it leaves Utils.ClipValue's comparisons false) and the test against the limit is made once per run
+__device__ __forceinline__ float clip_track(float v, float &peak)
+{
+    peak = fmaxf(peak, fabsf(v));
+    return clip_value(v);
+}
 // OverlapBuffers' `(v * v_lhs) + (v_prev * v_rhs)` (StreamDecoder.cs:788) with the reference's roundings --
 // two products, one sum, never contracted into an FMA -- so that every emission path of the kernel
 // (float4 / pair / scalar) gives the same bits for the same sample.
@@ -1069,7 +1076,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)ob), hi = __builtin_amdgcn_readfirstlane((uint32_t)(ob >> 32));
         out_base = reinterpret_cast<out_t *>(((uint64_t)hi << 32) | lo);
     }
-    bool clipped_any = false;
+    float clip_peak = 0.0f;
 
     // ---- software pipeline: the input of frame i+1 is in flight while frame i is synthesised
     float2 xcur[8];
@@ -1265,10 +1272,10 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                                   (reinterpret_cast<uintptr_t>(pair_row) & 15) == 0;
             auto store_pair = [&](int g, float l0, float l1, float l2, float l3, float r0, float r1, float r2, float r3) {
                 if (a.clip) {
-                    clipped_any |= was_clipped(l0) || was_clipped(l1) || was_clipped(l2) || was_clipped(l3) ||
-                                   was_clipped(r0) || was_clipped(r1) || was_clipped(r2) || was_clipped(r3);
-                    l0 = clip_value(l0); l1 = clip_value(l1); l2 = clip_value(l2); l3 = clip_value(l3);
-                    r0 = clip_value(r0); r1 = clip_value(r1); r2 = clip_value(r2); r3 = clip_value(r3);
+                    l0 = clip_track(l0, clip_peak); l1 = clip_track(l1, clip_peak);
+                    l2 = clip_track(l2, clip_peak); l3 = clip_track(l3, clip_peak);
+                    r0 = clip_track(r0, clip_peak); r1 = clip_track(r1, clip_peak);
+                    r2 = clip_track(r2, clip_peak); r3 = clip_track(r3, clip_peak);
                 }
                 if (kS16) {
                     store_nt(reinterpret_cast<uint4 *>(pair_row) + g, pack_s16(l0, r0), pack_s16(l1, r1), pack_s16(l2, r2),
@@ -1363,8 +1370,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         if (a.clip) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
-                                clipped_any |= was_clipped(o[r][c]);
-                                o[r][c] = clip_value(o[r][c]);
+                                o[r][c] = clip_track(o[r][c], clip_peak);
                             }
                         }
                         store4(g, o[r][0], o[r][1], o[r][2], o[r][3]);
@@ -1375,8 +1381,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            clipped_any |= was_clipped(o[r][c]);
-                            o[r][c] = clip_value(o[r][c]);
+                            o[r][c] = clip_track(o[r][c], clip_peak);
                         }
                 }
 #pragma unroll
@@ -1423,11 +1428,11 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     o2 = in ? o2 : v.z;
                     o3 = in ? o3 : v.w;
                     if (a.clip) {
-                        clipped_any |= live && (was_clipped(o0) || was_clipped(o1) || was_clipped(o2) || was_clipped(o3));
-                        o0 = clip_value(o0);
-                        o1 = clip_value(o1);
-                        o2 = clip_value(o2);
-                        o3 = clip_value(o3);
+                        // (a lane past the end has re-computed the last group: real samples, counted twice at worst)
+                        o0 = clip_track(o0, clip_peak);
+                        o1 = clip_track(o1, clip_peak);
+                        o2 = clip_track(o2, clip_peak);
+                        o3 = clip_track(o3, clip_peak);
                     }
                     if (live) store4(g, o0, o1, o2, o3);
                 }
@@ -1446,8 +1451,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         }
                     }
                     if (a.clip) {
-                        clipped_any |= was_clipped(v);
-                        v = clip_value(v);
+                        v = clip_track(v, clip_peak);
                     }
                     store_pcm(dst + i * ostep, kS16 ? (out_t)to_s16(v) : (out_t)v);
                 }
@@ -1490,7 +1494,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         for (int i = lane; i < prev_n4; i += 64) st[i] = tail[i];
     }
     // HasClipped is sticky until ResetDecoder: the flag holds the stream's reset epoch, so a reset costs no device work
-    if (a.clip && __any(clipped_any) && lane == 0) atomicMax(&a.clipped[run.stream], run.clip_epoch);
+    if (a.clip && __any(clip_peak > 0.99999994f) && lane == 0) atomicMax(&a.clipped[run.stream], run.clip_epoch);
 }
 
 // ---------------------------------------------------------------------------------------------
