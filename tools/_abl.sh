@@ -1,3 +1,6 @@
 cd /root/repo
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 &&
-timeout -k 10 200 python tools/kbench_synth.py --steps 20 2>&1 | grep -v "^$" | tail -3
+for rep in 1 2 3; do
+for a in 0 512; do
+  echo "ABLATE=$a"; VPZ_SYNTH_ABLATE=$a timeout -k 10 120 python tools/kbench_synth.py --which floor --steps 40 2>&1 | tail -1
+done
+done

@@ -869,7 +869,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     __shared__ float s_slope1[1024];
     __shared__ float s_slope0[kGeneral ? 512 : 128];
     __shared__ float s_db[kHasFloor ? 256 : 1];
-    __shared__ uint8_t s_steps[kGroup ? 2 * kGroupMaxStepPairs : 4];
+    __shared__ __attribute__((aligned(8))) uint8_t s_steps[kGroup ? 2 * kGroupMaxStepPairs + 8 : 8];
     __shared__ PacketGeom s_geom[8];
     __shared__ float s_work[kSynthWaves][kWaveBufFloats];   // h of the block being built
     __shared__ float s_tail[kSynthWaves][kWaveTailFloats];  // upper half of the previous block's h
@@ -957,6 +957,13 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     // the raw input of a frame into registers: this wave's channel, or -- for an interleaved packet in group mode --
     // this wave's share of the packet.  cp: this lane's active floor post (lane < count).
     int cc_run = 0;  // lane i: active floor posts of this wave's channel in the run's i-th staged frame
+    // the first four coupling steps of a frame's mapping (8 bytes; the host starts every mapping's steps on an 8-byte
+    // boundary), read a frame ahead like the input: the step loop then runs out of scalar registers instead of three
+    // dependent LDS round trips per step (step byte -> row address -> data)
+    auto steps_word = [&](const FrameDesc &fd, bool valid) -> uint2 {
+        const uint32_t off = valid ? 2u * (fd.flags >> kFrameStepsOffShift) : 0u;
+        return *reinterpret_cast<const uint2 *>(s_steps + (off < 2u * kGroupMaxStepPairs ? off : 0u));
+    };
     // Everything below is UNCONDITIONAL -- a frame that needs no input (none follows, a drain, a silent channel) reads
     // a few bytes from the start of the residue instead: a load under a condition leaves the compiler with a merge of
     // "loaded" and "not loaded" registers, which it resolves with copies right behind the loads, and the copies wait
@@ -1084,6 +1091,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     bool excur = false;
     FrameDesc fd_next = frame_at(fi0);
     prefetch(fd_next, 0, run.count > 0 && !(fd_next.flags & kFrameDrain), xcur, cpcur, cntcur, excur);
+    uint2 stwcur = make_uint2(0u, 0u);
+    if (kGroup) stwcur = steps_word(fd_next, run.count > 0 && !(fd_next.flags & kFrameDrain));
     // the first frame's input has to be there before the loop is entered: with loads pending at the loop header the
     // compiler's wait-count bookkeeping falls back to "wait for everything" at the first use inside the loop -- after
     // the next frame's loads have been issued, i.e. it would wait for those too
@@ -1127,11 +1136,13 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         float2 xnext[8];
         int cpnext = 0, cntnext = 0;
         bool exnext = false;
+        uint2 stwnext = make_uint2(0u, 0u);
         {
             const bool has_next = fi + 1 < run.count;  // (a wave that idles reads a stale descriptor; nothing of it is used)
             fd_next = frame_at(has_next ? fi + 1 : fi);
             prefetch(fd_next, fi + 1 - fi0, has_next && !(fd_next.flags & kFrameDrain) && !(a.ablate & 4), xnext, cpnext, cntnext,
                      exnext);
+            if (kGroup) stwnext = steps_word(fd_next, has_next && !(fd_next.flags & kFrameDrain));
         }
         const bool drain = fd.flags & kFrameDrain;
         const int nblk = size_of(fd.flags);
@@ -1157,14 +1168,19 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             // inverse coupling, steps in reverse order (Mapping.cs:166); the host has cut each mapping's steps into
             // LEVELS of steps that touch disjoint channels (bit 7 of a step's first byte: a new level starts here), so
             // that a workgroup barrier is needed between levels only -- (0,1),(2,3) of a 5.1 mapping run together
-            int sidx = (int)((fd.flags >> kFrameStepsShift) & 0xFF) - 1;
+            const int n_steps = (int)((fd.flags >> kFrameStepsShift) & 0xFF);
+            int sidx = n_steps - 1;
             const uint8_t *st = s_steps + 2 * (fd.flags >> kFrameStepsOffShift);
+            const unsigned long long stw = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.y) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.x);
+            // byte k of the mapping's steps: out of the prefetched word while the mapping has at most four
+            auto step_byte = [&](int k) -> uint32_t { return (n_steps <= 4 && !(a.ablate & 512)) ? (uint32_t)(stw >> (8 * k)) & 0xFFu : (uint32_t)st[k]; };
             for (int lvl = 0; lvl < a.max_steps; ++lvl) {
                 if (stage && !(a.ablate & 16)) {
                     bool first = true;
-                    while (sidx >= 0 && (first || !(st[2 * sidx] & 0x80))) {
-                        float4 *pm = reinterpret_cast<float4 *>(s_work[gw0 + (st[2 * sidx] & 0x7F)]);
-                        float4 *pa = reinterpret_cast<float4 *>(s_work[gw0 + st[2 * sidx + 1]]);
+                    while (sidx >= 0 && (first || !(step_byte(2 * sidx) & 0x80))) {
+                        float4 *pm = reinterpret_cast<float4 *>(s_work[gw0 + (step_byte(2 * sidx) & 0x7F)]);
+                        float4 *pa = reinterpret_cast<float4 *>(s_work[gw0 + step_byte(2 * sidx + 1)]);
                         for (int g = lane + 64 * ch; g < (nblk >> 3); g += 64 * C) {
                             float4 m4 = pm[g], a4 = pa[g];
                             couple(m4.x, a4.x);
@@ -1478,6 +1494,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         for (int m = 0; m < 8; ++m) xcur[m] = xnext[m];
         cpcur = cpnext;
         cntcur = cntnext;
+        stwcur = stwnext;
         excur = exnext;
         VPZ_STAMP(8);  // tail
     }

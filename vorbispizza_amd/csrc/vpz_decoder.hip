@@ -297,6 +297,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     for (size_t m = 0; m < D.mappings.size() && rc == VPZ_OK; ++m) {
         const vpz_mapping_config &mc = D.mappings[m];
         if (mc.coupling_steps < 0 || mc.coupling_steps > VPZ_MAX_COUPLING) { rc = VPZ_E_INVALID_ARG; break; }
+        while (mc.coupling_steps && steps.size() % 8) steps.push_back(0);  // (group mode reads 8 bytes of steps at once)
         D.mapping_steps_off.push_back(mc.coupling_steps ? (int32_t)steps.size() : -1);
         for (int i = 0; i < mc.coupling_steps; ++i) {
             const int mag = mc.coupling_magnitude[i], ang = mc.coupling_angle[i];
