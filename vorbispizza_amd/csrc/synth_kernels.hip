@@ -396,7 +396,7 @@ __device__ __forceinline__ bool render_floor_indices_fast(uint8_t *out, int *aux
 }
 
 // ---------------------------------------------------------------------------------------------
-// floor1_unwrap_kernel: everything serial about Floor1, one LANE per channel-record (64 records per wavefront):
+// floor1_unwrap_kernel: everything serial about Floor1, one LANE per channel-record (kUnwrapRecs records per wavefront):
 // Floor1.UnwrapPosts (Floor1.cs:270-353) and the walk over the posts in X order that picks the ones a line is drawn
 // to (Floor1.cs:236-252: post 0 and every post whose step flag is set).  Output per record: the active posts in X
 // order as x | (finalY * multiplier) << 16 (Apply's `* _multiplier`, Floor1.cs:237,245) and their count -- 0 when
@@ -424,8 +424,13 @@ constexpr int kPrepFloorsInLds = 4;
 // kFloorsInLds: the decoder's floors all fit the LDS copy (the usual case: a stream has one or two); otherwise they are
 // read from memory.  Two instantiations rather than one pointer that may point either way: that would be a FLAT
 // access, slow and -- in a chain of dependent steps -- waited for at every step.
+// kUnwrapRecs records per wavefront, one lane each (the other lanes only help to move data): the kernel is a single
+// round of latency -- staging, the walk, copy-out -- so a smaller tile means less of the first and the last per wave,
+// and twice the wavefronts fit (10 KB of LDS each).
+constexpr int kUnwrapRecs = 64;
+constexpr int kUnwrapWaves = 4;  // wavefronts per workgroup: the dispatcher's workgroup rate is a visible part of so short a kernel
 template <bool kFloorsInLds>
-__global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int16_t *__restrict__ posts,
+__global__ __launch_bounds__(64 * kUnwrapWaves) void floor1_unwrap_kernel(int n_rec, const int16_t *__restrict__ posts,
                                                           const uint8_t *__restrict__ post_counts,
                                                           const uint8_t *__restrict__ rec_info,
                                                           const FloorDev *__restrict__ g_floors, int n_floors,
@@ -437,33 +442,37 @@ __global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int1
     unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
-    // finalY of the 64 records, [post][record]; 16 bits hold every value a valid packet can produce (below 2 * range)
-    // -- beyond that the reference indexes outside its dB table anyway -- and keep the kernel at 20 KB of LDS, i.e.
-    // every wavefront of a large batch resident at once (the walk below is a chain of dependent LDS round trips)
-    __shared__ int16_t s_y[64][66];
-    __shared__ int16_t s_posts[64][66];  // raw posts of the 64 records, staged with coalesced loads
+    constexpr int R = kUnwrapRecs;
+    // finalY of the tile's records, [post][record]; 16 bits hold every value a valid packet can produce (below
+    // 2 * range) -- beyond that the reference indexes outside its dB table anyway
+    __shared__ int16_t s_y_all[kUnwrapWaves][64][R + 2];
+    __shared__ int16_t s_posts_all[kUnwrapWaves][R][66];  // raw posts, staged with coalesced loads (a row is 33 words)
     __shared__ FloorDev s_floors[kFloorsInLds ? kPrepFloorsInLds : 1];
-    const int lane = threadIdx.x;
-    const int first = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int16_t (*s_y)[R + 2] = s_y_all[wave];
+    int16_t (*s_posts)[66] = s_posts_all[wave];
+    const int first = (blockIdx.x * kUnwrapWaves + wave) * R;
     const int rec = first + lane;
+    const bool mine = lane < R && rec < n_rec;
     // (asked for up front: read after the staging they would be two more memory round trips in a row)
-    const int my_count = rec < n_rec ? post_counts[rec] : 0;
-    const uint8_t info = rec < n_rec ? rec_info[rec] : 0;
+    const int my_count = mine ? post_counts[rec] : 0;
+    const uint8_t info = mine ? rec_info[rec] : 0;
     // stage the inputs: a per-lane walk over global memory would put one DRAM round trip on every post.  Every load
     // -- the floors' tables included -- is in flight before the first LDS store.
     {
         constexpr int kFloorWords = (int)(sizeof(FloorDev) / 4);
         constexpr int kFloorLoads = kFloorsInLds ? (kPrepFloorsInLds * kFloorWords + 63) / 64 : 1;
+        constexpr int kPostLoads = R * 32 / 64;
         uint32_t fw[kFloorLoads];
         const int words = kFloorsInLds ? n_floors * kFloorWords : 0;
 #pragma unroll
-        for (int j = 0; j < kFloorLoads; ++j) {
+        for (int j = 0; j < kFloorLoads; ++j) {  // (every wave loads and stores the same words: simpler than a split)
             const int i = lane + 64 * j;
             fw[j] = i < words ? reinterpret_cast<const uint32_t *>(g_floors)[i] : 0u;
         }
-        uint32_t v[32];
+        uint32_t v[kPostLoads];
 #pragma unroll
-        for (int it = 0; it < 32; ++it) {
+        for (int it = 0; it < kPostLoads; ++it) {
             const int i = lane + it * 64;
             const int r = i >> 5, w = i & 31;
             const int rr = first + r < n_rec ? first + r : n_rec - 1;  // (the last tile re-reads its last record)
@@ -475,18 +484,18 @@ __global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int1
             if (i < words) reinterpret_cast<uint32_t *>(s_floors)[i] = fw[j];
         }
 #pragma unroll
-        for (int it = 0; it < 32; ++it) {
+        for (int it = 0; it < kPostLoads; ++it) {
             const int i = lane + it * 64;
             const int r = i >> 5, w = i & 31;
-            reinterpret_cast<uint32_t *>(&s_posts[r][0])[w] = v[it];  // (a row is 33 words)
+            reinterpret_cast<uint32_t *>(&s_posts[r][0])[w] = v[it];
         }
     }
     __syncthreads();
     VPZ_STAMP(0);
     // The active posts leave through LDS (the raw posts' area, free once the walk is done; 33 words per record, the first
-    // 32 staged): written by their lane one at a time straight to memory they are 64 scattered 4-byte stores per
-    // instruction, and the address unit takes them one lane per cycle -- that was a third of this kernel's time.
-    int32_t *s_out = reinterpret_cast<int32_t *>(&s_posts[0][0]) + lane * 33;
+    // 32 staged): written by their lane one at a time straight to memory they are scattered 4-byte stores, and the
+    // address unit takes those one lane per cycle -- that was a third of this kernel's time.
+    int32_t *s_out = reinterpret_cast<int32_t *>(&s_posts[0][0]) + (lane < R ? lane : 0) * 33;
     int count = 0;
     if (my_count != 0) {
         int32_t *row = cposts + (size_t)rec * 64;  // this lane's record: one 256-byte row, front to back
@@ -504,7 +513,8 @@ __global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int1
             s_y[0][lane] = p[0];
             s_y[1][lane] = p[1];
             // the walk is a chain of dependent LDS round trips (a step reads what earlier steps wrote): everything
-            // that does not depend on the packet -- neighbours, distances -- and the raw post are fetched a step ahead
+            // that does not depend on the packet -- neighbours, distances -- and the raw post are fetched a step ahead,
+            // and a step has no branch (Floor1.cs:286-352, every arm computed, the result selected)
             uint32_t st0 = f.step[2][0], st1 = f.step[2][1];
             int val_next = p[2];
             for (int i = 2; i < pc; ++i) {
@@ -523,17 +533,11 @@ __global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int1
                 const int highroom = range - predicted;
                 const int lowroom = predicted;
                 const int room = (highroom < lowroom ? highroom : lowroom) * 2;
-                int result;
-                if (val != 0) {
-                    flags |= (1ull << lo) | (1ull << hi) | (1ull << i);
-                    if (val >= room) {
-                        result = (highroom > lowroom) ? val - lowroom + predicted : predicted - val + highroom - 1;
-                    } else {
-                        result = ((val % 2) == 1) ? predicted - ((val + 1) / 2) : predicted + (val / 2);
-                    }
-                } else {
-                    result = predicted;  // (its flag stays clear, :344-347)
-                }
+                const int big = (highroom > lowroom) ? val - lowroom + predicted : predicted - val + highroom - 1;
+                const int small = ((val % 2) == 1) ? predicted - ((val + 1) / 2) : predicted + (val / 2);
+                const int result = val != 0 ? (val >= room ? big : small) : predicted;  // (val == 0: flag stays clear, :344-347)
+                const unsigned long long touched = (1ull << lo) | (1ull << hi) | (1ull << i);
+                flags |= val != 0 ? touched : 0ull;
                 s_y[i][lane] = (int16_t)clamp16(result);
             }
             VPZ_STAMP(1);
@@ -559,15 +563,15 @@ __global__ __launch_bounds__(64) void floor1_unwrap_kernel(int n_rec, const int1
         }
     }
     VPZ_STAMP(2);
-    if (rec < n_rec) ccount[rec] = (uint8_t)count;
+    if (mine) ccount[rec] = (uint8_t)count;
     // two records per pass: lanes 0..31 write the staged posts of one, lanes 32..63 of the next -- 128 contiguous bytes
     // each; the LDS reads of eight passes are issued together
     uint8_t *s_cnt = reinterpret_cast<uint8_t *>(&s_y[0][0]);  // (the walk's area is free now)
     __builtin_amdgcn_wave_barrier();
-    s_cnt[lane] = (uint8_t)(count < 32 ? count : 32);
+    if (lane < R) s_cnt[lane] = (uint8_t)(count < 32 ? count : 32);
     __builtin_amdgcn_wave_barrier();
     const int half = lane >> 5, c = lane & 31;
-    for (int it0 = 0; it0 < 32; it0 += 8) {
+    for (int it0 = 0; it0 < R / 2; it0 += 8) {
         int32_t v[8];
         int cn[8];
 #pragma unroll
@@ -1625,10 +1629,10 @@ hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *
     stamps = d_stamps;
 #endif
     if (n_floors <= kPrepFloorsInLds)
-        hipLaunchKernelGGL(floor1_unwrap_kernel<true>, dim3((n_rec + 63) / 64), dim3(64), 0, stream, n_rec, posts,
+        hipLaunchKernelGGL(floor1_unwrap_kernel<true>, dim3((n_rec + kUnwrapRecs * kUnwrapWaves - 1) / (kUnwrapRecs * kUnwrapWaves)), dim3(64 * kUnwrapWaves), 0, stream, n_rec, posts,
                            post_counts, rec_info, floors, n_floors, cposts, ccount, dbg_y, dbg_f, stamps);
     else
-        hipLaunchKernelGGL(floor1_unwrap_kernel<false>, dim3((n_rec + 63) / 64), dim3(64), 0, stream, n_rec, posts,
+        hipLaunchKernelGGL(floor1_unwrap_kernel<false>, dim3((n_rec + kUnwrapRecs * kUnwrapWaves - 1) / (kUnwrapRecs * kUnwrapWaves)), dim3(64 * kUnwrapWaves), 0, stream, n_rec, posts,
                            post_counts, rec_info, floors, n_floors, cposts, ccount, dbg_y, dbg_f, stamps);
 #ifdef VPZ_STAMPS
     {
