@@ -196,10 +196,14 @@ def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, 
     `copies` streams of each fixture, or `plan` = [global ids playing fixture 0, global ids playing fixture 1]
     (one decoder group per fixture: streams of a group share a setup header).  Returns (seconds per step, samples,
     host entropy-decode seconds a real host would spend, {global id: (samples, PCM checksum)})."""
-    from vorbispizza_amd import Decoder, SynthError, capi
+    from vorbispizza_amd import Decoder, SynthError, capi, sharding
     if plan is None:
         plan = [list(range(0, 2 * copies, 2)), list(range(1, 2 * copies, 2))]
-    groups = []
+    # ONE decoder over all the streams: the fixtures share channel count and block sizes, their floors and mappings are
+    # merged (sharding.merge_setups) and a packet's mapping index is shifted by its fixture's base -- one unwrap and one
+    # synth launch per step, with runs twice as long, instead of a pair per fixture.  VPZ_BENCH_SPLIT_SETUPS=1: the old way.
+    split = bool(os.environ.get("VPZ_BENCH_SPLIT_SETUPS"))
+    parts = []
     total_samples = 0
     t_front_total = 0.0
     for (name, samples), ids in zip(REAL_FIXTURES, plan):
@@ -207,14 +211,38 @@ def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, 
         if n == 0:
             continue
         f, pk, res, posts, counts, t_front = build_real_streams(torch, device, name, n)
-        dec = Decoder(ctx, f.channels, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings,
-                      n_streams=n)
-        cap = samples + 2048
-        out = torch.empty(n * cap * f.channels, device=device, dtype=torch.float32)
-        offs = np.arange(n, dtype=np.int64) * cap * f.channels
-        groups.append((dec, pk, res, posts, counts, out, offs, cap, samples, f.channels, ids))
+        parts.append((f, pk, res, posts, counts, samples, ids))
         total_samples += n * samples * f.channels
         t_front_total += t_front * n  # a real host decodes every stream; we decoded one copy
+    groups = []
+    if split or len(parts) == 1 or len({(p[0].channels, p[0].block_size0, p[0].block_size1) for p in parts}) != 1:
+        for f, pk, res, posts, counts, samples, ids in parts:
+            n = len(ids)
+            dec = Decoder(ctx, f.channels, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings, n_streams=n)
+            cap = samples + 2048
+            out = torch.empty(n * cap * f.channels, device=device, dtype=torch.float32)
+            offs = np.arange(n, dtype=np.int64) * cap * f.channels
+            groups.append((dec, pk, res, posts, counts, out, offs, cap, [samples] * n, f.channels, ids))
+    else:
+        f0 = parts[0][0]
+        floors, mappings, bases = sharding.merge_setups([(p[0].floors, p[0].mappings) for p in parts])
+        n_all = sum(len(p[6]) for p in parts)
+        dec = Decoder(ctx, f0.channels, f0.block_size0, f0.block_size1, floors=floors, mappings=mappings, n_streams=n_all)
+        cap = max(p[5] for p in parts) + 2048
+        pks, s0, r0 = [], 0, 0
+        for (f, pk, res, posts, counts, samples, ids), base in zip(parts, bases):
+            pk = pk.copy()
+            pk["stream"] += s0
+            pk["residue_offset"] += r0
+            pk["mapping"] += base
+            pks.append(pk)
+            s0 += len(ids)
+            r0 += res.numel()
+        out = torch.empty(n_all * cap * f0.channels, device=device, dtype=torch.float32)
+        offs = np.arange(n_all, dtype=np.int64) * cap * f0.channels
+        groups.append((dec, np.concatenate(pks), torch.cat([p[2] for p in parts]), torch.cat([p[3] for p in parts]),
+                       torch.cat([p[4] for p in parts]), out, offs, cap,
+                       [p[5] for p in parts for _ in p[6]], f0.channels, [i for p in parts for i in p[6]]))
 
     def step():
         for dec, pk, res, posts, counts, out, offs, cap, samples, ch, ids in groups:
@@ -225,7 +253,7 @@ def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, 
                 assert e.status == capi.E_WINDOW_MISMATCH
                 w = None
             if w is not None:
-                assert int(w[0]) == samples, (int(w[0]), samples)
+                assert [int(v) for v in w] == samples, "sample counts"
 
     for _ in range(warmup):
         step()
@@ -245,10 +273,9 @@ def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, 
     # per-stream PCM checksum: the sum of the stream's float32 bit patterns as integers (exact, order independent)
     results = {}
     for dec, pk, res, posts, counts, out, offs, cap, samples, ch, ids in groups:
-        view = out.view(len(ids), cap * ch)[:, : samples * ch].contiguous().view(torch.int32)
-        sums = view.sum(dim=1, dtype=torch.int64).cpu().numpy()
-        for sid, c in zip(ids, sums):
-            results[sid] = (samples, int(c))
+        view = out.view(len(ids), cap * ch).view(torch.int32)
+        for row, (sid, smp) in enumerate(zip(ids, samples)):
+            results[sid] = (smp, int(view[row, : smp * ch].sum(dtype=torch.int64).item()))
         dec.close()
     return dt, total_samples, t_front_total, results
 

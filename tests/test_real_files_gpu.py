@@ -205,3 +205,59 @@ def test_configs4_share_of_one_gpu_all_128_streams_both_layouts(ctx, oracle):
                 worst = max(worst, float(np.abs(got - ref).max()))
             assert worst <= tol, (name, layout, worst)
             dec.close()
+
+
+def test_streams_with_different_setup_headers_in_one_decoder(ctx):
+    """sharding.merge_setups: 3test.ogg and issue6test.ogg streams (different floors, same block sizes) decoded by ONE
+    decoder over the union of their floors and mappings -- what bench.py's configs[4] lines run -- give, stream for
+    stream, the bits the per-file decoders give (which the tests above hold against the oracle)."""
+    from vorbispizza_amd import Decoder, SynthError, capi, sharding
+    from vorbispizza_amd.front import OggVorbisFile
+    copies = 3
+    parts, separate = [], []
+    for name in ("3test.ogg", "issue6test.ogg"):
+        f = OggVorbisFile(os.path.join(GOLDEN, name))
+        pk, res, posts, counts = f.decode_packets()
+        n, total = len(pk), SAMPLES[name]
+        pk_all = np.tile(pk, copies)
+        pk_all["stream"] = np.repeat(np.arange(copies, dtype=np.int32), n)
+        pk_all["residue_offset"] += np.repeat(np.arange(copies, dtype=np.int64) * res.size, n)
+        parts.append((f, pk_all, np.tile(res, copies), np.tile(posts, (copies, 1)), np.tile(counts, copies), total))
+        cap = total + 2048
+        dec = Decoder(ctx, f.channels, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings, n_streams=copies)
+        out = np.zeros(copies * cap * f.channels, dtype=np.float32)
+        offs = np.arange(copies, dtype=np.int64) * cap * f.channels
+        try:
+            dec.synth_raw(parts[-1][1], parts[-1][2], parts[-1][3], parts[-1][4], out, offs, cap, capi.OUT_INTERLEAVED, cap,
+                          capi.MEM_HOST)
+        except SynthError as e:
+            assert e.status == capi.E_WINDOW_MISMATCH
+        separate += [out.reshape(copies, cap * f.channels)[s, : total * f.channels].copy() for s in range(copies)]
+        dec.close()
+    f0 = parts[0][0]
+    floors, mappings, bases = sharding.merge_setups([(p[0].floors, p[0].mappings) for p in parts])
+    assert len(floors) <= sum(len(p[0].floors) for p in parts) and bases == [0, len(parts[0][0].mappings)]
+    pks, s0, r0 = [], 0, 0
+    for (f, pk, res, posts, counts, total), base in zip(parts, bases):
+        pk = pk.copy()
+        pk["stream"] += s0
+        pk["residue_offset"] += r0
+        pk["mapping"] += base
+        pks.append(pk)
+        s0 += copies
+        r0 += res.size
+    n_all = 2 * copies
+    cap = max(p[5] for p in parts) + 2048
+    dec = Decoder(ctx, f0.channels, f0.block_size0, f0.block_size1, floors=floors, mappings=mappings, n_streams=n_all)
+    out = np.zeros(n_all * cap * f0.channels, dtype=np.float32)
+    offs = np.arange(n_all, dtype=np.int64) * cap * f0.channels
+    try:
+        dec.synth_raw(np.concatenate(pks), np.concatenate([p[2] for p in parts]), np.concatenate([p[3] for p in parts]),
+                      np.concatenate([p[4] for p in parts]), out, offs, cap, capi.OUT_INTERLEAVED, cap, capi.MEM_HOST)
+    except SynthError as e:
+        assert e.status == capi.E_WINDOW_MISMATCH
+    totals = [p[5] for p in parts for _ in range(copies)]
+    for s in range(n_all):
+        got = out.reshape(n_all, cap * f0.channels)[s, : totals[s] * f0.channels]
+        assert np.array_equal(got.view(np.uint32), separate[s].view(np.uint32)), s
+    dec.close()

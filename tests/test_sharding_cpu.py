@@ -96,3 +96,19 @@ def test_stream_plan_covers_every_stream_once_and_keeps_the_mix():
                 assert len(plan[0]) == len(plan[1]) == 512 // world
         assert sorted(seen) == list(range(1024))
     assert sharding.combine_stream_checksums({0: 5, 3: 7}) == 5 + 4 * 7
+
+
+def test_merge_setups_shares_equal_floors_and_shifts_the_mappings():
+    from vorbispizza_amd import sharding
+    a = ([([0, 128, 64], 2), ([0, 1024, 512, 256], 2)],
+         [{"coupling": [(0, 1)], "channel_floor": [0, 0]}, {"coupling": [(0, 1)], "channel_floor": [1, 1]}])
+    b = ([([0, 128, 32], 1), ([0, 1024, 512, 256], 2)],
+         [{"coupling": [], "channel_floor": [0, 0]}, {"coupling": [(1, 0)], "channel_floor": [1, 0]}])
+    floors, mappings, bases = sharding.merge_setups([a, b])
+    assert bases == [0, 2]
+    assert floors == [([0, 128, 64], 2), ([0, 1024, 512, 256], 2), ([0, 128, 32], 1)]  # the equal floor is shared
+    assert [m["channel_floor"] for m in mappings] == [[0, 0], [1, 1], [2, 2], [1, 2]]
+    assert [m["coupling"] for m in mappings] == [[(0, 1)], [(0, 1)], [], [(1, 0)]]
+    # a single setup comes back as it was
+    f1, m1, b1 = sharding.merge_setups([a])
+    assert f1 == a[0] and b1 == [0] and [m["channel_floor"] for m in m1] == [[0, 0], [1, 1]]

@@ -30,6 +30,38 @@ def plan_stream_shard(n_streams, world_size, rank, n_kinds=1):
     return [[s for s in range(lo, hi) if s % n_kinds == k] for k in range(n_kinds)]
 
 
+def merge_setups(setups):
+    """One decoder configuration for streams that come with DIFFERENT setup headers (same channel count and block
+    sizes): the union of their floors (equal ones shared) and of their mappings.  setups: [(floors, mappings), ...] in the
+    form `Decoder` takes.  Returns (floors, mappings, mapping_base): a packet of setup k with mapping index m carries
+    mapping_base[k] + m in the merged batch.  A synth call then covers all the streams at once -- one launch, longer runs
+    per wavefront -- instead of one call per setup (the reference has one StreamDecoder per stream, StreamDecoder.cs:45-49;
+    how streams are batched is this back end's business)."""
+    floors, mappings, bases = [], [], []
+
+    def key(fl):
+        if isinstance(fl, dict):
+            return ("f0",) + tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in fl.items()))
+        return ("f1", tuple(int(x) for x in fl[0]), int(fl[1]))
+
+    index = {}
+    for fls, mps in setups:
+        remap = []
+        for fl in fls:
+            k = key(fl)
+            if k not in index:
+                index[k] = len(floors)
+                floors.append(fl)
+            remap.append(index[k])
+        bases.append(len(mappings))
+        for m in mps:
+            mappings.append({"coupling": [tuple(p) for p in m["coupling"]],
+                             "channel_floor": [remap[f] for f in m["channel_floor"]]})
+    if len(mappings) > 256:
+        raise ValueError("merge_setups: more than 256 mappings do not fit a packet's mapping index")
+    return floors, mappings, bases
+
+
 _MASK64 = (1 << 64) - 1
 
 
