@@ -147,3 +147,36 @@ def test_record_total_and_q2_is_really_exercised(ctx, oracle):
     k = np.arange(n - 700)
     other = y700 + np.sign(y1500 - y700) * ((abs(y1500 - y700) * k) // (1500 - 700))
     assert not np.array_equal(other, want[700:]), "the case does not distinguish q2"
+
+
+def test_steep_lines_take_the_integer_walk_and_still_match(ctx, oracle):
+    """The fused kernel draws the curve in float32 closed form while |dy| * adx <= 2^21 per segment and falls back to the
+    integer walk of the reference (Floor1.cs:386-396) otherwise.  No valid stream breaks the bound; these records do --
+    absolute posts of several thousand at both ends of the block -- so the fallback stays under test, next to records
+    in the same batch that take the fast path."""
+    from vorbispizza_amd import Decoder
+    n, mult = 1024, 2
+    rng = np.random.default_rng(77)
+    xlist = random_xlist(rng, n, 24, False)
+    dec = Decoder(ctx, 1, 256, 2048, floors=[(xlist, mult), ([0, 128, 1], 1)],
+                  mappings=[{"coupling": [], "channel_floor": [0]}])
+    n_rec = 3000
+    posts, counts = random_records(rng, xlist, n_rec, mult, wild=0.0)
+    steep = rng.random(n_rec) < 0.5
+    posts[steep, 0] = rng.integers(-6000, 6000, size=int(steep.sum()))
+    posts[steep, 1] = rng.integers(-6000, 6000, size=int(steep.sum()))
+    posts[steep, 2:24] = 0    # (one line from end to end: |dy| * adx up to 24 000 * 1024)
+    curve, final_y, flags, active = dec.debug_floor1_indices(posts, counts, np.zeros(n_rec, np.uint8), np.ones(n_rec, np.uint8))
+    f = oracle.floor1_init(xlist, mult)
+    ys, fls, curs = oracle_rows(oracle, f, posts, counts, n)
+    beyond_bound = 0
+    for r in range(n_rec):
+        if counts[r] == 0:
+            continue
+        want_y = ys[r][:24] * mult
+        assert (np.abs(want_y) < 32768).all()
+        np.testing.assert_array_equal(final_y[r, :24], want_y)
+        np.testing.assert_array_equal(curve[r, :n], np.clip(curs[r], 0, 255).astype(np.uint8), err_msg="record %d" % r)
+        if steep[r] and abs(int(want_y[0]) - int(want_y[1])) * n > (1 << 21):
+            beyond_bound += 1
+    assert beyond_bound > 500
