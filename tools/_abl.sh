@@ -1,5 +1,3 @@
 cd /root/repo
-for rep in 1 2; do
-VPZ_BENCH_SPLIT_SETUPS=1 timeout -k 10 200 python tools/kbench_synth.py --which real --steps 20 2>&1 | tail -1
-timeout -k 10 200 python tools/kbench_synth.py --which real --steps 20 2>&1 | tail -1
-done
+timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 &&
+timeout -k 10 300 python tools/kbench_layouts.py 2>&1 | grep "ms/call"

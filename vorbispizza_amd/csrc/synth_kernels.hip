@@ -842,6 +842,48 @@ __device__ __forceinline__ void stage_planar(const float2 (&x)[8], float *row, i
     }
 }
 
+// Group mode, interleaved output of more than two channels, long block after long block: the C waves have left the
+// packet's 1024 output samples per channel in their rows; together they write the packet's [1024][C] block as dense
+// 16-byte pieces, piece q = lane + 64*w + 64*C*j -- the de-interleave of stage_interleaved run backwards (element
+// e = 4q + i is sample e / C of channel e % C, and piece j + 1 is the same channel 256 samples on).  A wave on its own
+// can only scatter 4-byte stores at a stride of C samples: 6 channels took 1.7 x the time of planar output that way.
+template <bool kS16>
+__device__ __forceinline__ void emit_interleaved_rows(const float *rows, void *out, int C, uint32_t magic, int w, int lane)
+{
+    asm volatile("" : "+v"(lane));
+    const int q0 = lane + 64 * w;
+    if (!kS16) {
+        float v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t e = 4u * (uint32_t)q0 + (uint32_t)i;
+            const uint32_t smp = (e * magic) >> 18;
+            const uint32_t c = e - smp * (uint32_t)C;
+            const float *src = rows + c * kWaveBufFloats + smp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j][i] = src[256 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            store_pcm4(reinterpret_cast<float4 *>(out) + q0 + 64 * C * j, make_float4(v[j][0], v[j][1], v[j][2], v[j][3]));
+    } else {
+        float v[2][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t e = 8u * (uint32_t)q0 + (uint32_t)i;
+            const uint32_t smp = (e * magic) >> 18;
+            const uint32_t c = e - smp * (uint32_t)C;
+            const float *src = rows + c * kWaveBufFloats + smp;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) v[j][i] = src[512 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            store_nt(reinterpret_cast<uint4 *>(out) + q0 + 64 * C * j, pack_s16(v[j][0], v[j][1]), pack_s16(v[j][2], v[j][3]),
+                     pack_s16(v[j][4], v[j][5]), pack_s16(v[j][6], v[j][7]));
+    }
+}
+
 // kOut: 0 planar output, 1 interleaved (any channel count: every wave scatters its own channel),
 //       2 interleaved stereo: the two waves of a stream (channels 0 / 1, adjacent in the workgroup) build
 //         their blocks, meet at a workgroup barrier, and each writes HALF of the packet's samples for BOTH
@@ -1248,6 +1290,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         VPZ_STAMP(6);  // wait for the next frame's input
 
         if (kPair) __syncthreads();  // both channels' blocks (and tails) are in LDS
+        constexpr bool kCoop = kGroup && kOut == 1;  // interleaved, any channel count, the group's waves together
+        float o[4][4];      // the 16 samples of a long-after-long frame
+        bool coop = false;  // ... wait in `o` for the cooperative store (uniform over the group's waves)
         if (live && fi >= 0 && fd.out_count > 0 && !(a.ablate & 1)) {
             // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 573-591)
             // equal block sizes share one slope table (s_slope0 only holds a 128-entry short slope)
@@ -1366,7 +1411,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 const float4 *h4 = reinterpret_cast<const float4 *>(hcur);
                 const float4 *t4 = reinterpret_cast<const float4 *>(tail);
                 const float4 *s4 = reinterpret_cast<const float4 *>(s_slope1);
-                float o[4][4];
+                coop = kCoop && C > 2 && (reinterpret_cast<uintptr_t>(out_base + fd.out_off * C) & 15) == 0;
                 int lf = lane;
                 asm volatile("" : "+v"(lf));  // (no store address of this path may be computed ahead of the frame loop)
 #pragma unroll
@@ -1386,7 +1431,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         o[r][2] = ola(hv.z, wl.z, pv.y, wr.y);
                         o[r][3] = ola(hv.w, wl.w, pv.x, wr.x);
                     }
-                    if (kInterleaved) {  // scattered stores: finish each group of four at once (short live ranges)
+                    if (kInterleaved && !coop) {  // scattered stores: finish each group of four at once (short live ranges)
                         if (a.clip) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
@@ -1396,7 +1441,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         store4(g, o[r][0], o[r][1], o[r][2], o[r][3]);
                     }
                 }
-                if (!kInterleaved && a.clip) {
+                if ((!kInterleaved || coop) && a.clip) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -1493,6 +1538,20 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 tail[lane] = hcur[64 + lane];
             }
             prev_n4 = n4;
+        }
+        if (kCoop) {
+            // the block is spent (its lower half went into `o`, its upper half into the tail): the row takes the frame's
+            // output, and once every channel's is there the group's waves write the packet out together
+            if (coop) {
+                __builtin_amdgcn_wave_barrier();
+                int lf = lane;
+                asm volatile("" : "+v"(lf));
+                float4 *row4 = reinterpret_cast<float4 *>(hcur);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) row4[lf + 64 * r] = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+            }
+            __syncthreads();
+            if (coop) emit_interleaved_rows<kS16>(s_work[gw0], out_base + fd.out_off * C, C, div_magic, ch, lane);
         }
 #pragma unroll
         for (int m = 0; m < 8; ++m) xcur[m] = xnext[m];
