@@ -389,17 +389,18 @@ def cpu_plumbing_2test():
             "note": "CPU only: C++ front end + C oracle driven packet by packet from Python"}
 
 
-def time_decoder(ctx, dec, torch, pk, residue, posts, counts, samples, channels, steps, warmup, repeats=3):
+def time_decoder(ctx, dec, torch, pk, residue, posts, counts, samples, channels, steps, warmup, repeats=3, layout=None):
     """Seconds per vpz_decoder_synth call: `repeats` timed loops of `steps` calls each, the best loop counts (the
     side workloads share the box's host cores with other tenants; one disturbed loop must not decide the figure).
     The contract line in main() is NOT measured this way: it times exactly --steps steps once."""
     from vorbispizza_amd import capi
     out = torch.empty(channels * (samples + 1024), device=residue.device, dtype=torch.float32)
     cap = samples + 1024
+    layout = capi.OUT_PLANAR if layout is None else layout
 
     def step():
         dec.reset(-1)
-        w = dec.synth_raw(pk, residue, posts, counts, out, None, cap, capi.OUT_PLANAR, cap, capi.MEM_DEVICE)
+        w = dec.synth_raw(pk, residue, posts, counts, out, None, cap, layout, cap, capi.MEM_DEVICE)
         assert int(w[0]) == samples, (int(w[0]), samples)
 
     for _ in range(warmup):
@@ -555,6 +556,11 @@ def main():
                 "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "2 kernels (Floor1 unwrap; fused de-interleave + coupling + floor + IMDCT + OLA); whole call; "
                         "best of 3 loops of 40 calls"}
+            # ... and as `ReadSamples(Span<float>)` hands a 5.1 stream over: interleaved (IStreamDecoder.cs:126)
+            dt, _ = time_decoder(ctx, dec, torch, pk, res6, posts, counts, samples6, 6, 40, 3, layout=capi.OUT_INTERLEAVED)
+            extras["configs[3] with interleaved output (the six waves of a packet write it together)"] = {
+                "Msamples_per_s": round(samples6 * 6 / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
+                "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4)}
             dec.close()
             del res6, posts, counts
             torch.cuda.empty_cache()
@@ -566,7 +572,8 @@ def main():
                 "algorithmic_GBps": round(8 * tot / dt / 1e9, 1), "frac_of_8TBps": round(8 * tot / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "cpu_entropy_decode_s_for_128_streams_1thread": round(t_front, 3),
                 "end_to_end_Msamples_per_s_incl_cpu_entropy_decode_1thread": round(tot / (dt + t_front) / 1e6, 2),
-                "note": "2 decoder groups (one per setup header); GPU stage = Floor1 unwrap + fused synth (group mode)"}
+                "note": "one decoder over both fixtures' setups (sharding.merge_setups); GPU stage = Floor1 unwrap + fused synth "
+                        "(group mode), one launch each per step"}
             thr = host_threads()
             tot_e, (t_all, t_dec, t_syn) = end_to_end_real_streams(ctx, torch, 64, thr)
             extras["configs[4] end to end, one GPU's share: 128 real stereo streams, container bytes in host memory "

@@ -419,3 +419,26 @@ def test_group_mode_with_the_other_block_sizes_and_16_bit_output(ctx, oracle, si
     s16 = outs[capi.OUT_INTERLEAVED_S16][0][s * channels * cap: s * channels * cap + ref.size]
     want = np.clip((f32 * np.float32(32768.0)).astype(np.int64), -32768, 32767).astype(np.int16)
     assert np.array_equal(s16, want)
+
+
+@pytest.mark.parametrize("channels,steps,interleaved_in", [(6, [(0, 1), (2, 3)], True), (5, [], False), (3, [(0, 2)], False)])
+def test_interleaved_output_of_many_channels_written_by_the_group(ctx, channels, steps, interleaved_in):
+    """`ReadSamples(Span<float>)` of a 5.1 stream: in group mode the waves of a packet write its [samples][channels] block
+    together as dense pieces (long block after long block; every other frame geometry scatters as before) -- and a
+    batch takes group mode for that alone, coupled or not.  Float and 16-bit, against the run that never groups."""
+    from vorbispizza_amd import capi
+    n_streams, frames = 3, 40
+    pk, res, posts, counts = stream_major_batch(n_streams, frames, channels, seed=900 + channels, floor=True,
+                                                interleaved=interleaved_in)
+    pk["mapping"] = pk["flags"] & 1
+    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)]
+    mappings = [{"coupling": steps, "channel_floor": [0] * channels}, {"coupling": steps, "channel_floor": [1] * channels}]
+    assert int((pk["flags"] & 1).sum()) > len(pk) // 2, "the batch must hold runs of long blocks"
+    for layout in (capi.OUT_INTERLEAVED, capi.OUT_INTERLEAVED_S16, capi.OUT_PLANAR):
+        with env(VPZ_NO_GROUP=None):
+            g = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
+        with env(VPZ_NO_GROUP=1):
+            l = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
+        assert np.array_equal(g[1], l[1]) and np.array_equal(g[2], l[2]) and g[3] == l[3]
+        assert np.array_equal(g[0], l[0]) if g[0].dtype == np.int16 else np.array_equal(g[0].view(np.uint32), l[0].view(np.uint32))
+        assert np.abs(g[0].astype(np.float64)).max() > 0

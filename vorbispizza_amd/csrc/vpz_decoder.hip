@@ -1502,7 +1502,9 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     if (rc == 0 && (rc = call.run_state_machine(samples_written)) != VPZ_OK) return rc;
     // group mode of the fused kernel (de-interleave and inverse coupling in LDS) when the batch needs either and
     // its packets can be read in 16-byte pieces; otherwise the separate pass through a planar temp
-    call.use_group = D.group_ok && call.need_coupling && !call.any_floor0 && call.group_align_ok &&
+    // ... and for interleaved output of more than two channels, which only a packet's waves together can write densely
+    const bool wants_group = call.need_coupling || (call.out_interleaved && D.channels > 2);
+    call.use_group = D.group_ok && wants_group && !call.any_floor0 && call.group_align_ok &&
                      (mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
     const auto t_pass1 = tick();
     const char *mismatch_text =
