@@ -24,6 +24,8 @@ def main():
     rows.sort()
     if args.ours:
         rows = [r for r in rows if "vpz::" in r[2] or r[2].startswith("COPY") or "fillBuffer" in r[2]]
+        while rows and "vpz::" not in rows[-1][2]:  # (what follows the last call -- checksums, copies back -- is not ours)
+            rows.pop()
     rows = rows[-args.last:]
     prev_end = rows[0][0]
     for s, e, name in rows:
