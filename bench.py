@@ -202,7 +202,10 @@ def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, 
     # ONE decoder over all the streams: the fixtures share channel count and block sizes, their floors and mappings are
     # merged (sharding.merge_setups) and a packet's mapping index is shifted by its fixture's base -- one unwrap and one
     # synth launch per step, with runs twice as long, instead of a pair per fixture.  VPZ_BENCH_SPLIT_SETUPS=1: the old way.
-    split = bool(os.environ.get("VPZ_BENCH_SPLIT_SETUPS"))
+    # (measured: 128 streams 0.366 -> 0.320 ms, 256: 0.657 -> 0.635, 512: 1.238 -> 1.213; at 1024 streams either way fills
+    # the GPU for milliseconds and the two calls per step overlap their host halves better: 2.35 vs 2.49 ms -- so a batch
+    # is merged up to 512 streams)
+    split = bool(os.environ.get("VPZ_BENCH_SPLIT_SETUPS")) or sum(len(ids) for ids in plan) > 512
     parts = []
     total_samples = 0
     t_front_total = 0.0

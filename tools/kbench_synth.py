@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--frames6", type=int, default=16384)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--which", default="both")
+    ap.add_argument("--copies", type=int, default=64, help="streams of each fixture for --which real")
     args = ap.parse_args()
     import torch
     import bench
@@ -41,9 +42,9 @@ def main():
               % (dt * 1e3, samples6 * 6 / dt / 1e6, byt / dt / 1e9))
         dec.close()
     if args.which in ("both", "real"):
-        dt, tot, _, _ = bench.time_real_streams(ctx, torch, dev, 64, steps=args.steps)
-        print("configs[4] share (128 real stereo streams, interleaved out): %.3f ms/step  %.1f Msamples/s"
-              % (dt * 1e3, tot / dt / 1e6))
+        dt, tot, _, _ = bench.time_real_streams(ctx, torch, dev, args.copies, steps=args.steps)
+        print("configs[4] share (%d real stereo streams, interleaved out): %.3f ms/step  %.1f Msamples/s"
+              % (2 * args.copies, dt * 1e3, tot / dt / 1e6))
     ctx.close()
 
 
