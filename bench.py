@@ -205,7 +205,8 @@ def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, 
     # (measured: 128 streams 0.366 -> 0.320 ms, 256: 0.657 -> 0.635, 512: 1.238 -> 1.213; at 1024 streams either way fills
     # the GPU for milliseconds and the two calls per step overlap their host halves better: 2.35 vs 2.49 ms -- so a batch
     # is merged up to 512 streams)
-    split = bool(os.environ.get("VPZ_BENCH_SPLIT_SETUPS")) or sum(len(ids) for ids in plan) > 512
+    split = bool(os.environ.get("VPZ_BENCH_SPLIT_SETUPS")) or \
+        (sum(len(ids) for ids in plan) > 512 and not os.environ.get("VPZ_BENCH_MERGE_SETUPS"))
     parts = []
     total_samples = 0
     t_front_total = 0.0
