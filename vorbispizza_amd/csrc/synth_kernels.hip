@@ -936,6 +936,53 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     __shared__ float s_tail[kSynthWaves][kWaveTailFloats];  // upper half of the previous block's h
     __shared__ uint4 s_desc[kSynthWaves][(kRunMax + 1) * 2];  // the run's frame descriptors
 
+    const int lane = threadIdx.x & 63;
+    // wave-uniform values are forced into SGPRs so the descriptor reads become scalar loads
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int C = a.channels;
+    // which run and channel this wave owns.  Free-running waves are numbered through the grid; in group mode a
+    // workgroup holds floor(8 / C) whole runs (the remaining waves idle but keep the barriers matched).
+    int run_idx, ch, gw0 = 0;  // gw0: first wave of this wave's group
+    bool active;
+    if (kGroup) {
+        // (uniform values: keep them out of the vector registers the integer division would leave them in)
+        const int groups = __builtin_amdgcn_readfirstlane(kSynthWaves / C);
+        // (waves that own no channel -- 8 - groups * C of them -- idle at the barriers; spreading them over the SIMDs by
+        // rotating the busy set in every other workgroup was measured: no difference)
+        const int slot = __builtin_amdgcn_readfirstlane(wave / C);
+        ch = wave - slot * C;
+        gw0 = slot * C;
+        run_idx = blockIdx.x * groups + slot;
+        active = slot < groups && run_idx < a.n_runs;
+    } else {
+        const int item = blockIdx.x * kSynthWaves + wave;
+        active = item < a.n_runs * C;
+        run_idx = active ? item / C : 0;
+        ch = active ? item - run_idx * C : (wave & 1);
+    }
+    const uint32_t div_magic =
+        kGroup ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(((1u << 18) + (uint32_t)C - 1u) / (uint32_t)C)) : 0u;
+    if (!active) { run_idx = 0; if (kGroup) ch = 0; }
+    RunDesc run = a.runs[run_idx];
+    if (kSync && !active) {  // an idle wave: nothing to load, emit or save
+        run.count = 0;
+        run.pre_kind = kPreNone;
+        run.flags = 0;
+    }
+    // The run record and a compact run's bytes sit in pinned HOST memory (read in place over the link: a round trip of
+    // microseconds each): they are asked for here, ahead of the table staging below, so that the two round trips -- and
+    // the post counts' -- pass while the tables load instead of after them.
+    const int fi0 = (run.pre_kind == kPreRecompute && run.count > 0) ? -1 : 0;
+    uint32_t cf_early = 0, mp_early = 0;
+    int cc_early = 0;
+    if (run.flags & kRunCompact) {
+        const int n = run.count - fi0, f0 = run.first + fi0;
+        if ((int)(threadIdx.x & 63) < n) {
+            cf_early = a.cflags[f0 + (threadIdx.x & 63)];
+            mp_early = a.cmap[f0 + (threadIdx.x & 63)];
+            if (kHasFloor && a.ccount != nullptr) cc_early = a.ccount[run.rec_base + (int)(threadIdx.x & 63) * C + ch];
+        }
+    }
     if (kGeneral) {
         for (int i = threadIdx.x; i < kFastTableCount; i += kSynthThreads) s_twL[i] = a.tw_long[i];
         for (int i = threadIdx.x; i < 256; i += kSynthThreads) {
@@ -966,41 +1013,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         for (int i = threadIdx.x; i < 2 * a.n_step_pairs && i < 2 * kGroupMaxStepPairs; i += kSynthThreads)
             s_steps[i] = a.steps[i];
     __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    // wave-uniform values are forced into SGPRs so the descriptor reads become scalar loads
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int C = a.channels;
-    // which run and channel this wave owns.  Free-running waves are numbered through the grid; in group mode a
-    // workgroup holds floor(8 / C) whole runs (the remaining waves idle but keep the barriers matched).
-    int run_idx, ch, gw0 = 0;  // gw0: first wave of this wave's group
-    bool active;
-    if (kGroup) {
-        // (uniform values: keep them out of the vector registers the integer division would leave them in)
-        const int groups = __builtin_amdgcn_readfirstlane(kSynthWaves / C);
-        // (waves that own no channel -- 8 - groups * C of them -- idle at the barriers; spreading them over the SIMDs by
-        // rotating the busy set in every other workgroup was measured: no difference)
-        const int slot = __builtin_amdgcn_readfirstlane(wave / C);
-        ch = wave - slot * C;
-        gw0 = slot * C;
-        run_idx = blockIdx.x * groups + slot;
-        active = slot < groups && run_idx < a.n_runs;
-    } else {
-        const int item = blockIdx.x * kSynthWaves + wave;
-        active = item < a.n_runs * C;
-        run_idx = active ? item / C : 0;
-        ch = active ? item - run_idx * C : (wave & 1);
-    }
-    const uint32_t div_magic =
-        kGroup ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(((1u << 18) + (uint32_t)C - 1u) / (uint32_t)C)) : 0u;
     if (!kSync && !active) return;  // (the lock-step variants keep idle waves around for their barriers)
-    if (!active) { run_idx = 0; if (kGroup) ch = 0; }
-    RunDesc run = a.runs[run_idx];
-    if (kSync && !active) {  // an idle wave: nothing to load, emit or save
-        run.count = 0;
-        run.pre_kind = kPreNone;
-        run.flags = 0;
-    }
+
     const int half1 = a.size1 >> 1;
 
     float *hcur = s_work[wave];
@@ -1049,7 +1063,6 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             cp = a.cposts[(size_t)(floored ? fd.rec + ch : 0) * 64 + l];
         }
     };
-    const int fi0 = (run.pre_kind == kPreRecompute && run.count > 0) ? -1 : 0;
     // trip count: the run's own in the free-running variants, the workgroup's longest in the lock-step ones
     int iters = run.count - fi0;
     if (kSync) {
@@ -1063,9 +1076,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     // every frame's critical path.  Explicit descriptors come with one coalesced read; a compact run builds them here.
     if (run.flags & kRunCompact) {
         const int n = run.count - fi0;  // staged frames (<= kRunMax + 1 <= 64), one lane each
-        const int f0 = run.first + fi0;
-        uint32_t cf = 0, mp = 0;
-        if (lane < n) { cf = a.cflags[f0 + lane]; mp = a.cmap[f0 + lane]; }
+        const uint32_t cf = cf_early, mp = mp_early;  // (lanes past the run hold zeros)
         const uint32_t pcf = __shfl_up(cf, 1);
         const PacketGeom g = s_geom[cf & 7], pg = s_geom[pcf & 7];
         const bool has_prev = lane > 0 || run.has_prev0;
@@ -1111,8 +1122,12 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     // ahead of the loop: read per frame, the count would put a dependent global load -- and, vmcnt being in order, the
     // drain of the previous frame's PCM stores -- in front of every prefetch.
     if (kHasFloor && a.ccount != nullptr) {
-        __builtin_amdgcn_wave_barrier();
-        if (lane < run.count - fi0) cc_run = a.ccount[(int)s_desc[wave][2 * lane + 1].x + ch];
+        if (run.flags & kRunCompact) {
+            cc_run = cc_early;
+        } else {
+            __builtin_amdgcn_wave_barrier();
+            if (lane < run.count - fi0) cc_run = a.ccount[(int)s_desc[wave][2 * lane + 1].x + ch];
+        }
     }
     auto frame_at = [&](int fi) -> FrameDesc {  // broadcast LDS read, then into SGPRs
         const uint4 lo = s_desc[wave][(fi - fi0) * 2], hi = s_desc[wave][(fi - fi0) * 2 + 1];
