@@ -101,3 +101,34 @@ def test_random_scenarios_match_the_oracle(ctx, oracle, size0, size1, seed):
         if ref.size:
             assert np.abs(got - ref).max() <= 1e-5
     dec.close()
+
+
+def test_a_call_that_only_drains(ctx, oracle):
+    """A batch whose only frame is the un-windowed drain of the previous block (an undecodable EOS packet,
+    StreamDecoder.cs:451-455): the kernel runs with nothing to load -- its unconditional prefetches must not touch the
+    (empty) residue -- and emits the rest of the previous block."""
+    from vorbispizza_amd import Decoder, capi, make_packets
+    channels, size0, size1 = 2, 256, 2048
+    spectra = helpers.gaussian_spectra((3, channels, 1024), seed=5)
+    pk = make_packets(4)
+    opk = []
+    for f in range(3):
+        pk[f]["flags"] = PKT_BLOCK_FLAG | PKT_PREV_FLAG | PKT_NEXT_FLAG | PKT_NO_FLOOR
+        pk[f]["granule"] = -1
+        pk[f]["residue_offset"] = f * channels * 1024
+        opk.append({"flags": int(pk[f]["flags"]), "granule": -1, "residue": spectra[f].reshape(-1)})
+    pk[3]["flags"] = PKT_NOT_DECODED | PKT_EOS
+    pk[3]["granule"] = -1
+    opk.append({"flags": int(pk[3]["flags"]), "granule": -1, "residue": np.zeros(0, np.float32)})
+    ref, pos, _ = helpers.oracle_decode(oracle, channels, size0, size1, opk)
+    dec = Decoder(ctx, channels, size0, size1)
+    cap = 4 * 1024
+    out_a = np.zeros(channels * cap, dtype=np.float32)
+    w_a = dec.synth_raw(pk[:3].copy(), spectra.reshape(-1), None, None, out_a, None, cap, capi.OUT_PLANAR, cap, capi.MEM_HOST)
+    out_b = np.zeros(channels * cap, dtype=np.float32)
+    w_b = dec.synth_raw(pk[3:].copy(), np.zeros(4, np.float32), None, None, out_b, None, cap, capi.OUT_PLANAR, cap, capi.MEM_HOST)
+    got = np.concatenate([out_a.reshape(channels, cap)[:, : int(w_a[0])], out_b.reshape(channels, cap)[:, : int(w_b[0])]], axis=1)
+    assert int(w_b[0]) > 0 and got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-5
+    assert dec.position(0) == pos
+    dec.close()

@@ -1040,8 +1040,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         return *reinterpret_cast<const uint2 *>(s_steps + (off < 2u * kGroupMaxStepPairs ? off : 0u));
     };
     // Everything below is UNCONDITIONAL -- a frame that needs no input (none follows, a drain, a silent channel) reads
-    // a few bytes from the start of the residue instead: a load under a condition leaves the compiler with a merge of
-    // "loaded" and "not loaded" registers, which it resolves with copies right behind the loads, and the copies wait
+    // a few bytes of a table that always exists (the inverse dB table) instead: a load under a condition leaves the
+    // compiler with a merge of "loaded" and "not loaded" registers, which it resolves with copies right behind the loads, and the copies wait
     // for the data.  That put the full memory latency in front of every frame of every variant with a floor.
     auto prefetch = [&](const FrameDesc &fd, int slot, bool valid, float2 (&x)[8], int &cp, int &cnt, bool &ex) {
         cnt = valid ? __builtin_amdgcn_readlane(cc_run, slot) : 0;  // active posts of this wave's channel (0: silent)
@@ -1050,10 +1050,10 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             const int hh = size_of(fd.flags) >> 1;
             const bool shared_input = fd.flags & kFrameInterleaved;
             const float *src = a.spec + fd.spec_off + (shared_input ? 0 : (int64_t)ch * hh);
-            load_group_share(x, valid ? src : a.spec, shared_input ? 64 * ch : 0, shared_input ? 64 * C : 64,
+            load_group_share(x, valid ? src : a.inv_db, shared_input ? 64 * ch : 0, shared_input ? 64 * C : 64,
                              valid ? ((shared_input ? C * hh : hh) >> 2) : 1, lane);
         } else {
-            load_spectrum(x, ex ? spectrum_of(fd) : a.spec, ex ? lpb_of(fd.flags) : 1, lane);
+            load_spectrum(x, ex ? spectrum_of(fd) : a.inv_db, ex ? lpb_of(fd.flags) : 1, lane);
         }
         if (kHasFloor) {
             // all 64 entries of the record's row (the ones past `cnt` are dropped where the curve is rendered)
