@@ -180,3 +180,40 @@ def test_steep_lines_take_the_integer_walk_and_still_match(ctx, oracle):
         if steep[r] and abs(int(want_y[0]) - int(want_y[1])) * n > (1 << 21):
             beyond_bound += 1
     assert beyond_bound > 500
+
+
+def test_more_floors_than_the_lds_copy_holds(ctx, oracle):
+    """floor1_unwrap_kernel keeps up to four floors' tables in LDS; a decoder with more reads them from memory (the
+    other instantiation).  Six floors, the records spread over all of them."""
+    from vorbispizza_amd import Decoder
+    n, mult = 1024, 2
+    rng = np.random.default_rng(99)
+    xlists = [random_xlist(rng, n, c, False) for c in (8, 17, 29, 40, 12, 64)]
+    dec = Decoder(ctx, 1, 256, 2048, floors=[(x, mult) for x in xlists],
+                  mappings=[{"coupling": [], "channel_floor": [0]}])
+    per = 300
+    posts_all, counts_all, which = [], [], []
+    for fi, xl in enumerate(xlists):
+        p, c = random_records(rng, xl, per, mult)
+        posts_all.append(p)
+        counts_all.append(c)
+        which += [fi] * per
+    posts, counts = np.concatenate(posts_all), np.concatenate(counts_all)
+    order = rng.permutation(len(which))
+    posts, counts, which = posts[order], counts[order], np.asarray(which, np.uint8)[order]
+    curve, final_y, flags, active = dec.debug_floor1_indices(posts, counts, which, np.ones(len(which), np.uint8))
+    handles = [oracle.floor1_init(x, mult) for x in xlists]
+    checked = 0
+    for r in range(len(which)):
+        if counts[r] == 0:
+            assert active[r] == 0
+            continue
+        xc = len(xlists[which[r]])
+        fy, fl, idx = oracle.floor1_indices(handles[which[r]], posts[r].astype(np.int32), int(counts[r]), n)
+        if not (np.abs(fy[:xc] * mult) < 32768).all():
+            continue
+        np.testing.assert_array_equal(final_y[r, :xc], fy[:xc] * mult)
+        np.testing.assert_array_equal(flags[r, :xc], fl[:xc])
+        np.testing.assert_array_equal(curve[r, :n], np.clip(idx, 0, 255).astype(np.uint8))
+        checked += 1
+    assert checked > 1500
