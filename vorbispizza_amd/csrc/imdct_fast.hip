@@ -75,15 +75,26 @@ __global__ __launch_bounds__(kThreads) void imdct2048_kernel(const float *__rest
 #pragma unroll
         for (int m = 0; m < 8; ++m) cur[m] = src[lane + 64 * m];
     }
+    // The first block has to be there before the loop is entered, and the loads of the next one are unconditional (the
+    // last pass re-reads its own block): with loads pending at the loop header, or under a condition, the compiler
+    // waits for EVERYTHING at the first use of `cur` -- i.e. for the prefetch it has just issued -- and the transform
+    // never overlaps a load of its own wave (found in round 2 with the ISA listing; the fused kernel had the same).
+#pragma unroll
+    for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(cur[m].x), "v"(cur[m].y));
     while (true) {
         const long nxt = blk + stride;
         float2 pre[8];
-        if (nxt < count) {
-            const float2 *src = reinterpret_cast<const float2 *>(spectra + (kGather ? src_off[nxt] : nxt * 1024));
+        {
+            const long ld = nxt < count ? nxt : blk;
+            const float2 *src = reinterpret_cast<const float2 *>(spectra + (kGather ? src_off[ld] : ld * 1024));
 #pragma unroll
             for (int m = 0; m < 8; ++m) pre[m] = src[lane + 64 * m];
         }
+        __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the loads into the transform to save registers)
         imdct2048_wave(cur, scratch, s_tw, s_twAB, s_twBC, lane);
+        // (vmcnt counts stores too, in issue order: the wait for the prefetch is placed ahead of this block's stores)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(pre[m].x), "v"(pre[m].y));
         store_full_block<2048, 64>(reinterpret_cast<const float *>(scratch), out + (kGather ? dst_off[blk] : blk * 2048), lane);
         if (nxt >= count) break;
 #pragma unroll
