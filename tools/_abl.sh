@@ -1,8 +1,3 @@
 cd /root/repo
-for g in 1 2 3 4 5 6; do
-export VPZ_IMDCT_GROUPS_PER_CU=$g
-for i in 1 2; do
-timeout -k 10 300 python bench.py --no-extras --no-cpu-baseline 2>/dev/null | python3 -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('groups_per_cu $g', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel_ms'])"
-done; done
+timeout -k 10 600 python -m pytest tests/test_imdct_gpu.py tests/test_full_size_gpu.py tests/test_synth_gpu.py -x -q 2>&1 | tail -3
+timeout -k 10 300 python tools/kbench_imdct_sizes.py 2>&1 | grep "N ="

@@ -126,18 +126,35 @@ __global__ __launch_bounds__(kThreads) void imdct256_kernel(const float *__restr
     float2 *scratch = s_scratch[wave];
     const long stride = (long)gridDim.x * kWavesPerGroup * 8;
     // every wavefront owns 8 consecutive channel-blocks per step; tail groups clamp and skip stores
-    for (long base = ((long)blockIdx.x * kWavesPerGroup + wave) * 8; base < count; base += stride) {
-        const long blk = base + g;
-        const bool live = blk < count;
-        const long ld = live ? blk : count - 1;
-        float2 xa[8];
+    // (software pipeline as in imdct2048_kernel: the next step's loads are in flight during the transform)
+    long base = ((long)blockIdx.x * kWavesPerGroup + wave) * 8;
+    if (base >= count) return;
+    auto load_step = [&](long at, float2 (&x)[8]) {
+        const long ld = at + g < count ? at + g : count - 1;
         const float2 *src = reinterpret_cast<const float2 *>(spectra + (kGather ? src_off[ld] : ld * 128));
 #pragma unroll
-        for (int m = 0; m < 8; ++m) xa[m] = src[l + 8 * m];
+        for (int m = 0; m < 8; ++m) x[m] = src[l + 8 * m];
+    };
+    float2 xa[8];
+    load_step(base, xa);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(xa[m].x), "v"(xa[m].y));
+    while (true) {
+        const long nxt = base + stride;
+        float2 pre[8];
+        load_step(nxt < count ? nxt : base, pre);
+        __builtin_amdgcn_sched_barrier(0);
+        const long blk = base + g;
         imdct256_wave8(xa, scratch, s_tw, s_twBC, lane);
-        if (live)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(pre[m].x), "v"(pre[m].y));
+        if (blk < count)
             store_full_block<256, 8>(reinterpret_cast<const float *>(scratch) + g * 128,
                                      out + (kGather ? dst_off[blk] : blk * 256), l);
+        if (nxt >= count) break;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) xa[m] = pre[m];
+        base = nxt;
     }
 }
 
@@ -165,18 +182,34 @@ __global__ __launch_bounds__(kThreads) void imdct_mid_kernel(const float *__rest
     const int b = lane / L, l = lane & (L - 1);
     float2 *scratch = s_scratch[wave];
     const long stride = (long)gridDim.x * kWavesPerGroup * B;
-    for (long base = ((long)blockIdx.x * kWavesPerGroup + wave) * B; base < count; base += stride) {
-        const long blk = base + b;
-        const bool live = blk < count;
-        const long ld = live ? blk : count - 1;
-        float2 xa[8];
+    long base = ((long)blockIdx.x * kWavesPerGroup + wave) * B;
+    if (base >= count) return;
+    auto load_step = [&](long at, float2 (&x)[8]) {
+        const long ld = at + b < count ? at + b : count - 1;
         const float2 *src = reinterpret_cast<const float2 *>(spectra + (src_off ? src_off[ld] : ld * (N / 2)));
 #pragma unroll
-        for (int m = 0; m < 8; ++m) xa[m] = src[l + L * m];
+        for (int m = 0; m < 8; ++m) x[m] = src[l + L * m];
+    };
+    float2 xa[8];
+    load_step(base, xa);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(xa[m].x), "v"(xa[m].y));
+    while (true) {
+        const long nxt = base + stride;
+        float2 pre[8];
+        load_step(nxt < count ? nxt : base, pre);
+        __builtin_amdgcn_sched_barrier(0);
+        const long blk = base + b;
         imdct_mid_wave<R>(xa, scratch, s_tw, s_twAB, s_twBC, lane);
-        if (live)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(pre[m].x), "v"(pre[m].y));
+        if (blk < count)
             store_full_block<N, L>(reinterpret_cast<const float *>(scratch) + b * (N / 2),
                                    out + (dst_off ? dst_off[blk] : blk * N), l);
+        if (nxt >= count) break;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) xa[m] = pre[m];
+        base = nxt;
     }
 }
 
