@@ -1,10 +1,6 @@
 cd /root/repo
-export VPZ_BENCH_REHEARSAL=1
-timeout -k 10 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline 2> gpurun_out/reh.err | tail -1 > gpurun_out/reh.json
-python3 - <<'PY'
-import json
-d=json.loads(open('gpurun_out/reh.json').read())
-print(d['n_gpus'], d['value'], d['ms_per_step'])
-for k,v in d['extra_workloads'].items():
-    if 'whole job' in k: print(k[:60], json.dumps(v)[:900])
-PY
+timeout -k 10 900 python -m pytest tests/test_host_paths_gpu.py tests/test_real_files_gpu.py tests/test_synth_gpu.py -x -q 2>&1 | tail -3
+for a in 0 32 0; do
+  echo "ABLATE=$a"; VPZ_SYNTH_ABLATE=$a timeout -k 10 120 python tools/kbench_synth.py --which floor --steps 40 2>&1 | tail -1
+done
+timeout -k 10 120 python tools/kbench_synth.py --which real --steps 40 2>&1 | tail -1

@@ -819,11 +819,14 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
     // frame loop and then has to park them in scratch memory.  An opaque lane id keeps them inside the loop.
     asm volatile("" : "+v"(lane));
     const int q0 = lane + 64 * w;
+    // a 2048-sample block has all four pieces of every lane (4 * 64 * C pieces): no lane condition per store -- sixteen
+    // `saveexec / branch / restore` sequences were most of what staging cost
+    const bool full = half == 1024;
     if (C == 2) {  // (L R L R): two bins of each channel, 8-byte stores
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int q = q0 + 128 * j;
-            if (q < total4) {
+            if (full || q < total4) {
                 reinterpret_cast<float2 *>(rows)[q] = make_float2(x[2 * j].x, x[2 * j + 1].x);
                 reinterpret_cast<float2 *>(rows + kWaveBufFloats)[q] = make_float2(x[2 * j].y, x[2 * j + 1].y);
             }
@@ -832,6 +835,19 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
     }
     // piece j holds elements 4*q0 + 256*C*j + i: the SAME channel as element 4*q0 + i, 256*j bins further on -- one
     // division per i, and the four pieces differ by a constant offset
+    if (full) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t e = 4u * (uint32_t)q0 + (uint32_t)i;
+            const uint32_t bin = (e * magic) >> 18;
+            const uint32_t c = e - bin * (uint32_t)C;
+            float *dst = rows + c * kWaveBufFloats + bin;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                dst[256 * j] = (i & 2) ? ((i & 1) ? x[2 * j + 1].y : x[2 * j + 1].x) : ((i & 1) ? x[2 * j].y : x[2 * j].x);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t e = 4u * (uint32_t)q0 + (uint32_t)i;
@@ -853,7 +869,8 @@ __device__ __forceinline__ void stage_planar(const float2 (&x)[8], float *row, i
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q = lane + 64 * j;
-        if (q < (half >> 2)) reinterpret_cast<float4 *>(row)[q] = make_float4(x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y);
+        if (half == 1024 || q < (half >> 2))  // (a long block has every piece: one wave-uniform test, no lane mask)
+            reinterpret_cast<float4 *>(row)[q] = make_float4(x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y);
     }
 }
 
