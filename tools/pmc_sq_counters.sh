@@ -1,3 +1,6 @@
+#!/bin/bash
+# SQ counters of the fused kernel for one decoder workload (run through gpurun; two rocprofv3 --pmc passes, eight
+# counters each, no trace domains):  WHICH=floor|ola|real bash tools/pmc_sq_counters.sh   -> gpurun_out/pmc3.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT -d $R/gpurun_out/pmc3a --output-format csv -- python3 $R/tools/kbench_synth.py --which ${WHICH:-floor} --steps 3 > $R/gpurun_out/pmc3a.log 2>&1 &&
