@@ -839,9 +839,9 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t e = 4u * (uint32_t)q0 + (uint32_t)i;
-            const uint32_t bin = (e * magic) >> 18;
-            const uint32_t c = e - bin * (uint32_t)C;
-            float *dst = rows + c * kWaveBufFloats + bin;
+            const uint32_t bin = __umul24(e, magic) >> 18;  // (24-bit multiplies are full rate, 32-bit ones a quarter)
+            const uint32_t c = e - __umul24(bin, (uint32_t)C);
+            float *dst = rows + __umul24(c, (uint32_t)kWaveBufFloats) + bin;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 dst[256 * j] = (i & 2) ? ((i & 1) ? x[2 * j + 1].y : x[2 * j + 1].x) : ((i & 1) ? x[2 * j].y : x[2 * j].x);
@@ -851,9 +851,9 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t e = 4u * (uint32_t)q0 + (uint32_t)i;
-        const uint32_t bin = (e * magic) >> 18;
-        const uint32_t c = e - bin * (uint32_t)C;
-        float *dst = rows + c * kWaveBufFloats + bin;
+        const uint32_t bin = __umul24(e, magic) >> 18;
+        const uint32_t c = e - __umul24(bin, (uint32_t)C);
+        float *dst = rows + __umul24(c, (uint32_t)kWaveBufFloats) + bin;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float v = (i & 2) ? ((i & 1) ? x[2 * j + 1].y : x[2 * j + 1].x) : ((i & 1) ? x[2 * j].y : x[2 * j].x);
@@ -889,9 +889,9 @@ __device__ __forceinline__ void emit_interleaved_rows(const float *rows, void *o
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t e = 4u * (uint32_t)q0 + (uint32_t)i;
-            const uint32_t smp = (e * magic) >> 18;
-            const uint32_t c = e - smp * (uint32_t)C;
-            const float *src = rows + c * kWaveBufFloats + smp;
+            const uint32_t smp = __umul24(e, magic) >> 18;
+            const uint32_t c = e - __umul24(smp, (uint32_t)C);
+            const float *src = rows + __umul24(c, (uint32_t)kWaveBufFloats) + smp;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j][i] = src[256 * j];
         }
@@ -903,9 +903,9 @@ __device__ __forceinline__ void emit_interleaved_rows(const float *rows, void *o
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint32_t e = 8u * (uint32_t)q0 + (uint32_t)i;
-            const uint32_t smp = (e * magic) >> 18;
-            const uint32_t c = e - smp * (uint32_t)C;
-            const float *src = rows + c * kWaveBufFloats + smp;
+            const uint32_t smp = __umul24(e, magic) >> 18;
+            const uint32_t c = e - __umul24(smp, (uint32_t)C);
+            const float *src = rows + __umul24(c, (uint32_t)kWaveBufFloats) + smp;
 #pragma unroll
             for (int j = 0; j < 2; ++j) v[j][i] = src[512 * j];
         }
