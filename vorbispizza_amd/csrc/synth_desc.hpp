@@ -137,7 +137,8 @@ struct SynthArgs {
     int32_t s16;                // PCM as int16 (`(int)(x * 32768f)` clamped) instead of float32
     int32_t clip;
     int32_t *clipped;           // [stream] sticky HasClipped
-    int32_t ablate;             // tuning only (VPZ_SYNTH_ABLATE): 1 skip PCM stores, 2 skip IMDCT, 4 skip loads
+    int32_t ablate;             // tuning only (VPZ_SYNTH_ABLATE): 1 skip PCM stores, 2 skip IMDCT, 4 skip loads, 8 skip the
+                                // curve, 16 skip coupling, 32 skip staging, 64 render every bin
     unsigned long long *stamps; // diagnostic builds only (-DVPZ_STAMPS): [16] cycles per phase, summed over the waves
 };
 

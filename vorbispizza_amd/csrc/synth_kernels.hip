@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         // ---- group mode: the packet goes through the group's LDS rows (de-interleave, inverse coupling)
         if (kGroup) {
             const bool stage = build;  // every packet goes through the rows (see load_group_share)
-            if (!(a.ablate & 256)) __syncthreads();  // every wave of the group is done with its row (previous block emitted)
+            __syncthreads();  // every wave of the group is done with its row (previous block emitted)
             VPZ_STAMP(1);  // first barrier
             if (stage && !(a.ablate & 32)) {
                 if (fd.flags & kFrameInterleaved) {
@@ -1256,7 +1256,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     stage_planar(xcur, hcur, nblk >> 1, lane);
                 }
             }
-            if (!(a.ablate & 256)) __syncthreads();
+            __syncthreads();
             VPZ_STAMP(2);  // staging + barrier
             // inverse coupling, steps in reverse order (Mapping.cs:166); the host has cut each mapping's steps into
             // LEVELS of steps that touch disjoint channels (bit 7 of a step's first byte: a new level starts here), so
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             const unsigned long long stw = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.y) << 32) |
                                            (uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.x);
             // byte k of the mapping's steps: out of the prefetched word while the mapping has at most four
-            auto step_byte = [&](int k) -> uint32_t { return (n_steps <= 4 && !(a.ablate & 512)) ? (uint32_t)(stw >> (8 * k)) & 0xFFu : (uint32_t)st[k]; };
+            auto step_byte = [&](int k) -> uint32_t { return n_steps <= 4 ? (uint32_t)(stw >> (8 * k)) & 0xFFu : (uint32_t)st[k]; };
             for (int lvl = 0; lvl < a.max_steps; ++lvl) {
                 if (stage && !(a.ablate & 16)) {
                     bool first = true;
@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         first = false;
                     }
                 }
-                if (!(a.ablate & 256)) __syncthreads();
+                __syncthreads();
             }
             VPZ_STAMP(3);  // coupling levels + barriers
             if (stage && exec) load_spectrum(xcur, hcur, lpb_of(fd.flags), lane);
