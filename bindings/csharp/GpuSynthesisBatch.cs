@@ -4,6 +4,7 @@
 // To be added on the reference side (NVorbis/Native/GpuSynthesisBatch.cs) together with the call-site edits listed in
 // INTEGRATION.md section 2.  Pure glue: no sample arithmetic happens in C#.
 using System;
+using System.Collections.Generic;
 using System.Buffers;
 
 namespace NVorbis.Native
@@ -114,5 +115,44 @@ namespace NVorbis.Native
         public bool HasClipped { get { VorbisPizzaSynth.vpz_decoder_has_clipped(_decoder, 0, out int c); return c != 0; } }
 
         public void Dispose() => _decoder.Dispose();
+
+        /// <summary>One decoder configuration for streams that come with different setup headers but the same channel
+        /// count and block sizes: the union of their floors (equal ones shared) and of their mappings.  A packet of setup
+        /// k with mapping index m carries mappingBase[k] + m in the merged batch -- one unwrap and one synthesis launch
+        /// cover all the streams, with longer runs per wavefront (vorbispizza_amd/sharding.py: merge_setups is the
+        /// same thing in Python; 128 streams of two kinds: 0.366 -> 0.320 ms per batch).</summary>
+        public static (VorbisPizzaSynth.Floor1Config[] Floors, VorbisPizzaSynth.MappingConfig[] Mappings, int[] MappingBase)
+            MergeSetups(IReadOnlyList<(VorbisPizzaSynth.Floor1Config[] Floors, VorbisPizzaSynth.MappingConfig[] Mappings)> setups,
+                        int channels)
+        {
+            var floors = new List<VorbisPizzaSynth.Floor1Config>();
+            var mappings = new List<VorbisPizzaSynth.MappingConfig>();
+            var bases = new int[setups.Count];
+            static bool Same(in VorbisPizzaSynth.Floor1Config a, in VorbisPizzaSynth.Floor1Config b)
+            {
+                if (a.XCount != b.XCount || a.Multiplier != b.Multiplier) return false;
+                for (int i = 0; i < a.XCount; i++) if (a.XList[i] != b.XList[i]) return false;
+                return true;
+            }
+            for (int k = 0; k < setups.Count; k++)
+            {
+                var remap = new byte[setups[k].Floors.Length];
+                for (int f = 0; f < remap.Length; f++)
+                {
+                    int at = floors.FindIndex(x => Same(x, setups[k].Floors[f]));
+                    if (at < 0) { at = floors.Count; floors.Add(setups[k].Floors[f]); }
+                    remap[f] = (byte)at;
+                }
+                bases[k] = mappings.Count;
+                foreach (var m in setups[k].Mappings)
+                {
+                    var merged = m;                                    // coupling steps unchanged
+                    for (int ch = 0; ch < channels; ch++) merged.ChannelFloor[ch] = remap[m.ChannelFloor[ch]];
+                    mappings.Add(merged);
+                }
+            }
+            if (mappings.Count > 256) throw new ArgumentException("more than 256 mappings do not fit Packet.Mapping");
+            return (floors.ToArray(), mappings.ToArray(), bases);
+        }
     }
 }
