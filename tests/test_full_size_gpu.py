@@ -88,4 +88,21 @@ def test_config3_full_size_properties(env, oracle):
     ref, _, _ = helpers.oracle_decode(oracle, 6, 256, 2048, opk, floors=floors, mappings=mappings)
     got = y[:, :ref.shape[1]].cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+    # the same batch as `ReadSamples(Span<float>)` delivers it: interleaved, written by a packet's six waves together --
+    # the planar result transposed, bit for bit; and as 16-bit samples, the reference conversion of those floats
+    from vorbispizza_amd import capi
+    cap = samples + 1024
+    for layout, dtype in ((capi.OUT_INTERLEAVED, torch.float32), (capi.OUT_INTERLEAVED_S16, torch.int16)):
+        out = torch.zeros(6 * cap, device=dev, dtype=dtype)
+        dec.reset(-1)
+        dec.set_position(0)
+        w = dec.synth_raw(pk, res, posts, counts, out, None, cap, layout, 0, capi.MEM_DEVICE)
+        ctx.synchronize()
+        assert int(w[0]) == samples
+        inter = out[: samples * 6].reshape(samples, 6).t()
+        if dtype == torch.float32:
+            assert torch.equal(inter.contiguous().view(torch.int32), y.contiguous().view(torch.int32))
+        else:
+            want = torch.clamp((y * 32768.0).to(torch.int32), -32768, 32767).to(torch.int16)
+            assert torch.equal(inter, want)
     dec.close()
