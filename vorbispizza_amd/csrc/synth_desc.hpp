@@ -17,7 +17,8 @@ constexpr uint32_t kFrameDrain = 4u;       // no new block: emit the previous ta
                                            // (StreamDecoder.cs:451-455, quirk q4)
 // group mode (the waves of a packet's channels share a workgroup and stage the packet in LDS):
 constexpr uint32_t kFrameInterleaved = 16u;  // spec_off addresses the Residue2 vector [n/2][channels]
-constexpr uint32_t kFrameStage = 32u;        // de-interleave and / or inverse coupling needed before the floor
+constexpr int kFrameBatchShift = 5;          // bits 5..7: this frame heads a batch of (value + 1) consecutive short blocks
+                                             // that one pass synthesises (set by the kernel's own run builder only)
 constexpr int kFrameStepsShift = 8;          // bits 8..15: coupling steps of the packet's mapping
 constexpr int kFrameStepsOffShift = 16;      // bits 16..31: first step (pair index) in the steps table
 constexpr int kGroupMaxChannels = 8;         // channels that fit one workgroup of 8 waves

@@ -880,11 +880,14 @@ __device__ __forceinline__ void stage_planar(const float2 (&x)[8], float *row, i
 // e = 4q + i is sample e / C of channel e % C, and piece j + 1 is the same channel 256 samples on).  A wave on its own
 // can only scatter 4-byte stores at a stride of C samples: 6 channels took 1.7 x the time of planar output that way.
 template <bool kS16>
-__device__ __forceinline__ void emit_interleaved_rows(const float *rows, void *out, int C, uint32_t magic, int w, int lane)
+__device__ __forceinline__ void emit_interleaved_rows(const float *rows, void *out, int C, uint32_t magic, int w, int lane,
+                                                      int samples = 1024)
 {
     asm volatile("" : "+v"(lane));
     const int q0 = lane + 64 * w;
+    const bool full = samples == 1024;  // (a batch of short blocks holds 128 samples per block: its tail pieces are tested)
     if (!kS16) {
+        const int total4 = (samples * C) >> 2;
         float v[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -893,12 +896,14 @@ __device__ __forceinline__ void emit_interleaved_rows(const float *rows, void *o
             const uint32_t c = e - __umul24(smp, (uint32_t)C);
             const float *src = rows + __umul24(c, (uint32_t)kWaveBufFloats) + smp;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j][i] = src[256 * j];
+            for (int j = 0; j < 4; ++j) v[j][i] = (full || q0 + 64 * C * j < total4) ? src[256 * j] : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            store_pcm4(reinterpret_cast<float4 *>(out) + q0 + 64 * C * j, make_float4(v[j][0], v[j][1], v[j][2], v[j][3]));
+            if (full || q0 + 64 * C * j < total4)
+                store_pcm4(reinterpret_cast<float4 *>(out) + q0 + 64 * C * j, make_float4(v[j][0], v[j][1], v[j][2], v[j][3]));
     } else {
+        const int total8 = (samples * C) >> 3;
         float v[2][8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -907,12 +912,13 @@ __device__ __forceinline__ void emit_interleaved_rows(const float *rows, void *o
             const uint32_t c = e - __umul24(smp, (uint32_t)C);
             const float *src = rows + __umul24(c, (uint32_t)kWaveBufFloats) + smp;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) v[j][i] = src[512 * j];
+            for (int j = 0; j < 2; ++j) v[j][i] = (full || q0 + 64 * C * j < total8) ? src[512 * j] : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            store_nt(reinterpret_cast<uint4 *>(out) + q0 + 64 * C * j, pack_s16(v[j][0], v[j][1]), pack_s16(v[j][2], v[j][3]),
-                     pack_s16(v[j][4], v[j][5]), pack_s16(v[j][6], v[j][7]));
+            if (full || q0 + 64 * C * j < total8)
+                store_nt(reinterpret_cast<uint4 *>(out) + q0 + 64 * C * j, pack_s16(v[j][0], v[j][1]), pack_s16(v[j][2], v[j][3]),
+                         pack_s16(v[j][4], v[j][5]), pack_s16(v[j][6], v[j][7]));
     }
 }
 
@@ -936,6 +942,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     constexpr bool kInterleaved = kOut != 0;
     constexpr bool kPair = kOut == 2;
     constexpr bool kSync = kPair || kGroup;  // the workgroup's waves run their loops in lock step
+    constexpr bool kBatchShort = kGroup && !kGeneral && kHasFloor;  // batches of short blocks (see the run builder)
     constexpr int kRunMax = kGeneral ? kMaxRunLengthGeneral : kMaxRunLength;
     __shared__ int s_iters;
     // tables: the plain variant keeps exactly what 2048 / 256 need; the general one holds the whole fast table
@@ -1064,7 +1071,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         cnt = valid ? __builtin_amdgcn_readlane(cc_run, slot) : 0;  // active posts of this wave's channel (0: silent)
         ex = valid && (a.ccount == nullptr || (fd.flags & kFrameNoFloor) || cnt != 0);
         if (kGroup) {
-            const int hh = size_of(fd.flags) >> 1;
+            // (a batch of short blocks: their vectors lie back to back -- one packet of batch * 128 bins)
+            const int hh = (size_of(fd.flags) >> 1) * (kBatchShort ? (int)((fd.flags >> kFrameBatchShift) & 7u) + 1 : 1);
             const bool shared_input = fd.flags & kFrameInterleaved;
             const float *src = a.spec + fd.spec_off + (shared_input ? 0 : (int64_t)ch * hh);
             load_group_share(x, valid ? src : a.inv_db, shared_input ? 64 * ch : 0, shared_input ? 64 * C : 64,
@@ -1080,15 +1088,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             cp = a.cposts[(size_t)(floored ? fd.rec + ch : 0) * 64 + l];
         }
     };
-    // trip count: the run's own in the free-running variants, the workgroup's longest in the lock-step ones
-    int iters = run.count - fi0;
-    if (kSync) {
-        if (threadIdx.x == 0) s_iters = 0;
-        __syncthreads();
-        if (lane == 0) atomicMax(&s_iters, iters);
-        __syncthreads();
-        iters = s_iters;
-    }
+    bool batch_head = false, batch_member = false;
     // Stage the run's descriptors in LDS: per-frame scalar loads from global memory would put an L2 round trip on
     // every frame's critical path.  Explicit descriptors come with one coalesced read; a compact run builds them here.
     if (run.flags & kRunCompact) {
@@ -1103,10 +1103,41 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         int out_count = has_prev ? max(0, (int)g.right_start - (int)g.left_start) : 0;
         uint32_t fl = ((cf & 1) ? kFrameLong : 0u) | (g.left_use_size1 ? kFrameSlope1 : 0u) |
                       ((cf & kCfNoFloor) ? kFrameNoFloor : 0u);
-        if (cf & kCfInterleaved) fl |= kFrameInterleaved | kFrameStage;
+        if (cf & kCfInterleaved) fl |= kFrameInterleaved;
         if (!(cf & kCfNoFloor)) fl |= a.map_bits[mp];
         if (cf & kCfSkip) { fl = kFrameDrain; out_count = 0; }
         if ((run.flags & kRunLastTrimmed) && lane == n - 1) { out_count = run.last_out_count; left_start = run.last_left_start; }
+        // Batches of SHORT blocks (group mode, 256 / 2048 kernel): a short block costs a pass 70 % of what a long one
+        // costs -- the transform computes eight copies of one block, the pass's fixed parts do not shrink -- for an
+        // eighth of the samples, and real streams hold them in streaks of 3 to 12.  Up to eight consecutive short
+        // blocks of a run go through ONE pass: their Residue2 vectors lie back to back, i.e. they de-interleave and
+        // de-couple exactly like one long packet; then every lane group of eight takes one block (as imdct256_wave8
+        // is laid out), and the pass emits up to 1 024 contiguous samples.  A block joins a batch if it is a plain
+        // short-after-short step (all of the geometry below) of the same mapping as its predecessor; the first short
+        // block after a long one goes alone (its overlap partner has the long block's shape).
+        if (kBatchShort) {
+            const uint32_t pmp = __shfl_up(mp, 1);
+            const bool base_ok = lane < n && lane >= -fi0 && a.size0 == 256 && !(cf & 1) && (cf & kCfInterleaved) &&
+                                 !(cf & (kCfNoFloor | kCfSkip)) && has_prev && out_count == 128 && left_start == 0 &&
+                                 prev_end == 128 && prev_stop == 256 && !(a.ablate & 128);
+            const bool base_prev = __shfl_up((int)base_ok, 1) != 0 && lane > 0;
+            const bool brk = !(base_ok && base_prev && mp == pmp);  // this frame does not continue its predecessor's streak
+            const unsigned long long mask_brk = __ballot(brk);
+            if (base_ok) {
+                const unsigned long long below = mask_brk & ((2ull << lane) - 1ull);  // (never empty: lane 0 breaks)
+                const int start = 63 - __clzll(below);
+                const unsigned long long above = lane < 63 ? (mask_brk >> (lane + 1)) : 0ull;
+                const int end = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+                const int pos = lane - start;
+                if ((pos & 7) == 0) {
+                    const int size = min(8, end - lane);
+                    fl |= (uint32_t)(size - 1) << kFrameBatchShift;
+                    batch_head = true;
+                } else {
+                    batch_member = true;
+                }
+            }
+        }
         // residue and output offsets: exclusive prefix sums over the run's frames
         const int half = (cf & 1) ? (a.size1 >> 1) : (a.size0 >> 1);
         int spec_sz = lane < n ? C * half : 0;
@@ -1145,6 +1176,17 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             __builtin_amdgcn_wave_barrier();
             if (lane < run.count - fi0) cc_run = a.ccount[(int)s_desc[wave][2 * lane + 1].x + ch];
         }
+    }
+    // trip count: the run's own in the free-running variants, the workgroup's longest in the lock-step ones; the members
+    // of a batch ride with its head
+    (void)batch_head;
+    int iters = run.count - fi0 - (kBatchShort ? (int)__popcll(__ballot(batch_member)) : 0);
+    if (kSync) {
+        if (threadIdx.x == 0) s_iters = 0;
+        __syncthreads();
+        if (lane == 0) atomicMax(&s_iters, iters);
+        __syncthreads();
+        iters = s_iters;
     }
     auto frame_at = [&](int fi) -> FrameDesc {  // broadcast LDS read, then into SGPRs
         const uint4 lo = s_desc[wave][(fi - fi0) * 2], hi = s_desc[wave][(fi - fi0) * 2 + 1];
@@ -1222,27 +1264,33 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
+    int fi = fi0;
     for (int it = 0; it < iters; ++it) {
-        const int fi = fi0 + it;
         const bool live = !kSync || fi < run.count;  // wave-uniform; idle iterations only keep the barriers matched
         const FrameDesc fd = fd_next;
+        // blocks this pass covers: 1, or a batch of short ones (see the run builder)
+        const int bsz = (kBatchShort && live) ? (int)((fd.flags >> kFrameBatchShift) & 7u) + 1 : 1;
+        const int fin = fi + bsz;
         float2 xnext[8];
         int cpnext = 0, cntnext = 0;
         bool exnext = false;
         uint2 stwnext = make_uint2(0u, 0u);
         {
-            const bool has_next = fi + 1 < run.count;  // (a wave that idles reads a stale descriptor; nothing of it is used)
-            fd_next = frame_at(has_next ? fi + 1 : fi);
-            prefetch(fd_next, fi + 1 - fi0, has_next && !(fd_next.flags & kFrameDrain) && !(a.ablate & 4), xnext, cpnext, cntnext,
+            const bool has_next = fin < run.count;  // (a wave that idles reads a stale descriptor; nothing of it is used)
+            fd_next = frame_at(has_next ? fin : fi);
+            prefetch(fd_next, fin - fi0, has_next && !(fd_next.flags & kFrameDrain) && !(a.ablate & 4), xnext, cpnext, cntnext,
                      exnext);
             if (kGroup) stwnext = steps_word(fd_next, has_next && !(fd_next.flags & kFrameDrain));
         }
         const bool drain = fd.flags & kFrameDrain;
+        const bool batch = kBatchShort && bsz > 1;      // (wave-uniform) 2..8 short blocks in this pass
         const int nblk = size_of(fd.flags);
+        const int nstage = batch ? 256 * bsz : nblk;    // what goes through the rows: the batch as one packet
+
         const bool is_long = nblk == 2048;  // "long" below means: the 2048-point transform
         const int n4 = kGeneral ? (nblk >> 2) : (is_long ? 512 : 64);
         const bool build = live && !drain;
-        const bool exec = build && excur;
+        const bool exec = build && (excur || (kBatchShort && bsz > 1));  // (a batch settles silence block by block)
         VPZ_STAMP(0);  // descriptor + prefetch issue
         // ---- group mode: the packet goes through the group's LDS rows (de-interleave, inverse coupling)
         if (kGroup) {
@@ -1251,7 +1299,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             VPZ_STAMP(1);  // first barrier
             if (stage && !(a.ablate & 32)) {
                 if (fd.flags & kFrameInterleaved) {
-                    stage_interleaved(xcur, s_work[gw0], C, div_magic, nblk >> 1, ch, lane);
+                    stage_interleaved(xcur, s_work[gw0], C, div_magic, nstage >> 1, ch, lane);
                 } else {
                     stage_planar(xcur, hcur, nblk >> 1, lane);
                 }
@@ -1274,7 +1322,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     while (sidx >= 0 && (first || !(step_byte(2 * sidx) & 0x80))) {
                         float4 *pm = reinterpret_cast<float4 *>(s_work[gw0 + (step_byte(2 * sidx) & 0x7F)]);
                         float4 *pa = reinterpret_cast<float4 *>(s_work[gw0 + step_byte(2 * sidx + 1)]);
-                        for (int g = lane + 64 * ch; g < (nblk >> 3); g += 64 * C) {
+                        for (int g = lane + 64 * ch; g < (nstage >> 3); g += 64 * C) {
                             float4 m4 = pm[g], a4 = pa[g];
                             couple(m4.x, a4.x);
                             couple(m4.y, a4.y);
@@ -1290,10 +1338,55 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 __syncthreads();
             }
             VPZ_STAMP(3);  // coupling levels + barriers
-            if (stage && exec) load_spectrum(xcur, hcur, lpb_of(fd.flags), lane);
+            if (batch) {  // lane group g takes block g of the batch: points l + 8 m of its 64
+                const float2 *row2 = reinterpret_cast<const float2 *>(hcur);
+                int lb = lane;
+                asm volatile("" : "+v"(lb));
+#pragma unroll
+                for (int m = 0; m < 8; ++m) xcur[m] = row2[(lb >> 3) * 64 + (lb & 7) + 8 * m];
+            } else if (stage && exec) {
+                load_spectrum(xcur, hcur, lpb_of(fd.flags), lane);
+            }
         }
         // ---- the curve, right before the row is needed for the transform
-        if (kHasFloor && exec && !(fd.flags & kFrameNoFloor) && !(a.ablate & 8)) render_curve(fd, cpcur, cntcur, xcur, fycur);
+        if (kBatchShort && batch) {
+            // the curves of the batch's blocks, one after the other, 128 bytes each (the row is free: every lane holds its
+            // spectrum); their posts are asked for here, together -- the one exposed memory round trip of the pass (asked for at
+            // the top of the pass they would be eight more live registers across the staging: the kernel spills)
+            const int slot0 = fi - fi0;
+            int cps[8], cns[8];
+            int lb = lane;
+            asm volatile("" : "+v"(lb));
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                const int ff = f < bsz ? f : 0;
+                cns[f] = f < bsz ? __builtin_amdgcn_readlane(cc_run, slot0 + ff) : 0;
+                cps[f] = a.cposts[(size_t)(fd.rec + ff * C + ch) * 64 + lb];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                if (f < bsz) {
+                    if (cns[f] == 0) {  // Mapping.cs:190-194: this block's channel is silent
+                        if ((lb >> 3) == f) {
+#pragma unroll
+                            for (int m = 0; m < 8; ++m) xcur[m] = make_float2(0.0f, 0.0f);
+                        }
+                    } else if (!(a.ablate & 8)) {
+                        const int cp = lb < cns[f] ? cps[f] : 0;
+                        uint8_t *dstc = reinterpret_cast<uint8_t *>(hcur) + 128 * f;
+                        if (!render_floor_indices_fast(dstc, reinterpret_cast<int *>(hcur) + 256, 128, 128, cp, cns[f], lane))
+                            render_floor_indices<32>(dstc, reinterpret_cast<int *>(hcur) + 256, 128, 128, cp, cns[f], lane);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            load_floor_indices(fycur, reinterpret_cast<const uint8_t *>(hcur) + 128 * (lb >> 3), 8, lane);
+            __builtin_amdgcn_wave_barrier();
+        } else if (kHasFloor && exec && !(fd.flags & kFrameNoFloor) && !(a.ablate & 8)) {
+            render_curve(fd, cpcur, cntcur, xcur, fycur);
+        }
         VPZ_STAMP(4);  // channel pick-up + curve
         if (build) {
             // The transforms address LDS by lane-derived indices that do not depend on the frame: computed ahead of the
@@ -1337,10 +1430,75 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         VPZ_STAMP(6);  // wait for the next frame's input
 
         if (kPair) __syncthreads();  // both channels' blocks (and tails) are in LDS
-        constexpr bool kCoop = kGroup && kOut == 1;  // interleaved, any channel count, the group's waves together
-        float o[4][4];      // the 16 samples of a long-after-long frame
+        constexpr bool kCoop = kGroup && kOut != 0;  // interleaved output written by the group's waves together
+        float o[4][4];      // the 16 samples of a long-after-long frame, or of a batch of short ones
         bool coop = false;  // ... wait in `o` for the cooperative store (uniform over the group's waves)
-        if (live && fi >= 0 && fd.out_count > 0 && !(a.ablate & 1)) {
+        if (kBatchShort && batch && !(a.ablate & 1)) {
+            // ---- a batch of short blocks: 128 * bsz contiguous samples.  Sample i of block f is y_f[i] over the previous
+            // block's y[128 + i] (StreamDecoder.cs:782-789 with both windows short): y_f[i] = -h_f[63 - i] (i < 64),
+            // h_f[i - 64] otherwise; the partner is hp[i] (i < 64), hp[127 - i] otherwise, hp = the upper half of the
+            // previous block's h -- the block before in the row, or the tail for block 0.
+            const float4 *h4 = reinterpret_cast<const float4 *>(hcur);
+            const float4 *t4 = reinterpret_cast<const float4 *>(tail);
+            const float4 *s4 = reinterpret_cast<const float4 *>(s_slope0);
+            out_t *dst = kInterleaved ? out_base + fd.out_off * a.channels + ch
+                                       : out_base + (int64_t)ch * a.channel_stride + fd.out_off;
+            const int64_t ostep = kInterleaved ? a.channels : 1;
+            const bool aligned = kInterleaved ? (reinterpret_cast<uintptr_t>(out_base + fd.out_off * C) & 15) == 0
+                                              : (reinterpret_cast<uintptr_t>(dst) & (kS16 ? 7 : 15)) == 0;
+            coop = kCoop && aligned;
+            int lf = lane;
+            asm volatile("" : "+v"(lf));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gq = lf + 64 * r;            // float4 group of the batch's output
+                const int f = gq >> 5, i4 = gq & 31;   // block, group inside the block
+                const bool lower = i4 < 16;
+                const bool valid = f < bsz;
+                const int fs = valid ? f : 0;
+                const float4 wl = s4[i4], wr = s4[31 - i4];
+                const float4 hv = h4[fs * 32 + (lower ? 15 - i4 : i4 - 16)];
+                const int pidx = lower ? i4 : 31 - i4;
+                const float4 *pp = fs > 0 ? h4 + (fs - 1) * 32 + 16 : t4;  // (both in LDS; a selected float4 would spill)
+                const float4 pv = pp[pidx];
+                const float4 v = apply_y4(hv, lower, lower);
+                const float4 t = apply_y4(pv, !lower, false);
+                o[r][0] = ola(v.x, wl.x, t.x, wr.w);
+                o[r][1] = ola(v.y, wl.y, t.y, wr.z);
+                o[r][2] = ola(v.z, wl.z, t.z, wr.y);
+                o[r][3] = ola(v.w, wl.w, t.w, wr.x);
+                if (valid) {
+                    if (a.clip) clip_group(o[r][0], o[r][1], o[r][2], o[r][3], clip_peak);
+                    if (!coop) {
+                        if (aligned || kInterleaved) {
+                            // (planar and aligned: one 16-byte store; interleaved and not: four at the channel stride)
+                            if (kInterleaved) {
+                                out_t *d = dst + (int64_t)(4 * gq) * ostep;
+                                if (kS16) {
+                                    store_pcm(d, (out_t)to_s16(o[r][0]));
+                                    store_pcm(d + ostep, (out_t)to_s16(o[r][1]));
+                                    store_pcm(d + 2 * ostep, (out_t)to_s16(o[r][2]));
+                                    store_pcm(d + 3 * ostep, (out_t)to_s16(o[r][3]));
+                                } else {
+                                    store_pcm(d, (out_t)o[r][0]);
+                                    store_pcm(d + ostep, (out_t)o[r][1]);
+                                    store_pcm(d + 2 * ostep, (out_t)o[r][2]);
+                                    store_pcm(d + 3 * ostep, (out_t)o[r][3]);
+                                }
+                            } else if (kS16) {
+                                store_nt(reinterpret_cast<uint2 *>(dst) + gq, pack_s16(o[r][0], o[r][1]), pack_s16(o[r][2], o[r][3]));
+                            } else {
+                                store_pcm4(reinterpret_cast<float4 *>(dst) + gq, make_float4(o[r][0], o[r][1], o[r][2], o[r][3]));
+                            }
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                store_pcm(dst + 4 * gq + c, kS16 ? (out_t)to_s16(o[r][c]) : (out_t)o[r][c]);
+                        }
+                    }
+                }
+            }
+        } else if (live && fi >= 0 && fd.out_count > 0 && !(a.ablate & 1)) {
             // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 573-591)
             // equal block sizes share one slope table (s_slope0 only holds a 128-entry short slope)
             const float *slope = ((fd.flags & kFrameSlope1) || a.size0 == a.size1) ? s_slope1 : s_slope0;
@@ -1568,7 +1726,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 dt[lane] = t0;
                 dt[lane + 64] = t1;
             } else {
-                tail[lane] = hcur[64 + lane];
+                tail[lane] = hcur[(batch ? 128 * (bsz - 1) : 0) + 64 + lane];  // (a batch: its last block)
             }
             prev_n4 = n4;
         }
@@ -1584,7 +1742,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 for (int r = 0; r < 4; ++r) row4[lf + 64 * r] = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
             }
             __syncthreads();
-            if (coop) emit_interleaved_rows<kS16>(s_work[gw0], out_base + fd.out_off * C, C, div_magic, ch, lane);
+            if (coop) emit_interleaved_rows<kS16>(s_work[gw0], out_base + fd.out_off * C, C, div_magic, ch, lane, batch ? 128 * bsz : 1024);
         }
 #pragma unroll
         for (int m = 0; m < 8; ++m) xcur[m] = xnext[m];
@@ -1592,6 +1750,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         cntcur = cntnext;
         stwcur = stwnext;
         excur = exnext;
+        fi = fin;
         VPZ_STAMP(8);  // tail
     }
 #ifdef VPZ_STAMPS

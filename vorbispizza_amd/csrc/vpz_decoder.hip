@@ -348,7 +348,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     for (size_t m = 0; m < D.mappings.size(); ++m) {
         const int n = D.mappings[m].coupling_steps;
         if (D.group_ok && n > 0)
-            map_bits[m] = kFrameStage | ((uint32_t)n << kFrameStepsShift) |
+            map_bits[m] = ((uint32_t)n << kFrameStepsShift) |
                           ((uint32_t)(D.mapping_steps_off[m] / 2) << kFrameStepsOffShift);
         for (int ch = 0; ch < D.channels; ++ch)
             if (!D.floor_types.empty() && D.floor_types[D.mappings[m].channel_floor[ch]] == 0) D.mapping_uses_floor0[m] = 1;
@@ -506,6 +506,7 @@ struct SynthCall {
     size_t n_frames = 0;
     uint8_t *rec_floor = nullptr;  // per channel record: floor index | 0x40 type-0 | 0x80 long block
     bool any_floor = false, any_floor0 = false, need_coupling = false;
+    bool any_short = false;       // the batch holds short blocks (run cutting by cost only pays then)
     bool group_align_ok = true;   // every interleaved packet starts on a 16-byte boundary (group mode loads 16 bytes)
     bool use_group = false;       // decided after pass 1: synth_kernel's group mode instead of the coupling pass
     bool compact = false;         // every run compact: two bytes per frame instead of a FrameDesc (parallel pass only)
@@ -585,9 +586,9 @@ struct SynthCall {
         uint32_t f = (bf ? kFrameLong : 0u) | (pi.left_use_size1 ? kFrameSlope1 : 0u) | (no_floor ? kFrameNoFloor : 0u);
         if (D.group_ok) {
             const int steps = no_floor ? 0 : D.mappings[pk.mapping].coupling_steps;
-            if (pk.flags & VPZ_PKT_INTERLEAVED) f |= kFrameInterleaved | kFrameStage;
+            if (pk.flags & VPZ_PKT_INTERLEAVED) f |= kFrameInterleaved;
             if (steps > 0)
-                f |= kFrameStage | ((uint32_t)steps << kFrameStepsShift) |
+                f |= ((uint32_t)steps << kFrameStepsShift) |
                      ((uint32_t)(D.mapping_steps_off[pk.mapping] / 2) << kFrameStepsOffShift);
         }
         return f;
@@ -628,7 +629,7 @@ struct SynthCall {
             int64_t tail_sum = 0;     // samples of the chunk's last stream segment
             int64_t base = 0;         // filled between the sweeps: samples of the leading stream before this chunk
             int64_t res_extent = 0;
-            bool any_floor = false, any_floor0 = false, need_coupling = false, align_ok = true;
+            bool any_floor = false, any_floor0 = false, need_coupling = false, align_ok = true, any_short = false;
             bool dense = true;        // every packet's residue starts where its predecessor's (same stream) ends
             char pad[64];
         };
@@ -713,6 +714,7 @@ struct SynthCall {
                     else if (D.anchor_pkt[pk.stream] == kNone) D.anchor_pkt[pk.stream] = p;
                 }
                 const bool bf = pk.flags & VPZ_PKT_BLOCK_FLAG;
+                if (!bf) K.any_short = true;
                 K.res_extent = std::max(K.res_extent, pk.residue_offset + (int64_t)C * (bf ? half1 : half0));
                 if (!no_floor) {
                     K.any_floor = true;
@@ -739,6 +741,7 @@ struct SynthCall {
         for (const Chunk &K : chunks) {
             all_dense &= K.dense;
             any_floor0 |= K.any_floor0;
+            any_short |= K.any_short;
             need_coupling |= K.need_coupling;
             group_align_ok &= K.align_ok;
         }
@@ -1036,6 +1039,7 @@ struct SynthCall {
             S.prev_start = S.prev_end;  // everything readable is handed out by this call
             fd.spec_off = pk.residue_offset;  // replaced by the temp offset when the coupling pass runs
             res_extent = std::max(res_extent, pk.residue_offset + (int64_t)C * (bf ? half1 : half0));
+            if (!bf) any_short = true;
             if (!no_floor) {
                 any_floor = true;
                 const vpz_mapping_config &mc = D.mappings[pk.mapping];
@@ -1074,10 +1078,64 @@ struct SynthCall {
     {
         const int64_t total_frames = (int64_t)n_frames;
         const int r_max = synth_needs_general(D.size0, D.size1) ? kMaxRunLengthGeneral : kMaxRunLength;
+        // Group mode synthesises up to eight consecutive SHORT blocks of a run in one pass (synth_kernel's run builder):
+        // a block that rides along costs a fraction of a pass.  Runs are cut to equal COST, in eighths of a pass -- a
+        // run rich in short blocks holds more frames --, so that every wavefront of the launch has the same amount to do.
+        // (cutting by cost walks every packet a few times: with enough streams it is split over the host pool, streams
+        // being independent; a small batch is walked on this thread; a large batch of few streams keeps runs of equal
+        // length -- the kernel still batches what it finds in them -- rather than spend a millisecond of host time)
+        HostPool *pool = static_cast<HostPool *>(ctx->host_pool);
+        const bool wide = pool && D.n_streams >= 2 * pool->parties();
+        const bool batches = compact && use_group && any_floor && any_short && !synth_needs_general(D.size0, D.size1) &&
+                             D.size0 == 256 && !D.generic && (wide || total_frames <= 4096);
+        const int parties = (batches && wide) ? pool->parties() : 1;
+        auto stream_range = [&](int c, int &lo, int &hi) {
+            lo = (int)((int64_t)D.n_streams * c / parties);
+            hi = (int)((int64_t)D.n_streams * (c + 1) / parties);
+        };
+        auto joins_batch = [&](int64_t p, bool prev_in_run_ok, bool &ok) -> bool {  // does packet p ride with its predecessor?
+            ok = false;
+            if (!batches || p == 0 || packets[p - 1].stream != packets[p].stream) return false;
+            const vpz_packet &pk = packets[p], &pp = packets[p - 1];
+            ok = !(pk.flags & VPZ_PKT_BLOCK_FLAG) && !(pp.flags & VPZ_PKT_BLOCK_FLAG) && (pk.flags & VPZ_PKT_INTERLEAVED) &&
+                 !(pk.flags & (VPZ_PKT_NO_FLOOR | VPZ_PKT_NOT_DECODED)) && !(pp.flags & VPZ_PKT_NOT_DECODED);
+            return ok && prev_in_run_ok && pk.mapping == pp.mapping;
+        };
+        // cost of a pass in eighths of a long block's (tools/kbench_short_long.py: a short block alone 0.74, eight in one
+        // batch 3.2 together)
+        auto unit_cost = [&](int64_t p, bool ok, int pos) -> int {
+            if (ok && (pos & 7) != 0) return 3;
+            return (batches && !(packets[p].flags & VPZ_PKT_BLOCK_FLAG)) ? 6 : 8;
+        };
+        int64_t total_units = 8 * total_frames;
+        if (batches) {
+            std::vector<int64_t> part(parties, 0);
+            auto count = [&](int c) {
+                int lo, hi;
+                stream_range(c, lo, hi);
+                int64_t units = 0;
+                for (int s = lo; s < hi; ++s) {
+                    int pos = -1;
+                    bool prev_ok = false;
+                    for (int64_t p = D.s_base[s], e = D.s_base[s] + D.s_cnt[s]; p < e; ++p) {
+                        bool ok;
+                        const bool link = joins_batch(p, prev_ok, ok);
+                        pos = ok ? (link ? pos + 1 : 0) : -1;
+                        units += unit_cost(p, ok, pos);
+                        prev_ok = ok;
+                    }
+                }
+                part[c] = units;
+            };
+            if (parties > 1) pool->run(count); else count(0);
+            total_units = 0;
+            for (int64_t v : part) total_units += v;
+        }
         int R = std::min(D.run_length_override, r_max);
+        int64_t run_slots = 0;  // runs that fit the rounds R was chosen for
         if (R <= 0) {
             const int64_t slots = std::max(1, synth_resident_waves(any_floor, ctx->num_cu, C, use_group));
-            const int64_t work = total_frames * C;
+            const int64_t work = (total_units + 7) / 8 * C;
             R = 4;
             int64_t best = -1;
             for (int k = 1; k <= 64; ++k) {
@@ -1085,17 +1143,64 @@ struct SynthCall {
                 if (r > r_max) continue;
                 if (r < 4) break;
                 const int64_t cost = (int64_t)k * (r + 1);
-                if (best < 0 || cost < best) { best = cost; R = (int)r; }
+                if (best < 0 || cost < best) { best = cost; R = (int)r; run_slots = k * slots / C; }
             }
         }
         runs = arena_alloc<RunDesc>(*A, (size_t)(total_frames / R) + (size_t)D.n_streams + 1);
         if (D.generic) return;
-        for (int s = 0; s < D.n_streams; ++s) {
+        int64_t target_units = 8 * (int64_t)R;
+        // one run of a frame: as many frames from f0 on as the cost target (and the descriptor area) allow
+        auto run_length = [&](int64_t base, int f0, int cnt, int64_t target) -> int {
+            int len = 0;
+            int64_t units = 0;
+            int pos = -1;
+            bool prev_ok = false;
+            while (f0 + len < cnt && len < r_max) {
+                bool ok;
+                const bool link = joins_batch(base + f0 + len, prev_ok, ok);
+                pos = ok ? (link ? pos + 1 : 0) : -1;
+                const int u = unit_cost(base + f0 + len, ok, pos);
+                if (len > 0 && units + u > target) break;
+                units += u;
+                prev_ok = ok;
+                ++len;
+            }
+            return len;
+        };
+        if (batches && run_slots > 0) {
+            // runs of equal cost do not pack as evenly as runs of equal length (and every stream ends with a partial
+            // one): a few more runs than the rounds hold would put a nearly empty round behind them -- count, and give
+            // every run a little more until they fit
+            for (int tries = 0; tries < 6 && target_units / 8 < r_max; ++tries) {
+                std::vector<int64_t> part(parties, 0);
+                auto count = [&](int c) {
+                    int lo, hi;
+                    stream_range(c, lo, hi);
+                    int64_t n = 0;
+                    for (int s = lo; s < hi; ++s)
+                        for (int f0 = 0, cnt = (int)D.s_cnt[s]; f0 < cnt; ++n) f0 += run_length(D.s_base[s], f0, cnt, target_units);
+                    part[c] = n;
+                };
+                if (parties > 1) pool->run(count); else count(0);
+                int64_t n_total = 0;
+                for (int64_t v : part) n_total += v;
+                if (n_total <= run_slots) break;
+                target_units += 4;
+            }
+        }
+        std::vector<std::vector<RunDesc>> cut(parties);
+        auto cut_streams = [&](int c) {
+          int s_lo, s_hi;
+          stream_range(c, s_lo, s_hi);
+          std::vector<RunDesc> &mine = cut[c];
+          if (parties > 1) mine.reserve((size_t)(((int64_t)D.s_base[s_hi - 1] + D.s_cnt[s_hi - 1] - D.s_base[s_lo]) / R) + (size_t)(s_hi - s_lo) + 1);
+          for (int s = s_lo; s < s_hi; ++s) {
             const int cnt = (int)D.s_cnt[s], base = (int)D.s_base[s];
-            for (int f0 = 0; f0 < cnt; f0 += R) {
+            for (int f0 = 0; f0 < cnt;) {
+                const int len = batches ? run_length(base, f0, cnt, target_units) : std::min(R, cnt - f0);
                 RunDesc r{};
                 r.first = base + f0;
-                r.count = std::min(R, cnt - f0);
+                r.count = len;
                 r.stream = s;
                 if (f0 == 0) {
                     r.pre_kind = started_with_prev[s] ? kPreState : kPreNone;
@@ -1103,7 +1208,8 @@ struct SynthCall {
                 } else {
                     r.pre_kind = kPreRecompute;
                 }
-                if (f0 + R >= cnt) r.flags |= kRunSaveState;
+                const bool last = f0 + len >= cnt;
+                if (last) r.flags |= kRunSaveState;
                 r.clip_epoch = D.states[s].clip_epoch;
                 if (compact) {
                     r.flags |= kRunCompact;
@@ -1122,14 +1228,26 @@ struct SynthCall {
                         r.prev_end0 = (uint16_t)S0.prev_end;
                         r.prev_stop0 = (uint16_t)S0.prev_stop;
                     }
-                    if (f0 + R >= cnt && D.trim_out_count[s] >= 0) {  // the stream's last frame was cut by the EOS trim
+                    if (last && D.trim_out_count[s] >= 0) {  // the stream's last frame was cut by the EOS trim
                         r.flags |= kRunLastTrimmed;
                         r.last_out_count = (uint16_t)D.trim_out_count[s];
                         r.last_left_start = (uint16_t)D.trim_left_start[s];
                     }
                 }
-                runs[n_runs++] = r;
+                if (parties > 1) mine.push_back(r);
+                else runs[n_runs++] = r;
+                f0 += len;
             }
+          }
+        };
+        if (parties > 1) {
+            pool->run(cut_streams);
+            for (const std::vector<RunDesc> &v : cut) {
+                memcpy(runs + n_runs, v.data(), v.size() * sizeof(RunDesc));
+                n_runs += v.size();
+            }
+        } else {
+            cut_streams(0);
         }
     }
 
