@@ -51,14 +51,15 @@ def random_xlist(rng, half, count):
     return [0, half] + [int(v) for v in rng.choice(np.arange(1, half), size=count - 2, replace=False)]
 
 
-def stream_major_batch(n_streams, frames, channels, seed, floor=False, interleaved=False, size0=256, size1=2048, xlists=None):
+def stream_major_batch(n_streams, frames, channels, seed, floor=False, interleaved=False, size0=256, size1=2048, xlists=None,
+                       p_ls=0.1, p_sl=0.3, silent_prob=0.1):
     from vorbispizza_amd import make_packets
     rng = np.random.default_rng(seed)
     pk = make_packets(n_streams * frames)
     res, posts, counts = [], [], []
     off, i = 0, 0
     for s in range(n_streams):
-        flags = helpers.markov_block_flags(frames, seed=seed * 1000 + s, start_long=bool(s & 1))
+        flags = helpers.markov_block_flags(frames, seed=seed * 1000 + s, p_ls=p_ls, p_sl=p_sl, start_long=bool(s & 1))
         for f in range(frames):
             half = (size1 if flags[f] & 1 else size0) // 2
             r = (rng.standard_normal((channels, half)) * (4.0 if floor else 2.0 ** -8)).astype(np.float32)
@@ -73,7 +74,7 @@ def stream_major_batch(n_streams, frames, channels, seed, floor=False, interleav
             if floor:
                 xl = (xlists[1] if flags[f] & 1 else xlists[0]) if xlists else \
                     (helpers.LONG_XLIST if flags[f] & 1 else helpers.SHORT_XLIST)
-                p, c = helpers.random_posts(rng, xl, 2, channels, silent_prob=0.1)
+                p, c = helpers.random_posts(rng, xl, 2, channels, silent_prob=silent_prob)
                 posts.append(p)
                 counts.append(c)
             i += 1
@@ -442,3 +443,42 @@ def test_interleaved_output_of_many_channels_written_by_the_group(ctx, channels,
         assert np.array_equal(g[1], l[1]) and np.array_equal(g[2], l[2]) and g[3] == l[3]
         assert np.array_equal(g[0], l[0]) if g[0].dtype == np.int16 else np.array_equal(g[0].view(np.uint32), l[0].view(np.uint32))
         assert np.abs(g[0].astype(np.float64)).max() > 0
+
+
+@pytest.mark.parametrize("channels,steps,p_sl", [(2, [(0, 1)], 0.08), (2, [(0, 1)], 0.5), (6, [(0, 1), (2, 3)], 0.1), (3, [], 0.15)])
+def test_batches_of_short_blocks(ctx, oracle, channels, steps, p_sl):
+    """Group mode synthesises up to eight consecutive short blocks of a run in one pass (and the host cuts runs by cost):
+    streams with long streaks of short blocks (p_sl small: streaks of a dozen and more, cut into batches of eight and a
+    rest), silent channels inside the streaks, every output layout -- against the run that never groups (one block per
+    pass), bit for bit, and against the oracle."""
+    from vorbispizza_amd import capi
+    n_streams, frames = 24, 90     # (24 streams: the host splits the run cutting over its pool)
+    pk, res, posts, counts = stream_major_batch(n_streams, frames, channels, seed=4000 + channels, floor=True, interleaved=True,
+                                                p_ls=0.25, p_sl=p_sl, silent_prob=0.15)
+    pk["mapping"] = pk["flags"] & 1
+    short = (pk["flags"] & 1) == 0
+    assert short.sum() > len(pk) // 3
+    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)]
+    mappings = [{"coupling": steps, "channel_floor": [0] * channels}, {"coupling": steps, "channel_floor": [1] * channels}]
+    outs = {}
+    for layout in (capi.OUT_PLANAR, capi.OUT_INTERLEAVED, capi.OUT_INTERLEAVED_S16, capi.OUT_PLANAR_S16):
+        with env(VPZ_NO_GROUP=None, VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=4):
+            g = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
+        with env(VPZ_NO_GROUP=1, VPZ_PAR_MIN_PACKETS=1 << 40):
+            l = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
+        assert np.array_equal(g[1], l[1]) and np.array_equal(g[2], l[2]) and g[3] == l[3]
+        assert np.array_equal(g[0], l[0]) if g[0].dtype == np.int16 else np.array_equal(g[0].view(np.uint32), l[0].view(np.uint32))
+        outs[layout] = g
+    s_, per = 5, frames
+    opk = []
+    for i in range(s_ * per, (s_ + 1) * per):
+        half = 1024 if pk["flags"][i] & 1 else 128
+        off = int(pk["residue_offset"][i])
+        opk.append({"flags": int(pk["flags"][i]), "granule": -1, "mapping": int(pk["mapping"][i]),
+                    "residue": res[off: off + channels * half], "posts": posts[i * channels:(i + 1) * channels],
+                    "post_count": counts[i * channels:(i + 1) * channels]})
+    ref, _, _ = helpers.oracle_decode(oracle, channels, 256, 2048, opk, floors=floors, mappings=mappings)
+    cap = per * 1024 + 64
+    got = outs[capi.OUT_PLANAR][0][s_ * channels * cap:(s_ + 1) * channels * cap].reshape(channels, cap)[:, :ref.shape[1]]
+    assert outs[capi.OUT_PLANAR][1][s_] == ref.shape[1] and ref.shape[1] > 0
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))

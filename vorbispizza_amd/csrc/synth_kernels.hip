@@ -1349,6 +1349,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             }
         }
         // ---- the curve, right before the row is needed for the transform
+        bool batch_silent = false;  // this lane's block of a batch is a silent channel's
         if (kBatchShort && batch) {
             // the curves of the batch's blocks, one after the other, 128 bytes each (the row is free: every lane holds its
             // spectrum); their posts are asked for here, together -- the one exposed memory round trip of the pass (asked for at
@@ -1369,6 +1370,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 if (f < bsz) {
                     if (cns[f] == 0) {  // Mapping.cs:190-194: this block's channel is silent
                         if ((lb >> 3) == f) {
+                            batch_silent = true;
 #pragma unroll
                             for (int m = 0; m < 8; ++m) xcur[m] = make_float2(0.0f, 0.0f);
                         }
@@ -1417,6 +1419,13 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 build_block<kHasFloor, true>(fd.flags, ln, xcur, fycur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
             } else {
                 build_block<kHasFloor, false>(fd.flags, ln, xcur, fycur, hcur, s_twL, s_twAB, s_twBC, s_twS, s_db);
+                if (kBatchShort && batch && batch_silent) {
+                    // the reference does not transform a silent channel, it clears the block (Mapping.cs:190-194): all
+                    // +0.0, where the transform of zeros leaves zeros of both signs
+                    float2 *h2 = reinterpret_cast<float2 *>(hcur);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) h2[(ln >> 3) * 64 + (ln & 7) + 8 * m] = make_float2(0.0f, 0.0f);
+                }
             }
         }
 
