@@ -278,6 +278,9 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     for (int f = 0; f < 8; ++f) D.packet_info[f] = get_packet_info(D.size0, D.size1, f & 1, f & 2, f & 4);
     if (const char *e = getenv("VPZ_RUN_LENGTH")) D.run_length_override = atoi(e);
     if (const char *e = getenv("VPZ_SYNTH_ABLATE")) D.ablate = atoi(e);
+    if (const char *e = getenv("VPZ_NO_BATCH")) {  // A/B tests: one short block per pass, runs of equal length
+        if (atoi(e)) D.ablate |= 128;
+    }
     if (const char *e = getenv("VPZ_HOST_THREADS")) D.host_threads = atoi(e);
     if (const char *e = getenv("VPZ_PAR_MIN_PACKETS")) D.par_min_packets = atoll(e);
 
@@ -1087,7 +1090,7 @@ struct SynthCall {
         HostPool *pool = static_cast<HostPool *>(ctx->host_pool);
         const bool wide = pool && D.n_streams >= 2 * pool->parties();
         const bool batches = compact && use_group && any_floor && any_short && !synth_needs_general(D.size0, D.size1) &&
-                             D.size0 == 256 && !D.generic && (wide || total_frames <= 4096);
+                             D.size0 == 256 && !D.generic && (wide || total_frames <= 4096) && !(D.ablate & 128);
         const int parties = (batches && wide) ? pool->parties() : 1;
         auto stream_range = [&](int c, int &lo, int &hi) {
             lo = (int)((int64_t)D.n_streams * c / parties);
