@@ -565,8 +565,8 @@ struct SynthCall {
         bool has_floor0_type = false;
         for (uint8_t t : D.floor_types) has_floor0_type |= (t == 0);
         const size_t np = (size_t)n_packets;
-        // (runs hold >= 4 frames unless VPZ_RUN_LENGTH says otherwise)
-        size_t need = (sizeof(FrameDesc) + (D.run_length_override > 0 ? sizeof(RunDesc) : sizeof(RunDesc) / 4) + 2 +
+        // (runs hold >= 3 frames unless VPZ_RUN_LENGTH says otherwise: see cut_runs)
+        size_t need = (sizeof(FrameDesc) + (D.run_length_override > 0 ? sizeof(RunDesc) : sizeof(RunDesc) / 2) + 2 +
                        coupling_packet_size()) * np +
                       sizeof(RunDesc) * ((size_t)D.n_streams + 1) + (have_posts ? (size_t)n_rec : 0) +
                       sizeof(int64_t) * (size_t)D.n_streams + 4096;
@@ -1149,7 +1149,8 @@ struct SynthCall {
                 if (best < 0 || cost < best) { best = cost; R = (int)r; run_slots = k * slots / C; }
             }
         }
-        runs = arena_alloc<RunDesc>(*A, (size_t)(total_frames / R) + (size_t)D.n_streams + 1);
+        // (a run cut by cost holds at least R - 1 frames unless its stream ends: every frame costs at most a whole pass)
+        runs = arena_alloc<RunDesc>(*A, (size_t)(total_frames / std::max(1, R - 1)) + (size_t)D.n_streams + 1);
         if (D.generic) return;
         int64_t target_units = 8 * (int64_t)R;
         // one run of a frame: as many frames from f0 on as the cost target (and the descriptor area) allow
