@@ -106,6 +106,10 @@ struct Decoder {
     std::vector<int64_t> out_off_scratch;    // compact batches: output offset of every frame (host only)
     std::vector<int32_t> trim_out_count, trim_left_start;  // per stream: EOS-trimmed last frame of the batch, -1: none
     bool no_compact = false;                 // VPZ_NO_COMPACT=1: always upload explicit frame descriptors (A/B tests)
+    std::vector<uint8_t> cut_code;           // cut_runs: one byte per packet (block size, batch eligibility)
+    int cut_hint_R = 0;                      // ... and the cost target the last call's runs were fitted with
+    int64_t cut_hint_slots = 0, cut_hint_target = 0, cut_hint_frames = -1;
+    int cut_hint_streams = -1;
     size_t zero_copy_max = 8u << 20;         // arenas up to this size are read in place by the kernels (VPZ_ZERO_COPY_MAX;
                                              // half a million packets, 1.5 MB: 2.42 -> 2.35 ms against the copy)
     std::vector<int32_t> mapping_steps_off;  // per mapping: offset into d_steps (pairs*2), -1 none
@@ -1111,7 +1115,20 @@ struct SynthCall {
             return (batches && !(packets[p].flags & VPZ_PKT_BLOCK_FLAG)) ? 6 : 8;
         };
         int64_t total_units = 8 * total_frames;
-        if (batches) {
+        // what the later walks need to know about a packet, one byte each (bit 0: short block, bit 1: may ride in a batch,
+        // bit 2: same mapping as its predecessor) -- they then touch no packet
+        std::vector<uint8_t> &code = D.cut_code;
+        // a decoder's next batch usually has the shape of its last one: R and the fitted cost target are taken over, the
+        // packets are walked ONCE (codes and cut together, one fork-join), and only if the runs do not fit the rounds
+        // after all is the whole procedure gone through
+        const bool reuse = batches && parties > 1 && D.cut_hint_frames == total_frames && D.cut_hint_streams == D.n_streams &&
+                           D.cut_hint_R > 0 && D.run_length_override <= 0;
+        auto packet_code = [&](int64_t p, bool ok) -> uint8_t {
+            return (uint8_t)(((packets[p].flags & VPZ_PKT_BLOCK_FLAG) ? 0 : 1) | (ok ? 2 : 0) |
+                             ((ok && p > 0 && packets[p].mapping == packets[p - 1].mapping) ? 4 : 0));
+        };
+        if (batches && code.size() < (size_t)total_frames) code.resize((size_t)total_frames);
+        if (batches && !reuse) {
             std::vector<int64_t> part(parties, 0);
             auto count = [&](int c) {
                 int lo, hi;
@@ -1123,6 +1140,7 @@ struct SynthCall {
                     for (int64_t p = D.s_base[s], e = D.s_base[s] + D.s_cnt[s]; p < e; ++p) {
                         bool ok;
                         const bool link = joins_batch(p, prev_ok, ok);
+                        code[(size_t)p] = packet_code(p, ok);
                         pos = ok ? (link ? pos + 1 : 0) : -1;
                         units += unit_cost(p, ok, pos);
                         prev_ok = ok;
@@ -1134,8 +1152,8 @@ struct SynthCall {
             total_units = 0;
             for (int64_t v : part) total_units += v;
         }
-        int R = std::min(D.run_length_override, r_max);
-        int64_t run_slots = 0;  // runs that fit the rounds R was chosen for
+        int R = reuse ? D.cut_hint_R : std::min(D.run_length_override, r_max);
+        int64_t run_slots = reuse ? D.cut_hint_slots : 0;  // runs that fit the rounds R was chosen for
         if (R <= 0) {
             const int64_t slots = std::max(1, synth_resident_waves(any_floor, ctx->num_cu, C, use_group));
             const int64_t work = (total_units + 7) / 8 * C;
@@ -1159,11 +1177,13 @@ struct SynthCall {
             int64_t units = 0;
             int pos = -1;
             bool prev_ok = false;
+            const uint8_t *cd = code.data() + base + f0;
             while (f0 + len < cnt && len < r_max) {
-                bool ok;
-                const bool link = joins_batch(base + f0 + len, prev_ok, ok);
+                const uint8_t c8 = cd[len];
+                const bool ok = c8 & 2;
+                const bool link = ok && prev_ok && (c8 & 4);
                 pos = ok ? (link ? pos + 1 : 0) : -1;
-                const int u = unit_cost(base + f0 + len, ok, pos);
+                const int u = (ok && (pos & 7) != 0) ? 3 : ((c8 & 1) ? 6 : 8);
                 if (len > 0 && units + u > target) break;
                 units += u;
                 prev_ok = ok;
@@ -1171,7 +1191,8 @@ struct SynthCall {
             }
             return len;
         };
-        if (batches && run_slots > 0) {
+        if (reuse) target_units = D.cut_hint_target;
+        if (batches && run_slots > 0 && !reuse) {
             // runs of equal cost do not pack as evenly as runs of equal length (and every stream ends with a partial
             // one): a few more runs than the rounds hold would put a nearly empty round behind them -- count, and give
             // every run a little more until they fit
@@ -1188,9 +1209,17 @@ struct SynthCall {
                 if (parties > 1) pool->run(count); else count(0);
                 int64_t n_total = 0;
                 for (int64_t v : part) n_total += v;
+                if (getenv("VPZ_HOST_PROFILE"))
+                    fprintf(stderr, "[vpz host] run cutting: R %d, target %lld eighths, %lld runs for %lld slots\n", R,
+                            (long long)target_units, (long long)n_total, (long long)run_slots);
                 if (n_total <= run_slots) break;
                 target_units += 4;
             }
+            D.cut_hint_R = R;
+            D.cut_hint_slots = run_slots;
+            D.cut_hint_target = target_units;
+            D.cut_hint_frames = total_frames;
+            D.cut_hint_streams = D.n_streams;
         }
         std::vector<std::vector<RunDesc>> cut(parties);
         auto cut_streams = [&](int c) {
@@ -1200,6 +1229,15 @@ struct SynthCall {
           if (parties > 1) mine.reserve((size_t)(((int64_t)D.s_base[s_hi - 1] + D.s_cnt[s_hi - 1] - D.s_base[s_lo]) / R) + (size_t)(s_hi - s_lo) + 1);
           for (int s = s_lo; s < s_hi; ++s) {
             const int cnt = (int)D.s_cnt[s], base = (int)D.s_base[s];
+            if (reuse) {  // (the codes of this stream's packets, skipped with the counting pass)
+                bool prev_ok = false;
+                for (int64_t p = base, e = (int64_t)base + cnt; p < e; ++p) {
+                    bool ok;
+                    (void)joins_batch(p, prev_ok, ok);
+                    code[(size_t)p] = packet_code(p, ok);
+                    prev_ok = ok;
+                }
+            }
             for (int f0 = 0; f0 < cnt;) {
                 const int len = batches ? run_length(base, f0, cnt, target_units) : std::min(R, cnt - f0);
                 RunDesc r{};
@@ -1252,6 +1290,11 @@ struct SynthCall {
             }
         } else {
             cut_streams(0);
+        }
+        if (reuse && (int64_t)n_runs > run_slots) {  // this batch is not like the last one after all
+            D.cut_hint_frames = -1;
+            n_runs = 0;
+            cut_runs();
         }
     }
 
