@@ -616,6 +616,8 @@ struct SynthCall {
         if (parties <= 0) {
             cpu_set_t set;
             parties = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+            // (one process per GPU: the node's cores are shared with the other ranks torchrun started here)
+            if (const char *lw = getenv("LOCAL_WORLD_SIZE")) parties /= std::max(1, atoi(lw));
             parties = std::max(1, std::min(parties, 16));
         }
         if (parties < 2) return 0;
