@@ -1117,10 +1117,14 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         // block after a long one goes alone (its overlap partner has the long block's shape).
         if (kBatchShort) {
             const uint32_t pmp = __shfl_up(mp, 1);
+            // (the block before may be a short one -- its upper half overlaps -- or, for the head of a batch, a long one
+            // with a short right window: the same 128 samples of overlap, further up in its tail)
+            const bool after_short = prev_end == 128 && prev_stop == 256;
+            const bool after_long = a.size1 == 2048 && prev_end == 1472 && prev_stop == 1600;
             const bool base_ok = lane < n && lane >= -fi0 && a.size0 == 256 && !(cf & 1) && (cf & kCfInterleaved) &&
                                  !(cf & (kCfNoFloor | kCfSkip)) && has_prev && out_count == 128 && left_start == 0 &&
-                                 prev_end == 128 && prev_stop == 256 && !(a.ablate & 128);
-            const bool base_prev = __shfl_up((int)base_ok, 1) != 0 && lane > 0;
+                                 (after_short || after_long) && !(a.ablate & 128);
+            const bool base_prev = __shfl_up((int)base_ok, 1) != 0 && lane > 0 && after_short;
             const bool brk = !(base_ok && base_prev && mp == pmp);  // this frame does not continue its predecessor's streak
             const unsigned long long mask_brk = __ballot(brk);
             if (base_ok) {
@@ -1468,7 +1472,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 const float4 wl = s4[i4], wr = s4[31 - i4];
                 const float4 hv = h4[fs * 32 + (lower ? 15 - i4 : i4 - 16)];
                 const int pidx = lower ? i4 : 31 - i4;
-                const float4 *pp = fs > 0 ? h4 + (fs - 1) * 32 + 16 : t4;  // (both in LDS; a selected float4 would spill)
+                // (both in LDS; a selected float4 would spill.  After a long block the overlap sits at y[1472..1600) of its
+                // output: floats 448..511 of the tail, straight and mirrored like a short block's)
+                const float4 *pp = fs > 0 ? h4 + (fs - 1) * 32 + 16 : t4 + (prev_n4 == 512 ? 112 : 0);
                 const float4 pv = pp[pidx];
                 const float4 v = apply_y4(hv, lower, lower);
                 const float4 t = apply_y4(pv, !lower, false);

@@ -1106,9 +1106,10 @@ struct SynthCall {
             ok = false;
             if (!batches || p == 0 || packets[p - 1].stream != packets[p].stream) return false;
             const vpz_packet &pk = packets[p], &pp = packets[p - 1];
-            ok = !(pk.flags & VPZ_PKT_BLOCK_FLAG) && !(pp.flags & VPZ_PKT_BLOCK_FLAG) && (pk.flags & VPZ_PKT_INTERLEAVED) &&
+            ok = !(pk.flags & VPZ_PKT_BLOCK_FLAG) && (pk.flags & VPZ_PKT_INTERLEAVED) &&
                  !(pk.flags & (VPZ_PKT_NO_FLOOR | VPZ_PKT_NOT_DECODED)) && !(pp.flags & VPZ_PKT_NOT_DECODED);
-            return ok && prev_in_run_ok && pk.mapping == pp.mapping;
+            // (after a long block it can head a batch; it rides with a short predecessor of its mapping)
+            return ok && prev_in_run_ok && !(pp.flags & VPZ_PKT_BLOCK_FLAG) && pk.mapping == pp.mapping;
         };
         // cost of a pass in eighths of a long block's (tools/kbench_short_long.py: a short block alone 0.74, eight in one
         // batch 3.2 together)
@@ -1127,7 +1128,8 @@ struct SynthCall {
                            D.cut_hint_R > 0 && D.run_length_override <= 0;
         auto packet_code = [&](int64_t p, bool ok) -> uint8_t {
             return (uint8_t)(((packets[p].flags & VPZ_PKT_BLOCK_FLAG) ? 0 : 1) | (ok ? 2 : 0) |
-                             ((ok && p > 0 && packets[p].mapping == packets[p - 1].mapping) ? 4 : 0));
+                             ((ok && p > 0 && packets[p].mapping == packets[p - 1].mapping &&
+                               !(packets[p - 1].flags & VPZ_PKT_BLOCK_FLAG)) ? 4 : 0));
         };
         if (batches && code.size() < (size_t)total_frames) code.resize((size_t)total_frames);
         if (batches && !reuse) {
