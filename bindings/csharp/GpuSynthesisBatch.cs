@@ -78,7 +78,7 @@ namespace NVorbis.Native
         public long Flush(Span<float> pcm, Span<int> perPacketSamples)
         {
             if (_count == 0) return 0;
-            long written = 0;
+            long written = 0, notOk = 0;
             int rc;
             fixed (VorbisPizzaSynth.Packet* pk = _packets)
             fixed (float* res = _residue)
@@ -87,17 +87,34 @@ namespace NVorbis.Native
             fixed (float* dst = pcm)
             fixed (int* per = perPacketSamples)
             {
-                rc = VorbisPizzaSynth.vpz_decoder_synth(_decoder, _count, pk, res, po, pc, VorbisPizzaSynth.MemHost, dst, null,
-                                                        pcm.Length / _channels, VorbisPizzaSynth.OutInterleaved, 0, &written);
+                // the extents are the queued part of the arrays: the library refuses a packet that points beyond them
+                rc = VorbisPizzaSynth.vpz_decoder_synth(_decoder, _count, pk, res, _residueUsed, po, pc, (long)_count * _channels,
+                                                        VorbisPizzaSynth.MemHost, dst, null, pcm.Length / _channels,
+                                                        VorbisPizzaSynth.OutInterleaved, 0, &written);
                 VorbisPizzaSynth.vpz_decoder_last_packet_samples(_decoder, per, Math.Min(perPacketSamples.Length, _count));
+                if (rc == VorbisPizzaSynth.Ok) VorbisPizzaSynth.vpz_decoder_last_packet_status(_decoder, null, 0, &notOk);
             }
+            int queued = _count;
             _count = 0;
             _residueUsed = 0;
-            // a window mismatch costs only the offending packet, like the exception out of OverlapBuffers
-            if (rc != VorbisPizzaSynth.Ok && rc != VorbisPizzaSynth.EWindowMismatch)
-                VorbisPizzaSynth.ThrowOnError(rc, _ctx, "vpz_decoder_synth");
+            VorbisPizzaSynth.ThrowOnError(rc, _ctx, "vpz_decoder_synth");
+            // A window mismatch costs only the offending packet, like the exception out of OverlapBuffers
+            // (StreamDecoder.cs:777-778): the batch is valid; PacketStatus tells the Read that reaches the packet to throw.
+            LastBatchHadMismatch = notOk > 0;
+            _lastQueued = queued;
             return written;
         }
+
+        /// <summary>Status of each packet of the last Flush (Ok / EWindowMismatch), for the Read loop that hands the
+        /// batch out packet by packet.</summary>
+        public void PacketStatus(Span<int> status)
+        {
+            fixed (int* st = status)
+                VorbisPizzaSynth.vpz_decoder_last_packet_status(_decoder, st, Math.Min(status.Length, _lastQueued), null);
+        }
+
+        public bool LastBatchHadMismatch { get; private set; }
+        private int _lastQueued;
 
         public void Reset()                                   // StreamDecoder.ResetDecoder (:357-369)
         {

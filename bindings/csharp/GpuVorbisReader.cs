@@ -98,6 +98,9 @@ namespace NVorbis.Native
         {
             if (status == 0) return;
             if (status == -1) throw new ArgumentOutOfRangeException(what, LastError());   // VPZ_E_INVALID_ARG
+            // VPZ_E_WINDOW_MISMATCH: `windowSlope.AsSpan(0, packetLen)` in OverlapBuffers (StreamDecoder.cs:777-778) throws this
+            // out of the Read that reaches the packet; the next Read goes on behind it
+            if (status == -5) throw new ArgumentOutOfRangeException(what, LastError());
             throw new InvalidOperationException(what + " failed (" + status + "): " + LastError());
         }
 

@@ -1,11 +1,11 @@
-// P/Invoke binding of include/vorbispizza_synth.h (ABI version 2) for the reference host.
+// P/Invoke binding of include/vorbispizza_synth.h (ABI version 3) for the reference host.
 //
 // To be added on the reference side as NVorbis/Native/VorbisPizzaSynth.cs.  The style is the one the repository
 // already uses for libvorbisfile (NVorbis.Tests/Bindings/Vorbisfile.cs:43-107: DllImport + Cdecl, LayoutKind.Sequential
 // structs, negative status codes, caller-owned pinned buffers) with handle ownership as in
 // NVorbis.Tests/Bindings/NativeDecoder.cs:6,16,46-55 (SafeHandle).  No .NET toolchain exists in the pipeline this file
-// was written in: the struct layouts are held to the C compiler's by tests/test_capi_cpu.py through the ctypes mirror
-// (vorbispizza_amd/capi.py), which has the same fields in the same order.
+// was written in: tests/test_csharp_binding_cpu.py parses this file and holds every DllImport (name, argument count and
+// kinds), every Sequential struct (fields in order, array bounds) and every constant to include/vorbispizza_synth.h.
 using System;
 using System.Runtime.InteropServices;
 using Microsoft.Win32.SafeHandles;
@@ -15,7 +15,7 @@ namespace NVorbis.Native
     internal static unsafe class VorbisPizzaSynth
     {
         private const string Lib = "vorbispizza_synth";              // libvorbispizza_synth.so
-        public const int AbiVersion = 2;
+        public const int AbiVersion = 3;
 
         // status codes (vorbispizza_synth.h), mapped to exceptions by ThrowOnError below the way
         // NativeDecoder.cs:145-161 maps OV_*
@@ -115,8 +115,12 @@ namespace NVorbis.Native
         // 764-791) + Store* (:515-638) for every packet of the batch.  pcmOut: float*, or short* for the S16 layouts.
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
         public static extern int vpz_decoder_synth(DecoderHandle decoder, long nPackets, Packet* packets, float* residue,
-            short* posts, byte* postCounts, int memSpace, void* pcmOut, long* streamOutOffset, long streamOutCapacity,
-            int outLayout, long channelStride, long* samplesWritten);
+            long residueFloats, short* posts, byte* postCounts, long nRecords, int memSpace, void* pcmOut,
+            long* streamOutOffset, long streamOutCapacity, int outLayout, long channelStride, long* samplesWritten);
+        // per-packet status of the last call: Ok, or EWindowMismatch where OverlapBuffers would have thrown
+        // (StreamDecoder.cs:777-778); nNotOk: how many packets are not Ok (status may be null with capacity 0)
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+        public static extern int vpz_decoder_last_packet_status(DecoderHandle decoder, int* status, long capacity, long* nNotOk);
 
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
         public static extern int vpz_decoder_set_floor0_data(DecoderHandle decoder, float* amp, float* coeff, int coeffStride);

@@ -27,7 +27,10 @@
 extern "C" {
 #endif
 
-#define VPZ_ABI_VERSION 2   /* 2: s16 output layouts, VPZ_PKT_RESYNC, vpz_decoder_set_position; structs unchanged */
+#define VPZ_ABI_VERSION 3   /* 2: s16 output layouts, VPZ_PKT_RESYNC, vpz_decoder_set_position; structs unchanged
+                               3: vpz_decoder_synth takes the extents of its input buffers (residue_floats, n_records) and
+                                  reports a window mismatch per packet (vpz_decoder_last_packet_status) instead of failing
+                                  the batch; structs unchanged */
 
 /* ---- status codes (negative like the OV_* codes, Vorbisfile.cs:10-24) ---- */
 #define VPZ_OK                 0
@@ -35,11 +38,12 @@ extern "C" {
 #define VPZ_E_UNSUPPORTED     (-2)  /* block size / layout this build has no kernel for */
 #define VPZ_E_HIP             (-3)  /* HIP runtime error; text via vpz_context_last_error */
 #define VPZ_E_NOMEM           (-4)
-#define VPZ_E_WINDOW_MISMATCH (-5)  /* previous tail longer than the window slope:
-                                       StreamDecoder.cs:777-778 would throw.  Like that exception the
-                                       condition costs only the offending packet: it is skipped, the
-                                       stream state is untouched, the rest of the batch is synthesised
-                                       and samples_written / PCM are valid on return */
+#define VPZ_E_WINDOW_MISMATCH (-5)  /* PER-PACKET status (vpz_decoder_last_packet_status), never the return value of
+                                       vpz_decoder_synth: the previous tail is longer than the packet's window slope,
+                                       where StreamDecoder.cs:777-778 would throw out of that packet's Read.  Like that
+                                       exception the condition costs only the offending packet: it is skipped, the
+                                       stream state is untouched, and the rest of the batch -- other streams included --
+                                       is synthesised */
 #define VPZ_E_NO_DEVICE       (-6)
 #define VPZ_E_CAPACITY        (-7)  /* output buffer too small for the samples produced */
 
@@ -186,24 +190,38 @@ int  vpz_decoder_reset(vpz_decoder *dec, int32_t stream);
  * Store* call of Read (:474-489), i.e. everything `while (idx == 0)` does for that packet.
  *
  * packets[n_packets]: packets of one stream must appear in stream order; streams may interleave.
- * residue: float32, addressed by vpz_packet.residue_offset.
+ * residue: float32, addressed by vpz_packet.residue_offset; residue_floats = floats readable at `residue`.  A packet
+ *   whose residue (channels * blocksize/2 floats from its offset) reaches beyond that is an error
+ *   (VPZ_E_INVALID_ARG, nothing is synthesised, no state changes) -- the reference's arguments are Span<float>,
+ *   bounds-checked the same way (Mapping.cs:98).
  * posts / post_counts: per packet p and channel c, record r = p*channels + c:
  *   post_counts[r] = Floor1.Data.PostCount (0 => ExecuteChannel false, channel outputs zeros),
  *   posts[r*64 + i] = Floor1.Data.Posts[i] as `Unpack` left them (raw, before UnwrapPosts).
- *   Both may be NULL when every packet has VPZ_PKT_NO_FLOOR.
+ *   n_records = records readable at both (n_records >= n_packets * channels, else VPZ_E_INVALID_ARG).
+ *   Both may be NULL (n_records 0) when every packet has VPZ_PKT_NO_FLOOR.
  * pcm_out: stream s writes at pcm_out + stream_out_offset[s] (float index; NULL offsets = all 0),
  *   interleaved [sample][channel] or planar with `channel_stride` floats between channels.
  *   At most stream_out_capacity samples per channel are written per stream.
  * samples_written[n_streams]: samples per channel produced by this call (host memory, always).
  *   The count is final when the call returns even in VPZ_MEM_DEVICE mode (it is computed by the
  *   host-side state machine); the PCM itself is ready after vpz_context_synchronize.
+ * Returns VPZ_OK when the batch was taken.  Conditions that cost ONE packet its Read in the reference (the window
+ * check of StreamDecoder.cs:777-778) do not fail the call: see vpz_decoder_last_packet_status.
  * ------------------------------------------------------------------------------------------ */
 int vpz_decoder_synth(vpz_decoder *dec, int64_t n_packets, const vpz_packet *packets,
-                      const float *residue, const int16_t *posts, const uint8_t *post_counts,
+                      const float *residue, int64_t residue_floats,
+                      const int16_t *posts, const uint8_t *post_counts, int64_t n_records,
                       int mem_space,
                       void *pcm_out, /* float32, or int16 for the _S16 layouts */ const int64_t *stream_out_offset, int64_t stream_out_capacity,
                       int out_layout, int64_t channel_stride,
                       int64_t *samples_written);
+
+/* Status of each packet of the LAST vpz_decoder_synth call, in packet order: VPZ_OK, or VPZ_E_WINDOW_MISMATCH for a
+ * packet the state machine skipped where `OverlapBuffers` would have thrown (StreamDecoder.cs:777-778: that one Read
+ * fails, the decoder state stays as it was, the next Read goes on with the next packet).  Copies
+ * min(n_packets, capacity) entries; `out` may be NULL with capacity 0.  n_not_ok (may be NULL) receives how many
+ * packets of the call are not VPZ_OK -- 0 is the common case and needs no per-packet look. */
+int vpz_decoder_last_packet_status(vpz_decoder *dec, int32_t *out, int64_t capacity, int64_t *n_not_ok);
 
 /* Floor 0 data of the NEXT vpz_decoder_synth call (Floor0.Data after Unpack, Floor0.cs:113-162), for the
  * channel records whose floor is type 0: amp[rec] = Data.Amp (0 => ExecuteChannel false; the caller also

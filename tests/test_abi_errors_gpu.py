@@ -74,8 +74,9 @@ def test_synth_rejects_bad_calls_and_keeps_its_state(ctx):
     out = np.zeros(2 * cap, dtype=np.float32)
 
     def call(packets=pk, residue=res, capacity=cap, layout=capi.OUT_PLANAR, stride=cap, mem=capi.MEM_HOST, posts=None,
-             counts=None, offs=None):
-        return dec.synth_raw(packets, residue, posts, counts, out, offs, capacity, layout, stride, mem)
+             counts=None, offs=None, residue_floats=None, n_records=None):
+        return dec.synth_raw(packets, residue, posts, counts, out, offs, capacity, layout, stride, mem,
+                             residue_floats=residue_floats, n_records=n_records)
 
     assert _status(lambda: call(mem=7)) == capi.E_INVALID_ARG
     assert _status(lambda: call(layout=5)) == capi.E_INVALID_ARG
@@ -91,6 +92,17 @@ def test_synth_rejects_bad_calls_and_keeps_its_state(ctx):
     bad = pk.copy()
     bad["flags"] &= ~np.uint8(capi.PKT_NO_FLOOR)                                        # floor wanted, none configured
     assert _status(lambda: call(packets=bad)) == capi.E_INVALID_ARG
+    # ABI v3: the extents of the input buffers are part of the call -- a packet whose residue reaches beyond them is
+    # refused instead of read (the reference's Span<float> would throw, Mapping.cs:98)
+    assert _status(lambda: call(residue_floats=res.size - 1)) == capi.E_INVALID_ARG
+    assert "residue_floats" in ctx.last_error()
+    assert _status(lambda: call(residue_floats=-1)) == capi.E_INVALID_ARG
+    bad = pk.copy()
+    bad["residue_offset"][len(pk) - 1] += 4
+    assert _status(lambda: call(packets=bad)) == capi.E_INVALID_ARG                     # one packet past the end
+    assert int(call(residue_floats=res.size)[0]) == 5 * 1024                            # exactly enough is enough
+    dec.reset(-1)
+    dec.set_position(0)
     # nothing above touched the stream state: the good call still decodes from the start
     w = call()
     assert int(w[0]) == 5 * 1024 and dec.position(0) == 5 * 1024
@@ -119,6 +131,10 @@ def test_floor0_needs_its_data_and_mapping_index_is_checked(ctx):
     bad["mapping"][0] = 5
     st = _status(lambda: dec.synth_raw(bad, res, posts, counts, out, None, 8192, capi.OUT_PLANAR, 8192, capi.MEM_HOST))
     assert st == capi.E_INVALID_ARG
+    # fewer post records than packets * channels (ABI v3)
+    st = _status(lambda: dec.synth_raw(pk, res, posts, counts, out, None, 8192, capi.OUT_PLANAR, 8192, capi.MEM_HOST,
+                                       n_records=len(pk) * 2 - 1))
+    assert st == capi.E_INVALID_ARG and "post records" in ctx.last_error()
     dec.close()
 
 

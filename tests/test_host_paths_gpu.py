@@ -482,3 +482,52 @@ def test_batches_of_short_blocks(ctx, oracle, channels, steps, p_sl):
     got = outs[capi.OUT_PLANAR][0][s_ * channels * cap:(s_ + 1) * channels * cap].reshape(channels, cap)[:, :ref.shape[1]]
     assert outs[capi.OUT_PLANAR][1][s_] == ref.shape[1] and ref.shape[1] > 0
     assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_streams_without_packets_in_a_call_parallel_run_cutting(ctx):
+    """Multi-stream decoding of files of different lengths: some streams have NO packet in a call (they ended earlier, or
+    have not started) -- among them the last stream of a host party's range, whose s_base / s_cnt stay 0 -- while the
+    batch takes the wide route of the run cutter (compact runs, group mode, short-block batches, >= 2 streams per party).
+    Two calls (the second one after some streams have reached EOS) against the serial route, bit for bit."""
+    from vorbispizza_amd import Decoder, capi
+    channels, n_streams, frames = 2, 16, 60
+    pk, res, posts, counts = stream_major_batch(n_streams, frames, channels, seed=77, floor=True, interleaved=True,
+                                                p_ls=0.25, p_sl=0.2, silent_prob=0.1)
+    pk["mapping"] = pk["flags"] & 1
+    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)]
+    mappings = [{"coupling": [(0, 1)], "channel_floor": [0] * channels}, {"coupling": [(0, 1)], "channel_floor": [1] * channels}]
+    idx = np.arange(len(pk)).reshape(n_streams, frames)
+    empty_first = {0, 3, 7, 11, 15}          # no packets in call 1 (3, 7, 11, 15 end a party's range of 4 streams)
+    ends_in_first = {2, 6, 14}               # EOS on their last packet of call 1; absent from call 2
+    half = frames // 2
+    sel1 = np.concatenate([idx[s, :half] for s in range(n_streams) if s not in empty_first])
+    sel2 = np.concatenate([idx[s, (0 if s in empty_first else half):] for s in range(n_streams) if s not in ends_in_first])
+    calls = []
+    for sel in (sel1, sel2):
+        sub = pk[sel].copy()
+        calls.append((sub, np.ascontiguousarray(posts.reshape(len(pk), channels, 64)[sel].reshape(-1, 64)),
+                      np.ascontiguousarray(counts.reshape(len(pk), channels)[sel].reshape(-1))))
+    for s in ends_in_first:
+        last = np.nonzero(calls[0][0]["stream"] == s)[0][-1]
+        calls[0][0]["flags"][last] |= PKT_EOS
+    cap = frames * 1024 + 64
+    results = {}
+    for mode, kv in (("serial", dict(VPZ_PAR_MIN_PACKETS=1 << 40, VPZ_NO_GROUP=1)),
+                     ("wide", dict(VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=4, VPZ_NO_GROUP=None))):
+        with env(**kv):
+            dec = Decoder(ctx, channels, 256, 2048, floors=floors, mappings=mappings, n_streams=n_streams)
+            out = np.zeros(n_streams * channels * cap, dtype=np.float32)
+            offs = np.arange(n_streams, dtype=np.int64) * channels * cap
+            total = np.zeros(n_streams, dtype=np.int64)
+            per_packet = []
+            for sub, p, c in calls:
+                w = dec.synth_raw(sub, res, p, c, out, offs + total * channels, cap - int(total.max()),
+                                  capi.OUT_INTERLEAVED, 0, capi.MEM_HOST)
+                per_packet.append(dec.last_packet_samples(len(sub)))
+                total += w
+            results[mode] = (out, total.copy(), np.concatenate(per_packet), [dec.position(s) for s in range(n_streams)])
+            dec.close()
+    a, b = results["serial"], results["wide"]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert a[1][0] > 0 and a[1][2] > 0 and np.abs(a[0]).max() > 0

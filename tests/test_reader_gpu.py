@@ -42,22 +42,31 @@ def to_s16(x):  # AssetTest.cs:131-132
 @pytest.mark.parametrize("name", ["1test.ogg", "2test.ogg", "3test.ogg", "issue6test.ogg"])
 @pytest.mark.parametrize("batch", [1, 7, 128])
 def test_read_samples_loop_matches_truth(ctx, oracle, name, batch):
+    from vorbispizza_amd import capi
     from vorbispizza_amd.front import VorbisReader
     path = os.path.join(GOLDEN, name)
     f, ref, ref_clipped = oracle_truth(oracle, path, interleave=True)
     rdr = VorbisReader(ctx, path, batch_packets=batch)
     assert (rdr.Channels, rdr.SampleRate) == (f.channels, 44100)
     buf = np.zeros(2048 * 8, dtype=np.float32)  # AssetTest.cs:98-100
-    chunks, calls = [], 0
+    chunks, calls, thrown = [], 0, 0
     while True:
-        n = rdr.ReadSamples(buf)
+        try:
+            n = rdr.ReadSamples(buf)
+        except capi.SynthError as e:
+            # issue6test.ogg's trailing empty packet: `OverlapBuffers` throws out of the Read that reaches it
+            # (StreamDecoder.cs:777-778; the reference's harness stops before, AssetTest.cs:107-118) -- that Read fails
+            # ONCE, nothing is lost, the next one goes on behind the packet
+            assert e.status == capi.E_WINDOW_MISMATCH and name == "issue6test.ogg"
+            thrown += 1
+            continue
         if n == 0:
             break
         calls += 1
         assert n <= 1472  # never more than one packet's worth (StreamDecoder.cs:436)
         chunks.append(buf[: n * rdr.Channels].reshape(n, rdr.Channels).copy())
     got = np.concatenate(chunks)
-    assert got.shape == ref.shape
+    assert got.shape == ref.shape and thrown == (1 if name == "issue6test.ogg" else 0)
     assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
     assert np.abs(to_s16(got) - to_s16(ref)).max() <= 1  # reference criterion is <= 2
     assert rdr.SamplePosition == ref.shape[0] and rdr.IsEndOfStream

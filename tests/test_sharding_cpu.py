@@ -37,6 +37,9 @@ local = {s: fake(s) for ids in plan for s in ids}
 samples, sums = sharding.merge_stream_results(1024, local)
 assert samples == [fake(s)[0] for s in range(1024)] and sums == [fake(s)[1] for s in range(1024)]
 job_checksum = sharding.combine_stream_checksums(sums)
+# per-rank diagnostics of bench.py's whole-job record: every rank sees every rank's row
+rows = sharding.gather_floats([10.0 + rank, 0.5 * (rank + 1)])
+assert rows == [[10.0, 0.5], [11.0, 1.0]]
 if rank == 0:
     print(json.dumps({"lo": lo, "hi": hi, "slowest": slowest, "total": total, "job_checksum": job_checksum,
                       "job_samples": sum(samples)}))

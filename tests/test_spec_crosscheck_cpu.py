@@ -63,8 +63,10 @@ def test_oracle_pcm_matches_the_specification_derived_synthesis(front, oracle, n
                                         floors=f.floors, mappings=f.mappings, clip=False)
     packets = spec_packets(f, pk, res, posts, counts)
     if name == "issue6test.ogg":
-        # its last packet is a long block whose window flags contradict the short block before it: the reference's
-        # OverlapBuffers throws on it (StreamDecoder.cs:777-778) and the oracle stops there; leave it out here too
+        # its last packet is EMPTY: VorbisPacket reads zeros past the end, so it decodes as a silent block of mode 0 -- a
+        # SHORT block -- behind a long block whose right window is long: the previous tail (1024 samples) is longer than
+        # the short window slope, the reference's OverlapBuffers throws on it (StreamDecoder.cs:777-778) and the oracle
+        # skips it; leave it out here too
         assert helpers.oracle_decode.last_mismatches == 1
         packets = packets[:-1]
     got = spec.decode(f.channels, f.block_size0, f.block_size1, f.floors, f.mappings, packets,

@@ -18,7 +18,10 @@ for name in ("3test.ogg", "issue6test.ogg", "2test.ogg"):
             buf = np.zeros(C * 4096, dtype=np.float32)
             tot = 0
             while True:
-                n = r.ReadSamples(buf)
+                try:
+                    n = r.ReadSamples(buf)
+                except Exception:  # issue6test.ogg's trailing packet: that one Read throws (StreamDecoder.cs:777-778)
+                    continue
                 if n == 0: break
                 tot += n
             dt = time.perf_counter() - t0

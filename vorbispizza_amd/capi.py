@@ -75,8 +75,9 @@ _SIGNATURES = [
     ("vpz_decoder_create", C.c_int, [_vp, C.POINTER(StreamConfig), C.c_int32, C.POINTER(_vp)]),
     ("vpz_decoder_destroy", None, [_vp]),
     ("vpz_decoder_reset", C.c_int, [_vp, C.c_int32]),
-    ("vpz_decoder_synth", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int64,
-                                    C.c_int, C.c_int64, _vp]),
+    ("vpz_decoder_synth", C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int, _vp, _vp,
+                                    C.c_int64, C.c_int, C.c_int64, _vp]),
+    ("vpz_decoder_last_packet_status", C.c_int, [_vp, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     ("vpz_decoder_set_floor0_data", C.c_int, [_vp, _vp, _vp, C.c_int32]),
     ("vpz_decoder_last_packet_samples", C.c_int, [_vp, _vp, C.c_int64]),
     ("vpz_decoder_has_clipped", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int32)]),
@@ -136,6 +137,12 @@ def _sync_producer(*tensors):
             import torch
             torch.cuda.current_stream(t.device).synchronize()
             return
+
+
+def _numel(x):
+    if x is None:
+        return 0
+    return int(x.numel()) if _is_torch(x) else int(np.asarray(x).size)
 
 
 def _ptr(x):
@@ -281,18 +288,40 @@ class Decoder:
         self.ctx._check(lib().vpz_decoder_reset(self._h, stream))
 
     def synth_raw(self, packets, residue, posts, post_counts, pcm_out, stream_out_offset, capacity,
-                  out_layout, channel_stride, mem_space):
-        """Thin call of vpz_decoder_synth; returns samples_written (int64 array, per stream)."""
+                  out_layout, channel_stride, mem_space, residue_floats=None, n_records=None, on_mismatch="raise"):
+        """Thin call of vpz_decoder_synth; returns samples_written (int64 array, per stream).
+        residue_floats / n_records default to the extents of the arrays handed in.  A packet skipped by the window check
+        (StreamDecoder.cs:777-778) is a per-packet status in the ABI; on_mismatch="raise" turns it into
+        SynthError(E_WINDOW_MISMATCH) AFTER the call has done all its work -- what a host does for the stream concerned --,
+        "ignore" leaves it to last_packet_status()."""
         written = np.zeros(self.n_streams, dtype=np.int64)
         packets = np.ascontiguousarray(packets, dtype=PACKET_DTYPE)
         offs = None if stream_out_offset is None else np.ascontiguousarray(stream_out_offset, dtype=np.int64)
         if mem_space == MEM_DEVICE:
             _sync_producer(residue, posts, post_counts, pcm_out)
-        rc = lib().vpz_decoder_synth(self._h, len(packets), _ptr(packets), _ptr(residue), _ptr(posts),
-                                     _ptr(post_counts), mem_space, _ptr(pcm_out), _ptr(offs), capacity,
+        if residue_floats is None:
+            residue_floats = _numel(residue)
+        if n_records is None:
+            n_records = 0 if post_counts is None else _numel(post_counts)
+        rc = lib().vpz_decoder_synth(self._h, len(packets), _ptr(packets), _ptr(residue), residue_floats, _ptr(posts),
+                                     _ptr(post_counts), n_records, mem_space, _ptr(pcm_out), _ptr(offs), capacity,
                                      out_layout, channel_stride, _ptr(written))
         self.ctx._check(rc)
+        self.last_written = written
+        if on_mismatch == "raise" and self.last_mismatches() > 0:
+            raise SynthError(E_WINDOW_MISMATCH, "a packet's previous tail is longer than its window slope "
+                             "(StreamDecoder.cs:777-778 throws); the packet was skipped, everything else was synthesised")
         return written
+
+    def last_mismatches(self):
+        n = C.c_int64()
+        self.ctx._check(lib().vpz_decoder_last_packet_status(self._h, None, 0, C.byref(n)))
+        return n.value
+
+    def last_packet_status(self, n_packets):
+        out = np.zeros(n_packets, dtype=np.int32)
+        self.ctx._check(lib().vpz_decoder_last_packet_status(self._h, _ptr(out), n_packets, None))
+        return out
 
     def synth(self, packets, residue, posts=None, post_counts=None, out_layout=OUT_PLANAR, capacity=None):
         """Host-memory convenience: returns a list (per stream) of PCM arrays, [channels, samples]

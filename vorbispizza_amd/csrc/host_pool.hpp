@@ -34,10 +34,13 @@ public:
 
     int parties() const { return parties_; }
 
-    // fn(i) for every i in [0, parties()); the caller runs i = 0.  Returns when all are done.
-    void run(const std::function<void(int)> &fn)
+    // fn(i) for every i in [0, parties()); the caller runs i = 0.  Returns when all are done: true, or false when any
+    // party's share threw (std::bad_alloc from a vector, ...) -- an exception must neither leave a worker thread
+    // (std::terminate) nor unwind through the extern "C" entry the caller sits in; the caller reports VPZ_E_NOMEM.
+    bool run(const std::function<void(int)> &fn)
     {
-        if (parties_ == 1) { fn(0); return; }
+        failed_.store(false, std::memory_order_relaxed);
+        if (parties_ == 1) { guarded(fn, 0); return !failed_.load(std::memory_order_relaxed); }
         {
             std::lock_guard<std::mutex> lk(m_);
             fn_ = &fn;
@@ -45,13 +48,23 @@ public:
             generation_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
-        fn(0);
+        guarded(fn, 0);
         // the workers' share is as long as the caller's: spin, it ends within microseconds
         while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
         fn_ = nullptr;
+        return !failed_.load(std::memory_order_acquire);
     }
 
 private:
+    void guarded(const std::function<void(int)> &fn, int index)
+    {
+        try {
+            fn(index);
+        } catch (...) {
+            failed_.store(true, std::memory_order_release);
+        }
+    }
+
     void worker(int index)
     {
         unsigned seen = 0;
@@ -73,7 +86,7 @@ private:
                 std::lock_guard<std::mutex> lk(m_);  // pairs with run(): fn_ is published under the lock
                 fn = fn_;
             }
-            if (fn) (*fn)(index);
+            if (fn) guarded(*fn, index);
             pending_.fetch_sub(1, std::memory_order_release);
         }
     }
@@ -84,6 +97,7 @@ private:
     std::condition_variable cv_;
     std::atomic<unsigned> generation_{0};
     std::atomic<int> pending_{0};
+    std::atomic<bool> failed_{false};
     const std::function<void(int)> *fn_ = nullptr;
     bool stop_ = false;
 };

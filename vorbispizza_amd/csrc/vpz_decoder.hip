@@ -108,7 +108,7 @@ struct Decoder {
     bool no_compact = false;                 // VPZ_NO_COMPACT=1: always upload explicit frame descriptors (A/B tests)
     std::vector<uint8_t> cut_code;           // cut_runs: one byte per packet (block size, batch eligibility)
     int cut_hint_R = 0;                      // ... and the cost target the last call's runs were fitted with
-    int64_t cut_hint_slots = 0, cut_hint_target = 0, cut_hint_frames = -1;
+    int64_t cut_hint_slots = 0, cut_hint_target = 0, cut_hint_frames = -1, cut_hint_runs = 0;
     int cut_hint_streams = -1;
     size_t zero_copy_max = 8u << 20;         // arenas up to this size are read in place by the kernels (VPZ_ZERO_COPY_MAX;
                                              // half a million packets, 1.5 MB: 2.42 -> 2.35 ms against the copy)
@@ -134,6 +134,7 @@ struct Decoder {
     int run_length_override = 0;
     int ablate = 0;  // VPZ_SYNTH_ABLATE, tuning experiments only
     std::vector<int32_t> packet_samples;  // per packet of the last synth call
+    std::vector<int64_t> mismatch_packets;  // packets of the last synth call that failed the window check (skipped)
 };
 
 static int grow(Context *ctx, DevBuf &b, size_t need)
@@ -350,6 +351,10 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         D.no_compact = nc && atoi(nc);
         if (const char *z = getenv("VPZ_ZERO_COPY_MAX")) D.zero_copy_max = (size_t)atoll(z);
     }
+    if (rc != VPZ_OK) {  // (before anything below indexes the floor / step tables with values that failed validation)
+        delete d;
+        return set_error(ctx, rc, "vpz_decoder_create: invalid floor1 / mapping configuration");
+    }
     std::vector<uint32_t> map_bits(std::max<size_t>(1, D.mappings.size()), 0u);
     D.mapping_uses_floor0.assign(D.mappings.size(), 0);
     for (size_t m = 0; m < D.mappings.size(); ++m) {
@@ -359,10 +364,6 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
                           ((uint32_t)(D.mapping_steps_off[m] / 2) << kFrameStepsOffShift);
         for (int ch = 0; ch < D.channels; ++ch)
             if (!D.floor_types.empty() && D.floor_types[D.mappings[m].channel_floor[ch]] == 0) D.mapping_uses_floor0[m] = 1;
-    }
-    if (rc != VPZ_OK) {
-        delete d;
-        return set_error(ctx, rc, "vpz_decoder_create: invalid floor1 / mapping configuration");
     }
     if ((rc = get_tables(ctx, D.size0, &D.t0)) != VPZ_OK || (rc = get_tables(ctx, D.size1, &D.t1)) != VPZ_OK) {
         delete d;
@@ -521,7 +522,7 @@ struct SynthCall {
     int64_t mismatches = 0, res_extent = 0;
     // ---- descriptor tables (pinned arena; dev() gives the device mirror's address)
     RunDesc *runs = nullptr;
-    size_t n_runs = 0;
+    size_t n_runs = 0, runs_cap = 0, runs_arena_mark = (size_t)-1;
     uint8_t *cpk = nullptr;
     int n_cpk = 0;
     int64_t temp_floats = 0;
@@ -560,6 +561,7 @@ struct SynthCall {
         return base + (static_cast<const char *>(host_ptr) - A->base);
     }
     bool zero_copy = false;
+    bool host_failed = false;  // a share of a fork-join threw (allocation): the call returns VPZ_E_NOMEM
 
     // Every per-call table (frame / run descriptors, coupling packets, per-record floor info, output
     // offsets, ...) is carved out of ONE pinned arena that goes to its device mirror in a single copy;
@@ -680,7 +682,7 @@ struct SynthCall {
         };
 
         // sweep A: validation, samples per packet (before any EOS trim), chunk-local sums
-        pool.run([&](int c) {
+        const bool ok_a = pool.run([&](int c) {
             Chunk &K = chunks[c];
             int64_t run = 0;
             bool leading = true;
@@ -741,6 +743,7 @@ struct SynthCall {
             if (leading) { K.lead_sum = run; K.lead_end = K.hi; }
             K.tail_sum = run;
         });
+        if (!ok_a) return set_error(ctx, VPZ_E_NOMEM, "vpz_decoder_synth: host pass failed (allocation)");
         for (const Chunk &K : chunks)
             if (!K.ok) {  // the serial pass expects the per-packet counts zeroed
                 std::fill(D.packet_samples.begin(), D.packet_samples.end(), 0);
@@ -796,7 +799,7 @@ struct SynthCall {
         if (D.generic) need_coupling = true;
         const bool group_bits = D.group_ok;  // (frame_flags' rule: group-mode bits only when the decoder can use them)
         // sweep B: the descriptors, the per-record floor info, where each stream's packets begin and end
-        pool.run([&](int c) {
+        const bool ok_b = pool.run([&](int c) {
             Chunk &K = chunks[c];
             int64_t run = K.base;
             for (int64_t p = K.lo; p < K.hi; ++p) {
@@ -858,6 +861,7 @@ struct SynthCall {
                 }
             }
         });
+        if (!ok_b) return set_error(ctx, VPZ_E_NOMEM, "vpz_decoder_synth: host pass failed (allocation)");
         // once per stream: its state after the batch (ReadNextPacket :640-694 for the last packet), the position
         // (:459-463, :493) and the EOS trim (:658-666)
         for (int s = 0; s < D.n_streams; ++s) {
@@ -884,6 +888,7 @@ struct SynthCall {
             }
             if (skipped) {
                 ++mismatches;
+                D.mismatch_packets.push_back(L);
                 if (s_cnt[s] > 1) {  // the state is the one the packet before it left
                     const vpz_packet &pp = packets[L - 1];
                     const PacketInfo &ppi = D.packet_info[pp.flags & 7];
@@ -1021,6 +1026,7 @@ struct SynthCall {
                     // consumed and the decoder state stays as it was.  The rest of the batch is still
                     // synthesised; the call reports the condition at the end.
                     ++mismatches;
+                    D.mismatch_packets.push_back(p);
                     continue;
                 }
                 fd.packet_len = (uint16_t)packet_len;
@@ -1152,7 +1158,7 @@ struct SynthCall {
                 }
                 part[c] = units;
             };
-            if (parties > 1) pool->run(count); else count(0);
+            if (parties > 1) host_failed |= !pool->run(count); else count(0);
             total_units = 0;
             for (int64_t v : part) total_units += v;
         }
@@ -1172,7 +1178,13 @@ struct SynthCall {
             }
         }
         // (a run cut by cost holds at least R - 1 frames unless its stream ends: every frame costs at most a whole pass)
-        runs = arena_alloc<RunDesc>(*A, (size_t)(total_frames / std::max(1, R - 1)) + (size_t)D.n_streams + 1);
+        // (a retry -- the reused cut hint did not fit, see the end of this function -- takes the first attempt's place
+        // in the arena instead of a second allocation)
+        if (runs_arena_mark == (size_t)-1) runs_arena_mark = A->used;
+        A->used = runs_arena_mark;
+        runs_cap = (size_t)(total_frames / std::max(1, R - 1)) + (size_t)D.n_streams + 1;
+        runs = arena_alloc<RunDesc>(*A, runs_cap);
+        if (A->used > A->cap) { host_failed = true; return; }  // (open_arena's budget is R >= 4 runs: never, but never silently)
         if (D.generic) return;
         int64_t target_units = 8 * (int64_t)R;
         // one run of a frame: as many frames from f0 on as the cost target (and the descriptor area) allow
@@ -1210,7 +1222,7 @@ struct SynthCall {
                         for (int f0 = 0, cnt = (int)D.s_cnt[s]; f0 < cnt; ++n) f0 += run_length(D.s_base[s], f0, cnt, target_units);
                     part[c] = n;
                 };
-                if (parties > 1) pool->run(count); else count(0);
+                if (parties > 1) host_failed |= !pool->run(count); else count(0);
                 int64_t n_total = 0;
                 for (int64_t v : part) n_total += v;
                 if (getenv("VPZ_HOST_PROFILE"))
@@ -1230,7 +1242,13 @@ struct SynthCall {
           int s_lo, s_hi;
           stream_range(c, s_lo, s_hi);
           std::vector<RunDesc> &mine = cut[c];
-          if (parties > 1) mine.reserve((size_t)(((int64_t)D.s_base[s_hi - 1] + D.s_cnt[s_hi - 1] - D.s_base[s_lo]) / R) + (size_t)(s_hi - s_lo) + 1);
+          if (parties > 1) {
+              // (a stream without packets in this call keeps s_base = s_cnt = 0: count the range's packets, never
+              // subtract bases)
+              int64_t pk_in_range = 0;
+              for (int s = s_lo; s < s_hi; ++s) pk_in_range += D.s_cnt[s];
+              mine.reserve((size_t)(pk_in_range / std::max(1, R - 1)) + (size_t)(s_hi - s_lo) + 1);
+          }
           for (int s = s_lo; s < s_hi; ++s) {
             const int cnt = (int)D.s_cnt[s], base = (int)D.s_base[s];
             if (reuse) {  // (the codes of this stream's packets, skipped with the counting pass)
@@ -1287,7 +1305,8 @@ struct SynthCall {
           }
         };
         if (parties > 1) {
-            pool->run(cut_streams);
+            host_failed |= !pool->run(cut_streams);
+            if (host_failed) { n_runs = 0; return; }
             for (const std::vector<RunDesc> &v : cut) {
                 memcpy(runs + n_runs, v.data(), v.size() * sizeof(RunDesc));
                 n_runs += v.size();
@@ -1295,11 +1314,15 @@ struct SynthCall {
         } else {
             cut_streams(0);
         }
-        if (reuse && (int64_t)n_runs > run_slots) {  // this batch is not like the last one after all
+        // this batch is not like the last one after all: more runs than the rounds hold, or -- a lighter mix of blocks, so
+        // fewer and longer runs -- so few that part of the resident waves would idle through the launch
+        if (reuse && ((int64_t)n_runs > run_slots || (int64_t)n_runs * 10 < D.cut_hint_runs * 9)) {
             D.cut_hint_frames = -1;
             n_runs = 0;
             cut_runs();
+            return;
         }
+        if (batches && !reuse) D.cut_hint_runs = (int64_t)n_runs;
     }
 
     // coupling packets: de-interleave + inverse coupling into a planar temp laid out in frame order
@@ -1637,16 +1660,23 @@ struct SynthCall {
 
 }  // namespace
 
-int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packets, const float *residue,
-                      const int16_t *posts, const uint8_t *post_counts, int mem_space, void *pcm_out,
-                      const int64_t *stream_out_offset, int64_t stream_out_capacity, int out_layout,
-                      int64_t channel_stride, int64_t *samples_written)
+static int synth_impl(vpz_decoder *d, int64_t n_packets, const vpz_packet *packets, const float *residue,
+                      int64_t residue_floats, const int16_t *posts, const uint8_t *post_counts, int64_t n_records,
+                      int mem_space, void *pcm_out, const int64_t *stream_out_offset, int64_t stream_out_capacity,
+                      int out_layout, int64_t channel_stride, int64_t *samples_written)
 {
-    if (!d) return VPZ_E_INVALID_ARG;
     Decoder &D = d->impl;
     Context *ctx = D.ctx;
+    D.mismatch_packets.clear();
     if (n_packets < 0 || (n_packets > 0 && (!packets || !residue || !pcm_out)) || !samples_written)
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: null argument");
+    // the extents of the caller's buffers are part of the call (the reference's arguments are Span<T>, bounds-checked:
+    // Mapping.cs:98): a packet that addresses residue beyond them, or a batch with fewer post records than
+    // packets * channels, is refused here -- it would be an out-of-bounds read on the device otherwise
+    if (residue_floats < 0 || n_records < 0)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: negative buffer extent");
+    if (posts && post_counts && n_records < n_packets * (int64_t)D.channels)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: fewer post records than packets * channels");
     if (mem_space != VPZ_MEM_HOST && mem_space != VPZ_MEM_DEVICE)
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: bad mem_space");
     if (out_layout < VPZ_OUT_INTERLEAVED || out_layout > VPZ_OUT_PLANAR_S16)
@@ -1676,15 +1706,15 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     const bool wants_group = call.need_coupling || (call.out_interleaved && D.channels > 2);
     call.use_group = D.group_ok && wants_group && !call.any_floor0 && call.group_align_ok &&
                      (mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
+    if (call.res_extent > residue_floats)
+        return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: a packet's residue lies beyond residue_floats");
     const auto t_pass1 = tick();
-    const char *mismatch_text =
-        "vpz_decoder_synth: a packet's previous tail is longer than its window slope (StreamDecoder.cs:777-778 "
-        "throws); the packet was skipped, everything else was synthesised";
     if (call.n_frames == 0) {
         D.states = call.st;
-        return call.mismatches ? set_error(ctx, VPZ_E_WINDOW_MISMATCH, mismatch_text) : VPZ_OK;
+        return VPZ_OK;  // (window mismatches are per-packet conditions: vpz_decoder_last_packet_status)
     }
     call.cut_runs();
+    if (call.host_failed) return set_error(ctx, VPZ_E_NOMEM, "vpz_decoder_synth: run cutting failed (allocation)");
     call.build_coupling_packets();
     if ((rc = call.build_floor0_records()) != VPZ_OK) return rc;
     if ((rc = call.build_output_offsets()) != VPZ_OK) return rc;
@@ -1705,7 +1735,36 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
                 (long long)n_packets, us(t_begin, t_arena), us(t_arena, t_pass1), was_parallel ? "parallel" : "serial",
                 us(t_pass1, t_pass2), us(t_pass2, t_end));
     }
-    return call.mismatches ? set_error(ctx, VPZ_E_WINDOW_MISMATCH, mismatch_text) : VPZ_OK;
+    return VPZ_OK;  // (window mismatches are per-packet conditions: vpz_decoder_last_packet_status)
+}
+
+int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packets, const float *residue,
+                      int64_t residue_floats, const int16_t *posts, const uint8_t *post_counts, int64_t n_records,
+                      int mem_space, void *pcm_out, const int64_t *stream_out_offset, int64_t stream_out_capacity,
+                      int out_layout, int64_t channel_stride, int64_t *samples_written)
+{
+    if (!d) return VPZ_E_INVALID_ARG;
+    // "never throws": the host half allocates (vectors, the descriptor arena); an allocation failure becomes a status
+    try {
+        return synth_impl(d, n_packets, packets, residue, residue_floats, posts, post_counts, n_records, mem_space, pcm_out,
+                          stream_out_offset, stream_out_capacity, out_layout, channel_stride, samples_written);
+    } catch (const std::bad_alloc &) {
+        return set_error(d->impl.ctx, VPZ_E_NOMEM, "vpz_decoder_synth: host allocation failed");
+    } catch (...) {
+        return set_error(d->impl.ctx, VPZ_E_NOMEM, "vpz_decoder_synth: host pass failed");
+    }
+}
+
+int vpz_decoder_last_packet_status(vpz_decoder *d, int32_t *out, int64_t capacity, int64_t *n_not_ok)
+{
+    if (!d || capacity < 0 || (capacity > 0 && !out)) return VPZ_E_INVALID_ARG;
+    Decoder &D = d->impl;
+    const int64_t n = std::min<int64_t>(capacity, (int64_t)D.packet_samples.size());
+    for (int64_t i = 0; i < n; ++i) out[i] = VPZ_OK;
+    for (int64_t p : D.mismatch_packets)
+        if (p < n) out[p] = VPZ_E_WINDOW_MISMATCH;
+    if (n_not_ok) *n_not_ok = (int64_t)D.mismatch_packets.size();
+    return VPZ_OK;
 }
 
 // test-only: the integers of the Floor1 device path (include/vorbispizza_synth_debug.h)

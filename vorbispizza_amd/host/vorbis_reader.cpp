@@ -41,6 +41,7 @@ struct Sub {
     // DecodeNextPacket): surfaced once by the Read that reaches it, the packets around it are unaffected
     int64_t failed_packet = -1;
     std::string failed_text;
+    std::vector<int32_t> packet_status;  // per packet of the batch, empty when all are VPZ_OK
     // scratch for the front end
     std::vector<vpz_packet> packets;
     std::vector<float> residue;
@@ -94,6 +95,7 @@ struct Sub {
         cur_offset = 0;
         cur_remaining = 0;
         failed_packet = -1;
+        packet_status.clear();
         if (next_packet >= info.audio_packets) { ended = true; return VPZ_OK; }
         int rc = ensure_decoder();
         if (rc != VPZ_OK) return rc;
@@ -128,14 +130,22 @@ struct Sub {
         if (s16) pcm16.assign((size_t)cap * C, 0);
         else pcm.assign((size_t)cap * C, 0.f);
         int64_t written = 0;
-        rc = vpz_decoder_synth(dec, n, packets.data(), residue.data(), posts.data(), counts.data(), VPZ_MEM_HOST,
+        rc = vpz_decoder_synth(dec, n, packets.data(), residue.data(), (int64_t)residue.size(), posts.data(), counts.data(),
+                               (int64_t)counts.size(), VPZ_MEM_HOST,
                                s16 ? static_cast<void *>(pcm16.data()) : static_cast<void *>(pcm.data()), nullptr, cap,
                                s16 ? VPZ_OUT_INTERLEAVED_S16 : VPZ_OUT_INTERLEAVED, 0, &written);
-        // a window mismatch (the reference's OverlapBuffers exception) costs only that packet; the
-        // reference test harness never reads that far (AssetTest.cs:107-118), so keep going
-        if (rc != VPZ_OK && rc != VPZ_E_WINDOW_MISMATCH) return fail(rc, vpz_context_last_error(ctx));
+        if (rc != VPZ_OK) return fail(rc, vpz_context_last_error(ctx));
         packet_samples.resize((size_t)n);
         vpz_decoder_last_packet_samples(dec, packet_samples.data(), n);
+        // a window mismatch (the reference's OverlapBuffers exception, StreamDecoder.cs:777-778) costs only that packet's
+        // Read: the Read that reaches the packet reports it, once, and the next one goes on behind it
+        int64_t not_ok = 0;
+        vpz_decoder_last_packet_status(dec, nullptr, 0, &not_ok);
+        packet_status.clear();
+        if (not_ok > 0) {
+            packet_status.resize((size_t)n);
+            vpz_decoder_last_packet_status(dec, packet_status.data(), n, nullptr);
+        }
         if (s16) pcm16.resize((size_t)written * C);
         else pcm.resize((size_t)written * C);
         return VPZ_OK;
@@ -169,6 +179,14 @@ struct Sub {
                             failed_packet = -1;
                             ++cur_packet;
                             *status = fail(VPZ_E_INVALID_ARG, failed_text.c_str());
+                            return idx;
+                        }
+                        if (!packet_status.empty() && packet_status[cur_packet] != VPZ_OK) {  // OverlapBuffers threw
+                            const int st = packet_status[cur_packet];
+                            packet_status[cur_packet] = VPZ_OK;
+                            ++cur_packet;
+                            *status = fail(st, "the packet's previous tail is longer than its window slope "
+                                               "(StreamDecoder.cs:777-778); the packet was skipped");
                             return idx;
                         }
                         cur_remaining = packet_samples[cur_packet++];

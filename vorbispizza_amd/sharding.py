@@ -138,6 +138,21 @@ def sum_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def gather_floats(values, device="cpu"):
+    """Every rank's list of python floats, as a list indexed by rank (one SUM all-reduce of a [world, len] matrix in
+    which a rank fills only its own row; [values] when not distributed).  Diagnostics only -- per-rank timings."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [[float(v) for v in values]]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = torch.zeros((world, len(values)), dtype=torch.float64)
+    t[rank] = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [[float(v) for v in row] for row in t.cpu()]
+
+
 def finalize():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
