@@ -1,0 +1,145 @@
+"""The stereo fast path (synth_dual.hip: one wavefront synthesises both channels of a stream -- 16-byte loads of the
+Residue2 vector, coupling in registers, two transforms side by side, dense L R L R stores) against the routes it
+replaces, bit for bit: group mode of synth_kernel (VPZ_NO_DUAL=1) and the separate coupling pass (VPZ_NO_GROUP=1 too);
+and against the oracle.  Residue2.cs:42-51, Mapping.cs:166-195, StreamDecoder.cs:764-791."""
+import numpy as np
+import pytest
+
+import helpers
+from helpers import PKT_EOS
+from test_host_paths_gpu import env, run, stream_major_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import __graft_entry__ as ge
+    ge.build()
+    from vorbispizza_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+ROUTES = (("dual", dict(VPZ_NO_DUAL=None, VPZ_NO_GROUP=None)), ("group", dict(VPZ_NO_DUAL=1, VPZ_NO_GROUP=None)),
+          ("separate", dict(VPZ_NO_DUAL=1, VPZ_NO_GROUP=1)))
+
+
+def same_bits(a, b):
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    if a[0].dtype == np.int16:
+        assert np.array_equal(a[0], b[0])
+    else:
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+
+
+@pytest.mark.parametrize("interleaved", [True, False])
+@pytest.mark.parametrize("steps", [[(0, 1)], [(1, 0)], [(0, 1), (1, 0), (0, 1)], []])
+@pytest.mark.parametrize("host", ["serial", "parallel"])
+def test_floored_stereo_dual_equals_group_and_separate(ctx, oracle, interleaved, steps, host):
+    """Floor1 + coupling, both input layouts, streams with streaks of short blocks and silent channels, every output
+    layout, two calls per stream (the overlap state crosses the call)."""
+    from vorbispizza_amd import capi
+    n_streams, frames, channels = 20, 70, 2
+    pk, res, posts, counts = stream_major_batch(n_streams, frames, channels, seed=9100 + len(steps) + 10 * interleaved,
+                                                floor=True, interleaved=interleaved, p_ls=0.2, p_sl=0.25, silent_prob=0.12)
+    pk["mapping"] = pk["flags"] & 1
+    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)]
+    mappings = [{"coupling": steps, "channel_floor": [0, 0]}, {"coupling": steps, "channel_floor": [1, 1]}]
+    hostkv = dict(VPZ_PAR_MIN_PACKETS=1 << 40) if host == "serial" else dict(VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=4)
+    for layout in (capi.OUT_PLANAR, capi.OUT_INTERLEAVED, capi.OUT_INTERLEAVED_S16, capi.OUT_PLANAR_S16):
+        outs = {}
+        for name, kv in ROUTES:
+            with env(**dict(kv, **hostkv)):
+                outs[name] = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
+        same_bits(outs["dual"], outs["group"])
+        same_bits(outs["dual"], outs["separate"])
+        assert np.abs(outs["dual"][0].astype(np.float64)).max() > 0
+    # ... and one stream against the oracle
+    s_, per = 7, frames
+    opk = []
+    for i in range(s_ * per, (s_ + 1) * per):
+        half = 1024 if pk["flags"][i] & 1 else 128
+        off = int(pk["residue_offset"][i])
+        opk.append({"flags": int(pk["flags"][i]), "granule": -1, "mapping": int(pk["mapping"][i]),
+                    "residue": res[off: off + channels * half], "posts": posts[i * channels:(i + 1) * channels],
+                    "post_count": counts[i * channels:(i + 1) * channels]})
+    ref, _, _ = helpers.oracle_decode(oracle, channels, 256, 2048, opk, floors=floors, mappings=mappings)
+    with env(**dict(ROUTES[0][1], **hostkv)):
+        got = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=capi.OUT_PLANAR, splits=2)
+    cap = per * 1024 + 64
+    pcm = got[0][s_ * channels * cap:(s_ + 1) * channels * cap].reshape(channels, cap)[:, :ref.shape[1]]
+    assert got[1][s_] == ref.shape[1] and ref.shape[1] > 0
+    assert np.abs(pcm - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("interleaved", [True, False])
+@pytest.mark.parametrize("p_sl", [0.1, 0.6])
+def test_already_floored_stereo_dual_equals_the_one_channel_kernel(ctx, interleaved, p_sl):
+    """VPZ_PKT_NO_FLOOR packets (BASELINE configs[2]'s shape): no coupling, no curve -- but batches of short blocks,
+    which only the stereo fast path forms for them."""
+    from vorbispizza_amd import capi
+    n_streams, frames, channels = 18, 120, 2
+    pk, res, _, _ = stream_major_batch(n_streams, frames, channels, seed=5200 + interleaved, floor=False, interleaved=interleaved,
+                                       p_ls=0.2, p_sl=p_sl)
+    for layout in (capi.OUT_PLANAR, capi.OUT_INTERLEAVED, capi.OUT_INTERLEAVED_S16, capi.OUT_PLANAR_S16):
+        outs = {}
+        for name, kv in ROUTES[:2]:
+            with env(**dict(kv, VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=3)):
+                outs[name] = run(ctx, pk, res, None, None, n_streams, channels, layout=layout, splits=3)
+        same_bits(outs["dual"], outs["group"])
+        assert np.abs(outs["dual"][0].astype(np.float64)).max() > 0
+
+
+def test_unaligned_output_rows_and_eos_trim(ctx, oracle):
+    """Output rows that start off a 16-byte boundary take the element-wise store path; an EOS-trimmed last packet cuts a
+    frame where groups of four samples no longer fit.  Dual against group, and the trimmed stream against the oracle."""
+    from vorbispizza_amd import Decoder, capi
+    channels, n_streams, frames = 2, 6, 40
+    pk, res, posts, counts = stream_major_batch(n_streams, frames, channels, seed=31, floor=True, interleaved=True, p_ls=0.3,
+                                                p_sl=0.3, silent_prob=0.0)
+    pk["mapping"] = pk["flags"] & 1
+    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)]
+    mappings = [{"coupling": [(0, 1)], "channel_floor": [0, 0]}, {"coupling": [(0, 1)], "channel_floor": [1, 1]}]
+    # every stream ends with EOS and a granule position that cuts 1..300 samples off its last packet
+    idx = np.arange(len(pk)).reshape(n_streams, frames)
+    full = None
+    cap = frames * 1024 + 64
+    results = {}
+    for name, kv in ROUTES[:2]:
+        with env(**dict(kv, VPZ_PAR_MIN_PACKETS=1 << 40)):
+            dec = Decoder(ctx, channels, 256, 2048, floors=floors, mappings=mappings, n_streams=n_streams)
+            out = np.zeros(n_streams * channels * cap + 8, dtype=np.float32)
+            offs = np.arange(n_streams, dtype=np.int64) * channels * cap + 1  # rows start 4 bytes off
+            if full is None:  # sample counts without a trim
+                full = dec.synth_raw(pk, res, posts, counts, out, offs, cap, capi.OUT_INTERLEAVED, 0, capi.MEM_HOST).copy()
+                dec.reset(-1)
+                for s in range(n_streams):
+                    dec.set_position(0, stream=s)
+            sub = pk.copy()
+            for s in range(n_streams):
+                last = idx[s, -1]
+                sub["flags"][last] |= PKT_EOS
+                sub["granule"][last] = int(full[s]) - (1 + 53 * s)
+            out[:] = 0
+            w = dec.synth_raw(sub, res, posts, counts, out, offs, cap, capi.OUT_INTERLEAVED, 0, capi.MEM_HOST)
+            results[name] = (out.copy(), w.copy())
+            dec.close()
+    assert np.array_equal(results["dual"][1], results["group"][1])
+    assert [int(full[s] - results["dual"][1][s]) for s in range(n_streams)] == [1 + 53 * s for s in range(n_streams)]
+    assert np.array_equal(results["dual"][0].view(np.uint32), results["group"][0].view(np.uint32))
+    s_ = 3
+    opk = []
+    for i in idx[s_]:
+        half = 1024 if pk["flags"][i] & 1 else 128
+        off = int(pk["residue_offset"][i])
+        fl = int(pk["flags"][i]) | (PKT_EOS if i == idx[s_, -1] else 0)
+        opk.append({"flags": fl, "granule": int(full[s_]) - (1 + 53 * s_) if i == idx[s_, -1] else -1,
+                    "mapping": int(pk["mapping"][i]), "residue": res[off: off + channels * half],
+                    "posts": posts[i * channels:(i + 1) * channels], "post_count": counts[i * channels:(i + 1) * channels]})
+    ref, _, _ = helpers.oracle_decode(oracle, channels, 256, 2048, opk, floors=floors, mappings=mappings, interleave=True)
+    n = int(results["dual"][1][s_])
+    got = results["dual"][0][1 + s_ * channels * cap: 1 + s_ * channels * cap + n * channels].reshape(n, channels)
+    assert ref.shape == got.shape
+    assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))

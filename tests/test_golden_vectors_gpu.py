@@ -105,19 +105,26 @@ def test_floor1_of_3test(ctx):
 
 @pytest.mark.parametrize("name", ["1test", "2test", "3test", "issue6test"])
 def test_fixture_pcm_heads(ctx, name):
+    from vorbispizza_amd import capi
     from vorbispizza_amd.front import VorbisReader
     v = load("fixture_pcm_heads.npz")
     channels, rate, packets, total, pos, clipped, mid = (int(x) for x in v[name + "_meta"])
     rdr = VorbisReader(ctx, os.path.join(GOLDEN, name + ".ogg"))
     assert (rdr.Channels, rdr.SampleRate) == (channels, rate)
     buf = np.zeros(channels * 4096, dtype=np.float32)
-    chunks = []
+    chunks, thrown = [], 0
     while True:
-        n = rdr.ReadSamples(buf)
+        try:
+            n = rdr.ReadSamples(buf)
+        except capi.SynthError as e:  # issue6test's trailing empty packet: that one Read throws (StreamDecoder.cs:777-778)
+            assert e.status == capi.E_WINDOW_MISMATCH and name == "issue6test"
+            thrown += 1
+            continue
         if n == 0:
             break
         chunks.append(buf[: n * channels].reshape(n, channels).copy())
     got = np.concatenate(chunks).T
+    assert thrown == (1 if name == "issue6test" else 0)
     assert got.shape == (channels, total) and rdr.SamplePosition == pos and rdr.HasClipped == bool(clipped)
     assert np.abs(got[:, :4096] - v[name + "_pcm"]).max() <= 1e-5
     assert np.abs(got[:, mid: mid + 2048] - v[name + "_mid"]).max() <= 1e-5

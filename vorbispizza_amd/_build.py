@@ -19,6 +19,7 @@ SOURCES = {
     "imdct_fast.hip": [],
     "imdct_exact.hip": ["-ffp-contract=off"],
     "synth_kernels.hip": [],
+    "synth_dual.hip": [],
     "floor0.hip": ["-ffp-contract=off"],
     "vpz_context.hip": ["-ffp-contract=off"],
     "vpz_decoder.hip": ["-ffp-contract=off"],

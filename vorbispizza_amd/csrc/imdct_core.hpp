@@ -223,6 +223,141 @@ __device__ __forceinline__ void imdct256_wave8(const float2 (&xa)[8], float2 *sc
 }
 
 // -------------------------------------------------------------------------------------------
+// Two independent transforms by ONE wavefront, step by step side by side (synth_dual.hip: both channels of a stereo
+// stream): every twiddle is read from LDS once for both, and each transform's LDS round trips (transposes, lane
+// mirrors) are covered by the other's arithmetic -- the wave carries two dependency chains instead of one.  The
+// operations per transform and their order are exactly those of the single versions above: same bits.
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dft512_wave_x2(float2 (&za)[8], float2 (&zb)[8], float2 *sa, float2 *sb,
+                                               const float2 *s_twAB, const float2 *s_twBC, int lane)
+{
+    radix8_inverse(za);
+    radix8_inverse(zb);
+#pragma unroll
+    for (int p = 1; p < 8; ++p) {
+        const float2 w = s_twAB[p * 64 + lane];
+        za[p] = cmul(za[p], w);
+        zb[p] = cmul(zb[p], w);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        sa[72 * p + lane] = za[p];
+        sb[72 * p + lane] = zb[p];
+    }
+    const int l0 = lane & 7, pp = lane >> 3;
+#pragma unroll
+    for (int l1 = 0; l1 < 8; ++l1) {
+        za[l1] = sa[72 * pp + l0 + 8 * l1];
+        zb[l1] = sb[72 * pp + l0 + 8 * l1];
+    }
+    radix8_inverse(za);
+    radix8_inverse(zb);
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+        const float2 w = s_twBC[l0 * 8 + q];
+        za[q] = cmul(za[q], w);
+        zb[q] = cmul(zb[q], w);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        sa[66 * l0 + pp + 8 * q] = za[q];
+        sb[66 * l0 + pp + 8 * q] = zb[q];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        za[r] = sa[66 * r + lane];
+        zb[r] = sb[66 * r + lane];
+    }
+    radix8_inverse(za);
+    radix8_inverse(zb);
+}
+
+// imdct2048_wave for two spectra (xa -> scratch_a, xb -> scratch_b)
+__device__ __forceinline__ void imdct2048_wave_x2(const float2 (&xa)[8], const float2 (&xb)[8], float2 *scratch_a,
+                                                  float2 *scratch_b, const float2 *s_tw, const float2 *s_twAB,
+                                                  const float2 *s_twBC, int lane)
+{
+    float2 za[8], zb[8];
+    float2 tw[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) tw[m] = s_tw[lane + 64 * m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const float ra = lane_mirror64(xa[7 - m].y, lane), rb = lane_mirror64(xb[7 - m].y, lane);
+        za[m] = cmul(make_float2(ra, xa[m].x), tw[m]);
+        zb[m] = cmul(make_float2(rb, xb[m].x), tw[m]);
+    }
+    dft512_wave_x2(za, zb, scratch_a, scratch_b, s_twAB, s_twBC, lane);
+    float wa[8], wb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float2 a = cmul(za[q], tw[q]), b = cmul(zb[q], tw[q]);
+        za[q].x = a.x;
+        wa[q] = -a.y;
+        zb[q].x = b.x;
+        wb[q] = -b.y;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float ha = lane_mirror64(wa[7 - q], lane), hb = lane_mirror64(wb[7 - q], lane);
+        scratch_a[lane + 64 * q] = make_float2(za[q].x, ha);
+        scratch_b[lane + 64 * q] = make_float2(zb[q].x, hb);
+    }
+}
+
+// imdct256_wave8 for two sets of eight blocks (lane group g transforms block g of each set)
+__device__ __forceinline__ void imdct256_wave8_x2(const float2 (&xa)[8], const float2 (&xb)[8], float2 *scratch_a,
+                                                  float2 *scratch_b, const float2 *s_tw, const float2 *s_twBC, int lane)
+{
+    const int g = lane >> 3, l = lane & 7;
+    float2 za[8], zb[8];
+    float2 tw[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) tw[m] = s_tw[l + 8 * m];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const float ra = lane_mirror8(xa[7 - m].y, lane), rb = lane_mirror8(xb[7 - m].y, lane);
+        za[m] = cmul(make_float2(ra, xa[m].x), tw[m]);
+        zb[m] = cmul(make_float2(rb, xb[m].x), tw[m]);
+    }
+    radix8_inverse(za);
+    radix8_inverse(zb);
+#pragma unroll
+    for (int p = 1; p < 8; ++p) {
+        const float2 w = s_twBC[l * 8 + p];
+        za[p] = cmul(za[p], w);
+        zb[p] = cmul(zb[p], w);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        scratch_a[72 * g + 9 * p + l] = za[p];
+        scratch_b[72 * g + 9 * p + l] = zb[p];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        za[r] = scratch_a[72 * g + 9 * l + r];
+        zb[r] = scratch_b[72 * g + 9 * l + r];
+    }
+    radix8_inverse(za);
+    radix8_inverse(zb);
+    float wa[8], wb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float2 a = cmul(za[q], tw[q]), b = cmul(zb[q], tw[q]);
+        za[q].x = a.x;
+        wa[q] = -a.y;
+        zb[q].x = b.x;
+        wb[q] = -b.y;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float ha = lane_mirror8(wa[7 - q], lane), hb = lane_mirror8(wb[7 - q], lane);
+        scratch_a[g * 64 + l + 8 * q] = make_float2(za[q].x, ha);
+        scratch_b[g * 64 + l + 8 * q] = make_float2(zb[q].x, hb);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // N = 4096: the 1024-point transform as two 512-point ones (even / odd input points) and one radix-2 step.
 // xa[m] = X[4k' .. 4k'+3] for k' = lane + 64*m.  On return `h` (>= 1024 float2, wave-private; its first 576
 // float2 double as the transposes' scratch) holds h[0..2048) in natural order.

@@ -1,0 +1,808 @@
+// synth_dual_kernel -- the stereo fast path of vpz_decoder_synth: ONE wavefront synthesises BOTH channels of a run of
+// consecutive blocks of one stream.
+//
+//   Residue2.cs:42-51   the interleaved vector [bin][2] never needs a de-interleave pass: the float4 at index k IS
+//                       (L[2k], R[2k], L[2k+1], R[2k+1]), i.e. point k of both channels' transforms for the lane that
+//                       loads it -- 16-byte loads, every wave-load one contiguous 1 KiB span;
+//   Mapping.cs:166-195  inverse coupling in registers (couple(), element-wise), steps in reverse order; then per channel
+//                       ExecuteChannel ? floor curve x spectrum -> inverse MDCT : a block of +0.0;
+//   Floor1.cs:222-397   both channels' curves rendered side by side into the two LDS rows the transforms then use;
+//   Mdct.cs             two transforms per wave, step by step side by side (imdct2048_wave_x2): twiddles read once for
+//                       both, each one's LDS round trips covered by the other's arithmetic;
+//   StreamDecoder.cs:764-791, 515-638   window + overlap-add + clip, and the store: interleaved output leaves as dense
+//                       (L R L R) 16-byte pieces written by the one wave that holds both channels.
+//
+// No workgroup barrier after the tables are staged, no lock step between waves, no LDS staging of the packet: what group
+// mode of synth_kernel spends on them (16 % on the de-interleave's LDS stores, 4 % on barriers, the
+// coupling's LDS round trip) is gone.  A workgroup is 4 waves x 2 channels: the same LDS per channel as synth_kernel's,
+// 2 workgroups = 8 waves per CU, up to 256 VGPRs per lane.
+// Up to eight consecutive SHORT blocks go through one pass (lane group g takes block g, both channels), for floored and
+// for already-floored (VPZ_PKT_NO_FLOOR) packets, interleaved or planar input.
+// Arithmetic per channel is operation for operation that of synth_kernel: the two give the same bits.
+#include <cstdlib>
+#include <type_traits>
+
+#include "imdct_core.hpp"
+#include "synth_common.hpp"
+#include "synth_desc.hpp"
+#include "vpz_internal.hpp"
+
+namespace vpz {
+
+constexpr int kDualWaves = 4;
+constexpr int kDualThreads = 64 * kDualWaves;
+
+// Both channels' Floor1 curves at once (render_floor_indices_fast, phase by phase for the two records): the phases are
+// chains of dependent LDS round trips, side by side they overlap.  c = 0 / 1: out[c] (one byte per bin), aux[c],
+// n_render[c] (0: nothing to render for this channel), cp[c] / m[c] (the record's active posts, this lane's and their
+// count).  Returns false -- nothing usable written -- if a record breaks the closed form's bound (corrupt streams only).
+__device__ __forceinline__ bool render_floor_indices_fast_x2(uint8_t *out0, uint8_t *out1, int *aux0, int *aux1, int n,
+                                                             int n_render0, int n_render1, int cp0, int cp1, int m0, int m1,
+                                                             int lane)
+{
+    uint8_t *out[2] = {out0, out1};
+    int *aux[2] = {aux0, aux1};
+    const int n_render[2] = {n_render0, n_render1}, cp[2] = {cp0, cp1}, mm[2] = {m0, m1};
+    int x0[2], x1[2];
+    float x0f[2], y0f[2], dyf[2], rinv[2];
+    bool mine[2];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int p1 = __shfl_down(cp[c], 1);
+        x0[c] = cp[c] & 0xFFFF;
+        const int y0 = cp[c] >> 16;
+        int x1raw = n, y1 = y0;  // flat tail after the last active post (Floor1.cs:259-262)
+        if (lane + 1 < mm[c]) { x1raw = p1 & 0xFFFF; y1 = p1 >> 16; }
+        x1[c] = x1raw < n ? x1raw : n;  // Math.Min(hx, n) enters the slope: quirk q2 (Floor1.cs:248)
+        const int adx = x1[c] - x0[c];
+        const int dy = y1 - y0;
+        mine[c] = n_render[c] > 0 && lane < mm[c] && adx > 0;
+        bad |= mine[c] && iabs(dy) * adx > (1 << 21);
+        x0f[c] = (float)x0[c];
+        y0f[c] = (float)y0;
+        dyf[c] = (float)dy;
+        rinv[c] = __builtin_amdgcn_rcpf((float)(adx > 0 ? adx : 1));
+    }
+    if (__any(bad)) return false;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+        if (lane < 32) aux[c][lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+        if (mine[c]) {
+            atomicOr(reinterpret_cast<unsigned int *>(&aux[c][x0[c] >> 5]), 1u << (x0[c] & 31));
+            reinterpret_cast<float4 *>(aux[c] + 64)[lane] = make_float4(x0f[c], y0f[c], dyf[c], rinv[c]);
+        }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int c0 = (lane < 32) ? __popc((unsigned)aux[0][lane]) : 0;
+        const int c1 = (lane < 32) ? __popc((unsigned)aux[1][lane]) : 0;
+        const int i0 = wave_scan32(c0), i1 = wave_scan32(c1);
+        if (lane < 32) {
+            aux[0][32 + lane] = i0 - c0;
+            aux[1][32 + lane] = i1 - c1;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int rounds0 = (n_render[0] + 255) >> 8, rounds1 = (n_render[1] + 255) >> 8;
+    const int rounds = rounds0 > rounds1 ? rounds0 : rounds1;
+    for (int r = 0; r < rounds; ++r) {
+        const int w = lane + 64 * r, x = 4 * w;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (x < n_render[c]) {
+                const int *bitmap = aux[c], *prefix = aux[c] + 32;
+                const float4 *seg = reinterpret_cast<const float4 *>(aux[c] + 64);
+                const unsigned bw = (unsigned)bitmap[x >> 5];
+                const int j = prefix[x >> 5] + __popc(bw & ((2u << (x & 31)) - 1u)) - 1;
+                const float4 sg = seg[j];
+                float t = fmaf((float)x - sg.x, sg.z, copysignf(0.5f, sg.z));
+                uint32_t pk = 0;
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(sg.y + truncf(t * sg.w), 0, pk);
+                t += sg.z;
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(sg.y + truncf(t * sg.w), 1, pk);
+                t += sg.z;
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(sg.y + truncf(t * sg.w), 2, pk);
+                t += sg.z;
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(sg.y + truncf(t * sg.w), 3, pk);
+                reinterpret_cast<uint32_t *>(out[c])[w] = pk;
+            }
+        }
+    }
+    // a post inside a word: its bins up to the end of that word (or of its segment) belong to its own line
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int xe = x1[c] < n_render[c] ? x1[c] : n_render[c];
+        const int al = x0[c] & 3;
+        if (mine[c] && al != 0 && x0[c] < xe) {
+            const int cnt = min(4 - al, xe - x0[c]);
+            float t = copysignf(0.5f, dyf[c]);
+            out[c][x0[c]] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(y0f[c] + truncf(t * rinv[c]), 0, 0u);
+            t += dyf[c];
+            if (cnt > 1) out[c][x0[c] + 1] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(y0f[c] + truncf(t * rinv[c]), 0, 0u);
+            t += dyf[c];
+            if (cnt > 2) out[c][x0[c] + 2] = (uint8_t)__builtin_amdgcn_cvt_pk_u8_f32(y0f[c] + truncf(t * rinv[c]), 0, 0u);
+        }
+    }
+    return true;
+}
+
+// highest bin pair below which a spectrum has non-zero values: bins [2 * (top + 1), n) are zero (the residue ends below
+// N/2 in real streams) and need no curve.  lpb: lanes that hold distinct points (64 for a 2048 block, 8 for a 256 one).
+__device__ __forceinline__ int spectrum_top(const float2 (&x)[8], int lpb)
+{
+    const unsigned long long group0 = lpb >= 64 ? ~0ull : ((1ull << lpb) - 1ull);
+    int top = -1;
+#pragma unroll
+    for (int m = 7; m >= 0; --m) {
+        const unsigned long long b = __ballot(x[m].x != 0.0f || x[m].y != 0.0f) & group0;
+        if (top < 0 && b != 0) top = lpb * m + 63 - __clzll(b);
+    }
+    return top;
+}
+
+// kIlvIn : every packet of the batch is the Residue2-interleaved vector [bin][2] (else: every packet planar [2][bin])
+// kOut   : 0 planar output, 1 interleaved
+template <bool kHasFloor, bool kIlvIn, int kOut, bool kS16>
+__global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a)
+{
+    using out_t = typename std::conditional<kS16, int16_t, float>::type;
+    constexpr bool kInterleavedOut = kOut != 0;
+    __shared__ float2 s_twL[512];
+    __shared__ float2 s_twAB[512];
+    __shared__ float2 s_twBC[64];
+    __shared__ float2 s_twS[64];
+    __shared__ float s_slope1[1024];
+    __shared__ float s_slope0[128];
+    __shared__ float s_db[kHasFloor ? 256 : 1];
+    __shared__ __attribute__((aligned(8))) uint8_t s_steps[2 * kGroupMaxStepPairs + 8];
+    __shared__ PacketGeom s_geom[8];
+    __shared__ float s_work[kDualWaves][2][kWaveBufFloats];   // h of the two blocks being built
+    __shared__ float s_tail[kDualWaves][2][kWaveTailFloats];  // upper halves of the previous blocks' h
+    __shared__ uint4 s_desc[kDualWaves][(kMaxRunLength + 1) * 2];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int run_idx = blockIdx.x * kDualWaves + wave;
+    const bool active = run_idx < a.n_runs;
+    RunDesc run = a.runs[active ? run_idx : 0];
+    if (!active) {
+        run.count = 0;
+        run.pre_kind = kPreNone;
+        run.flags = 0;
+    }
+    // (the run record and a compact run's bytes sit in pinned host memory: asked for ahead of the table staging)
+    const int fi0 = (run.pre_kind == kPreRecompute && run.count > 0) ? -1 : 0;
+    uint32_t cf_early = 0, mp_early = 0;
+    int cc_early = 0;
+    if (run.flags & kRunCompact) {
+        const int n = run.count - fi0, f0 = run.first + fi0;
+        if (lane < n) {
+            cf_early = a.cflags[f0 + lane];
+            mp_early = a.cmap[f0 + lane];
+            if (kHasFloor && a.ccount != nullptr)  // both channels' post counts: records 2p, 2p + 1
+                cc_early = *reinterpret_cast<const uint16_t *>(a.ccount + run.rec_base + lane * 2);
+        }
+    }
+    {
+        const bool has_long = a.size1 == 2048 || a.size0 == 2048;
+        const bool has_short = a.size0 == 256 || a.size1 == 256;
+        for (int i = threadIdx.x; i < 512; i += kDualThreads) {
+            if (has_long) {
+                s_twL[i] = a.tw_long[kFastTwOffset + i];
+                s_twAB[i] = a.tw_long[kFastTwABOffset + i];
+            }
+        }
+        const float2 *any = has_long ? a.tw_long : a.tw_short;
+        if (threadIdx.x < 64) {
+            s_twBC[threadIdx.x] = any[kFastTwBCOffset + threadIdx.x];
+            if (has_short) s_twS[threadIdx.x] = a.tw_short[kFastTwOffset + threadIdx.x];
+        }
+    }
+    for (int i = threadIdx.x; i < a.size1 / 2; i += kDualThreads) s_slope1[i] = a.slope1[i];
+    for (int i = threadIdx.x; i < a.size0 / 2 && i < 128; i += kDualThreads) s_slope0[i] = a.slope0[i];
+    if (kHasFloor && threadIdx.x < 256) s_db[threadIdx.x] = a.inv_db[threadIdx.x];
+    if (threadIdx.x < 8) s_geom[threadIdx.x] = a.geom[threadIdx.x];
+    for (int i = threadIdx.x; i < 2 * a.n_step_pairs && i < 2 * kGroupMaxStepPairs; i += kDualThreads) s_steps[i] = a.steps[i];
+    __syncthreads();
+    if (!active) return;  // the only workgroup barrier is behind us: waves run free from here
+
+    const int half1 = a.size1 >> 1;
+    float *hL = s_work[wave][0], *hR = s_work[wave][1];
+    float *tailL = s_tail[wave][0], *tailR = s_tail[wave][1];
+    int prev_n4 = 0;  // n/4 of the previous block (0: none yet)
+
+    auto size_of = [&](uint32_t flags) -> int { return (flags & kFrameLong) ? a.size1 : a.size0; };
+
+    // ---- the run's frame descriptors into LDS (explicit ones copied, a compact run's derived here)
+    bool batch_member = false;
+    if (run.flags & kRunCompact) {
+        const int n = run.count - fi0;  // staged frames (<= kMaxRunLength + 1 <= 64), one lane each
+        const uint32_t cf = cf_early, mp = mp_early;
+        const uint32_t pcf = __shfl_up(cf, 1);
+        const PacketGeom g = s_geom[cf & 7], pg = s_geom[pcf & 7];
+        const bool has_prev = lane > 0 || run.has_prev0;
+        const int prev_end = lane > 0 ? pg.right_start : run.prev_end0;
+        const int prev_stop = lane > 0 ? pg.right_end : run.prev_stop0;
+        int left_start = has_prev ? g.left_start : g.right_start;  // StreamDecoder.cs:674 / :679
+        int out_count = has_prev ? max(0, (int)g.right_start - (int)g.left_start) : 0;
+        uint32_t fl = ((cf & 1) ? kFrameLong : 0u) | (g.left_use_size1 ? kFrameSlope1 : 0u) |
+                      ((cf & kCfNoFloor) ? kFrameNoFloor : 0u);
+        if (!(cf & kCfNoFloor)) fl |= a.map_bits[mp];
+        if (cf & kCfSkip) { fl = kFrameDrain; out_count = 0; }
+        if ((run.flags & kRunLastTrimmed) && lane == n - 1) { out_count = run.last_out_count; left_start = run.last_left_start; }
+        // Batches of SHORT blocks: a short block costs a pass most of what a long one costs (the 256-point transform
+        // computes eight copies of one block, the pass's fixed parts do not shrink) for an eighth of the samples, and
+        // real streams hold them in streaks.  Up to eight consecutive short blocks of a run go through ONE pass: lane
+        // group g takes block g.  A block joins a batch if it is a plain short-after-short step of its predecessor's
+        // mapping and kind (floored or not); the first short block after a long one heads a batch.
+        {
+            const uint32_t pmp = __shfl_up(mp, 1);
+            const uint32_t pnf = __shfl_up(cf & kCfNoFloor, 1);
+            const bool after_short = prev_end == 128 && prev_stop == 256;
+            const bool after_long = a.size1 == 2048 && prev_end == 1472 && prev_stop == 1600;
+            const bool base_ok = lane < n && lane >= -fi0 && a.size0 == 256 && a.size1 != 256 && !(cf & 1) && !(cf & kCfSkip) &&
+                                 has_prev && out_count == 128 && left_start == 0 && (after_short || after_long) &&
+                                 !(a.ablate & 128);
+            const bool base_prev = __shfl_up((int)base_ok, 1) != 0 && lane > 0 && after_short;
+            const bool brk = !(base_ok && base_prev && mp == pmp && (cf & kCfNoFloor) == pnf);
+            const unsigned long long mask_brk = __ballot(brk);
+            if (base_ok) {
+                const unsigned long long below = mask_brk & ((2ull << lane) - 1ull);  // (never empty: lane 0 breaks)
+                const int start = 63 - __clzll(below);
+                const unsigned long long above = lane < 63 ? (mask_brk >> (lane + 1)) : 0ull;
+                const int end = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+                const int pos = lane - start;
+                if ((pos & 7) == 0) {
+                    const int size = min(8, end - lane);
+                    fl |= (uint32_t)(size - 1) << kFrameBatchShift;
+                } else {
+                    batch_member = true;
+                }
+            }
+        }
+        const int half = (cf & 1) ? (a.size1 >> 1) : (a.size0 >> 1);
+        int spec_sz = lane < n ? 2 * half : 0;
+        int out_sz = (lane < n && lane >= -fi0) ? out_count : 0;
+        int spec_incl = spec_sz, out_incl = out_sz;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t0 = __shfl_up(spec_incl, d), t1 = __shfl_up(out_incl, d);
+            if (lane >= d) { spec_incl += t0; out_incl += t1; }
+        }
+        if (lane < n) {
+            const int64_t spec_off = run.spec_base + (spec_incl - spec_sz);
+            const int64_t out_off = run.out_base + (out_incl - out_sz);
+            uint4 lo, hi;
+            lo.x = (uint32_t)spec_off; lo.y = (uint32_t)((uint64_t)spec_off >> 32);
+            lo.z = (uint32_t)out_off; lo.w = (uint32_t)((uint64_t)out_off >> 32);
+            hi.x = (uint32_t)(run.rec_base + lane * 2);
+            hi.y = (uint32_t)left_start | ((uint32_t)(has_prev && !(cf & kCfSkip) ? prev_stop - prev_end : 0) << 16);
+            hi.z = (uint32_t)((has_prev && !(cf & kCfSkip)) ? prev_end : 0) | ((uint32_t)out_count << 16);
+            hi.w = fl;
+            s_desc[wave][2 * lane] = lo;
+            s_desc[wave][2 * lane + 1] = hi;
+        }
+    } else {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.frames + (run.first + fi0));
+        const int n16 = (run.count - fi0) * 2;
+        for (int i = lane; i < n16; i += 64) s_desc[wave][i] = src[i];
+    }
+    // post counts of the run's frames (ExecuteChannel), both channels in one register: lane i = the i-th staged frame
+    int cc_run = 0;
+    if (kHasFloor && a.ccount != nullptr) {
+        if (run.flags & kRunCompact) {
+            cc_run = cc_early;
+        } else {
+            __builtin_amdgcn_wave_barrier();
+            if (lane < run.count - fi0)
+                cc_run = *reinterpret_cast<const uint16_t *>(a.ccount + (int)s_desc[wave][2 * lane + 1].x);
+        }
+    }
+    const int iters = run.count - fi0 - (int)__popcll(__ballot(batch_member));
+    __builtin_amdgcn_wave_barrier();
+    auto frame_at = [&](int fi) -> FrameDesc {  // broadcast LDS read, then into SGPRs
+        const uint4 lo = s_desc[wave][(fi - fi0) * 2], hi = s_desc[wave][(fi - fi0) * 2 + 1];
+        FrameDesc fd;
+        const uint32_t w0 = __builtin_amdgcn_readfirstlane(lo.x), w1 = __builtin_amdgcn_readfirstlane(lo.y);
+        const uint32_t w2 = __builtin_amdgcn_readfirstlane(lo.z), w3 = __builtin_amdgcn_readfirstlane(lo.w);
+        const uint32_t w4 = __builtin_amdgcn_readfirstlane(hi.x), w5 = __builtin_amdgcn_readfirstlane(hi.y);
+        const uint32_t w6 = __builtin_amdgcn_readfirstlane(hi.z), w7 = __builtin_amdgcn_readfirstlane(hi.w);
+        fd.spec_off = (int64_t)(((uint64_t)w1 << 32) | w0);
+        fd.out_off = (int64_t)(((uint64_t)w3 << 32) | w2);
+        fd.rec = (int32_t)w4;
+        fd.left_start = (uint16_t)(w5 & 0xFFFF);
+        fd.packet_len = (uint16_t)(w5 >> 16);
+        fd.prev_end = (uint16_t)(w6 & 0xFFFF);
+        fd.out_count = (uint16_t)(w6 >> 16);
+        fd.flags = w7;
+        return fd;
+    };
+
+    // ---- block preceding the run: from the saved state, or recomputed as "frame -1" of the loop
+    if (run.pre_kind == kPreState) {
+        const float *st = a.state_h + (size_t)run.stream * 2 * half1;
+        prev_n4 = run.prev_long ? (a.size1 >> 2) : (a.size0 >> 2);
+        for (int i = lane; i < prev_n4; i += 64) {
+            tailL[i] = st[i];
+            tailR[i] = st[half1 + i];
+        }
+    }
+    out_t *out_base = reinterpret_cast<out_t *>(a.out) + (a.stream_out_off ? a.stream_out_off[run.stream] : 0);
+    {   // wave-uniform, but the offset arrives through a vector load: move the pointer to scalar registers
+        const uint64_t ob = reinterpret_cast<uint64_t>(out_base);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)ob), hi = __builtin_amdgcn_readfirstlane((uint32_t)(ob >> 32));
+        out_base = reinterpret_cast<out_t *>(((uint64_t)hi << 32) | lo);
+    }
+    float clip_peak = 0.0f;
+
+    // The input of a frame: 32 registers, va[m] | vb[m] = the 16 bytes lane-point m of an interleaved packet comes in
+    // ((L[2k], R[2k]) | (L[2k+1], R[2k+1])), or the point's two 8-byte pairs of a planar one ((L[2k], L[2k+1]) |
+    // (R[2k], R[2k+1])).  Every load is UNCONDITIONAL (a frame that needs no input reads the head of the inverse dB
+    // table): a load under a condition would make the wave wait for it right behind the load (see synth_kernel).
+    // Points of a lane: k = lane + 64 m for a 2048 block; for 256 blocks lane group g = lane >> 3 takes block g of the
+    // pass (block 0 again where the pass has fewer), k = (lane & 7) + 8 m.
+    auto prefetch = [&](const FrameDesc &fd, bool valid, float2 (&va)[8], float2 (&vb)[8], int &cpa, int &cpb) {
+        const bool is_long = size_of(fd.flags) == 2048;
+        const int bsz = (int)((fd.flags >> kFrameBatchShift) & 7u) + 1;
+        int l = lane;
+        asm volatile("" : "+v"(l));  // (frame-invariant lane arithmetic stays inside the iteration that uses it)
+        const int g = l >> 3, gg = g < bsz ? g : 0;
+        const float *src = valid ? a.spec + fd.spec_off : a.inv_db;
+        if (kIlvIn) {
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            const int base = !valid ? 0 : (is_long ? l : 64 * gg + (l & 7));
+            const int step = !valid ? 0 : (is_long ? 64 : 8);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float4 v = s4[base + step * m];
+                va[m] = make_float2(v.x, v.y);
+                vb[m] = make_float2(v.z, v.w);
+            }
+        } else {
+            const float2 *s2 = reinterpret_cast<const float2 *>(src);
+            // block gg of the pass: its L row at + gg * 2 * 128 floats, its R row half a packet further on
+            const int base = !valid ? 0 : (is_long ? l : 128 * gg + (l & 7));
+            const int step = !valid ? 0 : (is_long ? 64 : 8);
+            const int rofs = !valid ? 0 : (is_long ? 512 : 64);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                va[m] = s2[base + step * m];
+                vb[m] = s2[base + step * m + rofs];
+            }
+        }
+        if (kHasFloor) {
+            const bool floored = valid && !(fd.flags & kFrameNoFloor) && a.cposts != nullptr;
+            const int32_t *cp = a.cposts != nullptr ? a.cposts : reinterpret_cast<const int32_t *>(a.inv_db);
+            const size_t rec = floored ? (size_t)fd.rec : 0;
+            cpa = cp[rec * 64 + l];
+            cpb = cp[(floored ? rec + 1 : 0) * 64 + l];
+        }
+    };
+    // the first four coupling steps of a frame's mapping, read a frame ahead like the input
+    auto steps_word = [&](const FrameDesc &fd, bool valid) -> uint2 {
+        const uint32_t off = valid ? 2u * (fd.flags >> kFrameStepsOffShift) : 0u;
+        return *reinterpret_cast<const uint2 *>(s_steps + (off < 2u * kGroupMaxStepPairs ? off : 0u));
+    };
+
+    float2 va[8], vb[8];
+    int cpa = 0, cpb = 0;
+    FrameDesc fd_next = frame_at(fi0);
+    bool valid_cur = run.count > 0 && !(fd_next.flags & kFrameDrain);
+    prefetch(fd_next, valid_cur, va, vb, cpa, cpb);
+    uint2 stwcur = steps_word(fd_next, valid_cur);
+    // the first frame's input has to be there before the loop is entered (see synth_kernel: wait-count bookkeeping)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(va[m].x), "v"(va[m].y), "v"(vb[m].x), "v"(vb[m].y));
+    if (kHasFloor) asm volatile("" ::"v"(cpa), "v"(cpb));
+
+    int fi = fi0;
+    for (int it = 0; it < iters; ++it) {
+        const FrameDesc fd = fd_next;
+        const int bsz = (int)((fd.flags >> kFrameBatchShift) & 7u) + 1;  // blocks this pass covers
+        const int fin = fi + bsz;
+        float2 na[8], nb[8];
+        int cpna = 0, cpnb = 0;
+        uint2 stwnext;
+        bool valid_next;
+        {
+            const bool has_next = fin < run.count;
+            fd_next = frame_at(has_next ? fin : fi);
+            valid_next = has_next && !(fd_next.flags & kFrameDrain);
+            prefetch(fd_next, valid_next, na, nb, cpna, cpnb);
+            stwnext = steps_word(fd_next, valid_next);
+        }
+        const bool drain = fd.flags & kFrameDrain;
+        const bool batch = bsz > 1;
+        const int nblk = size_of(fd.flags);
+        const bool is_long = nblk == 2048;
+        const int n4 = is_long ? 512 : 64;
+        const bool no_floor = !kHasFloor || (fd.flags & kFrameNoFloor) || a.ccount == nullptr;
+        const int slot = fi - fi0;
+
+        if (!drain) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            // ---- the two spectra of this lane's points
+            float2 xL[8], xR[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (kIlvIn) {
+                    xL[m] = make_float2(va[m].x, vb[m].x);
+                    xR[m] = make_float2(va[m].y, vb[m].y);
+                } else {
+                    xL[m] = va[m];
+                    xR[m] = vb[m];
+                }
+            }
+            // ---- inverse coupling, steps in reverse order (Mapping.cs:166-172); a stereo step is (0, 1) or (1, 0)
+            if (!(fd.flags & kFrameNoFloor)) {
+                const int n_steps = (int)((fd.flags >> kFrameStepsShift) & 0xFF);
+                const uint8_t *st = s_steps + 2 * (fd.flags >> kFrameStepsOffShift);
+                const unsigned long long stw = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.y) << 32) |
+                                               (uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.x);
+                for (int i = n_steps - 1; i >= 0; --i) {
+                    const uint32_t mag = (n_steps <= 4 ? (uint32_t)(stw >> (16 * i)) : (uint32_t)st[2 * i]) & 0x7Fu;
+                    if (mag == 0) {
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) { couple(xL[m].x, xR[m].x); couple(xL[m].y, xR[m].y); }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) { couple(xR[m].x, xL[m].x); couple(xR[m].y, xL[m].y); }
+                    }
+                }
+            }
+            // ---- Floor1 curves x spectra (Floor1.cs:222-268), silence (Mapping.cs:190-194)
+            bool silentL = false, silentR = false;  // per lane: this lane's block of the pass is a silent channel's
+            if (!no_floor) {
+                uint8_t *rowL = reinterpret_cast<uint8_t *>(hL), *rowR = reinterpret_cast<uint8_t *>(hR);
+                int *auxL = reinterpret_cast<int *>(hL) + 256, *auxR = reinterpret_cast<int *>(hR) + 256;
+                uint32_t fyL[4], fyR[4];
+                if (!batch) {
+                    const int cc = __builtin_amdgcn_readlane(cc_run, slot);
+                    const int cntL = cc & 0xFF, cntR = (cc >> 8) & 0xFF;
+                    silentL = cntL == 0;
+                    silentR = cntR == 0;
+                    const int lpb = is_long ? 64 : 8;
+                    const int n = nblk >> 1;
+                    const int nrL = silentL ? 0 : 2 * (spectrum_top(xL, lpb) + 1);
+                    const int nrR = silentR ? 0 : 2 * (spectrum_top(xR, lpb) + 1);
+                    const int pa = ln < cntL ? cpa : 0, pb = ln < cntR ? cpb : 0;
+                    if (nrL > 0 || nrR > 0) {
+                        if (!render_floor_indices_fast_x2(rowL, rowR, auxL, auxR, n, nrL, nrR, pa, pb, cntL, cntR, ln)) {
+                            if (nrL > 0) render_floor_indices<32>(rowL, auxL, n, nrL, pa, cntL, ln);
+                            if (nrR > 0) render_floor_indices<32>(rowR, auxR, n, nrR, pb, cntR, ln);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    load_floor_indices(fyL, rowL, lpb, ln);
+                    load_floor_indices(fyR, rowR, lpb, ln);
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    // the curves of the pass's blocks, 128 bytes each, block by block (both channels side by side); their
+                    // posts are asked for here together
+                    int cps[8][2];
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) {
+                        const int ff = f < bsz ? f : 0;
+                        cps[f][0] = a.cposts[(size_t)(fd.rec + 2 * ff) * 64 + ln];
+                        cps[f][1] = a.cposts[(size_t)(fd.rec + 2 * ff + 1) * 64 + ln];
+                    }
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) {
+                        if (f < bsz) {
+                            const int cc = __builtin_amdgcn_readlane(cc_run, slot + f);
+                            const int cntL = cc & 0xFF, cntR = (cc >> 8) & 0xFF;
+                            if ((ln >> 3) == f) {
+                                silentL = cntL == 0;
+                                silentR = cntR == 0;
+                            }
+                            const int pa = ln < cntL ? cps[f][0] : 0, pb = ln < cntR ? cps[f][1] : 0;
+                            const int nrL = cntL ? 128 : 0, nrR = cntR ? 128 : 0;
+                            if (nrL | nrR) {
+                                if (!render_floor_indices_fast_x2(rowL + 128 * f, rowR + 128 * f, auxL, auxR, 128, nrL, nrR, pa, pb,
+                                                                  cntL, cntR, ln)) {
+                                    if (nrL) render_floor_indices<32>(rowL + 128 * f, auxL, 128, 128, pa, cntL, ln);
+                                    if (nrR) render_floor_indices<32>(rowR + 128 * f, auxR, 128, 128, pb, cntR, ln);
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    load_floor_indices(fyL, rowL + 128 * (ln >> 3), 8, ln);
+                    load_floor_indices(fyR, rowR + 128 * (ln >> 3), 8, ln);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                apply_floor(xL, fyL, s_db);
+                apply_floor(xR, fyR, s_db);
+            }
+            // ---- the two transforms, side by side
+            if (is_long) {
+                imdct2048_wave_x2(xL, xR, reinterpret_cast<float2 *>(hL), reinterpret_cast<float2 *>(hR), s_twL, s_twAB, s_twBC, ln);
+            } else {
+                imdct256_wave8_x2(xL, xR, reinterpret_cast<float2 *>(hL), reinterpret_cast<float2 *>(hR), s_twS, s_twBC, ln);
+            }
+            // the reference does not transform a silent channel, it clears the block (Mapping.cs:190-194): all +0.0,
+            // where the transform of zeros (times a curve left over in the row) leaves zeros of both signs or worse
+            if (__any(silentL || silentR)) {
+                __builtin_amdgcn_wave_barrier();
+                float2 *h2L = reinterpret_cast<float2 *>(hL), *h2R = reinterpret_cast<float2 *>(hR);
+                if (is_long) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (silentL) h2L[ln + 64 * q] = make_float2(0.0f, 0.0f);
+                        if (silentR) h2R[ln + 64 * q] = make_float2(0.0f, 0.0f);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (silentL) h2L[(ln >> 3) * 64 + (ln & 7) + 8 * q] = make_float2(0.0f, 0.0f);
+                        if (silentR) h2R[(ln >> 3) * 64 + (ln & 7) + 8 * q] = make_float2(0.0f, 0.0f);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // gfx950's vmcnt counts stores as well as loads, in issue order: wait for the prefetched input HERE, ahead of
+        // this frame's stores
+#pragma unroll
+        for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(na[m].x), "v"(na[m].y), "v"(nb[m].x), "v"(nb[m].y));
+        if (kHasFloor) asm volatile("" ::"v"(cpna), "v"(cpnb));
+
+        // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 515-638)
+        // 4 consecutive samples of both channels, sample 4 g .. 4 g + 3 of the pass's output
+        out_t *row_i = out_base + fd.out_off * 2;                          // interleaved: sample s at [2 s, 2 s + 1]
+        out_t *row_l = out_base + fd.out_off;                              // planar
+        out_t *row_r = out_base + a.channel_stride + fd.out_off;
+        const bool aligned = kInterleavedOut ? (reinterpret_cast<uintptr_t>(row_i) & 15) == 0
+                                             : ((reinterpret_cast<uintptr_t>(row_l) | reinterpret_cast<uintptr_t>(row_r)) & (kS16 ? 7 : 15)) == 0;
+        auto emit4 = [&](int g, float l0, float l1, float l2, float l3, float r0, float r1, float r2, float r3) {
+            if (a.clip) {
+                clip_group(l0, l1, l2, l3, clip_peak);
+                clip_group(r0, r1, r2, r3, clip_peak);
+            }
+            if (kInterleavedOut) {
+                if (kS16) {
+                    store_nt(reinterpret_cast<uint4 *>(row_i) + g, pack_s16(l0, r0), pack_s16(l1, r1), pack_s16(l2, r2), pack_s16(l3, r3));
+                } else {
+                    float4 *d = reinterpret_cast<float4 *>(row_i) + 2 * g;
+                    store_pcm4(d, make_float4(l0, r0, l1, r1));
+                    store_pcm4(d + 1, make_float4(l2, r2, l3, r3));
+                }
+            } else if (kS16) {
+                store_nt(reinterpret_cast<uint2 *>(row_l) + g, pack_s16(l0, l1), pack_s16(l2, l3));
+                store_nt(reinterpret_cast<uint2 *>(row_r) + g, pack_s16(r0, r1), pack_s16(r2, r3));
+            } else {
+                store_pcm4(reinterpret_cast<float4 *>(row_l) + g, make_float4(l0, l1, l2, l3));
+                store_pcm4(reinterpret_cast<float4 *>(row_r) + g, make_float4(r0, r1, r2, r3));
+            }
+        };
+        auto emit1 = [&](int i, float l, float r) {  // sample i of the pass, no alignment assumed
+            if (a.clip) {
+                l = clip_track(l, clip_peak);
+                r = clip_track(r, clip_peak);
+            }
+            if (kInterleavedOut) {
+                store_pcm(row_i + 2 * i, kS16 ? (out_t)to_s16(l) : (out_t)l);
+                store_pcm(row_i + 2 * i + 1, kS16 ? (out_t)to_s16(r) : (out_t)r);
+            } else {
+                store_pcm(row_l + i, kS16 ? (out_t)to_s16(l) : (out_t)l);
+                store_pcm(row_r + i, kS16 ? (out_t)to_s16(r) : (out_t)r);
+            }
+        };
+        const float4 *hL4 = reinterpret_cast<const float4 *>(hL), *hR4 = reinterpret_cast<const float4 *>(hR);
+        const float4 *tL4 = reinterpret_cast<const float4 *>(tailL), *tR4 = reinterpret_cast<const float4 *>(tailR);
+        int lf = lane;
+        asm volatile("" : "+v"(lf));  // (no address of the epilogue may be computed ahead of the frame loop)
+        if (batch && fi >= 0) {
+            // ---- a batch of short blocks: 128 * bsz contiguous samples.  Sample i of block f is y_f[i] over the previous
+            // block's y[128 + i] (both windows short): y_f[i] = -h_f[63 - i] (i < 64), h_f[i - 64] otherwise; the partner
+            // is hp[i] (i < 64), hp[127 - i] otherwise, hp = the upper half of the previous block's h -- the block before
+            // in the row, or the tail for block 0 (after a long block: floats 448..511 of its tail).
+            const float4 *s4 = reinterpret_cast<const float4 *>(s_slope0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gq = lf + 64 * r;
+                const int f = gq >> 5, i4 = gq & 31;
+                const bool lower = i4 < 16;
+                const bool valid = f < bsz;
+                const int fs = valid ? f : 0;
+                const float4 wl = s4[i4], wr = s4[31 - i4];
+                const int hidx = fs * 32 + (lower ? 15 - i4 : i4 - 16);
+                const int pidx = lower ? i4 : 31 - i4;
+                // (the partner rows are LDS either way: select the address, not the loaded value)
+                const float4 *ppl = fs > 0 ? hL4 + (fs - 1) * 32 + 16 : tL4 + (prev_n4 == 512 ? 112 : 0);
+                const float4 *ppr = fs > 0 ? hR4 + (fs - 1) * 32 + 16 : tR4 + (prev_n4 == 512 ? 112 : 0);
+                const float4 hl = hL4[hidx], hr = hR4[hidx];
+                const float4 pl = ppl[pidx], pr = ppr[pidx];
+                const float4 vl = apply_y4(hl, lower, lower), vr = apply_y4(hr, lower, lower);
+                const float4 ql = apply_y4(pl, !lower, false), qr = apply_y4(pr, !lower, false);
+                const float l0 = ola(vl.x, wl.x, ql.x, wr.w), l1 = ola(vl.y, wl.y, ql.y, wr.z);
+                const float l2 = ola(vl.z, wl.z, ql.z, wr.y), l3 = ola(vl.w, wl.w, ql.w, wr.x);
+                const float r0 = ola(vr.x, wl.x, qr.x, wr.w), r1 = ola(vr.y, wl.y, qr.y, wr.z);
+                const float r2 = ola(vr.z, wl.z, qr.z, wr.y), r3 = ola(vr.w, wl.w, qr.w, wr.x);
+                if (valid) {
+                    if (aligned) {
+                        emit4(gq, l0, l1, l2, l3, r0, r1, r2, r3);
+                    } else {
+                        emit1(4 * gq, l0, r0);
+                        emit1(4 * gq + 1, l1, r1);
+                        emit1(4 * gq + 2, l2, r2);
+                        emit1(4 * gq + 3, l3, r3);
+                    }
+                }
+            }
+        } else if (fi >= 0 && fd.out_count > 0) {
+            // equal block sizes share one slope table (s_slope0 only holds a 128-entry short slope)
+            const float *slope = ((fd.flags & kFrameSlope1) || a.size0 == a.size1) ? s_slope1 : s_slope0;
+            const int plen = fd.packet_len;
+            // every window boundary of the 256 / 2048 geometries is a multiple of 64 samples, so unless an EOS trim cut the
+            // packet a group of four samples never straddles a mirror / overlap boundary
+            const bool vec = !drain && aligned && ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0;
+            if (vec && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 && fd.prev_end == 1024 &&
+                fd.out_count == 1024 && prev_n4 == 512 && a.size1 == 2048) {
+                // long after long with long windows on both sides (the steady state of every stream): first half of the
+                // output = negated mirror of h[0:512) over the straight previous tail, second half = h[0:512) straight over
+                // the mirrored tail; the window values are read once for both channels
+                const float4 *s4 = reinterpret_cast<const float4 *>(s_slope1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = lf + 64 * r;
+                    const float4 wl = s4[g], wr = s4[255 - g];
+                    if (r < 2) {
+                        const float4 hl = hL4[127 - g], pl = tL4[g], hr = hR4[127 - g], pr = tR4[g];
+                        emit4(g, ola(-hl.w, wl.x, pl.x, wr.w), ola(-hl.z, wl.y, pl.y, wr.z), ola(-hl.y, wl.z, pl.z, wr.y),
+                              ola(-hl.x, wl.w, pl.w, wr.x), ola(-hr.w, wl.x, pr.x, wr.w), ola(-hr.z, wl.y, pr.y, wr.z),
+                              ola(-hr.y, wl.z, pr.z, wr.y), ola(-hr.x, wl.w, pr.w, wr.x));
+                    } else {
+                        const float4 hl = hL4[g - 128], pl = tL4[255 - g], hr = hR4[g - 128], pr = tR4[255 - g];
+                        emit4(g, ola(hl.x, wl.x, pl.w, wr.w), ola(hl.y, wl.y, pl.z, wr.z), ola(hl.z, wl.z, pl.y, wr.y),
+                              ola(hl.w, wl.w, pl.x, wr.x), ola(hr.x, wl.x, pr.w, wr.w), ola(hr.y, wl.y, pr.z, wr.z),
+                              ola(hr.z, wl.z, pr.y, wr.y), ola(hr.w, wl.w, pr.x, wr.x));
+                    }
+                }
+            } else if (vec) {
+                // any other aligned geometry, branch-free: lanes past the end clamp their reads and skip only the store;
+                // samples past the overlap take weights (1, 0)
+                const float4 *s4 = reinterpret_cast<const float4 *>(slope);
+                const int cnt4 = fd.out_count >> 2;
+                const int nr = (cnt4 + 63) >> 6;
+                const int pn4 = prev_n4;
+                for (int r = 0; r < nr; ++r) {
+                    const int g = lf + 64 * r;
+                    const bool lv = g < cnt4;
+                    const int i = (lv ? g : cnt4 - 1) << 2;
+                    const Y4Map mc = map_y4(fd.left_start + i, n4);
+                    const bool in = i < plen;
+                    const int ii = in ? i : 0;
+                    const int q = fd.prev_end + ii;  // in [2 pn4, 4 pn4) whenever `in`
+                    const bool pc = q >= 3 * pn4;
+                    int pidx = (pc ? (4 * pn4 - 4 - q) : (q - 2 * pn4)) >> 2;
+                    pidx = in ? pidx : 0;
+                    const int ridx = in ? ((plen - 4 - ii) >> 2) : 0;
+                    const float4 wl = s4[ii >> 2], wr = s4[ridx];
+                    const float4 vl = apply_y4(hL4[mc.idx4], mc.rev, mc.neg), ql = apply_y4(tL4[pidx], pc, false);
+                    const float4 vr = apply_y4(hR4[mc.idx4], mc.rev, mc.neg), qr = apply_y4(tR4[pidx], pc, false);
+                    const float l0 = in ? ola(vl.x, wl.x, ql.x, wr.w) : vl.x, l1 = in ? ola(vl.y, wl.y, ql.y, wr.z) : vl.y;
+                    const float l2 = in ? ola(vl.z, wl.z, ql.z, wr.y) : vl.z, l3 = in ? ola(vl.w, wl.w, ql.w, wr.x) : vl.w;
+                    const float r0 = in ? ola(vr.x, wl.x, qr.x, wr.w) : vr.x, r1 = in ? ola(vr.y, wl.y, qr.y, wr.z) : vr.y;
+                    const float r2 = in ? ola(vr.z, wl.z, qr.z, wr.y) : vr.z, r3 = in ? ola(vr.w, wl.w, qr.w, wr.x) : vr.w;
+                    if (lv) emit4(g, l0, l1, l2, l3, r0, r1, r2, r3);
+                }
+            } else {
+                for (int i = lf; i < fd.out_count; i += 64) {
+                    float l, r;
+                    if (drain) {
+                        l = tail_at(tailL, fd.prev_end + i, prev_n4);
+                        r = tail_at(tailR, fd.prev_end + i, prev_n4);
+                    } else {
+                        l = y_from_h(hL, fd.left_start + i, n4);
+                        r = y_from_h(hR, fd.left_start + i, n4);
+                        if (i < plen) {
+                            const float wl = slope[i], wr = slope[plen - 1 - i];
+                            l = ola(l, wl, tail_at(tailL, fd.prev_end + i, prev_n4), wr);
+                            r = ola(r, wl, tail_at(tailR, fd.prev_end + i, prev_n4), wr);
+                        }
+                    }
+                    emit1(i, l, r);
+                }
+            }
+        }
+        // ---- keep what a later block can overlap with: y[N/2 .. N) lives in the upper half of h
+        if (!drain) {
+            __builtin_amdgcn_wave_barrier();
+            if (is_long) {
+                const float4 *sl = reinterpret_cast<const float4 *>(hL + 512), *sr = reinterpret_cast<const float4 *>(hR + 512);
+                float4 *dl = reinterpret_cast<float4 *>(tailL), *dr = reinterpret_cast<float4 *>(tailR);
+                const float4 a0 = sl[lf], a1 = sl[lf + 64], b0 = sr[lf], b1 = sr[lf + 64];
+                dl[lf] = a0;
+                dl[lf + 64] = a1;
+                dr[lf] = b0;
+                dr[lf + 64] = b1;
+            } else {
+                const int o = (batch ? 128 * (bsz - 1) : 0) + 64 + lf;  // (a batch: its last block)
+                const float tl = hL[o], tr = hR[o];
+                tailL[lf] = tl;
+                tailR[lf] = tr;
+            }
+            prev_n4 = n4;
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            va[m] = na[m];
+            vb[m] = nb[m];
+        }
+        cpa = cpna;
+        cpb = cpnb;
+        stwcur = stwnext;
+        fi = fin;
+    }
+
+    // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
+    if ((run.flags & kRunSaveState) && prev_n4 > 0) {
+        float *st = a.state_h + (size_t)run.stream * 2 * half1;
+        for (int i = lane; i < prev_n4; i += 64) {
+            st[i] = tailL[i];
+            st[half1 + i] = tailR[i];
+        }
+    }
+    // HasClipped is sticky until ResetDecoder: the flag holds the stream's reset epoch
+    if (a.clip && __any(clip_peak > 0.99999994f) && lane == 0) atomicMax(&a.clipped[run.stream], run.clip_epoch);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------------
+bool synth_dual_supported(int channels, int size0, int size1)
+{
+    auto plain = [](int n) { return n == 256 || n == 2048; };
+    return channels == 2 && plain(size0) && plain(size1);
+}
+
+hipError_t launch_synth_dual(const SynthArgs &args, bool has_floor, bool interleaved_in, hipStream_t stream)
+{
+    if (args.n_runs <= 0) return hipSuccess;
+    const int grid = (args.n_runs + kDualWaves - 1) / kDualWaves;
+#define VPZ_LAUNCH_DUAL(F, I, O)                                                                                          \
+    do {                                                                                                                  \
+        if (args.s16)                                                                                                     \
+            hipLaunchKernelGGL((synth_dual_kernel<F, I, O, true>), dim3(grid), dim3(kDualThreads), 0, stream, args);      \
+        else                                                                                                              \
+            hipLaunchKernelGGL((synth_dual_kernel<F, I, O, false>), dim3(grid), dim3(kDualThreads), 0, stream, args);     \
+    } while (0)
+#define VPZ_LAUNCH_DUAL_OUT(F, I)                \
+    do {                                         \
+        if (args.interleaved) VPZ_LAUNCH_DUAL(F, I, 1); \
+        else VPZ_LAUNCH_DUAL(F, I, 0);           \
+    } while (0)
+    if (has_floor) {
+        if (interleaved_in) VPZ_LAUNCH_DUAL_OUT(true, true);
+        else VPZ_LAUNCH_DUAL_OUT(true, false);
+    } else {
+        if (interleaved_in) VPZ_LAUNCH_DUAL_OUT(false, true);
+        else VPZ_LAUNCH_DUAL_OUT(false, false);
+    }
+#undef VPZ_LAUNCH_DUAL_OUT
+#undef VPZ_LAUNCH_DUAL
+    return hipGetLastError();
+}
+
+// channel-blocks the chip keeps resident and busy under synth_dual_kernel (a wavefront holds two)
+int synth_dual_resident_slots(bool has_floor, int num_cu)
+{
+    int per_cu = 0;
+    hipError_t e = has_floor ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_dual_kernel<true, true, 1, false>, kDualThreads, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_dual_kernel<false, false, 0, false>, kDualThreads, 0);
+    if (e != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 2;
+    }
+    return num_cu * per_cu * kDualWaves * 2;
+}
+
+}  // namespace vpz

@@ -29,6 +29,9 @@ bool synth_supports_sizes(int size0, int size1);
 bool synth_needs_general(int size0, int size1);
 int synth_resident_waves(bool has_floor, int num_cu, int channels, bool group);
 bool synth_group_supported(int channels);
+bool synth_dual_supported(int channels, int size0, int size1);
+hipError_t launch_synth_dual(const SynthArgs &args, bool has_floor, bool interleaved_in, hipStream_t stream);
+int synth_dual_resident_slots(bool has_floor, int num_cu);
 hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, int half1, float *spec,
                                 const uint8_t *post_counts, const uint8_t *curve_y, const float *inv_db,
                                 hipStream_t stream);
@@ -116,6 +119,8 @@ struct Decoder {
     DevBuf b_curve, b_temp, b_cposts, b_ccount;
     // group mode of synth_kernel (channels of a packet share a workgroup; de-interleave + coupling in LDS)
     bool group_ok = false;       // channel count, step tables and floor types allow it
+    // stereo fast path (synth_dual.hip: one wavefront per stream synthesises both channels, coupling in registers)
+    bool dual_ok = false;        // two channels, 256 / 2048 blocks, type-1 floors only (VPZ_NO_DUAL=1: off, for A/B tests)
     int max_steps = 0, n_step_pairs = 0;
     int host_threads = 0;        // parties of the parallel state machine (VPZ_HOST_THREADS; 0: pick)
     int64_t par_min_packets = 16384;  // batches below this take the serial state machine (VPZ_PAR_MIN_PACKETS)
@@ -346,6 +351,9 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         const char *no_group = getenv("VPZ_NO_GROUP");  // tuning / A-B tests: force the separate coupling pass
         D.group_ok = synth_group_supported(D.channels) && !D.generic && !has_floor0 && D.max_steps <= 255 &&
                      D.n_step_pairs <= kGroupMaxStepPairs && !(no_group && atoi(no_group));
+        const char *no_dual = getenv("VPZ_NO_DUAL");
+        D.dual_ok = synth_dual_supported(D.channels, D.size0, D.size1) && !D.generic && !has_floor0 && D.max_steps <= 255 &&
+                    D.n_step_pairs <= kGroupMaxStepPairs && !(no_dual && atoi(no_dual));
         D.max_steps = max_levels;  // from here on: the barriers a frame's coupling needs in group mode
         const char *nc = getenv("VPZ_NO_COMPACT");
         D.no_compact = nc && atoi(nc);
@@ -359,7 +367,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     D.mapping_uses_floor0.assign(D.mappings.size(), 0);
     for (size_t m = 0; m < D.mappings.size(); ++m) {
         const int n = D.mappings[m].coupling_steps;
-        if (D.group_ok && n > 0)
+        if ((D.group_ok || D.dual_ok) && n > 0)
             map_bits[m] = ((uint32_t)n << kFrameStepsShift) |
                           ((uint32_t)(D.mapping_steps_off[m] / 2) << kFrameStepsOffShift);
         for (int ch = 0; ch < D.channels; ++ch)
@@ -517,6 +525,9 @@ struct SynthCall {
     bool any_short = false;       // the batch holds short blocks (run cutting by cost only pays then)
     bool group_align_ok = true;   // every interleaved packet starts on a 16-byte boundary (group mode loads 16 bytes)
     bool use_group = false;       // decided after pass 1: synth_kernel's group mode instead of the coupling pass
+    bool use_dual = false;        // ... or the stereo fast path (synth_dual.hip), which takes precedence
+    bool ilv_seen = false, planar_seen = false;  // layouts of the packets that become frames (the dual kernel wants one)
+    bool align2_ok = true;        // every packet starts on an 8-byte boundary (planar packets are read 8 bytes at a time)
     bool compact = false;         // every run compact: two bytes per frame instead of a FrameDesc (parallel pass only)
     uint8_t *cflags = nullptr, *cmap = nullptr;
     int64_t mismatches = 0, res_extent = 0;
@@ -560,6 +571,14 @@ struct SynthCall {
         char *base = zero_copy ? A->mapped : static_cast<char *>(A->dev.p);
         return base + (static_cast<const char *>(host_ptr) - A->base);
     }
+    // The stereo fast path takes a batch whose packets all have ONE input layout (its loads are unconditional: the
+    // layout is a template parameter) and start where its loads are aligned: 16 bytes for the Residue2 vector, 8 for planar.
+    bool dual_usable() const
+    {
+        if (!D.dual_ok || any_floor0 || (ilv_seen && planar_seen)) return false;
+        const bool dev_ok = mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & (ilv_seen ? 15 : 7)) == 0;
+        return dev_ok && (ilv_seen ? group_align_ok : align2_ok);
+    }
     bool zero_copy = false;
     bool host_failed = false;  // a share of a fork-join threw (allocation): the call returns VPZ_E_NOMEM
 
@@ -593,7 +612,7 @@ struct SynthCall {
     {
         const bool bf = pk.flags & VPZ_PKT_BLOCK_FLAG, no_floor = pk.flags & VPZ_PKT_NO_FLOOR;
         uint32_t f = (bf ? kFrameLong : 0u) | (pi.left_use_size1 ? kFrameSlope1 : 0u) | (no_floor ? kFrameNoFloor : 0u);
-        if (D.group_ok) {
+        if (D.group_ok || D.dual_ok) {
             const int steps = no_floor ? 0 : D.mappings[pk.mapping].coupling_steps;
             if (pk.flags & VPZ_PKT_INTERLEAVED) f |= kFrameInterleaved;
             if (steps > 0)
@@ -641,6 +660,7 @@ struct SynthCall {
             int64_t base = 0;         // filled between the sweeps: samples of the leading stream before this chunk
             int64_t res_extent = 0;
             bool any_floor = false, any_floor0 = false, need_coupling = false, align_ok = true, any_short = false;
+            bool ilv = false, planar = false, align2 = true;
             bool dense = true;        // every packet's residue starts where its predecessor's (same stream) ends
             char pad[64];
         };
@@ -732,8 +752,10 @@ struct SynthCall {
                     if (D.mappings[pk.mapping].coupling_steps > 0) K.need_coupling = true;
                     if (D.mapping_uses_floor0[pk.mapping]) K.any_floor0 = true;
                 }
-                if (pk.flags & VPZ_PKT_INTERLEAVED) K.need_coupling = true;
+                if (pk.flags & VPZ_PKT_INTERLEAVED) { K.need_coupling = true; K.ilv = true; }
+                else K.planar = true;
                 if (pk.residue_offset & 3) K.align_ok = false;  // group mode reads every packet in 16-byte pieces
+                if (pk.residue_offset & 1) K.align2 = false;
                 if (!new_stream) {
                     const vpz_packet &pp = packets[p - 1];
                     const int64_t prev_floats = (int64_t)C * ((pp.flags & VPZ_PKT_BLOCK_FLAG) ? half1 : half0);
@@ -756,12 +778,15 @@ struct SynthCall {
             any_short |= K.any_short;
             need_coupling |= K.need_coupling;
             group_align_ok &= K.align_ok;
+            align2_ok &= K.align2;
+            ilv_seen |= K.ilv;
+            planar_seen |= K.planar;
         }
         // Compact runs (two bytes per frame, descriptors built on the device) need consecutive packets with back to
         // back residues and a batch the fused kernel takes as it is (no planar temp, no type-0 floor pass)
         const bool group_usable = D.group_ok && group_align_ok &&
                                   (mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
-        compact = all_dense && !D.generic && !any_floor0 && !D.no_compact && (!need_coupling || group_usable);
+        compact = all_dense && !D.generic && !any_floor0 && !D.no_compact && (!need_coupling || group_usable || dual_usable());
         if (compact) {
             cflags = arena_alloc<uint8_t>(*A, (size_t)n_packets);
             cmap = arena_alloc<uint8_t>(*A, (size_t)n_packets);
@@ -797,7 +822,7 @@ struct SynthCall {
             }
         }
         if (D.generic) need_coupling = true;
-        const bool group_bits = D.group_ok;  // (frame_flags' rule: group-mode bits only when the decoder can use them)
+        const bool group_bits = D.group_ok || D.dual_ok;  // (frame_flags' rule: these bits only when the decoder can use them)
         // sweep B: the descriptors, the per-record floor info, where each stream's packets begin and end
         const bool ok_b = pool.run([&](int c) {
             Chunk &K = chunks[c];
@@ -1067,8 +1092,10 @@ struct SynthCall {
                     rec_floor[(size_t)(p * C + ch)] = (uint8_t)(fl | long_bit | (f0 ? 0x40 : 0));
                 }
             }
-            if (pk.flags & VPZ_PKT_INTERLEAVED) need_coupling = true;
+            if (pk.flags & VPZ_PKT_INTERLEAVED) { need_coupling = true; ilv_seen = true; }
+            else planar_seen = true;
             if (pk.residue_offset & 3) group_align_ok = false;  // group mode reads every packet in 16-byte pieces
+            if (pk.residue_offset & 1) align2_ok = false;
             frames[s_base[pk.stream] + s_cnt[pk.stream]++] = fd;
         }
         for (int s = 0; s < D.n_streams; ++s)
@@ -1101,8 +1128,9 @@ struct SynthCall {
         // length -- the kernel still batches what it finds in them -- rather than spend a millisecond of host time)
         HostPool *pool = static_cast<HostPool *>(ctx->host_pool);
         const bool wide = pool && D.n_streams >= 2 * pool->parties();
-        const bool batches = compact && use_group && any_floor && any_short && !synth_needs_general(D.size0, D.size1) &&
-                             D.size0 == 256 && !D.generic && (wide || total_frames <= 4096) && !(D.ablate & 128);
+        const bool batches = compact && (use_dual || (use_group && any_floor)) && any_short &&
+                             !synth_needs_general(D.size0, D.size1) && D.size0 == 256 && D.size1 != 256 && !D.generic &&
+                             (wide || total_frames <= 4096) && !(D.ablate & 128);
         const int parties = (batches && wide) ? pool->parties() : 1;
         auto stream_range = [&](int c, int &lo, int &hi) {
             lo = (int)((int64_t)D.n_streams * c / parties);
@@ -1112,10 +1140,12 @@ struct SynthCall {
             ok = false;
             if (!batches || p == 0 || packets[p - 1].stream != packets[p].stream) return false;
             const vpz_packet &pk = packets[p], &pp = packets[p - 1];
-            ok = !(pk.flags & VPZ_PKT_BLOCK_FLAG) && (pk.flags & VPZ_PKT_INTERLEAVED) &&
-                 !(pk.flags & (VPZ_PKT_NO_FLOOR | VPZ_PKT_NOT_DECODED)) && !(pp.flags & VPZ_PKT_NOT_DECODED);
+            // (the stereo fast path batches planar and already-floored packets too; a batch holds one kind)
+            ok = !(pk.flags & VPZ_PKT_BLOCK_FLAG) && !(pk.flags & VPZ_PKT_NOT_DECODED) && !(pp.flags & VPZ_PKT_NOT_DECODED) &&
+                 (use_dual || ((pk.flags & VPZ_PKT_INTERLEAVED) && !(pk.flags & VPZ_PKT_NO_FLOOR)));
             // (after a long block it can head a batch; it rides with a short predecessor of its mapping)
-            return ok && prev_in_run_ok && !(pp.flags & VPZ_PKT_BLOCK_FLAG) && pk.mapping == pp.mapping;
+            return ok && prev_in_run_ok && !(pp.flags & VPZ_PKT_BLOCK_FLAG) && pk.mapping == pp.mapping &&
+                   ((pk.flags ^ pp.flags) & VPZ_PKT_NO_FLOOR) == 0;
         };
         // cost of a pass in eighths of a long block's (tools/kbench_short_long.py: a short block alone 0.74, eight in one
         // batch 3.2 together)
@@ -1165,7 +1195,8 @@ struct SynthCall {
         int R = reuse ? D.cut_hint_R : std::min(D.run_length_override, r_max);
         int64_t run_slots = reuse ? D.cut_hint_slots : 0;  // runs that fit the rounds R was chosen for
         if (R <= 0) {
-            const int64_t slots = std::max(1, synth_resident_waves(any_floor, ctx->num_cu, C, use_group));
+            const int64_t slots = std::max(1, use_dual ? synth_dual_resident_slots(any_floor, ctx->num_cu)
+                                                       : synth_resident_waves(any_floor, ctx->num_cu, C, use_group));
             const int64_t work = (total_units + 7) / 8 * C;
             R = 4;
             int64_t best = -1;
@@ -1328,7 +1359,7 @@ struct SynthCall {
     // coupling packets: de-interleave + inverse coupling into a planar temp laid out in frame order
     void build_coupling_packets()
     {
-        if (!need_coupling || use_group) return;
+        if (!need_coupling || use_group || use_dual) return;
         // the separate pass hands planar, de-coupled spectra over: the frames lose their group-mode bits
         for (size_t fi = 0; fi < n_frames; ++fi) frames[fi].flags &= 0xFu;
         const size_t cps = coupling_packet_size();
@@ -1478,7 +1509,7 @@ struct SynthCall {
             if ((rc = grow(ctx, D.b_out, out_elem * (size_t)out_floats + 16)) != VPZ_OK) return rc;
             d_out = D.b_out.p;
         }
-        if (need_coupling && !use_group && (rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK)
+        if (need_coupling && !use_group && !use_dual && (rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK)
             return rc;
         if (any_floor) {
             if ((rc = grow(ctx, D.b_cposts, sizeof(int32_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
@@ -1507,7 +1538,7 @@ struct SynthCall {
     {
         const float *d_spec = d_res;
         const int64_t *d_outoff = stream_out_offset ? static_cast<const int64_t *>(dev(offs)) : nullptr;
-        if (need_coupling && !use_group) {
+        if (need_coupling && !use_group && !use_dual) {
             hipError_t e = launch_coupling(dev(cpk), n_cpk, D.d_steps, C, d_res, static_cast<float *>(D.b_temp.p), half1,
                                            ctx->stream);
             if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "coupling kernel launch", e);
@@ -1614,7 +1645,7 @@ struct SynthCall {
         (void)hipMemsetAsync(d_stamps, 0, 16 * sizeof(unsigned long long), ctx->stream);
         a.stamps = d_stamps;
 #endif
-        hipError_t e = launch_synth(a, any_floor, ctx->stream);
+        hipError_t e = use_dual ? launch_synth_dual(a, any_floor, ilv_seen, ctx->stream) : launch_synth(a, any_floor, ctx->stream);
         if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "synth kernel launch", e);
 #ifdef VPZ_STAMPS
         {
@@ -1704,7 +1735,8 @@ static int synth_impl(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     // its packets can be read in 16-byte pieces; otherwise the separate pass through a planar temp
     // ... and for interleaved output of more than two channels, which only a packet's waves together can write densely
     const bool wants_group = call.need_coupling || (call.out_interleaved && D.channels > 2);
-    call.use_group = D.group_ok && wants_group && !call.any_floor0 && call.group_align_ok &&
+    call.use_dual = call.dual_usable();
+    call.use_group = !call.use_dual && D.group_ok && wants_group && !call.any_floor0 && call.group_align_ok &&
                      (mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
     if (call.res_extent > residue_floats)
         return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: a packet's residue lies beyond residue_floats");
