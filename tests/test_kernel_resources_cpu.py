@@ -43,3 +43,13 @@ def test_every_synth_kernel_instantiation_is_built_and_keeps_two_workgroups_per_
         assert k["vgprs"] <= 128, k["name"]            # 4 waves per SIMD: 512 / 4
         assert k["lds"] <= 80 * 1024, (k["name"], k["lds"])  # two 8-wave workgroups per CU (160 KiB)
         assert k.get("occupancy", 4) >= 4, k["name"]
+
+
+def test_stereo_fast_path_instantiations_and_their_budget(kernels):
+    dual = [k for k in kernels.values() if "synth_dual_kernel" in k["name"]]
+    # <floor?, Residue2-interleaved / planar input, planar / interleaved output, float32 / int16 samples>
+    assert len(dual) == 2 * 2 * 2 * 2
+    for k in dual:
+        assert k["vgprs"] <= 256, k["name"]                   # 2 waves per SIMD: 512 / 2
+        assert k["lds"] <= 80 * 1024, (k["name"], k["lds"])   # two 4-wave workgroups per CU (160 KiB)
+        assert k.get("occupancy", 2) >= 2, k["name"]
