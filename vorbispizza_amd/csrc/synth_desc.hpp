@@ -84,7 +84,7 @@ struct RunDesc {         // 64 bytes
     uint8_t has_prev0;
     uint8_t pad[3];
     int32_t clip_epoch;  // what the run stores into clipped[stream] when a sample was clipped (see vpz_decoder_reset)
-    int32_t reserved;
+    int32_t state_slot;  // which copy of the stream's saved state is current (0 / 1)
 };
 static_assert(sizeof(RunDesc) == 64, "RunDesc layout");
 
@@ -127,7 +127,10 @@ struct SynthArgs {
     int32_t max_steps;          // most coupling LEVELS any mapping has: barriers per frame in group mode
     int32_t group;              // 1: channels of a run share a workgroup (LDS staging), 0: waves are independent
     const float *inv_db;        // 256 floats
-    float *state_h;             // [stream][channel][size1/2]
+    float *state_h;             // [2][stream][channel][size1/2]: two copies -- a run that starts from the saved state reads
+                                // copy RunDesc.state_slot, the run that ends its stream's batch writes the OTHER one (the
+                                // two may be different wavefronts of one launch: no order between them)
+    int64_t state_slot_floats;  // floats per copy
     const float2 *tw_long;      // fast tables of size1 (BlockTables::d_fast)
     const float2 *tw_short;     // fast tables of size0
     const float *slope0, *slope1;

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
 
     // ---- block preceding the run: from the saved state, or recomputed as "frame -1" of the loop
     if (run.pre_kind == kPreState) {
-        const float *st = a.state_h + (size_t)run.stream * 2 * half1;
+        const float *st = a.state_h + (size_t)run.state_slot * a.state_slot_floats + (size_t)run.stream * 2 * half1;
         prev_n4 = run.prev_long ? (a.size1 >> 2) : (a.size0 >> 2);
         for (int i = lane; i < prev_n4; i += 64) {
             tailL[i] = st[i];
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
 
     // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
     if ((run.flags & kRunSaveState) && prev_n4 > 0) {
-        float *st = a.state_h + (size_t)run.stream * 2 * half1;
+        float *st = a.state_h + (size_t)(run.state_slot ^ 1) * a.state_slot_floats + (size_t)run.stream * 2 * half1;
         for (int i = lane; i < prev_n4; i += 64) {
             st[i] = tailL[i];
             st[half1 + i] = tailR[i];

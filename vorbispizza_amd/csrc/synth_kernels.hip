@@ -771,7 +771,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 
     // ---- block preceding the run: from the saved state, or recomputed as "frame -1" of the loop
     if (run.pre_kind == kPreState) {
-        const float *st = a.state_h + ((size_t)run.stream * a.channels + ch) * half1;
+        const float *st = a.state_h + (size_t)run.state_slot * a.state_slot_floats + ((size_t)run.stream * a.channels + ch) * half1;
         prev_n4 = run.prev_long ? (a.size1 >> 2) : (a.size0 >> 2);
         for (int i = lane; i < prev_n4; i += 64) tail[i] = st[i];
     }
@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 
     // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
     if ((run.flags & kRunSaveState) && prev_n4 > 0) {
-        float *st = a.state_h + ((size_t)run.stream * a.channels + ch) * half1;
+        float *st = a.state_h + (size_t)(run.state_slot ^ 1) * a.state_slot_floats + ((size_t)run.stream * a.channels + ch) * half1;
         for (int i = lane; i < prev_n4; i += 64) st[i] = tail[i];
     }
     // HasClipped is sticky until ResetDecoder: the flag holds the stream's reset epoch, so a reset costs no device work

@@ -66,6 +66,10 @@ struct StreamState {
     bool eos_found = false;
     bool has_clipped = false;
     int32_t clip_epoch = 1;     // resets so far + 1: clipped[stream] == clip_epoch <=> HasClipped
+    int32_t state_slot = 0;     // which of the two device copies of the saved overlap state is current: a batch reads it in
+                                // the stream's first run and writes the other copy in its last one -- two wavefronts of
+                                // one launch with no order between them (the last run of a stream rich in short blocks can
+                                // be done before the first one has read)
 };
 
 struct DevBuf {
@@ -378,7 +382,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         return rc;
     }
     hipError_t e = hipSuccess;
-    const size_t state_bytes = sizeof(float) * (size_t)n_streams * D.channels * (D.size1 / 2);
+    const size_t state_bytes = 2 * sizeof(float) * (size_t)n_streams * D.channels * (D.size1 / 2);  // two copies, see StreamState
     if (!ctx->d_inv_db) {
         e = hipMalloc((void **)&ctx->d_inv_db, 256 * sizeof(float));
         if (e == hipSuccess)
@@ -1306,6 +1310,7 @@ struct SynthCall {
                 const bool last = f0 + len >= cnt;
                 if (last) r.flags |= kRunSaveState;
                 r.clip_epoch = D.states[s].clip_epoch;
+                r.state_slot = D.states[s].state_slot;
                 if (compact) {
                     r.flags |= kRunCompact;
                     const int64_t q = (int64_t)r.first + (r.pre_kind == kPreRecompute ? -1 : 0);  // first staged frame
@@ -1626,6 +1631,7 @@ struct SynthCall {
         a.group = use_group ? 1 : 0;
         a.inv_db = ctx->d_inv_db;
         a.state_h = D.d_state_h;
+        a.state_slot_floats = (int64_t)D.n_streams * C * half1;
         a.tw_long = D.t1->d_fast;
         a.tw_short = D.t0->d_fast;
         a.slope0 = D.t0->d_slope;
@@ -1759,6 +1765,9 @@ static int synth_impl(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         call.A->pending = true;
     }
     if ((rc = call.copy_back()) != VPZ_OK) return rc;
+    if (!D.generic)  // every stream with frames in this batch has had its state written to the other copy
+        for (int s = 0; s < D.n_streams; ++s)
+            if (D.s_cnt[s] > 0) call.st[s].state_slot ^= 1;
     D.states = call.st;
     if (host_profile) {
         const auto t_end = tick();
