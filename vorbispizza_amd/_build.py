@@ -79,7 +79,7 @@ def build(force=False, verbose=False):
         force = True
         with open(flags_file, "w") as f:
             f.write(extra_env)
-    objs, relink = [], force or not os.path.exists(LIB_PATH)
+    objs, relink, jobs = [], force or not os.path.exists(LIB_PATH), []
     for name, extra in SOURCES.items():
         src = os.path.join(CSRC, name)
         if not os.path.exists(src):
@@ -88,12 +88,19 @@ def build(force=False, verbose=False):
         stale = force or not os.path.exists(obj) or any(
             os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src))
         if stale:
-            cmd = [hipcc] + COMMON + extra + extra_env.split() + ["-c", src, "-o", obj]
+            jobs.append([hipcc] + COMMON + extra + extra_env.split() + ["-c", src, "-o", obj])
+            relink = True
+        objs.append(obj)
+    if jobs:  # the translation units are independent: compile them side by side (a handful of hipcc processes)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def compile_one(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
-            relink = True
-        objs.append(obj)
+
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as pool:
+            list(pool.map(compile_one, jobs))
     if relink:
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
         if verbose:

@@ -145,7 +145,8 @@ __device__ __forceinline__ int spectrum_top(const float2 (&x)[8], int lpb)
 
 // kIlvIn : every packet of the batch is the Residue2-interleaved vector [bin][2] (else: every packet planar [2][bin])
 // kOut   : 0 planar output, 1 interleaved
-template <bool kHasFloor, bool kIlvIn, int kOut, bool kS16>
+// kExp: tuning experiments, A/B on one box through VPZ_DUAL_EXP (none at the moment; DESIGN.md 4.7 lists what was tried)
+template <bool kHasFloor, bool kIlvIn, int kOut, bool kS16, int kExp = 0>
 __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a)
 {
     using out_t = typename std::conditional<kS16, int16_t, float>::type;
@@ -303,8 +304,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
     }
     const int iters = run.count - fi0 - (int)__popcll(__ballot(batch_member));
     __builtin_amdgcn_wave_barrier();
-    auto frame_at = [&](int fi) -> FrameDesc {  // broadcast LDS read, then into SGPRs
-        const uint4 lo = s_desc[wave][(fi - fi0) * 2], hi = s_desc[wave][(fi - fi0) * 2 + 1];
+    auto frame_from = [&](const uint4 lo, const uint4 hi) -> FrameDesc {  // a descriptor's two LDS words into SGPRs
         FrameDesc fd;
         const uint32_t w0 = __builtin_amdgcn_readfirstlane(lo.x), w1 = __builtin_amdgcn_readfirstlane(lo.y);
         const uint32_t w2 = __builtin_amdgcn_readfirstlane(lo.z), w3 = __builtin_amdgcn_readfirstlane(lo.w);
@@ -319,6 +319,9 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
         fd.out_count = (uint16_t)(w6 >> 16);
         fd.flags = w7;
         return fd;
+    };
+    auto frame_at = [&](int fi) -> FrameDesc {  // broadcast LDS read, then into SGPRs
+        return frame_from(s_desc[wave][(fi - fi0) * 2], s_desc[wave][(fi - fi0) * 2 + 1]);
     };
 
     // ---- block preceding the run: from the saved state, or recomputed as "frame -1" of the loop
@@ -398,6 +401,10 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
     for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(va[m].x), "v"(va[m].y), "v"(vb[m].x), "v"(vb[m].y));
     if (kHasFloor) asm volatile("" ::"v"(cpa), "v"(cpb));
 
+#ifdef VPZ_STAMPS
+    unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
     int fi = fi0;
     for (int it = 0; it < iters; ++it) {
         const FrameDesc fd = fd_next;
@@ -414,6 +421,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
             prefetch(fd_next, valid_next, na, nb, cpna, cpnb);
             stwnext = steps_word(fd_next, valid_next);
         }
+        VPZ_STAMP(0);  // descriptor + prefetch issue
         const bool drain = fd.flags & kFrameDrain;
         const bool batch = bsz > 1;
         const int nblk = size_of(fd.flags);
@@ -454,6 +462,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
                     }
                 }
             }
+            VPZ_STAMP(1);  // unpack + coupling
             // ---- Floor1 curves x spectra (Floor1.cs:222-268), silence (Mapping.cs:190-194)
             bool silentL = false, silentR = false;  // per lane: this lane's block of the pass is a silent channel's
             if (!no_floor) {
@@ -516,6 +525,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
                     load_floor_indices(fyR, rowR + 128 * (ln >> 3), 8, ln);
                     __builtin_amdgcn_wave_barrier();
                 }
+                VPZ_STAMP(2);  // curves
                 apply_floor(xL, fyL, s_db);
                 apply_floor(xR, fyR, s_db);
             }
@@ -547,12 +557,14 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
             __builtin_amdgcn_wave_barrier();
         }
 
+        VPZ_STAMP(3);  // floor multiply + transforms
         // gfx950's vmcnt counts stores as well as loads, in issue order: wait for the prefetched input HERE, ahead of
         // this frame's stores
 #pragma unroll
         for (int m = 0; m < 8; ++m) asm volatile("" ::"v"(na[m].x), "v"(na[m].y), "v"(nb[m].x), "v"(nb[m].y));
         if (kHasFloor) asm volatile("" ::"v"(cpna), "v"(cpnb));
 
+        VPZ_STAMP(4);  // wait for the next frame's input
         // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 515-638)
         // 4 consecutive samples of both channels, sample 4 g .. 4 g + 3 of the pass's output
         out_t *row_i = out_base + fd.out_off * 2;                          // interleaved: sample s at [2 s, 2 s + 1]
@@ -712,6 +724,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
                 }
             }
         }
+        VPZ_STAMP(5);  // window + overlap-add + stores
         // ---- keep what a later block can overlap with: y[N/2 .. N) lives in the upper half of h
         if (!drain) {
             __builtin_amdgcn_wave_barrier();
@@ -741,7 +754,14 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
         cpb = cpnb;
         stwcur = stwnext;
         fi = fin;
+        VPZ_STAMP(6);  // tail
     }
+#ifdef VPZ_STAMPS
+    if (a.stamps && lane == 0) {
+        for (int k = 0; k < 9; ++k) atomicAdd(&a.stamps[k], t_acc[k]);
+        atomicAdd(&a.stamps[15], 1ull);
+    }
+#endif
 
     // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
     if ((run.flags & kRunSaveState) && prev_n4 > 0) {

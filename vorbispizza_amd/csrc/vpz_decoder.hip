@@ -1658,8 +1658,11 @@ struct SynthCall {
             unsigned long long h[16];
             (void)hipMemcpyAsync(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
             (void)hipStreamSynchronize(ctx->stream);
-            static const char *names[9] = {"desc+prefetch", "barrier0", "stage+barrier", "coupling", "pickup+curve",
-                                           "floor*+imdct", "wait next", "ola+stores", "tail"};
+            static const char *names_one[9] = {"desc+prefetch", "barrier0", "stage+barrier", "coupling", "pickup+curve",
+                                               "floor*+imdct", "wait next", "ola+stores", "tail"};
+            static const char *names_dual[9] = {"desc+prefetch", "unpack+coupling", "curves", "floor*+imdct x2", "wait next",
+                                                "ola+stores", "tail", "-", "-"};
+            const char **names = use_dual ? names_dual : names_one;
             unsigned long long tot = 0;
             for (int k = 0; k < 9; ++k) tot += h[k];
             fprintf(stderr, "[stamps] %llu waves, %.0f cycles per wave:", h[15], h[15] ? (double)tot / h[15] : 0.0);

@@ -13,6 +13,10 @@
 #include <string>
 #include <vector>
 
+#ifdef VPZH_STATS
+extern long g_vpzh_stats[64];  // diagnostic builds only (tools/front_prof.cpp)
+#endif
+
 namespace {
 
 struct InvalidData : std::runtime_error {
@@ -110,7 +114,11 @@ struct Codebook {
     int dimensions = 0, entries = 0, map_type = 0, max_bits = 0, prefix_bits = 0;
     std::vector<int> lengths;
     std::vector<float> lookup;
-    std::vector<HuffNode> prefix, overflow;
+    // prefix table of the first `prefix_bits` bits of a code (Huffman.cs:24-105), one 32-bit word per entry:
+    // value << 6 | length, 0 = the code is longer than the table (overflow list).  4 KiB per book instead of the 16 KiB of
+    // a table of nodes: the dozen books a packet touches stay in the L1 cache together.
+    std::vector<uint32_t> prefix;
+    std::vector<HuffNode> overflow;
 
     void read(BitReader &p)
     {
@@ -211,13 +219,14 @@ struct Codebook {
         if (count == 1 && lengths[last_valid] != 1) throw InvalidData("Invalid single entry.");
         int table_bits = max_len > 10 ? 10 : max_len;
         prefix_bits = table_bits;
-        prefix.assign((size_t)1 << table_bits, HuffNode());
+        prefix.assign((size_t)1 << table_bits, 0u);
         for (const HuffNode &n : list) {
             if (n.length > table_bits) {
                 overflow.push_back(n);
             } else {
-                int max_val = 1 << (table_bits - n.length);
-                for (int j = 0; j < max_val; ++j) prefix[(size_t)((j << n.length) | n.bits)] = n;
+                const int max_val = 1 << (table_bits - n.length);
+                const uint32_t word = ((uint32_t)n.value << 6) | (uint32_t)n.length;  // entries < 2^24, length <= 32
+                for (int j = 0; j < max_val; ++j) prefix[(size_t)((j << n.length) | n.bits)] = word;
             }
         }
     }
@@ -242,18 +251,47 @@ struct Codebook {
         size_t mcount = map_type == 1 ? (size_t)lookup1_values(entries, dimensions) : count;
         std::vector<uint16_t> mult(mcount);
         for (size_t i = 0; i < mcount; ++i) mult[i] = (uint16_t)p.read_bits(value_bits);
+        // (separately rounded multiply, add, add: the translation unit is built with -ffp-contract=off)
+        // map type 1: dimension i of entry idx takes multiplicand (idx / mcount^i) % mcount -- the digits of idx in base
+        // mcount, kept as an odometer instead of two divisions per value (Codebook.cs:262-270 wraps its uint `idxDiv` the
+        // same way: a digit whose weight has overflowed 2^32 is computed from the wrapped weight)
+        std::vector<float> scaled(mcount);
+        for (size_t i = 0; i < mcount; ++i) scaled[i] = (float)mult[i] * delta_value;
+        bool plain_digits = map_type == 1;
+        if (map_type == 1) {  // the odometer equals the reference's arithmetic while mcount^(dimensions-1) fits 32 bits
+            uint64_t wgt = 1;
+            for (int i = 1; i < dimensions && plain_digits; ++i) {
+                wgt *= mcount;
+                if (wgt > 0xFFFFFFFFull) plain_digits = false;
+            }
+        }
+        std::vector<uint32_t> digit((size_t)(dimensions > 0 ? dimensions : 1), 0u);
         for (int idx = 0; idx < entries; ++idx) {
             float last = 0.f;
-            uint32_t idx_div = 1;
-            for (int i = 0; i < dimensions; ++i) {
-                size_t moff = map_type == 1 ? (size_t)(((uint32_t)idx / idx_div) % (uint32_t)mcount)
-                                            : (size_t)idx * dimensions + i;
-                volatile float prod = (float)mult[moff] * delta_value;  // separately rounded mul, add, add
-                volatile float sum = prod + min_value;
-                float value = sum + last;
-                lookup[(size_t)idx * dimensions + i] = value;
-                if (sequence_p) last = value;
-                if (map_type == 1) idx_div *= (uint32_t)mcount;
+            float *dst = lookup.data() + (size_t)idx * dimensions;  // (a book without dimensions has no values)
+            if (map_type == 1 && plain_digits) {
+                for (int i = 0; i < dimensions; ++i) {
+                    const float sum = scaled[digit[i]] + min_value;
+                    const float value = sum + last;
+                    dst[i] = value;
+                    if (sequence_p) last = value;
+                }
+                for (int i = 0; i < dimensions; ++i) {  // idx + 1 in base mcount
+                    if (++digit[i] < (uint32_t)mcount) break;
+                    digit[i] = 0;
+                }
+            } else {
+                uint32_t idx_div = 1;
+                for (int i = 0; i < dimensions; ++i) {
+                    // (a weight that wrapped to 0 is the reference's DivideByZeroException: the value of digit 0 stands in)
+                    const size_t moff = map_type == 1 ? (size_t)(idx_div ? ((uint32_t)idx / idx_div) % (uint32_t)mcount : 0)
+                                                      : (size_t)idx * dimensions + i;
+                    const float sum = scaled[moff] + min_value;
+                    const float value = sum + last;
+                    dst[i] = value;
+                    if (sequence_p) last = value;
+                    if (map_type == 1) idx_div *= (uint32_t)mcount;
+                }
             }
         }
     }
@@ -265,19 +303,19 @@ struct Codebook {
         if (p.pos + 64 <= p.total_bits && !prefix.empty()) {
             uint64_t w;
             memcpy(&w, p.data + (p.pos >> 3), 8);
-            const HuffNode &node = prefix[(size_t)((w >> (p.pos & 7)) & (((uint64_t)1 << prefix_bits) - 1))];
-            if (node.length != 0) {
-                p.pos += node.length;
-                return node.value;
+            const uint32_t e = prefix[(size_t)((w >> (p.pos & 7)) & (((uint64_t)1 << prefix_bits) - 1))];
+            if (e & 63u) {
+                p.pos += e & 63u;
+                return (int)(e >> 6);
             }
         }
         int n;
         uint64_t data = p.try_peek(prefix_bits, &n);
         if (n != 0 && !prefix.empty()) {
-            const HuffNode &node = prefix[(size_t)data];
-            if (node.length != 0) {
-                p.skip(node.length);
-                return node.value;
+            const uint32_t e = prefix[(size_t)data];
+            if (e & 63u) {
+                p.skip((int)(e & 63u));
+                return (int)(e >> 6);
             }
         }
         int d = (int)p.try_peek(max_bits, &n);
@@ -491,12 +529,102 @@ struct Residue {
                 decode_map[(size_t)j * cb.dimensions + k] = deco;
             }
         }
+        finish_setup();
+    }
+
+    // per (classification, stage): the value book, or -1 (flattened `books`: one load in the partition loop)
+    std::vector<int16_t> stage_book;
+    void finish_setup()
+    {
+        stage_book.assign((size_t)classifications * 8, -1);
+        for (int j = 0; j < classifications; ++j)
+            for (size_t k = 0; k < books[j].size() && k < 8; ++k)
+                if (cascade[j] & (1 << k)) stage_book[(size_t)j * 8 + k] = books[j][k];
+    }
+
+    // Residue1.WriteVectors (Residue1.cs:12-34) for a partition that lies inside the channel with room for a last
+    // vector that overhangs it: no per-vector bounds test, the add loop specialised for the usual dimensions.
+    // Returns true when the packet ran out (Codebook.DecodeScalar == -1).
+    template <int kDim>
+    static bool write_vectors_fast(const Codebook &cb, BitReader &p, float *dst, int partition_size)
+    {
+        const float *lookup = cb.lookup.data();
+        const int dim = kDim ? kDim : cb.dimensions;
+        int i = 0;
+        // The bulk of a packet: a 64-bit window of the bit stream in a register, refilled every few symbols -- the chain
+        // from one symbol to the next is a shift and one table read instead of an address computation, an unaligned load,
+        // a shift and the table read.  Same bits consumed, same entries as Codebook.DecodeScalar (Codebook.cs:301-335);
+        // codes longer than the prefix table and the last bytes of the packet take decode_scalar itself.
+        if (!cb.prefix.empty()) {
+            const uint32_t *table = cb.prefix.data();
+            const uint64_t mask = ((uint64_t)1 << cb.prefix_bits) - 1;
+            int64_t pos = p.pos;
+            const int64_t safe_end = p.total_bits - 64;  // an 8-byte load at or below this bit position stays inside
+            while (i < partition_size && pos <= safe_end) {
+                uint64_t w;
+                memcpy(&w, p.data + (pos >> 3), 8);
+                int avail = 64 - (int)(pos & 7);
+                w >>= (pos & 7);
+                // symbols out of this window: each needs at most prefix_bits (<= 10) valid bits
+                while (i < partition_size && avail >= 10) {
+                    const uint32_t e = table[w & mask];
+                    const int len = (int)(e & 63u);
+                    if (len == 0) goto general;  // longer than the table: the overflow list
+                    w >>= len;
+                    avail -= len;
+                    pos += len;
+                    const float *lk = lookup + (size_t)(e >> 6) * dim;
+                    if (kDim) {
+#pragma GCC unroll 8
+                        for (int j = 0; j < kDim; ++j) dst[i + j] += lk[j];
+                    } else {
+                        for (int j = 0; j < dim; ++j) dst[i + j] += lk[j];
+                    }
+                    i += dim;
+                }
+            }
+        general:
+            p.pos = pos;
+        }
+        for (; i < partition_size; i += dim) {
+            const int entry = cb.decode_scalar(p);
+            if (entry == -1) return true;
+            const float *lk = lookup + (size_t)entry * dim;
+            if (kDim) {
+#pragma GCC unroll 8
+                for (int j = 0; j < kDim; ++j) dst[i + j] += lk[j];
+            } else {
+                for (int j = 0; j < dim; ++j) dst[i + j] += lk[j];
+            }
+        }
+        return false;
     }
 
     // WriteVectors: Residue0.cs:208-231 (type 0, sums the entry into ONE bin: quirk q9) and
     // Residue1.cs:12-34 (types 1 and 2)
     bool write_vectors(const Codebook &cb, BitReader &p, float *chan, int chan_len, int offset) const
     {
+#ifdef VPZH_STATS
+        g_vpzh_stats[cb.dimensions < 16 ? cb.dimensions : 15] += 1;
+        g_vpzh_stats[16] = partition_size;
+        g_vpzh_stats[17] = type;
+        g_vpzh_stats[20 + (cb.prefix_bits < 11 ? cb.prefix_bits : 11)] += 1;
+        g_vpzh_stats[40 + (cb.max_bits < 20 ? cb.max_bits : 20)] += 1;
+#endif
+        if (type != 0) {
+            const int dim = cb.dimensions;
+            const int reach = (partition_size + dim - 1) / dim * dim;  // a last vector may overhang the partition
+            if (offset + reach <= chan_len) {
+                float *dst = chan + offset;
+                switch (dim) {
+                    case 1: return write_vectors_fast<1>(cb, p, dst, partition_size);
+                    case 2: return write_vectors_fast<2>(cb, p, dst, partition_size);
+                    case 4: return write_vectors_fast<4>(cb, p, dst, partition_size);
+                    case 8: return write_vectors_fast<8>(cb, p, dst, partition_size);
+                    default: return write_vectors_fast<0>(cb, p, dst, partition_size);
+                }
+            }
+        }
         if (type == 0) {
             int steps = partition_size / cb.dimensions;
             for (int step = 0; step < steps; ++step) {
@@ -557,9 +685,9 @@ struct Residue {
                         if (do_not_decode[ch]) continue;
                         int map_index = part_word_cache[(size_t)ch * partition_words + entry_idx] * dim;
                         int idx = decode_map[(size_t)map_index + dim_idx];
-                        if ((cascade[idx] & (1 << stage)) == 0) continue;
-                        if (books[idx].empty()) continue;
-                        const Codebook &book = cbs[books[idx][stage]];
+                        const int bk = stage < 8 ? stage_book[(size_t)idx * 8 + stage] : -1;  // (cascade bit + book list)
+                        if (bk < 0) continue;
+                        const Codebook &book = cbs[bk];
                         if (write_vectors(book, p, buffer + (size_t)ch * stride, stride, offset)) {
                             partition_idx = partition_count;
                             stage = max_stages;
@@ -623,22 +751,38 @@ struct OggPacket {
     bool resync = false;   // VorbisPacket.IsResync: the page that completes the packet was found after lost sync
 };
 
-// Ogg CRC (polynomial 0x04c11db7, no reflection), Ogg/Crc.cs
-uint32_t g_crc_table[256];
-bool g_crc_ready = false;
-void crc_init()
-{
-    if (g_crc_ready) return;
-    for (uint32_t i = 0; i < 256; ++i) {
-        uint32_t r = i << 24;
-        for (int j = 0; j < 8; ++j) r = (r << 1) ^ ((r & 0x80000000u) ? 0x04c11db7u : 0u);
-        g_crc_table[i] = r;
+// Ogg CRC (polynomial 0x04c11db7, no reflection), Ogg/Crc.cs.  Eight tables (slicing by 8): the byte-at-a-time form is a
+// chain of dependent table reads, ~6 cycles per byte -- a third of a millisecond for a 190 KB file, as much as all its
+// setup headers cost; eight bytes per step bring it below a tenth of that.
+struct CrcTables {
+    uint32_t t[8][256];
+    CrcTables()
+    {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t r = i << 24;
+            for (int j = 0; j < 8; ++j) r = (r << 1) ^ ((r & 0x80000000u) ? 0x04c11db7u : 0u);
+            t[0][i] = r;
+        }
+        for (int k = 1; k < 8; ++k)
+            for (uint32_t i = 0; i < 256; ++i) t[k][i] = (t[k - 1][i] << 8) ^ t[0][t[k - 1][i] >> 24];
     }
-    g_crc_ready = true;
+};
+const CrcTables &crc_tables()
+{
+    static const CrcTables tables;  // (initialised once, thread-safe: streams are opened from many threads)
+    return tables;
 }
+void crc_init() { (void)crc_tables(); }
 uint32_t crc_update(uint32_t crc, const uint8_t *d, size_t n)
 {
-    for (size_t i = 0; i < n; ++i) crc = (crc << 8) ^ g_crc_table[((crc >> 24) & 0xff) ^ d[i]];
+    const CrcTables &T = crc_tables();
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const uint32_t x = crc ^ (((uint32_t)d[i] << 24) | ((uint32_t)d[i + 1] << 16) | ((uint32_t)d[i + 2] << 8) | (uint32_t)d[i + 3]);
+        crc = T.t[7][x >> 24] ^ T.t[6][(x >> 16) & 0xff] ^ T.t[5][(x >> 8) & 0xff] ^ T.t[4][x & 0xff] ^
+              T.t[3][d[i + 4]] ^ T.t[2][d[i + 5]] ^ T.t[1][d[i + 6]] ^ T.t[0][d[i + 7]];
+    }
+    for (; i < n; ++i) crc = (crc << 8) ^ T.t[0][((crc >> 24) & 0xff) ^ d[i]];
     return crc;
 }
 
@@ -969,8 +1113,10 @@ struct vpzh_stream {
                 if (any) {
                     one_flag.assign(1, 0);
                     residues[map.submap_residue[0]].decode(p, one_flag, block_size * channels, dst, half * channels, books);
-                    out->flags |= VPZ_PKT_INTERLEAVED;
                 }
+                // (a packet whose channels are all silent is zeros in either layout: it keeps the stream's layout, so that
+                // a batch has ONE input layout and the back end's fast paths -- whose loads are unconditional -- take it)
+                out->flags |= VPZ_PKT_INTERLEAVED;
                 return;
             }
         }
