@@ -162,12 +162,15 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
     __shared__ PacketGeom s_geom[8];
     __shared__ float s_work[kDualWaves][2][kWaveBufFloats];   // h of the two blocks being built
     __shared__ float s_tail[kDualWaves][2][kWaveTailFloats];  // upper halves of the previous blocks' h
-    __shared__ uint4 s_desc[kDualWaves][(kMaxRunLength + 1) * 2];
+    __shared__ uint4 s_desc[kDualWaves][(kMaxRunLengthDual + 1) * 2];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int run_idx = blockIdx.x * kDualWaves + wave;
     const bool active = run_idx < a.n_runs;
+#ifdef VPZ_WAVE_TIMES
+    const unsigned long long t_wave_begin = __builtin_amdgcn_s_memtime();
+#endif
     RunDesc run = a.runs[active ? run_idx : 0];
     if (!active) {
         run.count = 0;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
     // ---- the run's frame descriptors into LDS (explicit ones copied, a compact run's derived here)
     bool batch_member = false;
     if (run.flags & kRunCompact) {
-        const int n = run.count - fi0;  // staged frames (<= kMaxRunLength + 1 <= 64), one lane each
+        const int n = run.count - fi0;  // staged frames (<= kMaxRunLengthDual + 1 = 64), one lane each
         const uint32_t cf = cf_early, mp = mp_early;
         const uint32_t pcf = __shfl_up(cf, 1);
         const PacketGeom g = s_geom[cf & 7], pg = s_geom[pcf & 7];
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
 #ifdef VPZ_STAMPS
     unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
+    unsigned long long n_long_frames = 0;
 #endif
     int fi = fi0;
     for (int it = 0; it < iters; ++it) {
@@ -422,6 +426,9 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
             stwnext = steps_word(fd_next, valid_next);
         }
         VPZ_STAMP(0);  // descriptor + prefetch issue
+#ifdef VPZ_STAMPS
+        if (size_of(fd.flags) == 2048) ++n_long_frames;
+#endif
         const bool drain = fd.flags & kFrameDrain;
         const bool batch = bsz > 1;
         const int nblk = size_of(fd.flags);
@@ -758,8 +765,18 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
     }
 #ifdef VPZ_STAMPS
     if (a.stamps && lane == 0) {
-        for (int k = 0; k < 9; ++k) atomicAdd(&a.stamps[k], t_acc[k]);
+        unsigned long long tot = 0;
+        for (int k = 0; k < 9; ++k) { atomicAdd(&a.stamps[k], t_acc[k]); tot += t_acc[k]; }
         atomicAdd(&a.stamps[15], 1ull);
+        atomicMax(&a.stamps[14], tot);                      // slowest wave
+        atomicAdd(&a.stamps[13], tot * tot / 1000000ull);   // (for the spread)
+        atomicAdd(&a.stamps[12], (unsigned long long)iters);
+        if (run_idx < (1 << 16)) {  // this wave's own record (VPZ_STAMPS_DUMP)
+            unsigned long long *rec = a.stamps + 16 + 16 * (size_t)run_idx;
+            for (int k = 0; k < 9; ++k) rec[k] = t_acc[k];
+            rec[9] = (unsigned long long)iters;
+            rec[10] = n_long_frames;
+        }
     }
 #endif
 
@@ -773,6 +790,17 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
     }
     // HasClipped is sticky until ResetDecoder: the flag holds the stream's reset epoch
     if (a.clip && __any(clip_peak > 0.99999994f) && lane == 0) atomicMax(&a.clipped[run.stream], run.clip_epoch);
+#ifdef VPZ_WAVE_TIMES
+    // diagnostic builds (-DVPZ_WAVE_TIMES): when each wave ran and where (HW_ID), two clock reads per wave
+    if (a.stamps && lane == 0 && run_idx < (1 << 16)) {
+        unsigned long long *rec = a.stamps + 16 + 16 * (size_t)run_idx;
+        rec[0] = t_wave_begin;
+        rec[1] = __builtin_amdgcn_s_memtime();
+        rec[9] = (unsigned long long)iters;
+        rec[10] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID, all 32 bits
+        atomicAdd(&a.stamps[15], 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1123,7 +1123,7 @@ struct SynthCall {
     void cut_runs()
     {
         const int64_t total_frames = (int64_t)n_frames;
-        const int r_max = synth_needs_general(D.size0, D.size1) ? kMaxRunLengthGeneral : kMaxRunLength;
+        const int r_max = use_dual ? kMaxRunLengthDual : (synth_needs_general(D.size0, D.size1) ? kMaxRunLengthGeneral : kMaxRunLength);
         // Group mode synthesises up to eight consecutive SHORT blocks of a run in one pass (synth_kernel's run builder):
         // a block that rides along costs a fraction of a pass.  Runs are cut to equal COST, in eighths of a pass -- a
         // run rich in short blocks holds more frames --, so that every wavefront of the launch has the same amount to do.
@@ -1645,15 +1645,16 @@ struct SynthCall {
         a.clipped = D.d_clipped;
         a.ablate = D.ablate;
         a.stamps = nullptr;
-#ifdef VPZ_STAMPS
+#if defined(VPZ_STAMPS) || defined(VPZ_WAVE_TIMES)
         static unsigned long long *d_stamps = nullptr;
-        if (!d_stamps) (void)hipMalloc(&d_stamps, 16 * sizeof(unsigned long long));
-        (void)hipMemsetAsync(d_stamps, 0, 16 * sizeof(unsigned long long), ctx->stream);
+        constexpr size_t kStampWaves = 1 << 16;  // per-wave records behind the 16 sums: [16 + 16 * run]
+        if (!d_stamps) (void)hipMalloc(&d_stamps, (16 + 16 * kStampWaves) * sizeof(unsigned long long));
+        (void)hipMemsetAsync(d_stamps, 0, (16 + 16 * std::min<size_t>(kStampWaves, n_runs)) * sizeof(unsigned long long), ctx->stream);
         a.stamps = d_stamps;
 #endif
         hipError_t e = use_dual ? launch_synth_dual(a, any_floor, ilv_seen, ctx->stream) : launch_synth(a, any_floor, ctx->stream);
         if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "synth kernel launch", e);
-#ifdef VPZ_STAMPS
+#if defined(VPZ_STAMPS) || defined(VPZ_WAVE_TIMES)
         {
             unsigned long long h[16];
             (void)hipMemcpyAsync(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
@@ -1667,7 +1668,26 @@ struct SynthCall {
             for (int k = 0; k < 9; ++k) tot += h[k];
             fprintf(stderr, "[stamps] %llu waves, %.0f cycles per wave:", h[15], h[15] ? (double)tot / h[15] : 0.0);
             for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %.1f%%", names[k], tot ? 100.0 * h[k] / tot : 0.0);
+            if (h[14] && h[15]) {
+                const double mean = (double)tot / h[15], var = (double)h[13] * 1e6 / h[15] - mean * mean;
+                fprintf(stderr, " | slowest wave %.0f cycles = %.2f x mean, sigma %.2f x mean, %.1f passes per wave, %d runs", (double)h[14],
+                        (double)h[14] / mean, var > 0 ? sqrt(var) / mean : 0.0, (double)h[12] / h[15], (int)n_runs);
+            }
             fprintf(stderr, "\n");
+            if (const char *dump = getenv("VPZ_STAMPS_DUMP")) {  // per-wave records: run, frames, passes, cycles per phase
+                const size_t nw = std::min<size_t>(kStampWaves, n_runs);
+                std::vector<unsigned long long> w(16 * nw);
+                (void)hipMemcpy(w.data(), d_stamps + 16, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+                if (FILE *f = fopen(dump, "w")) {
+                    fprintf(f, "run,stream,frames,passes,long_frames,c0,c1,c2,c3,c4,c5,c6\n");
+                    for (size_t r = 0; r < nw; ++r) {
+                        fprintf(f, "%zu,%d,%d,%llu,%llu", r, runs[r].stream, runs[r].count, w[16 * r + 9], w[16 * r + 10]);
+                        for (int k = 0; k < 7; ++k) fprintf(f, ",%llu", w[16 * r + k]);
+                        fprintf(f, "\n");
+                    }
+                    fclose(f);
+                }
+            }
         }
 #endif
         return VPZ_OK;
