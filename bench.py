@@ -39,22 +39,23 @@ CHANNELS = 2
 N = 2048
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel as measured with the PMC counters (rocprofv3 --pmc FETCH_SIZE /
+def pmc_traffic_bytes(workload="headline"):
+    """HBM bytes per launch of a workload's kernels as measured with the PMC counters (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE, separate passes, gfx950 corrections): counters cannot be collected inside this process, so the figure
     comes from profiles/traffic_stamp.json, written on the GPU box by tools/stamp_traffic.py together with the SHA-256
-    of the kernel's sources.  Null when there is no stamp or when the sources have changed since it was taken."""
+    of the kernels' sources.  Null when there is no stamp or when the sources have changed since it was taken."""
     import hashlib
     path = os.path.join(ROOT, "profiles", "traffic_stamp.json")
     try:
         stamp = json.load(open(path))
+        entry = stamp.get("workloads", {}).get(workload) or (stamp if workload == "headline" else None)
         h = hashlib.sha256()
-        for rel in stamp["kernel_sources"]:
+        for rel in entry["kernel_sources"]:
             h.update(open(os.path.join(ROOT, rel), "rb").read())
-        if h.hexdigest() != stamp["kernel_sources_sha256"]:
+        if h.hexdigest() != entry["kernel_sources_sha256"]:
             return None
-        return int(stamp["traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+        return int(entry["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
@@ -535,6 +536,8 @@ def main():
                 "Msamples_per_s": round(samples * CHANNELS / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "roofline": {"bound": "hbm", "achieved": round(byt / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": byt,
+                             "traffic": pmc_traffic_bytes("north_star_line") if args.extras_frames == FRAMES else None,
+                             "kernel": "synth_dual_kernel<false, false, 0, false> (stereo fast path, no floor, planar in / out)",
                              "bytes_per_sample": round(byt / (samples * CHANNELS), 3)},
                 "note": "whole vpz_decoder_synth call incl. the host state machine; 8 B per sample; best of 3 loops of 40 calls"}
             dec.close()
@@ -548,6 +551,7 @@ def main():
             extras["configs[2] mixed 256/2048 + window + OLA, stereo, %d frames, planar out" % args.extras_frames] = {
                 "Msamples_per_s": round(samples * CHANNELS / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes": byt, "traffic": pmc_traffic_bytes("configs2") if args.extras_frames == FRAMES else None,
                 "note": "whole vpz_decoder_synth call incl. the host state machine; best of 3 loops of 40 calls"}
             dec.close()
             del residue
@@ -576,10 +580,11 @@ def main():
                    "interleaved out, decoded spectra device-resident"] = {
                 "Msamples_per_s": round(tot / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "algorithmic_GBps": round(8 * tot / dt / 1e9, 1), "frac_of_8TBps": round(8 * tot / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes": 8 * tot, "traffic": pmc_traffic_bytes("configs4_share"),
                 "cpu_entropy_decode_s_for_128_streams_1thread": round(t_front, 3),
                 "end_to_end_Msamples_per_s_incl_cpu_entropy_decode_1thread": round(tot / (dt + t_front) / 1e6, 2),
-                "note": "one decoder over both fixtures' setups (sharding.merge_setups); GPU stage = Floor1 unwrap + fused synth "
-                        "(group mode), one launch each per step"}
+                "note": "one decoder over both fixtures' setups (sharding.merge_setups); GPU stage = Floor1 unwrap + the stereo "
+                        "fast path (synth_dual_kernel: one wavefront per stream-run, both channels), one launch each per step"}
             thr = host_threads()
             tot_e, (t_all, t_dec, t_syn) = end_to_end_real_streams(ctx, torch, 64, thr)
             extras["configs[4] end to end, one GPU's share: 128 real stereo streams, container bytes in host memory "

@@ -10,7 +10,7 @@ OUT=gpurun_out/profiles_$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats -d "$OUT/bench" -o b --output-format csv -- python bench.py --steps 20 --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
 python tools/prof_summary.py "$OUT/bench/b_kernel_stats.csv" > "$OUT/bench_kernel_stats.txt"
-for w in ola floor real; do
+for w in olalong ola floor real; do
   rocprofv3 --kernel-trace --memory-copy-trace --stats -d "$OUT/$w" -o k --output-format csv -- python tools/kbench_synth.py --steps 8 --which $w > "$OUT/$w.log" 2>&1
   python tools/prof_summary.py "$OUT/$w/k_kernel_stats.csv" > "$OUT/${w}_kernel_stats.txt"
   python tools/timeline.py "$OUT/$w" --last 12 --ours > "$OUT/${w}_timeline.txt"

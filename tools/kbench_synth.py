@@ -29,8 +29,17 @@ def main():
         dec = Decoder(ctx, 2, 256, 2048)
         dt, _ = bench.time_decoder(ctx, dec, torch, pk, residue, None, None, samples, 2, args.steps, 2)
         byt = 4 * res_floats + 4 * samples * 2
-        print("configs[2]: %.3f ms/call  %.1f Msamples/s  %.0f GB/s algorithmic (whole call)"
-              % (dt * 1e3, samples * 2 / dt / 1e6, byt / dt / 1e9))
+        print("configs[2]: %.3f ms/call  %.1f Msamples/s  %.0f GB/s algorithmic (whole call); algorithmic bytes %d"
+              % (dt * 1e3, samples * 2 / dt / 1e6, byt / dt / 1e9, byt))
+        dec.close()
+        del residue
+    if args.which == "olalong":  # north_star's literal line: all-long stereo IMDCT + window + OLA through the fused kernel
+        pk, residue, samples, res_floats = bench.build_synth_ola(torch, dev, args.frames, all_long=True)
+        dec = Decoder(ctx, 2, 256, 2048)
+        dt, _ = bench.time_decoder(ctx, dec, torch, pk, residue, None, None, samples, 2, args.steps, 2)
+        byt = 4 * res_floats + 4 * samples * 2
+        print("north_star line: %.3f ms/call  %.1f Msamples/s  %.0f GB/s algorithmic (whole call); algorithmic bytes %d"
+              % (dt * 1e3, samples * 2 / dt / 1e6, byt / dt / 1e9, byt))
         dec.close()
         del residue
     if args.which in ("both", "floor"):
@@ -43,8 +52,8 @@ def main():
         dec.close()
     if args.which in ("both", "real"):
         dt, tot, _, _ = bench.time_real_streams(ctx, torch, dev, args.copies, steps=args.steps)
-        print("configs[4] share (%d real stereo streams, interleaved out): %.3f ms/step  %.1f Msamples/s"
-              % (2 * args.copies, dt * 1e3, tot / dt / 1e6))
+        print("configs[4] share (%d real stereo streams, interleaved out): %.3f ms/step  %.1f Msamples/s; algorithmic bytes %d"
+              % (2 * args.copies, dt * 1e3, tot / dt / 1e6, 8 * tot))
     ctx.close()
 
 

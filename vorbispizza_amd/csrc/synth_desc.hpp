@@ -37,7 +37,10 @@ struct FrameDesc {        // 32 bytes: staged per run into LDS by the wavefront 
 static_assert(sizeof(FrameDesc) == 32, "FrameDesc is staged as two 16-byte words");
 constexpr int kMaxRunLength = 32;
 constexpr int kMaxRunLengthGeneral = 16;  // the general-size kernel variant trades descriptor space for tables
-constexpr int kMaxRunLengthDual = 63;     // the stereo fast path: a run's frames (+ the recomputed one) are one lane each while
+#ifndef VPZ_DUAL_WAVES
+#define VPZ_DUAL_WAVES 4   // wavefronts per workgroup of the stereo fast path (tuning builds: -DVPZ_DUAL_WAVES=10, one workgroup per CU)
+#endif
+constexpr int kMaxRunLengthDual = VPZ_DUAL_WAVES >= 10 ? 44 : 63;     // the stereo fast path: a run's frames (+ the recomputed one) are one lane each while
                                           // its descriptors are built; runs cut to equal COST need the room -- a run rich in
                                           // short blocks holds many frames (capped at 32 frames, such runs were done in 3/4 of
                                           // the time of the others: the launch waited for the all-long ones)

@@ -29,7 +29,8 @@
 
 namespace vpz {
 
-constexpr int kDualWaves = 4;
+constexpr int kDualWaves = VPZ_DUAL_WAVES;
+constexpr int kDualWavesPerSimd = VPZ_DUAL_WAVES >= 10 ? 3 : 2;  // 4-wave workgroups: two per CU (LDS); 10-wave ones: one
 constexpr int kDualThreads = 64 * kDualWaves;
 
 // Both channels' Floor1 curves at once (render_floor_indices_fast, phase by phase for the two records): the phases are
@@ -147,7 +148,7 @@ __device__ __forceinline__ int spectrum_top(const float2 (&x)[8], int lpb)
 // kOut   : 0 planar output, 1 interleaved
 // kExp: tuning experiments, A/B on one box through VPZ_DUAL_EXP (none at the moment; DESIGN.md 4.7 lists what was tried)
 template <bool kHasFloor, bool kIlvIn, int kOut, bool kS16, int kExp = 0>
-__global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a)
+__global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_kernel(SynthArgs a)
 {
     using out_t = typename std::conditional<kS16, int16_t, float>::type;
     constexpr bool kInterleavedOut = kOut != 0;
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
                 }
             }
             // ---- inverse coupling, steps in reverse order (Mapping.cs:166-172); a stereo step is (0, 1) or (1, 0)
-            if (!(fd.flags & kFrameNoFloor)) {
+            if (!(fd.flags & kFrameNoFloor) && !(a.ablate & 16)) {
                 const int n_steps = (int)((fd.flags >> kFrameStepsShift) & 0xFF);
                 const uint8_t *st = s_steps + 2 * (fd.flags >> kFrameStepsOffShift);
                 const unsigned long long stw = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.y) << 32) |
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
                     const int nrL = silentL ? 0 : 2 * (spectrum_top(xL, lpb) + 1);
                     const int nrR = silentR ? 0 : 2 * (spectrum_top(xR, lpb) + 1);
                     const int pa = ln < cntL ? cpa : 0, pb = ln < cntR ? cpb : 0;
-                    if (nrL > 0 || nrR > 0) {
+                    if ((nrL > 0 || nrR > 0) && !(a.ablate & 8)) {
                         if (!render_floor_indices_fast_x2(rowL, rowR, auxL, auxR, n, nrL, nrR, pa, pb, cntL, cntR, ln)) {
                             if (nrL > 0) render_floor_indices<32>(rowL, auxL, n, nrL, pa, cntL, ln);
                             if (nrR > 0) render_floor_indices<32>(rowR, auxR, n, nrR, pb, cntR, ln);
@@ -537,7 +538,12 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
                 apply_floor(xR, fyR, s_db);
             }
             // ---- the two transforms, side by side
-            if (is_long) {
+            if (a.ablate & 2) {
+                // (tuning only: the spectra as they are)
+                float2 *h2L = reinterpret_cast<float2 *>(hL), *h2R = reinterpret_cast<float2 *>(hR);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { h2L[ln + 64 * m] = xL[m]; h2R[ln + 64 * m] = xR[m]; }
+            } else if (is_long) {
                 imdct2048_wave_x2(xL, xR, reinterpret_cast<float2 *>(hL), reinterpret_cast<float2 *>(hR), s_twL, s_twAB, s_twBC, ln);
             } else {
                 imdct256_wave8_x2(xL, xR, reinterpret_cast<float2 *>(hL), reinterpret_cast<float2 *>(hR), s_twS, s_twBC, ln);
@@ -617,7 +623,9 @@ __global__ __launch_bounds__(kDualThreads, 2) void synth_dual_kernel(SynthArgs a
         const float4 *tL4 = reinterpret_cast<const float4 *>(tailL), *tR4 = reinterpret_cast<const float4 *>(tailR);
         int lf = lane;
         asm volatile("" : "+v"(lf));  // (no address of the epilogue may be computed ahead of the frame loop)
-        if (batch && fi >= 0) {
+        if (a.ablate & 1) {
+            // (tuning only: no window / overlap-add / stores)
+        } else if (batch && fi >= 0) {
             // ---- a batch of short blocks: 128 * bsz contiguous samples.  Sample i of block f is y_f[i] over the previous
             // block's y[128 + i] (both windows short): y_f[i] = -h_f[63 - i] (i < 64), h_f[i - 64] otherwise; the partner
             // is hp[i] (i < 64), hp[127 - i] otherwise, hp = the upper half of the previous block's h -- the block before
@@ -816,12 +824,13 @@ hipError_t launch_synth_dual(const SynthArgs &args, bool has_floor, bool interle
 {
     if (args.n_runs <= 0) return hipSuccess;
     const int grid = (args.n_runs + kDualWaves - 1) / kDualWaves;
+    static const int extra_lds = getenv("VPZ_SYNTH_EXTRA_LDS") ? atoi(getenv("VPZ_SYNTH_EXTRA_LDS")) : 0;  // occupancy experiments
 #define VPZ_LAUNCH_DUAL(F, I, O)                                                                                          \
     do {                                                                                                                  \
         if (args.s16)                                                                                                     \
-            hipLaunchKernelGGL((synth_dual_kernel<F, I, O, true>), dim3(grid), dim3(kDualThreads), 0, stream, args);      \
+            hipLaunchKernelGGL((synth_dual_kernel<F, I, O, true>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
         else                                                                                                              \
-            hipLaunchKernelGGL((synth_dual_kernel<F, I, O, false>), dim3(grid), dim3(kDualThreads), 0, stream, args);     \
+            hipLaunchKernelGGL((synth_dual_kernel<F, I, O, false>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
     } while (0)
 #define VPZ_LAUNCH_DUAL_OUT(F, I)                \
     do {                                         \
