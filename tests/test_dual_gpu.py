@@ -146,42 +146,3 @@ def test_unaligned_output_rows_and_eos_trim(ctx, oracle):
     got = results["dual"][0][1 + s_ * channels * cap: 1 + s_ * channels * cap + n * channels].reshape(n, channels)
     assert ref.shape == got.shape
     assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
-
-
-@pytest.mark.parametrize("channels,steps", [(6, [(0, 1), (2, 3)]), (4, [(1, 0), (2, 3), (3, 2)]), (6, []), (8, [(6, 7), (0, 1)]),
-                                            (4, [(0, 2)])])
-@pytest.mark.parametrize("interleaved", [True, False])
-def test_channel_pairs_of_multichannel_streams(ctx, oracle, channels, steps, interleaved):
-    """More than two channels (an even number), planar output: one wavefront per channel PAIR of a run -- the usual 5.1
-    mapping couples (0, 1) and (2, 3), inside pairs.  Against group mode and the separate coupling pass, bit for bit; a
-    mapping with a step ACROSS pairs ((0, 2)) must not take the pair path (and still decodes the same)."""
-    from vorbispizza_amd import capi
-    n_streams, frames = 9, 48
-    pk, res, posts, counts = stream_major_batch(n_streams, frames, channels, seed=700 + channels + 10 * interleaved, floor=True,
-                                                interleaved=interleaved, p_ls=0.2, p_sl=0.2, silent_prob=0.12)
-    pk["mapping"] = pk["flags"] & 1
-    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)]
-    mappings = [{"coupling": steps, "channel_floor": [0] * channels}, {"coupling": steps, "channel_floor": [1] * channels}]
-    for host in (dict(VPZ_PAR_MIN_PACKETS=1 << 40), dict(VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=4)):
-        for layout in (capi.OUT_PLANAR, capi.OUT_PLANAR_S16, capi.OUT_INTERLEAVED):
-            outs = {}
-            for name, kv in ROUTES:
-                with env(**dict(kv, **host)):
-                    outs[name] = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
-            same_bits(outs["dual"], outs["group"], "pairs vs group, layout %d" % layout)
-            same_bits(outs["dual"], outs["separate"], "pairs vs separate, layout %d" % layout)
-    s_, per = 4, frames
-    opk = []
-    for i in range(s_ * per, (s_ + 1) * per):
-        half = 1024 if pk["flags"][i] & 1 else 128
-        off = int(pk["residue_offset"][i])
-        opk.append({"flags": int(pk["flags"][i]), "granule": -1, "mapping": int(pk["mapping"][i]),
-                    "residue": res[off: off + channels * half], "posts": posts[i * channels:(i + 1) * channels],
-                    "post_count": counts[i * channels:(i + 1) * channels]})
-    ref, _, _ = helpers.oracle_decode(oracle, channels, 256, 2048, opk, floors=floors, mappings=mappings)
-    with env(**ROUTES[0][1]):
-        got = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=capi.OUT_PLANAR, splits=2)
-    cap = per * 1024 + 64
-    pcm = got[0][s_ * channels * cap:(s_ + 1) * channels * cap].reshape(channels, cap)[:, :ref.shape[1]]
-    assert got[1][s_] == ref.shape[1] and ref.shape[1] > 0
-    assert np.abs(pcm - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))

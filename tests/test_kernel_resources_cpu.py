@@ -47,9 +47,8 @@ def test_every_synth_kernel_instantiation_is_built_and_keeps_two_workgroups_per_
 
 def test_stereo_fast_path_instantiations_and_their_budget(kernels):
     dual = [k for k in kernels.values() if "synth_dual_kernel" in k["name"]]
-    # <floor?, Residue2-interleaved / planar input, planar / interleaved output, float32 / int16 samples>, and for streams
-    # of more than two channels (one wavefront per channel pair, planar output): <floor?, input layout, sample format>
-    assert len(dual) == 2 * 2 * 2 * 2 + 2 * 2 * 2
+    # <floor?, Residue2-interleaved / planar input, planar / interleaved output, float32 / int16 samples>
+    assert len(dual) == 2 * 2 * 2 * 2
     for k in dual:
         assert k["vgprs"] <= 256, k["name"]                   # 2 waves per SIMD: 512 / 2
         assert k["lds"] <= 80 * 1024, (k["name"], k["lds"])   # two 4-wave workgroups per CU (160 KiB)

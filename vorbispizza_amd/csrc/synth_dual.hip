@@ -147,11 +147,7 @@ __device__ __forceinline__ int spectrum_top(const float2 (&x)[8], int lpb)
 // kIlvIn : every packet of the batch is the Residue2-interleaved vector [bin][2] (else: every packet planar [2][bin])
 // kOut   : 0 planar output, 1 interleaved
 // kExp: tuning experiments, A/B on one box through VPZ_DUAL_EXP (none at the moment; DESIGN.md 4.7 lists what was tried)
-// kMulti : the stream has MORE than two channels (an even number): a wavefront takes one channel PAIR (2p, 2p + 1) of a
-//          run -- the pairs of a run are independent wavefronts (planar output only; a mapping's coupling steps must
-//          stay inside pairs: the usual 5.1 mapping couples (0, 1) and (2, 3)).  Of the Residue2 vector [bin][C] the wave
-//          reads its pair's 8 bytes per bin; the C / 2 waves of a run use every byte of the lines they touch between them.
-template <bool kHasFloor, bool kIlvIn, int kOut, bool kS16, bool kMulti = false, int kExp = 0>
+template <bool kHasFloor, bool kIlvIn, int kOut, bool kS16, int kExp = 0>
 __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_kernel(SynthArgs a)
 {
     using out_t = typename std::conditional<kS16, int16_t, float>::type;
@@ -171,13 +167,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int C = kMulti ? a.channels : 2;
-    const int pairs = C >> 1;
-    const int item = blockIdx.x * kDualWaves + wave;
-    // (uniform values: the division stays out of the vector registers)
-    const int run_idx = kMulti ? __builtin_amdgcn_readfirstlane(item / pairs) : item;
-    const int pair = kMulti ? item - run_idx * pairs : 0;
-    const int ch0 = 2 * pair;  // this wave's channels: ch0 ("L" below) and ch0 + 1 ("R")
+    const int run_idx = blockIdx.x * kDualWaves + wave;
     const bool active = run_idx < a.n_runs;
 #ifdef VPZ_WAVE_TIMES
     const unsigned long long t_wave_begin = __builtin_amdgcn_s_memtime();
@@ -198,7 +188,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             cf_early = a.cflags[f0 + lane];
             mp_early = a.cmap[f0 + lane];
             if (kHasFloor && a.ccount != nullptr)  // both channels' post counts: records 2p, 2p + 1
-                cc_early = *reinterpret_cast<const uint16_t *>(a.ccount + run.rec_base + lane * C + ch0);
+                cc_early = *reinterpret_cast<const uint16_t *>(a.ccount + run.rec_base + lane * 2);
         }
     }
     {
@@ -279,7 +269,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             }
         }
         const int half = (cf & 1) ? (a.size1 >> 1) : (a.size0 >> 1);
-        int spec_sz = lane < n ? C * half : 0;
+        int spec_sz = lane < n ? 2 * half : 0;
         int out_sz = (lane < n && lane >= -fi0) ? out_count : 0;
         int spec_incl = spec_sz, out_incl = out_sz;
 #pragma unroll
@@ -293,7 +283,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             uint4 lo, hi;
             lo.x = (uint32_t)spec_off; lo.y = (uint32_t)((uint64_t)spec_off >> 32);
             lo.z = (uint32_t)out_off; lo.w = (uint32_t)((uint64_t)out_off >> 32);
-            hi.x = (uint32_t)(run.rec_base + lane * C);
+            hi.x = (uint32_t)(run.rec_base + lane * 2);
             hi.y = (uint32_t)left_start | ((uint32_t)(has_prev && !(cf & kCfSkip) ? prev_stop - prev_end : 0) << 16);
             hi.z = (uint32_t)((has_prev && !(cf & kCfSkip)) ? prev_end : 0) | ((uint32_t)out_count << 16);
             hi.w = fl;
@@ -313,7 +303,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         } else {
             __builtin_amdgcn_wave_barrier();
             if (lane < run.count - fi0)
-                cc_run = *reinterpret_cast<const uint16_t *>(a.ccount + (int)s_desc[wave][2 * lane + 1].x + ch0);
+                cc_run = *reinterpret_cast<const uint16_t *>(a.ccount + (int)s_desc[wave][2 * lane + 1].x);
         }
     }
     const int iters = run.count - fi0 - (int)__popcll(__ballot(batch_member));
@@ -340,7 +330,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
 
     // ---- block preceding the run: from the saved state, or recomputed as "frame -1" of the loop
     if (run.pre_kind == kPreState) {
-        const float *st = a.state_h + (size_t)run.state_slot * a.state_slot_floats + ((size_t)run.stream * C + ch0) * half1;
+        const float *st = a.state_h + (size_t)run.state_slot * a.state_slot_floats + (size_t)run.stream * 2 * half1;
         prev_n4 = run.prev_long ? (a.size1 >> 2) : (a.size0 >> 2);
         for (int i = lane; i < prev_n4; i += 64) {
             tailL[i] = st[i];
@@ -368,7 +358,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         asm volatile("" : "+v"(l));  // (frame-invariant lane arithmetic stays inside the iteration that uses it)
         const int g = l >> 3, gg = g < bsz ? g : 0;
         const float *src = valid ? a.spec + fd.spec_off : a.inv_db;
-        if (kIlvIn && !kMulti) {
+        if (kIlvIn) {
             const float4 *s4 = reinterpret_cast<const float4 *>(src);
             const int base = !valid ? 0 : (is_long ? l : 64 * gg + (l & 7));
             const int step = !valid ? 0 : (is_long ? 64 : 8);
@@ -378,26 +368,12 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 va[m] = make_float2(v.x, v.y);
                 vb[m] = make_float2(v.z, v.w);
             }
-        } else if (kIlvIn) {
-            // [bin][C]: bins 2k, 2k + 1 of channels ch0, ch0 + 1 are the 8-byte pairs at float2 index k * C + pair and
-            // C / 2 further on; block gg of a pass starts gg * 128 * C floats into the pass's vectors
-            const float2 *s2 = reinterpret_cast<const float2 *>(src);
-            const int k0 = is_long ? l : (l & 7);
-            const int base = !valid ? 0 : (is_long ? 0 : 64 * gg * C) + k0 * C + pair;
-            const int step = !valid ? 0 : (is_long ? 64 : 8) * C;
-            const int rofs = !valid ? 0 : pairs;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                va[m] = s2[base + step * m];
-                vb[m] = s2[base + step * m + rofs];
-            }
         } else {
             const float2 *s2 = reinterpret_cast<const float2 *>(src);
-            // block gg of the pass: its packet gg * C * 128 floats on; row of channel c at + c * half floats
-            const int hh2 = is_long ? 512 : 64;  // float2 per row
-            const int base = !valid ? 0 : (is_long ? l : 64 * C * gg + (l & 7)) + ch0 * hh2;
+            // block gg of the pass: its L row at + gg * 2 * 128 floats, its R row half a packet further on
+            const int base = !valid ? 0 : (is_long ? l : 128 * gg + (l & 7));
             const int step = !valid ? 0 : (is_long ? 64 : 8);
-            const int rofs = !valid ? 0 : hh2;
+            const int rofs = !valid ? 0 : (is_long ? 512 : 64);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 va[m] = s2[base + step * m];
@@ -407,7 +383,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         if (kHasFloor) {
             const bool floored = valid && !(fd.flags & kFrameNoFloor) && a.cposts != nullptr;
             const int32_t *cp = a.cposts != nullptr ? a.cposts : reinterpret_cast<const int32_t *>(a.inv_db);
-            const size_t rec = floored ? (size_t)(fd.rec + ch0) : 0;
+            const size_t rec = floored ? (size_t)fd.rec : 0;
             cpa = cp[rec * 64 + l];
             cpb = cp[(floored ? rec + 1 : 0) * 64 + l];
         }
@@ -485,8 +461,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                                                (uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.x);
                 for (int i = n_steps - 1; i >= 0; --i) {
                     const uint32_t mag = (n_steps <= 4 ? (uint32_t)(stw >> (16 * i)) : (uint32_t)st[2 * i]) & 0x7Fu;
-                    if (kMulti && (int)(mag >> 1) != pair) continue;  // another pair's step (the host admits no step across pairs)
-                    if ((int)mag == ch0) {
+                    if (mag == 0) {
 #pragma unroll
                         for (int m = 0; m < 8; ++m) { couple(xL[m].x, xR[m].x); couple(xL[m].y, xR[m].y); }
                     } else {
@@ -529,8 +504,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
 #pragma unroll
                     for (int f = 0; f < 8; ++f) {
                         const int ff = f < bsz ? f : 0;
-                        cps[f][0] = a.cposts[(size_t)(fd.rec + C * ff + ch0) * 64 + ln];
-                        cps[f][1] = a.cposts[(size_t)(fd.rec + C * ff + ch0 + 1) * 64 + ln];
+                        cps[f][0] = a.cposts[(size_t)(fd.rec + 2 * ff) * 64 + ln];
+                        cps[f][1] = a.cposts[(size_t)(fd.rec + 2 * ff + 1) * 64 + ln];
                     }
 #pragma unroll
                     for (int f = 0; f < 8; ++f) {
@@ -606,8 +581,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 515-638)
         // 4 consecutive samples of both channels, sample 4 g .. 4 g + 3 of the pass's output
         out_t *row_i = out_base + fd.out_off * 2;                          // interleaved: sample s at [2 s, 2 s + 1]
-        out_t *row_l = out_base + (int64_t)ch0 * a.channel_stride + fd.out_off;  // planar
-        out_t *row_r = row_l + a.channel_stride;
+        out_t *row_l = out_base + fd.out_off;                              // planar
+        out_t *row_r = out_base + a.channel_stride + fd.out_off;
         const bool aligned = kInterleavedOut ? (reinterpret_cast<uintptr_t>(row_i) & 15) == 0
                                              : ((reinterpret_cast<uintptr_t>(row_l) | reinterpret_cast<uintptr_t>(row_r)) & (kS16 ? 7 : 15)) == 0;
         auto emit4 = [&](int g, float l0, float l1, float l2, float l3, float r0, float r1, float r2, float r3) {
@@ -804,8 +779,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         atomicMax(&a.stamps[14], tot);                      // slowest wave
         atomicAdd(&a.stamps[13], tot * tot / 1000000ull);   // (for the spread)
         atomicAdd(&a.stamps[12], (unsigned long long)iters);
-        if (item < (1 << 16)) {  // this wave's own record (VPZ_STAMPS_DUMP)
-            unsigned long long *rec = a.stamps + 16 + 16 * (size_t)item;
+        if (run_idx < (1 << 16)) {  // this wave's own record (VPZ_STAMPS_DUMP)
+            unsigned long long *rec = a.stamps + 16 + 16 * (size_t)run_idx;
             for (int k = 0; k < 9; ++k) rec[k] = t_acc[k];
             rec[9] = (unsigned long long)iters;
             rec[10] = n_long_frames;
@@ -815,7 +790,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
 
     // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
     if ((run.flags & kRunSaveState) && prev_n4 > 0) {
-        float *st = a.state_h + (size_t)(run.state_slot ^ 1) * a.state_slot_floats + ((size_t)run.stream * C + ch0) * half1;
+        float *st = a.state_h + (size_t)(run.state_slot ^ 1) * a.state_slot_floats + (size_t)run.stream * 2 * half1;
         for (int i = lane; i < prev_n4; i += 64) {
             st[i] = tailL[i];
             st[half1 + i] = tailR[i];
@@ -825,8 +800,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     if (a.clip && __any(clip_peak > 0.99999994f) && lane == 0) atomicMax(&a.clipped[run.stream], run.clip_epoch);
 #ifdef VPZ_WAVE_TIMES
     // diagnostic builds (-DVPZ_WAVE_TIMES): when each wave ran and where (HW_ID), two clock reads per wave
-    if (a.stamps && lane == 0 && item < (1 << 16)) {
-        unsigned long long *rec = a.stamps + 16 + 16 * (size_t)item;
+    if (a.stamps && lane == 0 && run_idx < (1 << 16)) {
+        unsigned long long *rec = a.stamps + 16 + 16 * (size_t)run_idx;
         rec[0] = t_wave_begin;
         rec[1] = __builtin_amdgcn_s_memtime();
         rec[9] = (unsigned long long)iters;
@@ -842,27 +817,25 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
 bool synth_dual_supported(int channels, int size0, int size1)
 {
     auto plain = [](int n) { return n == 256 || n == 2048; };
-    return channels >= 2 && (channels & 1) == 0 && plain(size0) && plain(size1);
+    return channels == 2 && plain(size0) && plain(size1);
 }
 
 hipError_t launch_synth_dual(const SynthArgs &args, bool has_floor, bool interleaved_in, hipStream_t stream)
 {
     if (args.n_runs <= 0) return hipSuccess;
-    const long items = (long)args.n_runs * (args.channels / 2);
-    const int grid = (int)((items + kDualWaves - 1) / kDualWaves);
+    const int grid = (args.n_runs + kDualWaves - 1) / kDualWaves;
     static const int extra_lds = getenv("VPZ_SYNTH_EXTRA_LDS") ? atoi(getenv("VPZ_SYNTH_EXTRA_LDS")) : 0;  // occupancy experiments
-#define VPZ_LAUNCH_DUAL(F, I, O, M)                                                                                          \
-    do {                                                                                                                     \
-        if (args.s16)                                                                                                        \
-            hipLaunchKernelGGL((synth_dual_kernel<F, I, O, true, M>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args);  \
-        else                                                                                                                 \
-            hipLaunchKernelGGL((synth_dual_kernel<F, I, O, false, M>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
+#define VPZ_LAUNCH_DUAL(F, I, O)                                                                                          \
+    do {                                                                                                                  \
+        if (args.s16)                                                                                                     \
+            hipLaunchKernelGGL((synth_dual_kernel<F, I, O, true>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
+        else                                                                                                              \
+            hipLaunchKernelGGL((synth_dual_kernel<F, I, O, false>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
     } while (0)
-#define VPZ_LAUNCH_DUAL_OUT(F, I)                                                    \
-    do {                                                                             \
-        if (args.channels > 2) VPZ_LAUNCH_DUAL(F, I, 0, true); /* planar output only */ \
-        else if (args.interleaved) VPZ_LAUNCH_DUAL(F, I, 1, false);                  \
-        else VPZ_LAUNCH_DUAL(F, I, 0, false);                                        \
+#define VPZ_LAUNCH_DUAL_OUT(F, I)                \
+    do {                                         \
+        if (args.interleaved) VPZ_LAUNCH_DUAL(F, I, 1); \
+        else VPZ_LAUNCH_DUAL(F, I, 0);           \
     } while (0)
     if (has_floor) {
         if (interleaved_in) VPZ_LAUNCH_DUAL_OUT(true, true);

@@ -356,11 +356,8 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         D.group_ok = synth_group_supported(D.channels) && !D.generic && !has_floor0 && D.max_steps <= 255 &&
                      D.n_step_pairs <= kGroupMaxStepPairs && !(no_group && atoi(no_group));
         const char *no_dual = getenv("VPZ_NO_DUAL");
-        // (more than two channels: one wavefront per channel PAIR, so every coupling step must stay inside a pair)
-        bool steps_in_pairs = true;
-        for (size_t i = 0; i + 1 < steps.size(); i += 2) steps_in_pairs &= (steps[i] >> 1) == (steps[i + 1] >> 1);
         D.dual_ok = synth_dual_supported(D.channels, D.size0, D.size1) && !D.generic && !has_floor0 && D.max_steps <= 255 &&
-                    D.n_step_pairs <= kGroupMaxStepPairs && (D.channels == 2 || steps_in_pairs) && !(no_dual && atoi(no_dual));
+                    D.n_step_pairs <= kGroupMaxStepPairs && !(no_dual && atoi(no_dual));
         D.max_steps = max_levels;  // from here on: the barriers a frame's coupling needs in group mode
         const char *nc = getenv("VPZ_NO_COMPACT");
         D.no_compact = nc && atoi(nc);
@@ -583,11 +580,6 @@ struct SynthCall {
     bool dual_usable() const
     {
         if (!D.dual_ok || any_floor0 || (ilv_seen && planar_seen)) return false;
-        if (C > 2 && out_interleaved) return false;  // interleaved rows of many channels are written by a packet's waves together
-        if (C > 2 && ilv_seen) {  // a channel pair's 8 bytes per bin: packets on 8-byte boundaries
-            const bool dev_ok8 = mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & 7) == 0;
-            return dev_ok8 && align2_ok;
-        }
         const bool dev_ok = mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & (ilv_seen ? 15 : 7)) == 0;
         return dev_ok && (ilv_seen ? group_align_ok : align2_ok);
     }
