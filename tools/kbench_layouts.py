@@ -53,6 +53,13 @@ def main():
     for layout, name in ((capi.OUT_PLANAR, "planar"), (capi.OUT_INTERLEAVED, "interleaved")):
         run("6 ch coupled + Floor1 (group mode), %s" % name, Decoder(ctx, 6, 256, 2048, floors=floors, mappings=mappings),
             pk6, res6, posts, counts, samples6, 6, layout)
+    # ... and the same stream handed over PLANAR ([channel][bin] per packet): no de-interleave -- the channel-pair path of
+    # synth_dual_kernel reads contiguous rows (VPZ_NO_DUAL=1: group mode)
+    pk6p = pk6.copy()
+    pk6p["flags"] &= ~np.uint8(capi.PKT_INTERLEAVED)
+    res6p = res6.view(16384, 1024, 6).permute(0, 2, 1).contiguous().view(-1)
+    run("6 ch coupled + Floor1, planar INPUT, planar out", Decoder(ctx, 6, 256, 2048, floors=floors, mappings=mappings),
+        pk6p, res6p, posts, counts, samples6, 6, capi.OUT_PLANAR)
     ctx.close()
 
 

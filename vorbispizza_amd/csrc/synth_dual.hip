@@ -306,7 +306,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 cc_run = *reinterpret_cast<const uint16_t *>(a.ccount + (int)s_desc[wave][2 * lane + 1].x);
         }
     }
-    const int iters = run.count - fi0 - (int)__popcll(__ballot(batch_member));
+    int iters = run.count - fi0 - (int)__popcll(__ballot(batch_member));
+    if (a.ablate & 64) iters = 0;  // (tuning only: the kernel's prologue and nothing else)
     __builtin_amdgcn_wave_barrier();
     auto frame_from = [&](const uint4 lo, const uint4 hi) -> FrameDesc {  // a descriptor's two LDS words into SGPRs
         FrameDesc fd;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         {
             const bool has_next = fin < run.count;
             fd_next = frame_at(has_next ? fin : fi);
-            valid_next = has_next && !(fd_next.flags & kFrameDrain);
+            valid_next = has_next && !(fd_next.flags & kFrameDrain) && !(a.ablate & 4);  // (4: tuning only, no input loads)
             prefetch(fd_next, valid_next, na, nb, cpna, cpnb);
             stwnext = steps_word(fd_next, valid_next);
         }
@@ -586,6 +587,10 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         const bool aligned = kInterleavedOut ? (reinterpret_cast<uintptr_t>(row_i) & 15) == 0
                                              : ((reinterpret_cast<uintptr_t>(row_l) | reinterpret_cast<uintptr_t>(row_r)) & (kS16 ? 7 : 15)) == 0;
         auto emit4 = [&](int g, float l0, float l1, float l2, float l3, float r0, float r1, float r2, float r3) {
+            if (a.ablate & 32) {  // (tuning only: the arithmetic without the stores)
+                clip_peak = fmaxf(clip_peak, fmaxf(fmaxf(l0 + r0, l1 + r1), fmaxf(l2 + r2, l3 + r3)));
+                return;
+            }
             if (a.clip) {
                 clip_group(l0, l1, l2, l3, clip_peak);
                 clip_group(r0, r1, r2, r3, clip_peak);
