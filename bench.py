@@ -290,8 +290,8 @@ def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, 
 
 def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2, plan=None, s16=False):
     """configs[4] end to end for one GPU's share: every one of the 2 x `copies` streams is opened and
-    entropy-decoded on the host (`threads` host threads, one stream at a time each -- the reference's model
-    of one decoder per thread), straight into pinned batch buffers; the streams go to the GPU in sub-batches
+    entropy-decoded on the host (`threads` host threads of the host library, vpzh_decode_many: one stream at a time each -- the
+    reference's model of one decoder per thread), straight into pinned batch buffers; the streams go to the GPU in sub-batches
     of `sub` streams, one host-memory synth call each (H2D + kernels + D2H), issued by the calling thread as
     soon as a sub-batch is decoded while the pool keeps decoding the following ones.  `synth_lanes` contexts
     (one HIP stream each, one issuing thread each) take the sub-batches in turn, so the H2D copy of one
@@ -318,7 +318,7 @@ def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2, 
         probe = OggVorbisFile(data)
         n, C_, rf = probe.audio_packets, probe.channels, probe.info.residue_floats
         g = {"data": data, "probe": probe, "n": n, "C": C_, "rf": rf, "samples": samples, "cap": samples + 2048,
-             "copies": copies, "sub": sub_k,
+             "copies": copies, "sub": sub_k, "bytes": np.frombuffer(data, dtype=np.uint8),
              "pk": capi.make_packets(n * copies), "res": pinned(rf * copies, torch.float32),
              "posts": pinned(n * copies * C_ * 64, torch.int16).reshape(n * copies * C_, 64),
              "counts": pinned(n * copies * C_, torch.uint8),
@@ -327,13 +327,15 @@ def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2, 
                               mappings=probe.mappings, n_streams=sub_k) for b in range(copies // sub_k)]}
         groups.append(g)
 
-    def decode_one(job):
-        g, k = job
-        f = OggVorbisFile(g["data"])
-        n, C_, rf = g["n"], g["C"], g["rf"]
-        f.decode_into(g["pk"][k * n:(k + 1) * n], g["res"][k * rf:(k + 1) * rf], g["posts"][k * n * C_:(k + 1) * n * C_],
-                      g["counts"][k * n * C_:(k + 1) * n * C_], stream_id=k % g["sub"], residue_base=(k % g["sub"]) * rf)
-        f.close()
+    from vorbispizza_amd import front
+
+    def decode_sub(g, b):
+        # one sub-batch: its streams opened and entropy-decoded by the host library's own threads (vpzh_decode_many: one
+        # stream at a time per thread, no Python in the loop), straight into the pinned batch arrays
+        n, rf, sub = g["n"], g["rf"], g["sub"]
+        lo = b * sub
+        front.decode_many([g["bytes"]] * sub, [(lo + j) * n for j in range(sub)], [(lo + j) * rf for j in range(sub)],
+                          g["pk"], g["res"], g["posts"], g["counts"], threads=threads, stream_id0=0, residue_origin=lo * rf)
 
     def synth_sub(g, b):
         n, C_, rf, cap, sub = g["n"], g["C"], g["rf"], g["cap"], g["sub"]
@@ -352,18 +354,16 @@ def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2, 
         return time.perf_counter() - t
 
     best = None
-    with ThreadPoolExecutor(max_workers=threads) as pool, ThreadPoolExecutor(max_workers=len(lanes)) as synth_pool:
+    with ThreadPoolExecutor(max_workers=len(lanes)) as synth_pool:
         for _ in range(3):
             t0 = time.perf_counter()
-            futs = [(g, b, [pool.submit(decode_one, (g, k)) for k in range(b * g["sub"], (b + 1) * g["sub"])])
-                    for g in groups for b in range(g["copies"] // g["sub"])]
             pending = []
             t_dec_done = t0
-            for g, b, fs in futs:
-                for f in fs:
-                    f.result()
-                t_dec_done = time.perf_counter()
-                pending.append(synth_pool.submit(timed_synth, g, b))
+            for g in groups:
+                for b in range(g["copies"] // g["sub"]):
+                    decode_sub(g, b)  # (the GIL is released inside: the synth calls of earlier sub-batches run meanwhile)
+                    t_dec_done = time.perf_counter()
+                    pending.append(synth_pool.submit(timed_synth, g, b))
             t_syn = sum(f.result() for f in pending)
             t2 = time.perf_counter()
             if best is None or t2 - t0 < best[0]:

@@ -86,6 +86,18 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
                          vpz_packet *packets, float *residue, int16_t *posts, uint8_t *post_counts,
                          int64_t *residue_floats_used, float *f0_amp, float *f0_coeff, int32_t f0_stride);
 
+/* Many containers at once -- what a host that transcodes a library of files does: opens and entropy-decodes `n` in-memory
+ * containers (first logical stream of each) on `threads` host threads (0: as many as the machine reports), one stream at a
+ * time per thread, the reference's model of one decoder per stream.  Stream k writes its packets at packets + packet_base[k]
+ * (records of posts / post_counts at packet_base[k] * channels), its residue at residue + residue_base[k]; its packets carry
+ * stream id stream_id0 + k and residue offsets relative to residue + residue_origin (the start of the buffer a later
+ * vpz_decoder_synth call is given).  The caller sizes the slices from a vpzh_get_info of each distinct file.  All streams
+ * must have the same channel count.  failed_packets (may be NULL): packets whose decode failed (see vpzh_decode_failures).
+ * Type-0 floor data is not collected here. */
+int vpzh_decode_many(int32_t n, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
+                     const int64_t *packet_base, const int64_t *residue_base, int64_t residue_origin, vpz_packet *packets,
+                     float *residue, int16_t *posts, uint8_t *post_counts, int64_t *failed_packets);
+
 /* Packets of the LAST vpzh_decode_range* / vpzh_decode_all call whose entropy decode failed the way the reference's
  * DecodeNextPacket throws (InvalidDataException "Unused mode index.", a residue vector overrunning its block, ...).
  * Such a packet costs only itself, like the reference's exception: it is handed over with VPZ_PKT_NOT_DECODED and

@@ -205,3 +205,44 @@ def test_a_dropped_page_marks_the_next_packet_as_resync(front):
     g = front.OggVorbisFile(cut)
     assert g.info.bad_crc_pages == 0
     assert np.array_equal(g.decode_packets()[0]["flags"], pk["flags"])
+
+
+def test_decode_many_equals_one_stream_at_a_time():
+    """vpzh_decode_many (a library of files entropy-decoded on the host library's own threads, straight into batch arrays)
+    writes for every stream exactly what vpzh_decode_all writes for it alone -- at its slices, with its stream id and with
+    residue offsets relative to the origin the later synth call will see."""
+    from vorbispizza_amd import capi, front
+    datas = {name: open(os.path.join(GOLDEN, name), "rb").read() for name in ("3test.ogg", "issue6test.ogg")}
+    singles = {}
+    for name, raw in datas.items():
+        f = front.OggVorbisFile(raw)
+        singles[name] = (f.audio_packets, f.channels, f.info.residue_floats) + tuple(f.decode_packets())
+    order = ["3test.ogg", "issue6test.ogg", "3test.ogg", "3test.ogg", "issue6test.ogg"]
+    C_ = 2
+    pbase, rbase, np_, nr = [], [], 0, 0
+    lead_p, lead_r = 7, 1000  # (the batch arrays hold other streams in front: the call writes at the bases it is given)
+    np_, nr = lead_p, lead_r
+    for name in order:
+        n, _, rf = singles[name][:3]
+        pbase.append(np_)
+        rbase.append(nr)
+        np_ += n
+        nr += rf
+    pk = capi.make_packets(np_)
+    res = np.full(nr, 7.0, dtype=np.float32)
+    posts = np.full((np_ * C_, 64), -3, dtype=np.int16)
+    counts = np.full(np_ * C_, 200, dtype=np.uint8)
+    arrays = [np.frombuffer(datas[name], dtype=np.uint8) for name in order]
+    failed = front.decode_many(arrays, pbase, rbase, pk, res, posts, counts, threads=3, stream_id0=10, residue_origin=lead_r)
+    assert failed == 0
+    for k, name in enumerate(order):
+        n, _, rf, spk, sres, sposts, scounts = singles[name]
+        a = pk[pbase[k]: pbase[k] + n]
+        assert (a["stream"] == 10 + k).all()
+        for field in ("flags", "mapping", "granule"):
+            assert np.array_equal(a[field], spk[field]), (name, field)
+        assert np.array_equal(a["residue_offset"], spk["residue_offset"] + (rbase[k] - lead_r))
+        assert np.array_equal(res[rbase[k]: rbase[k] + rf], sres)
+        assert np.array_equal(posts[pbase[k] * C_: (pbase[k] + n) * C_], sposts)
+        assert np.array_equal(counts[pbase[k] * C_: (pbase[k] + n) * C_], scounts)
+    assert (res[:lead_r] == 7.0).all() and (counts[: lead_p * C_] == 200).all()  # nothing in front was touched

@@ -4,6 +4,8 @@
 #include "../../include/vorbispizza_front.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 #include <cmath>
 #include <cstdio>
@@ -1317,6 +1319,50 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
     }
     if (residue_floats_used) *residue_floats_used = off;
     return VPZH_OK;
+}
+
+int vpzh_decode_many(int32_t n, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
+                     const int64_t *packet_base, const int64_t *residue_base, int64_t residue_origin, vpz_packet *packets,
+                     float *residue, int16_t *posts, uint8_t *post_counts, int64_t *failed_packets)
+{
+    if (n < 0 || (n > 0 && (!data || !size || !packet_base || !residue_base || !packets || !residue || !posts || !post_counts)))
+        return VPZH_E_ARG;
+    if (failed_packets) *failed_packets = 0;
+    if (n == 0) return VPZH_OK;
+    int workers = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    workers = std::max(1, std::min(workers, (int)n));
+    std::atomic<int32_t> next{0};
+    std::atomic<int64_t> failed{0};
+    std::atomic<int> status{VPZH_OK};
+    // one container at a time per thread (the reference's model: a decoder per stream, a stream per thread); every stream
+    // writes its own slices of the batch arrays
+    auto work = [&]() {
+        for (;;) {
+            const int32_t k = next.fetch_add(1, std::memory_order_relaxed);
+            if (k >= n) return;
+            vpzh_stream *s = nullptr;
+            int rc = vpzh_open_memory(data[k], size[k], &s);
+            if (rc == VPZH_OK) {
+                const size_t C = (size_t)s->channels;
+                const int64_t pb = packet_base[k];
+                rc = vpzh_decode_range_ex(s, 0, (int64_t)s->audio.size(), stream_id0 + k, residue_base[k] - residue_origin,
+                                          packets + pb, residue + residue_base[k], posts + (size_t)pb * 64 * C,
+                                          post_counts + (size_t)pb * C, nullptr, nullptr, nullptr, 0);
+                failed.fetch_add(s->decode_failures, std::memory_order_relaxed);
+            }
+            if (rc != VPZH_OK) status.store(rc, std::memory_order_relaxed);
+            if (s) vpzh_close(s);
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int t = 1; t < workers; ++t) pool.emplace_back(work);
+    } catch (...) {  // (thread creation failed: the calling thread does what is left)
+    }
+    work();
+    for (std::thread &t : pool) t.join();
+    if (failed_packets) *failed_packets = failed.load();
+    return status.load();
 }
 
 int64_t vpzh_decode_failures(vpzh_stream *s, int64_t *first_failed_packet)
