@@ -208,6 +208,39 @@ def test_window_mismatch_is_reported_and_costs_only_that_packet(ctx, oracle):
     dec.close()
 
 
+def test_window_mismatch_is_a_per_packet_status_in_a_batch_of_streams(ctx, oracle):
+    """ABI v3: in a batch of several streams the packet that fails the window check (StreamDecoder.cs:777-778 throws out
+    of THAT Read) is one entry of vpz_decoder_last_packet_status -- the call succeeds, every other packet of every stream
+    is synthesised, and the status points at exactly the packets the oracle's state machine skips."""
+    from vorbispizza_amd import Decoder, capi
+    L3 = PKT_BLOCK_FLAG | PKT_PREV_FLAG | PKT_NEXT_FLAG
+    flag_sets = [np.array([L3, L3, L3, L3], dtype=np.uint8),
+                 np.array([L3, L3, 0, L3, L3], dtype=np.uint8),        # packet 2 of this stream does not fit
+                 np.array([L3, 0, L3, L3, 0, L3], dtype=np.uint8),     # packets 1 and 4 of this one
+                 np.array([L3, L3, L3], dtype=np.uint8)]
+    specs = [helpers.gaussian_spectra((len(f), 1, 1024), seed=40 + i) for i, f in enumerate(flag_sets)]
+    pk, res, opk = build_batch(flag_sets, specs, 1, extra_flags=PKT_NO_FLOOR)
+    dec = Decoder(ctx, 1, 256, 2048, n_streams=4)
+    cap = 8192
+    out = np.zeros(4 * cap, dtype=np.float32)
+    offs = np.arange(4, dtype=np.int64) * cap
+    w = dec.synth_raw(pk, res, None, None, out, offs, cap, capi.OUT_PLANAR, cap, capi.MEM_HOST, on_mismatch="ignore")
+    status = dec.last_packet_status(len(pk))
+    bad = [(int(pk["stream"][i]), i) for i in np.nonzero(status)[0]]
+    assert dec.last_mismatches() == 3 and all(status[i] == capi.E_WINDOW_MISMATCH for _, i in bad)
+    # (the batch interleaves the streams round robin: a packet's ordinal inside its stream)
+    per_stream_index = {s: [np.nonzero(pk["stream"] == s)[0].tolist().index(i) for t, i in bad if t == s] for s in range(4)}
+    assert per_stream_index == {0: [], 1: [2], 2: [1, 4], 3: []}
+    counts = dec.last_packet_samples(len(pk))
+    assert all(counts[i] == 0 for _, i in bad)
+    for s in range(4):
+        ref, pos, _ = helpers.oracle_decode(oracle, 1, 256, 2048, opk[s])
+        assert helpers.oracle_decode.last_mismatches == len(per_stream_index[s])
+        assert int(w[s]) == ref.shape[1] and dec.position(s) == pos
+        assert np.abs(out[s * cap: s * cap + ref.shape[1]] - ref[0]).max() <= TOL
+    dec.close()
+
+
 def make_floor_packets(rng, frames, channels, flags, interleaved, silent_prob=0.1):
     """Residue (zero above a cutoff bin, like `end < N/2`) + raw floor posts per packet."""
     pks = []
