@@ -91,12 +91,14 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
  * time per thread, the reference's model of one decoder per stream.  Stream k writes its packets at packets + packet_base[k]
  * (records of posts / post_counts at packet_base[k] * channels), its residue at residue + residue_base[k]; its packets carry
  * stream id stream_id0 + k and residue offsets relative to residue + residue_origin (the start of the buffer a later
- * vpz_decoder_synth call is given).  The caller sizes the slices from a vpzh_get_info of each distinct file.  All streams
- * must have the same channel count.  failed_packets (may be NULL): packets whose decode failed (see vpzh_decode_failures).
- * Type-0 floor data is not collected here. */
+ * vpz_decoder_synth call is given).  The caller sizes the slices from a vpzh_get_info of each distinct file and says how much
+ * room each has (packet_room[k] packets, residue_room[k] floats): a container that holds more is refused (VPZH_E_ARG, nothing of
+ * it written; the other streams are still decoded).  All streams must have the same channel count.  failed_packets (may be
+ * NULL): packets whose decode failed (see vpzh_decode_failures).  Type-0 floor data is not collected here. */
 int vpzh_decode_many(int32_t n, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
-                     const int64_t *packet_base, const int64_t *residue_base, int64_t residue_origin, vpz_packet *packets,
-                     float *residue, int16_t *posts, uint8_t *post_counts, int64_t *failed_packets);
+                     const int64_t *packet_base, const int64_t *packet_room, const int64_t *residue_base,
+                     const int64_t *residue_room, int64_t residue_origin, vpz_packet *packets, float *residue, int16_t *posts,
+                     uint8_t *post_counts, int64_t *failed_packets);
 
 /* Packets of the LAST vpzh_decode_range* / vpzh_decode_all call whose entropy decode failed the way the reference's
  * DecodeNextPacket throws (InvalidDataException "Unused mode index.", a residue vector overrunning its block, ...).

@@ -246,3 +246,7 @@ def test_decode_many_equals_one_stream_at_a_time():
         assert np.array_equal(posts[pbase[k] * C_: (pbase[k] + n) * C_], sposts)
         assert np.array_equal(counts[pbase[k] * C_: (pbase[k] + n) * C_], scounts)
     assert (res[:lead_r] == 7.0).all() and (counts[: lead_p * C_] == 200).all()  # nothing in front was touched
+    # a container that does not fit the room its slice has is refused, and nothing of it is written
+    with pytest.raises(front.FrontError):
+        front.decode_many(arrays[:1], pbase[:1], rbase[:1], pk, res, posts, counts, threads=1,
+                          packet_room=[singles[order[0]][0] - 1], residue_room=[singles[order[0]][2]])

@@ -64,7 +64,7 @@ def lib():
         L.vpzh_decode_range.argtypes = [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int64, vp, vp, vp, vp,
                                         C.POINTER(C.c_int64)]
         L.vpzh_decode_range.restype = C.c_int
-        L.vpzh_decode_many.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp, vp, vp, vp,
+        L.vpzh_decode_many.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp,
                                        C.POINTER(C.c_int64)]
         L.vpzh_decode_many.restype = C.c_int
         L.vpzh_decode_failures.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -223,18 +223,31 @@ class OggVorbisFile:
             raise FrontError(lib().vpzh_last_error(self._h).decode())
 
 
-def decode_many(datas, packet_base, residue_base, packets, residue, posts, counts, threads=0, stream_id0=0, residue_origin=0):
+def decode_many(datas, packet_base, residue_base, packets, residue, posts, counts, threads=0, stream_id0=0, residue_origin=0,
+                packet_room=None, residue_room=None):
     """vpzh_decode_many: opens and entropy-decodes the containers `datas` (numpy uint8 arrays) on `threads` host threads of
     the library's own (no Python in the loop, the GIL is released for the whole call), stream k into packets[packet_base[k]:],
-    residue[residue_base[k]:], posts / counts at record packet_base[k] * channels.  Returns the number of packets that failed."""
+    residue[residue_base[k]:], posts / counts at record packet_base[k] * channels.  packet_room / residue_room: what each slice
+    holds (default: up to the next stream's base, or the end of the array).  Returns the number of packets that failed."""
     n = len(datas)
     ptrs = (C.c_void_p * n)(*[d.ctypes.data for d in datas])
     sizes = (C.c_uint64 * n)(*[d.size for d in datas])
     pb = np.ascontiguousarray(packet_base, dtype=np.int64)
     rb = np.ascontiguousarray(residue_base, dtype=np.int64)
+
+    def room(bases, total, given):
+        if given is not None:
+            return np.ascontiguousarray(given, dtype=np.int64)
+        order = np.argsort(bases, kind="stable")
+        ends = np.empty(n, dtype=np.int64)
+        ends[order] = np.concatenate([bases[order][1:], [total]])
+        return np.ascontiguousarray(ends - bases, dtype=np.int64)
+
+    pr, rr = room(pb, len(packets), packet_room), room(rb, residue.size, residue_room)
     failed = C.c_int64(0)
-    rc = lib().vpzh_decode_many(n, ptrs, sizes, int(threads), int(stream_id0), pb.ctypes.data, rb.ctypes.data, int(residue_origin),
-                                packets.ctypes.data, residue.ctypes.data, posts.ctypes.data, counts.ctypes.data, C.byref(failed))
+    rc = lib().vpzh_decode_many(n, ptrs, sizes, int(threads), int(stream_id0), pb.ctypes.data, pr.ctypes.data, rb.ctypes.data,
+                                rr.ctypes.data, int(residue_origin), packets.ctypes.data, residue.ctypes.data, posts.ctypes.data,
+                                counts.ctypes.data, C.byref(failed))
     if rc != 0:
         raise FrontError("vpzh_decode_many failed (status %d)" % rc)
     return failed.value

@@ -1322,10 +1322,12 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
 }
 
 int vpzh_decode_many(int32_t n, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
-                     const int64_t *packet_base, const int64_t *residue_base, int64_t residue_origin, vpz_packet *packets,
-                     float *residue, int16_t *posts, uint8_t *post_counts, int64_t *failed_packets)
+                     const int64_t *packet_base, const int64_t *packet_room, const int64_t *residue_base,
+                     const int64_t *residue_room, int64_t residue_origin, vpz_packet *packets, float *residue, int16_t *posts,
+                     uint8_t *post_counts, int64_t *failed_packets)
 {
-    if (n < 0 || (n > 0 && (!data || !size || !packet_base || !residue_base || !packets || !residue || !posts || !post_counts)))
+    if (n < 0 || (n > 0 && (!data || !size || !packet_base || !packet_room || !residue_base || !residue_room || !packets ||
+                            !residue || !posts || !post_counts)))
         return VPZH_E_ARG;
     if (failed_packets) *failed_packets = 0;
     if (n == 0) return VPZH_OK;
@@ -1342,6 +1344,9 @@ int vpzh_decode_many(int32_t n, const uint8_t *const *data, const uint64_t *size
             if (k >= n) return;
             vpzh_stream *s = nullptr;
             int rc = vpzh_open_memory(data[k], size[k], &s);
+            // (the slices were sized by the caller from a probe of the file: a container that holds more than its slice has
+            // room for is refused, nothing of it is written)
+            if (rc == VPZH_OK && ((int64_t)s->audio.size() > packet_room[k] || s->residue_floats > residue_room[k])) rc = VPZH_E_ARG;
             if (rc == VPZH_OK) {
                 const size_t C = (size_t)s->channels;
                 const int64_t pb = packet_base[k];
