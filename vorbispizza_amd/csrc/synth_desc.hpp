@@ -148,8 +148,11 @@ struct SynthArgs {
     int32_t s16;                // PCM as int16 (`(int)(x * 32768f)` clamped) instead of float32
     int32_t clip;
     int32_t *clipped;           // [stream] sticky HasClipped
-    int32_t ablate;             // tuning only (VPZ_SYNTH_ABLATE): 1 skip PCM stores, 2 skip IMDCT, 4 skip loads, 8 skip the
-                                // curve, 16 skip coupling, 32 skip staging, 64 render every bin
+    int32_t ablate;             // tuning only (VPZ_SYNTH_ABLATE; wrong results, right timing): 1 no window / overlap-add / stores, 2 no
+                                // transform, 4 no input loads, 8 no curve, 16 no coupling, 32 no staging (group mode) / no stores
+                                // but the arithmetic (stereo path), 64 render every bin (group mode) / prologue only (stereo path),
+                                // 128 no batches of short blocks (also set by the host when runs were not cut by cost); stereo
+                                // path only: 256 no floor multiply, 512 no zero-tail bound, 1024 no tail save
     unsigned long long *stamps; // diagnostic builds only (-DVPZ_STAMPS): [16] cycles per phase, summed over the waves
 };
 

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             if (!no_floor) {
                 uint8_t *rowL = reinterpret_cast<uint8_t *>(hL), *rowR = reinterpret_cast<uint8_t *>(hR);
                 int *auxL = reinterpret_cast<int *>(hL) + 256, *auxR = reinterpret_cast<int *>(hR) + 256;
-                uint32_t fyL[4], fyR[4];
+                uint32_t fyL[4] = {0, 0, 0, 0}, fyR[4] = {0, 0, 0, 0};
                 if (!batch) {
                     const int cc = __builtin_amdgcn_readlane(cc_run, slot);
                     const int cntL = cc & 0xFF, cntR = (cc >> 8) & 0xFF;
@@ -485,8 +485,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                     silentR = cntR == 0;
                     const int lpb = is_long ? 64 : 8;
                     const int n = nblk >> 1;
-                    const int nrL = silentL ? 0 : 2 * (spectrum_top(xL, lpb) + 1);
-                    const int nrR = silentR ? 0 : 2 * (spectrum_top(xR, lpb) + 1);
+                    const int nrL = (silentL || (a.ablate & 512)) ? 0 : 2 * (spectrum_top(xL, lpb) + 1);
+                    const int nrR = (silentR || (a.ablate & 512)) ? 0 : 2 * (spectrum_top(xR, lpb) + 1);
                     const int pa = ln < cntL ? cpa : 0, pb = ln < cntR ? cpb : 0;
                     if ((nrL > 0 || nrR > 0) && !(a.ablate & 8)) {
                         if (!render_floor_indices_fast_x2(rowL, rowR, auxL, auxR, n, nrL, nrR, pa, pb, cntL, cntR, ln)) {
@@ -495,8 +495,10 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
+                    if (!(a.ablate & 256)) {
                     load_floor_indices(fyL, rowL, lpb, ln);
                     load_floor_indices(fyR, rowR, lpb, ln);
+                    }
                     __builtin_amdgcn_wave_barrier();
                 } else {
                     // the curves of the pass's blocks, 128 bytes each, block by block (both channels side by side); their
@@ -535,8 +537,10 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                     __builtin_amdgcn_wave_barrier();
                 }
                 VPZ_STAMP(2);  // curves
+                if (!(a.ablate & 256)) {
                 apply_floor(xL, fyL, s_db);
                 apply_floor(xR, fyR, s_db);
+                }
             }
             // ---- the two transforms, side by side
             if (a.ablate & 2) {
@@ -746,7 +750,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         }
         VPZ_STAMP(5);  // window + overlap-add + stores
         // ---- keep what a later block can overlap with: y[N/2 .. N) lives in the upper half of h
-        if (!drain) {
+        if (!drain && !(a.ablate & 1024)) {
             __builtin_amdgcn_wave_barrier();
             if (is_long) {
                 const float4 *sl = reinterpret_cast<const float4 *>(hL + 512), *sr = reinterpret_cast<const float4 *>(hR + 512);
