@@ -15,7 +15,10 @@ namespace vpz {
 
 class HostPool {
 public:
-    explicit HostPool(int parties) : parties_(parties < 1 ? 1 : parties)
+    // spin_us: how long an idle worker polls before it blocks (VPZ_HOST_SPIN_US; a host that calls the decoder back to back
+    // -- a call every few hundred microseconds -- saves a futex wake-up per fork by polling through the gap, at the price of
+    // busy cores; the default only bridges the forks of ONE call)
+    explicit HostPool(int parties, int spin_us = 50) : parties_(parties < 1 ? 1 : parties), spin_us_(spin_us < 0 ? 0 : spin_us)
     {
         for (int i = 1; i < parties_; ++i) workers_.emplace_back([this, i] { worker(i); });
     }
@@ -72,7 +75,7 @@ private:
             // short spin first: the second fork of a call follows the first within tens of microseconds
             const auto t0 = std::chrono::steady_clock::now();
             bool got = false;
-            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(50)) {
+            while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us_)) {
                 if (generation_.load(std::memory_order_acquire) != seen) { got = true; break; }
             }
             if (!got) {
@@ -92,6 +95,7 @@ private:
     }
 
     const int parties_;
+    const int spin_us_;
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::condition_variable cv_;

@@ -651,7 +651,8 @@ struct SynthCall {
         if (parties < 2) return 0;
         if (!ctx->host_pool || static_cast<HostPool *>(ctx->host_pool)->parties() != parties) {
             if (ctx->host_pool) ctx->host_pool_free(ctx->host_pool);
-            ctx->host_pool = new HostPool(parties);
+            static const int spin_us = getenv("VPZ_HOST_SPIN_US") ? atoi(getenv("VPZ_HOST_SPIN_US")) : 50;
+            ctx->host_pool = new HostPool(parties, spin_us);
             ctx->host_pool_free = [](void *p) { delete static_cast<HostPool *>(p); };
         }
         HostPool &pool = *static_cast<HostPool *>(ctx->host_pool);
