@@ -146,3 +146,56 @@ def test_unaligned_output_rows_and_eos_trim(ctx, oracle):
     got = results["dual"][0][1 + s_ * channels * cap: 1 + s_ * channels * cap + n * channels].reshape(n, channels)
     assert ref.shape == got.shape
     assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_streams_come_and_go_between_calls(ctx, seed):
+    """The saved overlap state lives in two copies that a stream flips only when it has frames in a call: streams that
+    skip calls, start late, or end early (EOS) while others go on -- random subsets of the streams in every call, random
+    amounts of packets -- through the stereo fast path (parallel host pass, compact runs, batches) against the separate
+    coupling pass with the serial host pass, bit for bit, sample counts and positions included."""
+    from vorbispizza_amd import Decoder, capi
+    rng = np.random.default_rng(seed)
+    channels, n_streams, frames = 2, 12, 64
+    pk, res, posts, counts = stream_major_batch(n_streams, frames, channels, seed=9000 + seed, floor=True, interleaved=True,
+                                                p_ls=0.25, p_sl=0.2, silent_prob=0.1)
+    pk["mapping"] = pk["flags"] & 1
+    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)]
+    mappings = [{"coupling": [(0, 1)], "channel_floor": [0, 0]}, {"coupling": [(0, 1)], "channel_floor": [1, 1]}]
+    idx = np.arange(len(pk)).reshape(n_streams, frames)
+    # the schedule: per call, per stream, how many of its remaining packets it sends (0: it sits the call out)
+    cursor = np.zeros(n_streams, dtype=int)
+    calls = []
+    while (cursor < frames).any() and len(calls) < 40:
+        sel = []
+        for s in range(n_streams):
+            left = frames - cursor[s]
+            if left == 0 or rng.random() < 0.35:
+                continue
+            take = int(min(left, rng.integers(1, 14)))
+            sel.append(idx[s, cursor[s]: cursor[s] + take])
+            cursor[s] += take
+        if sel:
+            calls.append(np.concatenate(sel))
+    cap = frames * 1024 + 64
+    results = {}
+    for name, kv in (("dual", dict(VPZ_NO_DUAL=None, VPZ_NO_GROUP=None, VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=4)),
+                     ("separate", dict(VPZ_NO_DUAL=1, VPZ_NO_GROUP=1, VPZ_PAR_MIN_PACKETS=1 << 40))):
+        with env(**kv):
+            dec = Decoder(ctx, channels, 256, 2048, floors=floors, mappings=mappings, n_streams=n_streams)
+            out = np.zeros(n_streams * channels * cap, dtype=np.float32)
+            offs = np.arange(n_streams, dtype=np.int64) * channels * cap
+            total = np.zeros(n_streams, dtype=np.int64)
+            per_packet = []
+            for sel in calls:
+                sub = pk[sel].copy()
+                p = np.ascontiguousarray(posts.reshape(len(pk), channels, 64)[sel].reshape(-1, 64))
+                c = np.ascontiguousarray(counts.reshape(len(pk), channels)[sel].reshape(-1))
+                w = dec.synth_raw(sub, res, p, c, out, offs + total * channels, cap - int(total.max()), capi.OUT_INTERLEAVED, 0,
+                                  capi.MEM_HOST)
+                per_packet.append(dec.last_packet_samples(len(sub)))
+                total += w
+            results[name] = (out, total.copy(), np.concatenate(per_packet), [dec.position(s) for s in range(n_streams)])
+            dec.close()
+    same_bits(results["dual"], results["separate"], "streams coming and going, seed %d" % seed)
+    assert len(calls) >= 8 and results["dual"][1].min() > 0
