@@ -103,6 +103,39 @@ __device__ __forceinline__ void radix8_inverse(float2 (&vv)[8])
     vv[3] = f2(cadd_i(c2_, e7)); vv[7] = f2(csub_i(c2_, e7));
 }
 
+// Tuning builds only (-DVPZ_REG_TRANSPOSE): transpose 1 of dft512_wave without LDS -- register index bit b against lane
+// bit 3 + b, b = 0, 1, 2: lane bit 5 and 4 with one `v_permlane32_swap` / `v_permlane16_swap` per register pair, lane bit 3
+// with three row-rotating DPP moves.  Pure data movement: same bits.  Measured and not adopted, see DESIGN.md 4.7.
+#ifdef VPZ_REG_TRANSPOSE
+template <int kLaneBit>
+__device__ __forceinline__ void lane_reg_exchange(float &a, float &b)
+{
+    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    if (kLaneBit == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);  // a[32..63] <-> b[0..31]
+        ua = r[0]; ub = r[1];
+    } else if (kLaneBit == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(ua, ub, false, false);  // odd rows of a <-> even rows of b
+        ua = r[0]; ub = r[1];
+    } else {
+        const unsigned t = __builtin_amdgcn_update_dpp(0u, ua, 0x128, 0xF, 0xF, false);  // row_ror:8: t[l] = a[l ^ 8]
+        ua = __builtin_amdgcn_update_dpp(ua, ub, 0x128, 0xF, 0xC, false);                // lanes 8..15 of a row: b[l ^ 8]
+        ub = __builtin_amdgcn_update_dpp(ub, t, 0xE4, 0xF, 0x3, false);                  // lanes 0..7 of a row: old a[l ^ 8]
+    }
+    a = __uint_as_float(ua); b = __uint_as_float(ub);
+}
+// (lane l0 + 8*l1, reg p) -> (lane l0 + 8*p, reg l1)
+__device__ __forceinline__ void transpose_lane_hi(float2 (&z)[8])
+{
+#pragma unroll
+    for (int p = 0; p < 8; ++p) if (!(p & 1)) { lane_reg_exchange<8>(z[p].x, z[p | 1].x); lane_reg_exchange<8>(z[p].y, z[p | 1].y); }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) if (!(p & 2)) { lane_reg_exchange<16>(z[p].x, z[p | 2].x); lane_reg_exchange<16>(z[p].y, z[p | 2].y); }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) if (!(p & 4)) { lane_reg_exchange<32>(z[p].x, z[p | 4].x); lane_reg_exchange<32>(z[p].y, z[p | 4].y); }
+}
+#endif
+
 // LDS floats a wavefront needs for the transposes / the h staging area.
 constexpr int kWaveScratchFloat2 = 576;  // 72*8 (stage A->B), 66*7+64 = 526 (stage B->C), 512 (h)
 
@@ -121,11 +154,15 @@ __device__ __forceinline__ void dft512_wave(float2 (&z)[8], float2 *scratch, con
 #pragma unroll
     for (int p = 1; p < 8; ++p) z[p] = cmul(z[p], s_twAB[p * 64 + lane]);
     // transpose 1: (lane l = l0 + 8*l1, reg p) -> (lane l0 + 8*p, reg l1); rows padded to 72
+    const int l0 = lane & 7, pp = lane >> 3;
+#ifdef VPZ_REG_TRANSPOSE
+    transpose_lane_hi(z);
+#else
 #pragma unroll
     for (int p = 0; p < 8; ++p) scratch[72 * p + lane] = z[p];
-    const int l0 = lane & 7, pp = lane >> 3;
 #pragma unroll
     for (int l1 = 0; l1 < 8; ++l1) z[l1] = scratch[72 * pp + l0 + 8 * l1];
+#endif
     // stage B: DFT over l1, output digit q1
     radix8_inverse(z);
 #pragma unroll
@@ -239,17 +276,22 @@ __device__ __forceinline__ void dft512_wave_x2(float2 (&za)[8], float2 (&zb)[8],
         za[p] = cmul(za[p], w);
         zb[p] = cmul(zb[p], w);
     }
+    const int l0 = lane & 7, pp = lane >> 3;
+#ifdef VPZ_REG_TRANSPOSE
+    transpose_lane_hi(za);
+    transpose_lane_hi(zb);
+#else
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         sa[72 * p + lane] = za[p];
         sb[72 * p + lane] = zb[p];
     }
-    const int l0 = lane & 7, pp = lane >> 3;
 #pragma unroll
     for (int l1 = 0; l1 < 8; ++l1) {
         za[l1] = sa[72 * pp + l0 + 8 * l1];
         zb[l1] = sb[72 * pp + l0 + 8 * l1];
     }
+#endif
     radix8_inverse(za);
     radix8_inverse(zb);
 #pragma unroll

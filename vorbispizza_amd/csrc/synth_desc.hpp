@@ -152,7 +152,8 @@ struct SynthArgs {
                                 // transform, 4 no input loads, 8 no curve, 16 no coupling, 32 no staging (group mode) / no stores
                                 // but the arithmetic (stereo path), 64 render every bin (group mode) / prologue only (stereo path),
                                 // 128 no batches of short blocks (also set by the host when runs were not cut by cost); stereo
-                                // path only: 256 no floor multiply, 512 no zero-tail bound, 1024 no tail save
+                                // path only: 256 no floor multiply, 512 no zero-tail bound, 1024 no tail save; group mode only: 2048 the interleaved
+                                // packet lands in the rows linearly by LDS-DMA (wrong results), 4096 ... as a per-channel dword gather (right results)
     unsigned long long *stamps; // diagnostic builds only (-DVPZ_STAMPS): [16] cycles per phase, summed over the waves
 };
 

@@ -422,6 +422,35 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
 }
 
 // ... or, for a planar packet, the wave's own channel straight into its row
+// Timing experiment only (VPZ_SYNTH_ABLATE bit 2048; results are wrong): the interleaved packet lands in the group's rows
+// by LDS-DMA (`global_load_lds_dwordx4`: no registers, no ds_write), linearly -- i.e. still as [bin][C] -- after the rows
+// have been given up by the previous frame; the wave then waits for it.  See DESIGN.md 4.7.
+__device__ __forceinline__ void stage_by_lds_dma(const float *src, float *rows, int C, int half, int w, int lane)
+{
+    const int total4 = (C * half) >> 2;  // 16-byte pieces of the packet
+    typedef __attribute__((address_space(1))) const void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    asm volatile("" : "+v"(lane));
+    for (int g = 64 * w; g < total4; g += 64 * C)
+        __builtin_amdgcn_global_load_lds((gvoid *)(reinterpret_cast<const float4 *>(src) + g + lane), (lvoid *)(rows + 4 * g), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ... and as a GATHER (bit 4096; results are right): wave w asks for ITS channel's bins one dword per lane -- lane i of piece m
+// reads element (64 m + i) * C + w -- and LDS-DMA lands a wave-load's 64 dwords back to back: the row comes out de-interleaved,
+// no register, no ds_write, no strided LDS read.
+__device__ __forceinline__ void stage_by_lds_dma_gather(const float *src, float *row, int C, int half, int w, int lane)
+{
+    typedef __attribute__((address_space(1))) const void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    asm volatile("" : "+v"(lane));
+    const float *p = src + (size_t)lane * C + w;
+    for (int b = 0; b < half; b += 64) {
+        if (b + lane < half) __builtin_amdgcn_global_load_lds((gvoid *)(p + (size_t)b * C), (lvoid *)(row + b), 4, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ void stage_planar(const float2 (&x)[8], float *row, int half, int lane)
 {
     asm volatile("" : "+v"(lane));
@@ -634,8 +663,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             const int hh = (size_of(fd.flags) >> 1) * (kBatchShort ? (int)((fd.flags >> kFrameBatchShift) & 7u) + 1 : 1);
             const bool shared_input = fd.flags & kFrameInterleaved;
             const float *src = a.spec + fd.spec_off + (shared_input ? 0 : (int64_t)ch * hh);
-            load_group_share(x, valid ? src : a.inv_db, shared_input ? 64 * ch : 0, shared_input ? 64 * C : 64,
-                             valid ? ((shared_input ? C * hh : hh) >> 2) : 1, lane);
+            const bool regs = valid && !(shared_input && (a.ablate & (2048 | 4096)));  // (2048: the packet comes by LDS-DMA)
+            load_group_share(x, regs ? src : a.inv_db, shared_input ? 64 * ch : 0, shared_input ? 64 * C : 64,
+                             regs ? ((shared_input ? C * hh : hh) >> 2) : 1, lane);
         } else {
             load_spectrum(x, ex ? spectrum_of(fd) : a.inv_db, ex ? lpb_of(fd.flags) : 1, lane);
         }
@@ -861,7 +891,11 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             __syncthreads();  // every wave of the group is done with its row (previous block emitted)
             VPZ_STAMP(1);  // first barrier
             if (stage && !(a.ablate & 32)) {
-                if (fd.flags & kFrameInterleaved) {
+                if ((fd.flags & kFrameInterleaved) && (a.ablate & 4096)) {
+                    stage_by_lds_dma_gather(a.spec + fd.spec_off, hcur, C, nstage >> 1, ch, lane);
+                } else if ((fd.flags & kFrameInterleaved) && (a.ablate & 2048)) {
+                    stage_by_lds_dma(a.spec + fd.spec_off, s_work[gw0], C, nstage >> 1, ch, lane);
+                } else if (fd.flags & kFrameInterleaved) {
                     stage_interleaved(xcur, s_work[gw0], C, div_magic, nstage >> 1, ch, lane);
                 } else {
                     stage_planar(xcur, hcur, nblk >> 1, lane);
