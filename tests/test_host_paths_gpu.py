@@ -216,7 +216,7 @@ def test_batches_the_parallel_pass_must_refuse_take_the_serial_route(ctx, oracle
 
 
 @pytest.mark.parametrize("channels,steps", [(2, [(0, 1)]), (3, [(0, 1), (2, 0)]), (6, [(0, 1), (2, 3)]), (8, [(7, 0), (1, 6), (0, 1)]),
-                                            (4, [])])
+                                            (4, []), (6, [(0, 2), (3, 4)]), (4, [(3, 0)])])
 @pytest.mark.parametrize("interleaved", [True, False])
 def test_group_mode_equals_the_separate_coupling_pass(ctx, oracle, channels, steps, interleaved):
     from vorbispizza_amd import capi
@@ -235,6 +235,11 @@ def test_group_mode_equals_the_separate_coupling_pass(ctx, oracle, channels, ste
             l = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
         assert np.array_equal(g[1], l[1]) and np.array_equal(g[2], l[2])
         assert np.array_equal(g[0].view(np.uint32), l[0].view(np.uint32)), (channels, layout)
+        # ... and the opt-in variant that leaves the interleaved packet as it is in LDS (LDS-DMA landing, the wave's own
+        # coupling step applied at pick-up; even channel counts, no channel in two steps -- otherwise the switch does nothing)
+        with env(VPZ_NO_GROUP=None, VPZ_NO_DUAL=1, VPZ_GROUP_DMA=1):
+            d = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
+        assert np.array_equal(d[1], g[1]) and np.array_equal(d[0].view(np.uint32), g[0].view(np.uint32)), (channels, layout)
         outs[layout] = g
     # the oracle, stream 1, planar
     s, per = 1, frames

@@ -133,6 +133,9 @@ struct SynthArgs {
     int32_t n_step_pairs;
     int32_t max_steps;          // most coupling LEVELS any mapping has: barriers per frame in group mode
     int32_t group;              // 1: channels of a run share a workgroup (LDS staging), 0: waves are independent
+    int32_t group_dma;          // group mode: an interleaved packet lands in the group's rows AS IT IS ([bin][C], LDS-DMA) and every
+                                // wave picks its channel up with the inverse coupling applied in registers (even channel
+                                // counts, no channel in more than one step of any mapping)
     const float *inv_db;        // 256 floats
     float *state_h;             // [2][stream][channel][size1/2]: two copies -- a run that starts from the saved state reads
                                 // copy RunDesc.state_slot, the run that ends its stream's batch writes the OTHER one (the

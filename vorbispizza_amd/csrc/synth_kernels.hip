@@ -422,9 +422,49 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
 }
 
 // ... or, for a planar packet, the wave's own channel straight into its row
-// Timing experiment only (VPZ_SYNTH_ABLATE bit 2048; results are wrong): the interleaved packet lands in the group's rows
-// by LDS-DMA (`global_load_lds_dwordx4`: no registers, no ds_write), linearly -- i.e. still as [bin][C] -- after the rows
-// have been given up by the previous frame; the wave then waits for it.  See DESIGN.md 4.7.
+// Group mode, SynthArgs.group_dma: the packet lies in the group's rows as it came -- [bin][C], C even, i.e. C/2 float2 per bin
+// (stage_by_lds_dma below) -- and wave w takes the lane's 8 points of ITS channel out of it: the float2 that holds the channel,
+// and the one that holds the other channel of w's coupling step (`partner`, -1: none; usually the same float2), with the step
+// applied to the values in registers (Mapping.cs:166-225; a channel is in one step at most, so there is no order to keep).
+// Point kk = kk0 + kst * m is bins 2kk, 2kk + 1.  No ds_write, no coupling pass over LDS -- but 8-byte reads at a stride of C
+// dwords (2-way bank conflicts for C = 6) and every wave of a pair runs the step: measured SLOWER than the product's staging
+// (configs[3] 0.353 against 0.321 ms), hence opt-in only (VPZ_GROUP_DMA=1).
+__device__ __forceinline__ void pickup_interleaved(float2 (&x)[8], const float *rows, int C, int w, int partner, bool is_mag,
+                                                   int kk0, int kst)
+{
+    const float2 *v2 = reinterpret_cast<const float2 *>(rows);
+    const int hc = C >> 1;
+    const bool odd = w & 1, podd = partner & 1;
+    const float2 *own = v2 + (w >> 1) + 2 * kk0 * hc;
+    const float2 *oth = v2 + (partner >= 0 ? partner >> 1 : 0) + 2 * kk0 * hc;
+    const bool same = partner >= 0 && (partner >> 1) == (w >> 1);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int o = 2 * kst * m * hc;
+        const float2 a0 = own[o], a1 = own[o + hc];
+        float s0 = odd ? a0.y : a0.x, s1 = odd ? a1.y : a1.x;
+        if (partner >= 0) {  // (wave-uniform)
+            float p0, p1;
+            if (same) {
+                p0 = odd ? a0.x : a0.y;
+                p1 = odd ? a1.x : a1.y;
+            } else {
+                const float2 b0 = oth[o], b1 = oth[o + hc];
+                p0 = podd ? b0.y : b0.x;
+                p1 = podd ? b1.y : b1.x;
+            }
+            if (is_mag) { couple(s0, p0); couple(s1, p1); }
+            else { couple(p0, s0); couple(p1, s1); }
+        }
+        x[m] = make_float2(s0, s1);
+    }
+}
+
+// ... landed there by LDS-DMA (`global_load_lds_dwordx4`: 16 bytes per lane straight from memory into LDS, a wave-load's 64
+// pieces back to back; no registers, no ds_write), wave w of the C taking pieces 64 w + lane + 64 C j.  The rows must have
+// been given up by the previous frame (they are one landing area: a piece lands in whichever row it falls into); the wave
+// waits for its pieces here -- nothing is in flight a frame ahead.  Also the timing experiment of VPZ_SYNTH_ABLATE bit 2048
+// (product pick-up on the landed vector: wrong results).
 __device__ __forceinline__ void stage_by_lds_dma(const float *src, float *rows, int C, int half, int w, int lane)
 {
     const int total4 = (C * half) >> 2;  // 16-byte pieces of the packet
@@ -663,7 +703,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             const int hh = (size_of(fd.flags) >> 1) * (kBatchShort ? (int)((fd.flags >> kFrameBatchShift) & 7u) + 1 : 1);
             const bool shared_input = fd.flags & kFrameInterleaved;
             const float *src = a.spec + fd.spec_off + (shared_input ? 0 : (int64_t)ch * hh);
-            const bool regs = valid && !(shared_input && (a.ablate & (2048 | 4096)));  // (2048: the packet comes by LDS-DMA)
+            const bool regs = valid && !(shared_input && (a.group_dma || (a.ablate & (2048 | 4096))));  // (the packet comes by LDS-DMA)
             load_group_share(x, regs ? src : a.inv_db, shared_input ? 64 * ch : 0, shared_input ? 64 * C : 64,
                              regs ? ((shared_input ? C * hh : hh) >> 2) : 1, lane);
         } else {
@@ -893,7 +933,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             if (stage && !(a.ablate & 32)) {
                 if ((fd.flags & kFrameInterleaved) && (a.ablate & 4096)) {
                     stage_by_lds_dma_gather(a.spec + fd.spec_off, hcur, C, nstage >> 1, ch, lane);
-                } else if ((fd.flags & kFrameInterleaved) && (a.ablate & 2048)) {
+                } else if ((fd.flags & kFrameInterleaved) && (a.group_dma || (a.ablate & 2048))) {
                     stage_by_lds_dma(a.spec + fd.spec_off, s_work[gw0], C, nstage >> 1, ch, lane);
                 } else if (fd.flags & kFrameInterleaved) {
                     stage_interleaved(xcur, s_work[gw0], C, div_magic, nstage >> 1, ch, lane);
@@ -913,8 +953,26 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                                            (uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.x);
             // byte k of the mapping's steps: out of the prefetched word while the mapping has at most four
             auto step_byte = [&](int k) -> uint32_t { return n_steps <= 4 ? (uint32_t)(stw >> (8 * k)) & 0xFFu : (uint32_t)st[k]; };
-            for (int lvl = 0; lvl < a.max_steps; ++lvl) {
-                if (stage && !(a.ablate & 16)) {
+            // (group_dma) the packet lies in the rows as it came: every wave takes its channel out of it, its own coupling step
+            // applied on the way; the barrier(s) below then stand between the last pick-up and the first transform
+            const bool in_place = stage && a.group_dma && (fd.flags & kFrameInterleaved);
+            if (in_place && (exec || batch)) {
+                int partner = -1;
+                bool is_mag = false;
+                for (int k = 0; k < n_steps; ++k) {
+                    const int sm = (int)(step_byte(2 * k) & 0x7F), sa = (int)step_byte(2 * k + 1);
+                    if (sm == ch) { partner = sa; is_mag = true; }
+                    else if (sa == ch) { partner = sm; }
+                }
+                if (a.ablate & 16) partner = -1;
+                int lb = lane;
+                asm volatile("" : "+v"(lb));  // (frame-invariant LDS addresses: keep them inside the iteration)
+                const int lpb = batch ? 8 : lpb_of(fd.flags);
+                pickup_interleaved(xcur, s_work[gw0], C, ch, partner, is_mag, batch ? (lb >> 3) * 64 + (lb & 7) : (lb & (lpb - 1)), lpb);
+            }
+            const int n_levels = a.group_dma ? max(a.max_steps, 1) : a.max_steps;
+            for (int lvl = 0; lvl < n_levels; ++lvl) {
+                if (stage && !in_place && !(a.ablate & 16)) {
                     bool first = true;
                     while (sidx >= 0 && (first || !(step_byte(2 * sidx) & 0x80))) {
                         float4 *pm = reinterpret_cast<float4 *>(s_work[gw0 + (step_byte(2 * sidx) & 0x7F)]);
@@ -935,7 +993,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 __syncthreads();
             }
             VPZ_STAMP(3);  // coupling levels + barriers
-            if (batch) {  // lane group g takes block g of the batch: points l + 8 m of its 64
+            if (in_place) {
+                // (already in xcur)
+            } else if (batch) {  // lane group g takes block g of the batch: points l + 8 m of its 64
                 const float2 *row2 = reinterpret_cast<const float2 *>(hcur);
                 int lb = lane;
                 asm volatile("" : "+v"(lb));

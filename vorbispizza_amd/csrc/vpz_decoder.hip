@@ -123,6 +123,7 @@ struct Decoder {
     DevBuf b_curve, b_temp, b_cposts, b_ccount;
     // group mode of synth_kernel (channels of a packet share a workgroup; de-interleave + coupling in LDS)
     bool group_ok = false;       // channel count, step tables and floor types allow it
+    bool group_dma = false;      // ... and interleaved packets may land in LDS as they are (SynthArgs.group_dma)
     // stereo fast path (synth_dual.hip: one wavefront per stream synthesises both channels, coupling in registers)
     bool dual_ok = false;        // two channels, 256 / 2048 blocks, type-1 floors only (VPZ_NO_DUAL=1: off, for A/B tests)
     int max_steps = 0, n_step_pairs = 0;
@@ -358,6 +359,21 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         const char *no_dual = getenv("VPZ_NO_DUAL");
         D.dual_ok = synth_dual_supported(D.channels, D.size0, D.size1) && !D.generic && !has_floor0 && D.max_steps <= 255 &&
                     D.n_step_pairs <= kGroupMaxStepPairs && !(no_dual && atoi(no_dual));
+        // every channel in at most one step of its mapping (then a mapping has one level, and a wave can apply its own step
+        // to the pair of values it reads): the packet may stay interleaved in LDS
+        bool single_step = true;
+        for (size_t m = 0; m < D.mappings.size(); ++m) {
+            uint32_t seen[8] = {};
+            const int n = D.mappings[m].coupling_steps, off = D.mapping_steps_off[m];
+            for (int i = 0; i < n; ++i)
+                for (int k = 0; k < 2; ++k) {
+                    const uint8_t c = steps[off + 2 * i + k];
+                    if (seen[c >> 5] >> (c & 31) & 1) single_step = false;
+                    seen[c >> 5] |= 1u << (c & 31);
+                }
+        }
+        const char *want_dma = getenv("VPZ_GROUP_DMA");  // measured slower than staging through registers: opt-in
+        D.group_dma = D.group_ok && single_step && (D.channels & 1) == 0 && D.max_steps <= 4 && want_dma && atoi(want_dma);
         D.max_steps = max_levels;  // from here on: the barriers a frame's coupling needs in group mode
         const char *nc = getenv("VPZ_NO_COMPACT");
         D.no_compact = nc && atoi(nc);
@@ -1634,6 +1650,7 @@ struct SynthCall {
         a.n_step_pairs = D.n_step_pairs;
         a.max_steps = D.max_steps;
         a.group = use_group ? 1 : 0;
+        a.group_dma = (use_group && D.group_dma) ? 1 : 0;
         a.inv_db = ctx->d_inv_db;
         a.state_h = D.d_state_h;
         a.state_slot_floats = (int64_t)D.n_streams * C * half1;
