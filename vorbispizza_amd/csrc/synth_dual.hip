@@ -411,6 +411,9 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
     unsigned long long n_long_frames = 0;
 #endif
+#ifdef VPZ_WAVE_TIMES
+    unsigned wt_long = 0, wt_short = 0, wt_batch = 0, wt_members = 0;
+#endif
     int fi = fi0;
     for (int it = 0; it < iters; ++it) {
         const FrameDesc fd = fd_next;
@@ -430,6 +433,9 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         VPZ_STAMP(0);  // descriptor + prefetch issue
 #ifdef VPZ_STAMPS
         if (size_of(fd.flags) == 2048) ++n_long_frames;
+#endif
+#ifdef VPZ_WAVE_TIMES
+        if (size_of(fd.flags) == 2048) ++wt_long; else if (bsz > 1) { ++wt_batch; wt_members += bsz; } else ++wt_short;
 #endif
         const bool drain = fd.flags & kFrameDrain;
         const bool batch = bsz > 1;
@@ -791,7 +797,9 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         if (run_idx < (1 << 16)) {  // this wave's own record (VPZ_STAMPS_DUMP)
             unsigned long long *rec = a.stamps + 16 + 16 * (size_t)run_idx;
             for (int k = 0; k < 9; ++k) rec[k] = t_acc[k];
-            rec[9] = (unsigned long long)iters;
+            rec[2] = wt_long; rec[3] = wt_short; rec[4] = wt_batch; rec[5] = wt_members;  // passes by kind, blocks in batches
+        rec[6] = (unsigned long long)run.pre_kind;
+        rec[9] = (unsigned long long)iters;
             rec[10] = n_long_frames;
         }
     }
@@ -813,6 +821,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         unsigned long long *rec = a.stamps + 16 + 16 * (size_t)run_idx;
         rec[0] = t_wave_begin;
         rec[1] = __builtin_amdgcn_s_memtime();
+        rec[2] = wt_long; rec[3] = wt_short; rec[4] = wt_batch; rec[5] = wt_members;  // passes by kind, blocks in batches
+        rec[6] = (unsigned long long)run.pre_kind;
         rec[9] = (unsigned long long)iters;
         rec[10] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID, all 32 bits
         atomicAdd(&a.stamps[15], 1ull);

@@ -1172,11 +1172,17 @@ struct SynthCall {
             return ok && prev_in_run_ok && !(pp.flags & VPZ_PKT_BLOCK_FLAG) && pk.mapping == pp.mapping &&
                    ((pk.flags ^ pp.flags) & VPZ_PKT_NO_FLOOR) == 0;
         };
-        // cost of a pass in eighths of a long block's (tools/kbench_short_long.py: a short block alone 0.74, eight in one
-        // batch 3.2 together)
+        // cost of a pass in eighths of a long block's (group mode, tools/kbench_short_long.py: a short block alone 0.74, eight
+        // in one batch 3.2 together; the stereo fast path, fitted to the waves' durations on real streams -- tools/wave_times.sh,
+        // wave_times_fit.py: a short block alone or at the head of a batch costs a whole pass, 8.6 / 7.7 eighths, every block
+        // riding along 2.0)
+        int w_short = use_dual ? 8 : 6, w_member = use_dual ? 2 : 3;
+        if (const char *w = getenv("VPZ_CUT_WEIGHTS")) (void)sscanf(w, "%d,%d", &w_short, &w_member);  // tuning
+        w_short = std::min(std::max(w_short, 1), 8);  // (a frame costs at most a whole pass: see the runs' capacity below)
+        w_member = std::min(std::max(w_member, 1), 8);
         auto unit_cost = [&](int64_t p, bool ok, int pos) -> int {
-            if (ok && (pos & 7) != 0) return 3;
-            return (batches && !(packets[p].flags & VPZ_PKT_BLOCK_FLAG)) ? 6 : 8;
+            if (ok && (pos & 7) != 0) return w_member;
+            return (batches && !(packets[p].flags & VPZ_PKT_BLOCK_FLAG)) ? w_short : 8;
         };
         int64_t total_units = 8 * total_frames;
         // what the later walks need to know about a packet, one byte each (bit 0: short block, bit 1: may ride in a batch,
@@ -1255,7 +1261,7 @@ struct SynthCall {
                 const bool ok = c8 & 2;
                 const bool link = ok && prev_ok && (c8 & 4);
                 pos = ok ? (link ? pos + 1 : 0) : -1;
-                const int u = (ok && (pos & 7) != 0) ? 3 : ((c8 & 1) ? 6 : 8);
+                const int u = (ok && (pos & 7) != 0) ? w_member : ((c8 & 1) ? w_short : 8);
                 if (len > 0 && units + u > target) break;
                 units += u;
                 prev_ok = ok;
