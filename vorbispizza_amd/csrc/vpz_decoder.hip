@@ -362,7 +362,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         // every channel in at most one step of its mapping (then a mapping has one level, and a wave can apply its own step
         // to the pair of values it reads): the packet may stay interleaved in LDS
         bool single_step = true;
-        for (size_t m = 0; m < D.mappings.size(); ++m) {
+        for (size_t m = 0; m < D.mappings.size() && rc == VPZ_OK; ++m) {  // (the step tables are complete only then)
             uint32_t seen[8] = {};
             const int n = D.mappings[m].coupling_steps, off = D.mapping_steps_off[m];
             for (int i = 0; i < n; ++i)
