@@ -112,8 +112,50 @@ def stereo_floor0(seed=4):
     return vw.Stream(2, 16000, 9, 9, books, [f0, f1], [r], maps, [(0, 0), (1, 1)]), rng
 
 
+def six_channels_51(seed=5):
+    """5.1 as libvorbis lays it out: 6 channels in one submap, coupling (0,2) and (3,4) -- front and rear pairs, the
+    centre between them --, residue 2, 256/2048: group mode with a real Residue2 vector and non-adjacent pairs."""
+    rng = np.random.default_rng(seed)
+    books = []
+    f_short = _floor1(rng, books, 128, 4, 2)
+    f_long = _floor1(rng, books, 1024, 8, 3)
+    r_short = _residue(rng, books, 2, 6 * 128, 16, 3, 2, [(2, 1, 9), (4, 1, 81)])
+    r_long = _residue(rng, books, 2, 6 * 1024, 32, 4, 3, [(2, 1, 49), (4, 2, 12), (8, 1, 300)])
+    coupling = [(0, 2), (3, 4)]
+    maps = [vw.Mapping(6, coupling, [0] * 6, [0], [0]), vw.Mapping(6, coupling, [0] * 6, [1], [1])]
+    return vw.Stream(6, 48000, 8, 11, books, [f_short, f_long], [r_short, r_long], maps, [(0, 0), (1, 1)]), rng
+
+
+def three_channels_chained(seed=7):
+    """3 channels, two CHAINED coupling steps (0,1) then (2,0) -- the inverse must run them in reverse order --, residue 1,
+    block sizes 512/1024 (the general-size kernels)."""
+    rng = np.random.default_rng(seed)
+    books = []
+    f_short = _floor1(rng, books, 256, 5, 2)
+    f_long = _floor1(rng, books, 512, 6, 1)
+    r_short = _residue(rng, books, 1, 256, 16, 3, 2, [(2, 1, 9), (4, 1, 16)])
+    r_long = _residue(rng, books, 1, 512, 32, 3, 2, [(2, 1, 25), (4, 2, 9)])
+    coupling = [(0, 1), (2, 0)]
+    maps = [vw.Mapping(3, coupling, [0, 0, 0], [0], [0]), vw.Mapping(3, coupling, [0, 0, 0], [1], [1])]
+    return vw.Stream(3, 22050, 9, 10, books, [f_short, f_long], [r_short, r_long], maps, [(0, 0), (1, 1)]), rng
+
+
+def four_channels_quad(seed=6):
+    """4 channels, coupling (0,1) and (2,3), residue 2, 256/2048."""
+    rng = np.random.default_rng(seed)
+    books = []
+    f_short = _floor1(rng, books, 128, 3, 1)
+    f_long = _floor1(rng, books, 1024, 7, 2)
+    r_short = _residue(rng, books, 2, 4 * 128, 8, 3, 2, [(2, 1, 9), (4, 1, 16)])
+    r_long = _residue(rng, books, 2, 4 * 1024, 32, 4, 2, [(2, 1, 25), (4, 2, 10), (8, 1, 256)])
+    coupling = [(0, 1), (2, 3)]
+    maps = [vw.Mapping(4, coupling, [0] * 4, [0], [0]), vw.Mapping(4, coupling, [0] * 4, [1], [1])]
+    return vw.Stream(4, 44100, 8, 11, books, [f_short, f_long], [r_short, r_long], maps, [(0, 0), (1, 1)]), rng
+
+
 ALL = {"mono_floor1_res1": mono_floor1_res1, "stereo_coupled_res2": stereo_coupled_res2,
-       "three_channels_two_submaps": three_channels_two_submaps, "stereo_floor0": stereo_floor0}
+       "three_channels_two_submaps": three_channels_two_submaps, "stereo_floor0": stereo_floor0,
+       "six_channels_51": six_channels_51, "four_channels_quad": four_channels_quad, "three_channels_chained": three_channels_chained}
 
 
 def random_stream(seed):
