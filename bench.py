@@ -288,12 +288,13 @@ def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, 
     return dt, total_samples, t_front_total, results
 
 
-def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2, plan=None, s16=False):
+def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2, plan=None, s16=False, streamed=True):
     """configs[4] end to end for one GPU's share: every one of the 2 x `copies` streams is opened and
-    entropy-decoded on the host (`threads` host threads of the host library, vpzh_decode_many: one stream at a time each -- the
-    reference's model of one decoder per thread), straight into pinned batch buffers; the streams go to the GPU in sub-batches
-    of `sub` streams, one host-memory synth call each (H2D + kernels + D2H), issued by the calling thread as
-    soon as a sub-batch is decoded while the pool keeps decoding the following ones.  `synth_lanes` contexts
+    entropy-decoded on the host (`threads` host threads of the host library, vpzh_decode_many_progress: one stream at a time
+    each -- the reference's model of one decoder per thread), straight into pinned batch buffers; the streams go to the GPU in
+    sub-batches of `sub` streams, one host-memory synth call each (H2D + kernels + D2H), issued by the calling thread as
+    soon as the sub-batch's streams are reported complete while the pool keeps decoding the following ones (streamed=False:
+    one vpzh_decode_many call per sub-batch, i.e. a fork-join of the decode threads in front of every synth call).  `synth_lanes` contexts
     (one HIP stream each, one issuing thread each) take the sub-batches in turn, so the H2D copy of one
     sub-batch overlaps the D2H copy of the previous one (PCIe is full duplex).
     s16: PCM leaves the GPU as the 16-bit samples the reference's tests derive (VPZ_OUT_INTERLEAVED_S16): half the
@@ -353,17 +354,46 @@ def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2, 
         synth_sub(g, b)
         return time.perf_counter() - t
 
+    def decode_group(g, done):
+        # all of the group's streams in ONE vpzh_decode_many_progress call (no fork-join per sub-batch: a thread that is done
+        # with its stream takes the next one of the whole group); `done` tells the issuing thread which streams are complete
+        n, rf, copies = g["n"], g["rf"], g["copies"]
+        front.decode_many([g["bytes"]] * copies, [j * n for j in range(copies)], [j * rf for j in range(copies)],
+                          g["pk"], g["res"], g["posts"], g["counts"], threads=threads, stream_id0=0, residue_origin=0, done=done)
+        return time.perf_counter()
+
+    def rebase_sub(g, b):
+        # the synth call of a sub-batch sees its own slices: stream ids and residue offsets from the slices' start
+        n, rf, sub = g["n"], g["rf"], g["sub"]
+        lo, hi = b * sub, (b + 1) * sub
+        g["pk"]["stream"][lo * n:hi * n] -= lo
+        g["pk"]["residue_offset"][lo * n:hi * n] -= lo * rf
+
     best = None
-    with ThreadPoolExecutor(max_workers=len(lanes)) as synth_pool:
+    with ThreadPoolExecutor(max_workers=len(lanes)) as synth_pool, ThreadPoolExecutor(max_workers=1) as decode_pool:
         for _ in range(3):
             t0 = time.perf_counter()
             pending = []
             t_dec_done = t0
             for g in groups:
+                if not streamed:
+                    for b in range(g["copies"] // g["sub"]):
+                        decode_sub(g, b)  # (the GIL is released inside: the synth calls of earlier sub-batches run meanwhile)
+                        t_dec_done = time.perf_counter()
+                        pending.append(synth_pool.submit(timed_synth, g, b))
+                    continue
+                done = np.zeros(g["copies"], dtype=np.int32)
+                decoding = decode_pool.submit(decode_group, g, done)
                 for b in range(g["copies"] // g["sub"]):
-                    decode_sub(g, b)  # (the GIL is released inside: the synth calls of earlier sub-batches run meanwhile)
-                    t_dec_done = time.perf_counter()
+                    mine = done[b * g["sub"]:(b + 1) * g["sub"]]
+                    while not mine.all():
+                        if decoding.done():
+                            decoding.result()  # (raises what the decode raised; otherwise the flags are all set by now)
+                        time.sleep(2e-5)
+                    assert (mine == 1).all()
+                    rebase_sub(g, b)
                     pending.append(synth_pool.submit(timed_synth, g, b))
+                t_dec_done = decoding.result()
             t_syn = sum(f.result() for f in pending)
             t2 = time.perf_counter()
             if best is None or t2 - t0 < best[0]:

@@ -100,6 +100,15 @@ int vpzh_decode_many(int32_t n, const uint8_t *const *data, const uint64_t *size
                      const int64_t *residue_room, int64_t residue_origin, vpz_packet *packets, float *residue, int16_t *posts,
                      uint8_t *post_counts, int64_t *failed_packets);
 
+/* The same with a progress report, for a caller that hands finished streams on (to vpz_decoder_synth) while the rest is still
+ * being decoded: done[k] (caller-zeroed, n entries) becomes 1 once stream k's slices are complete, -1 if it was refused or
+ * failed to open; streams are taken in index order, one per thread at a time.  The flags are stored with release semantics --
+ * read them from another thread, see non-zero, then read the slices. */
+int vpzh_decode_many_progress(int32_t n, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
+                              const int64_t *packet_base, const int64_t *packet_room, const int64_t *residue_base,
+                              const int64_t *residue_room, int64_t residue_origin, vpz_packet *packets, float *residue,
+                              int16_t *posts, uint8_t *post_counts, int64_t *failed_packets, int32_t *done);
+
 /* Packets of the LAST vpzh_decode_range* / vpzh_decode_all call whose entropy decode failed the way the reference's
  * DecodeNextPacket throws (InvalidDataException "Unused mode index.", a residue vector overrunning its block, ...).
  * Such a packet costs only itself, like the reference's exception: it is handed over with VPZ_PKT_NOT_DECODED and

@@ -4,6 +4,7 @@ Known answers: channels, rates, block sizes, packet counts
 coupling layout, and the decoded sample count, which must equal the stream's granule span."""
 import hashlib
 import os
+import time
 
 import numpy as np
 import pytest
@@ -233,8 +234,10 @@ def test_decode_many_equals_one_stream_at_a_time():
     posts = np.full((np_ * C_, 64), -3, dtype=np.int16)
     counts = np.full(np_ * C_, 200, dtype=np.uint8)
     arrays = [np.frombuffer(datas[name], dtype=np.uint8) for name in order]
-    failed = front.decode_many(arrays, pbase, rbase, pk, res, posts, counts, threads=3, stream_id0=10, residue_origin=lead_r)
-    assert failed == 0
+    done = np.zeros(len(order), dtype=np.int32)
+    failed = front.decode_many(arrays, pbase, rbase, pk, res, posts, counts, threads=3, stream_id0=10, residue_origin=lead_r,
+                               done=done)
+    assert failed == 0 and (done == 1).all()  # (vpzh_decode_many_progress: every stream reported complete)
     for k, name in enumerate(order):
         n, _, rf, spk, sres, sposts, scounts = singles[name]
         a = pk[pbase[k]: pbase[k] + n]
@@ -250,3 +253,39 @@ def test_decode_many_equals_one_stream_at_a_time():
     with pytest.raises(front.FrontError):
         front.decode_many(arrays[:1], pbase[:1], rbase[:1], pk, res, posts, counts, threads=1,
                           packet_room=[singles[order[0]][0] - 1], residue_room=[singles[order[0]][2]])
+    # ... and says so in its progress entry, while the streams next to it are decoded
+    done = np.zeros(2, dtype=np.int32)
+    with pytest.raises(front.FrontError):
+        front.decode_many(arrays[:2], pbase[:2], rbase[:2], pk, res, posts, counts, threads=2, done=done,
+                          packet_room=[singles[order[0]][0] - 1, singles[order[1]][0]],
+                          residue_room=[singles[order[0]][2], singles[order[1]][2]])
+    assert list(done) == [-1, 1]
+
+
+def test_decode_many_progress_lets_another_thread_take_finished_streams():
+    """The pipeline bench.py's end-to-end leg runs: one thread inside vpzh_decode_many_progress, another one watching the
+    flags and picking streams up in order as they complete -- what it picks up is final."""
+    import threading
+    from vorbispizza_amd import capi, front
+    raw = np.frombuffer(open(os.path.join(GOLDEN, "1test.ogg"), "rb").read(), dtype=np.uint8)
+    f = front.OggVorbisFile(raw.tobytes())
+    n, C_, rf = f.audio_packets, f.channels, f.info.residue_floats
+    want = f.decode_packets()
+    streams = 12
+    pk = capi.make_packets(n * streams)
+    res = np.zeros(rf * streams, dtype=np.float32)
+    posts = np.zeros((n * streams * C_, 64), dtype=np.int16)
+    counts = np.zeros(n * streams * C_, dtype=np.uint8)
+    done = np.zeros(streams, dtype=np.int32)
+    t = threading.Thread(target=front.decode_many, args=([raw] * streams, [k * n for k in range(streams)], [k * rf for k in range(streams)],
+                                                         pk, res, posts, counts), kwargs=dict(threads=3, done=done))
+    t.start()
+    seen = []
+    for k in range(streams):
+        while done[k] == 0:
+            time.sleep(1e-4)
+        assert done[k] == 1
+        seen.append(bool(np.array_equal(res[k * rf:(k + 1) * rf], want[1]) and
+                         np.array_equal(counts[k * n * C_:(k + 1) * n * C_], want[3])))
+    t.join()
+    assert all(seen)

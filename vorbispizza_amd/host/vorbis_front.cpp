@@ -1326,6 +1326,15 @@ int vpzh_decode_many(int32_t n, const uint8_t *const *data, const uint64_t *size
                      const int64_t *residue_room, int64_t residue_origin, vpz_packet *packets, float *residue, int16_t *posts,
                      uint8_t *post_counts, int64_t *failed_packets)
 {
+    return vpzh_decode_many_progress(n, data, size, threads, stream_id0, packet_base, packet_room, residue_base, residue_room,
+                                     residue_origin, packets, residue, posts, post_counts, failed_packets, nullptr);
+}
+
+int vpzh_decode_many_progress(int32_t n, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
+                              const int64_t *packet_base, const int64_t *packet_room, const int64_t *residue_base,
+                              const int64_t *residue_room, int64_t residue_origin, vpz_packet *packets, float *residue,
+                              int16_t *posts, uint8_t *post_counts, int64_t *failed_packets, int32_t *done)
+{
     if (n < 0 || (n > 0 && (!data || !size || !packet_base || !packet_room || !residue_base || !residue_room || !packets ||
                             !residue || !posts || !post_counts)))
         return VPZH_E_ARG;
@@ -1357,6 +1366,8 @@ int vpzh_decode_many(int32_t n, const uint8_t *const *data, const uint64_t *size
             }
             if (rc != VPZH_OK) status.store(rc, std::memory_order_relaxed);
             if (s) vpzh_close(s);
+            // (release: whoever sees the flag sees the stream's slices)
+            if (done) __atomic_store_n(&done[k], rc == VPZH_OK ? 1 : -1, __ATOMIC_RELEASE);
         }
     };
     std::vector<std::thread> pool;
