@@ -289,3 +289,32 @@ def test_decode_many_progress_lets_another_thread_take_finished_streams():
                          np.array_equal(counts[k * n * C_:(k + 1) * n * C_], want[3])))
     t.join()
     assert all(seen)
+
+
+def _decode_digest(names, rounds):
+    from vorbispizza_amd import front
+    h = hashlib.sha256()
+    for _ in range(rounds):
+        for name in names:
+            f = front.OggVorbisFile(os.path.join(GOLDEN, name))
+            pk, res, posts, counts = f.decode_packets()
+            for a in (pk, res, posts, counts):
+                h.update(np.ascontiguousarray(a).tobytes())
+            h.update(repr((f.channels, f.block_size0, f.block_size1, f.floors, f.mappings)).encode())
+    return h.hexdigest()
+
+
+def test_setup_cache_hits_decode_exactly_like_a_fresh_unpack():
+    """A stream whose identification + setup headers were seen before copies their unpacked form (codebook tables, floors,
+    residues, mappings, modes) instead of unpacking them again: the second and third opening of every fixture (hits) give the
+    bytes a process with the cache switched off (VPZH_NO_SETUP_CACHE=1) gives."""
+    import subprocess
+    import sys
+    names = ["1test.ogg", "2test.ogg", "3test.ogg", "issue6test.ogg"]
+    here = _decode_digest(names, 3)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_front_cpu as t; "
+            "print(t._decode_digest(%r, 3))" % (os.path.dirname(GOLDEN), os.path.dirname(os.path.dirname(GOLDEN)), names))
+    env = dict(os.environ, VPZH_NO_SETUP_CACHE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == here

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -790,6 +791,64 @@ uint32_t crc_update(uint32_t crc, const uint8_t *d, size_t n)
 
 }  // namespace
 
+// What the setup header of a stream unpacks into (StreamDecoder.cs:262-321): codebooks with their decode tables, floors,
+// residues, mappings, modes.  Files that come out of one encoder at one setting carry byte-identical setup headers, and a host
+// that transcodes a library opens thousands of them: the unpacked form of the last few distinct (identification, setup)
+// header pairs is kept, and a stream whose headers match one byte for byte copies it instead of building ~40 Huffman tables
+// again (0.36 -> 0.1 ms of a 2 ms file).  VPZH_NO_SETUP_CACHE=1 switches it off.
+struct SetupBlob {
+    std::vector<uint8_t> ident, setup;  // the key: both packets, compared in full
+    std::vector<Codebook> books;
+    std::vector<Floor1> floors;
+    std::vector<Floor0> floors0;
+    std::vector<uint8_t> floor_types;
+    int max_floor0_order = 0;
+    std::vector<Residue> residues;
+    std::vector<Mapping> mappings;
+    std::vector<Mode> modes;
+    int mode_field_bits = 0;
+};
+struct SetupCache {
+    static constexpr size_t kEntries = 16;
+    std::mutex mu;
+    std::vector<std::shared_ptr<const SetupBlob>> entries;
+    size_t next = 0;  // round robin once full
+    bool enabled = true;
+    SetupCache()
+    {
+        const char *e = getenv("VPZH_NO_SETUP_CACHE");
+        enabled = !(e && atoi(e));
+    }
+    std::shared_ptr<const SetupBlob> find(const std::vector<uint8_t> &ident, const std::vector<uint8_t> &setup)
+    {
+        if (!enabled) return nullptr;
+        std::lock_guard<std::mutex> lock(mu);
+        for (const auto &b : entries)
+            if (b->setup.size() == setup.size() && b->ident.size() == ident.size() &&
+                memcmp(b->setup.data(), setup.data(), setup.size()) == 0 && memcmp(b->ident.data(), ident.data(), ident.size()) == 0)
+                return b;
+        return nullptr;
+    }
+    void insert(std::shared_ptr<const SetupBlob> b)
+    {
+        if (!enabled) return;
+        std::lock_guard<std::mutex> lock(mu);
+        for (const auto &e : entries)  // (threads that opened the same headers at the same time: one copy)
+            if (e->setup == b->setup && e->ident == b->ident) return;
+        if (entries.size() < kEntries) {
+            entries.push_back(std::move(b));
+        } else {
+            entries[next] = std::move(b);
+            next = (next + 1) % kEntries;
+        }
+    }
+};
+static SetupCache &setup_cache()
+{
+    static SetupCache c;  // (thread-safe initialisation)
+    return c;
+}
+
 struct vpzh_stream {
     std::string error;
     int channels = 0, sample_rate = 0, size0 = 0, size1 = 0;
@@ -946,7 +1005,19 @@ struct vpzh_stream {
             static const uint8_t sig[7] = {0x03, 'v', 'o', 'r', 'b', 'i', 's'};
             for (uint8_t c : sig) if (p.read_bits(8) != c) throw InvalidData("not a Vorbis comment header");
         }
-        // setup, StreamDecoder.cs:262-321
+        // setup, StreamDecoder.cs:262-321 -- or its unpacked form, if these very headers have been seen before
+        if (std::shared_ptr<const SetupBlob> hit = setup_cache().find(pk[0].data, pk[2].data)) {
+            books = hit->books;
+            floors = hit->floors;
+            floors0 = hit->floors0;
+            floor_types = hit->floor_types;
+            max_floor0_order = hit->max_floor0_order;
+            residues = hit->residues;
+            mappings = hit->mappings;
+            modes = hit->modes;
+            mode_field_bits = hit->mode_field_bits;
+            return;
+        }
         BitReader p;
         p.init(pk[2].data.data(), pk[2].data.size());
         static const uint8_t sig[7] = {0x05, 'v', 'o', 'r', 'b', 'i', 's'};
@@ -994,6 +1065,21 @@ struct vpzh_stream {
         }
         if (!p.read_bit()) throw InvalidData("Book packet did not end on correct bit!");
         mode_field_bits = ilog(n_modes - 1);
+        if (setup_cache().enabled) {
+            auto blob = std::make_shared<SetupBlob>();
+            blob->ident = pk[0].data;
+            blob->setup = pk[2].data;
+            blob->books = books;
+            blob->floors = floors;
+            blob->floors0 = floors0;
+            blob->floor_types = floor_types;
+            blob->max_floor0_order = max_floor0_order;
+            blob->residues = residues;
+            blob->mappings = mappings;
+            blob->modes = modes;
+            blob->mode_field_bits = mode_field_bits;
+            setup_cache().insert(std::move(blob));
+        }
     }
 
     // residue floats one packet contributes to the batch
