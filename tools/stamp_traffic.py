@@ -97,6 +97,9 @@ def main():
                       "algorithmic_bytes_per_launch": h["algorithmic_bytes_per_launch"], "ratio_to_algorithmic": h["ratio_to_algorithmic"]})
     os.makedirs(os.path.dirname(STAMP), exist_ok=True)
     json.dump(stamp, open(STAMP, "w"), indent=1)
+    # (gpurun brings back only gpurun_out/: leave a copy there, to be copied over profiles/traffic_stamp.json)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(stamp, open(os.path.join(ROOT, "gpurun_out", "traffic_stamp.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
