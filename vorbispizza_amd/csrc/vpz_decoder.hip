@@ -573,6 +573,8 @@ struct SynthCall {
     const int16_t *d_posts = nullptr;
     const uint8_t *d_counts = nullptr;
     void *d_out = nullptr;
+    bool early_residue = false, early_posts = false;  // stage_inputs_early has the copies under way
+    int64_t early_res_extent = 0;
 
     SynthCall(Decoder &dec, int64_t n, const vpz_packet *pk, const float *res, const int16_t *po, const uint8_t *pc,
               int mem, void *out, const int64_t *out_off, int64_t out_cap, int layout, int64_t stride)
@@ -1498,6 +1500,39 @@ struct SynthCall {
     }
 
     // Device side, part 1: VPZ_MEM_HOST inputs are staged, work buffers grown, the arena uploaded.
+    // VPZ_MEM_HOST: the caller's residue (and floor records) start their way to the device BEFORE the host state machine runs
+    // -- neither depends on it, and the link is what a host-memory call waits for: the pass over the packets (50 us for a
+    // sub-batch of 16 real streams on an idle core, several times that while the cores decode) passes under the copy.  What
+    // is copied: up to the highest residue a decodable packet names (>= what the state machine will use; within the extent
+    // the caller stated, else nothing is started here and the call fails where it always did).  The caller's buffers are
+    // read asynchronously from here on: every way out of the call synchronises (see EarlyUploadGuard).
+    int stage_inputs_early(int64_t residue_floats, int64_t n_records)
+    {
+        if (mem_space != VPZ_MEM_HOST || !residue) return VPZ_OK;
+        int64_t ext = 0;
+        for (int64_t p = 0; p < n_packets; ++p) {
+            const vpz_packet &pk = packets[p];
+            if (pk.flags & VPZ_PKT_NOT_DECODED) continue;
+            if (pk.residue_offset < 0) return VPZ_OK;
+            ext = std::max(ext, pk.residue_offset + (int64_t)C * ((pk.flags & VPZ_PKT_BLOCK_FLAG) ? half1 : half0));
+        }
+        if (ext <= 0 || ext > residue_floats) return VPZ_OK;
+        int rc;
+        if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)ext)) != VPZ_OK) return rc;
+        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res.p, residue, sizeof(float) * (size_t)ext, hipMemcpyHostToDevice, ctx->stream));
+        early_residue = true;
+        early_res_extent = ext;
+        if (have_posts && n_records >= n_rec && n_rec > 0) {
+            if ((rc = grow(ctx, D.b_in_posts, sizeof(int16_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
+            if ((rc = grow(ctx, D.b_in_counts, (size_t)n_rec)) != VPZ_OK) return rc;
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_posts.p, posts, sizeof(int16_t) * 64 * (size_t)n_rec, hipMemcpyHostToDevice,
+                                            ctx->stream));
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_counts.p, post_counts, (size_t)n_rec, hipMemcpyHostToDevice, ctx->stream));
+            early_posts = true;
+        }
+        return VPZ_OK;
+    }
+
     int stage_inputs()
     {
         int rc;
@@ -1508,17 +1543,21 @@ struct SynthCall {
         d_coeff = D.f0_coeff;
         d_out = pcm_out;
         if (mem_space == VPZ_MEM_HOST) {
-            if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)res_extent)) != VPZ_OK) return rc;
-            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res.p, residue, sizeof(float) * (size_t)res_extent,
-                                            hipMemcpyHostToDevice, ctx->stream));
+            if (!(early_residue && early_res_extent >= res_extent)) {
+                if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)res_extent)) != VPZ_OK) return rc;
+                VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res.p, residue, sizeof(float) * (size_t)res_extent,
+                                                hipMemcpyHostToDevice, ctx->stream));
+            }
             d_res = static_cast<const float *>(D.b_in_res.p);
             if (any_floor) {
-                if ((rc = grow(ctx, D.b_in_posts, sizeof(int16_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
-                if ((rc = grow(ctx, D.b_in_counts, (size_t)n_rec)) != VPZ_OK) return rc;
-                VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_posts.p, posts, sizeof(int16_t) * 64 * (size_t)n_rec,
-                                                hipMemcpyHostToDevice, ctx->stream));
-                VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_counts.p, post_counts, (size_t)n_rec, hipMemcpyHostToDevice,
-                                                ctx->stream));
+                if (!early_posts) {
+                    if ((rc = grow(ctx, D.b_in_posts, sizeof(int16_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
+                    if ((rc = grow(ctx, D.b_in_counts, (size_t)n_rec)) != VPZ_OK) return rc;
+                    VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_posts.p, posts, sizeof(int16_t) * 64 * (size_t)n_rec,
+                                                    hipMemcpyHostToDevice, ctx->stream));
+                    VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_counts.p, post_counts, (size_t)n_rec, hipMemcpyHostToDevice,
+                                                    ctx->stream));
+                }
                 d_posts = static_cast<const int16_t *>(D.b_in_posts.p);
                 d_counts = static_cast<const uint8_t *>(D.b_in_counts.p);
             }
@@ -1782,6 +1821,18 @@ static int synth_impl(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     SynthCall call(D, n_packets, packets, residue, posts, post_counts, mem_space, pcm_out, stream_out_offset,
                    stream_out_capacity, out_layout, channel_stride);
     int rc;
+    // (whatever the way out: no copy may still be reading the caller's buffers when the call returns)
+    struct EarlyUploadGuard {
+        Context *ctx;
+        SynthCall &call;
+        bool completed = false;
+        ~EarlyUploadGuard()
+        {
+            if ((call.early_residue || call.early_posts) && !completed) (void)hipStreamSynchronize(ctx->stream);
+        }
+    } early_guard{ctx, call};
+    static const bool no_early = getenv("VPZ_NO_EARLY_UPLOAD") != nullptr;  // A/B tests
+    if (!no_early && (rc = call.stage_inputs_early(residue_floats, n_records)) != VPZ_OK) return rc;
     if ((rc = call.open_arena()) != VPZ_OK) return rc;
     const auto t_arena = tick();
     rc = call.run_state_machine_parallel(samples_written);
@@ -1816,6 +1867,7 @@ static int synth_impl(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
         call.A->pending = true;
     }
     if ((rc = call.copy_back()) != VPZ_OK) return rc;
+    early_guard.completed = mem_space == VPZ_MEM_HOST;  // (copy_back has waited for the stream)
     if (!D.generic)  // every stream with frames in this batch has had its state written to the other copy
         for (int s = 0; s < D.n_streams; ++s)
             if (D.s_cnt[s] > 0) call.st[s].state_slot ^= 1;
