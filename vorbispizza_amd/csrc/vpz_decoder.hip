@@ -117,6 +117,9 @@ struct Decoder {
     int cut_hint_R = 0;                      // ... and the cost target the last call's runs were fitted with
     int64_t cut_hint_slots = 0, cut_hint_target = 0, cut_hint_frames = -1, cut_hint_runs = 0;
     int cut_hint_streams = -1;
+    int64_t cut_hint_heavy = -1;             // runs that start below this cost position get the heavier target (cut_runs: THE SKEW)
+    std::vector<int64_t> s_units;            // cost of each stream's packets in this call (cut_runs), then
+    std::vector<int64_t> cut_prefix;         // ... the cost of all streams in front of each one
     size_t zero_copy_max = 8u << 20;         // arenas up to this size are read in place by the kernels (VPZ_ZERO_COPY_MAX;
                                              // half a million packets, 1.5 MB: 2.42 -> 2.35 ms against the copy)
     std::vector<int32_t> mapping_steps_off;  // per mapping: offset into d_steps (pairs*2), -1 none
@@ -1201,6 +1204,7 @@ struct SynthCall {
                                !(packets[p - 1].flags & VPZ_PKT_BLOCK_FLAG)) ? 4 : 0));
         };
         if (batches && code.size() < (size_t)total_frames) code.resize((size_t)total_frames);
+        if (batches) D.s_units.assign((size_t)D.n_streams, 0);
         if (batches && !reuse) {
             std::vector<int64_t> part(parties, 0);
             auto count = [&](int c) {
@@ -1210,14 +1214,17 @@ struct SynthCall {
                 for (int s = lo; s < hi; ++s) {
                     int pos = -1;
                     bool prev_ok = false;
+                    int64_t mine = 0;
                     for (int64_t p = D.s_base[s], e = D.s_base[s] + D.s_cnt[s]; p < e; ++p) {
                         bool ok;
                         const bool link = joins_batch(p, prev_ok, ok);
                         code[(size_t)p] = packet_code(p, ok);
                         pos = ok ? (link ? pos + 1 : 0) : -1;
-                        units += unit_cost(p, ok, pos);
+                        mine += unit_cost(p, ok, pos);
                         prev_ok = ok;
                     }
+                    D.s_units[(size_t)s] = mine;
+                    units += mine;
                 }
                 part[c] = units;
             };
@@ -1227,6 +1234,7 @@ struct SynthCall {
         }
         int R = reuse ? D.cut_hint_R : std::min(D.run_length_override, r_max);
         int64_t run_slots = reuse ? D.cut_hint_slots : 0;  // runs that fit the rounds R was chosen for
+        bool single_round = false;  // every run has a resident wave slot of its own from the start of the launch
         if (R <= 0) {
             const int64_t slots = std::max(1, use_dual ? synth_dual_resident_slots(any_floor, ctx->num_cu)
                                                        : synth_resident_waves(any_floor, ctx->num_cu, C, use_group));
@@ -1238,7 +1246,7 @@ struct SynthCall {
                 if (r > r_max) continue;
                 if (r < 4) break;
                 const int64_t cost = (int64_t)k * (r + 1);
-                if (best < 0 || cost < best) { best = cost; R = (int)r; run_slots = k * slots / C; }
+                if (best < 0 || cost < best) { best = cost; R = (int)r; run_slots = k * slots / C; single_round = k == 1; }
             }
         }
         // (a run cut by cost holds at least R - 1 frames unless its stream ends: every frame costs at most a whole pass)
@@ -1246,15 +1254,18 @@ struct SynthCall {
         // in the arena instead of a second allocation)
         if (runs_arena_mark == (size_t)-1) runs_arena_mark = A->used;
         A->used = runs_arena_mark;
-        runs_cap = (size_t)(total_frames / std::max(1, R - 1)) + (size_t)D.n_streams + 1;
+        // (... and the lighter half of a skewed cut holds that much less: see THE SKEW below)
+        static const int skew_cap_permille = [] { const char *e = getenv("VPZ_CUT_SKEW"); return e ? std::max(0, atoi(e)) : 25; }();
+        const int min_run_frames = std::max(1, R - 1 - ((skew_cap_permille > 0 && R >= 16) ? R * skew_cap_permille / 1000 + 2 : 0));
+        runs_cap = (size_t)(total_frames / min_run_frames) + (size_t)D.n_streams + 1;
         runs = arena_alloc<RunDesc>(*A, runs_cap);
         if (A->used > A->cap) { host_failed = true; return; }  // (open_arena's budget is R >= 4 runs: never, but never silently)
         if (D.generic) return;
         int64_t target_units = 8 * (int64_t)R;
         // one run of a frame: as many frames from f0 on as the cost target (and the descriptor area) allow
-        auto run_length = [&](int64_t base, int f0, int cnt, int64_t target) -> int {
+        auto run_length = [&](int64_t base, int f0, int cnt, int64_t target, int64_t &units) -> int {
             int len = 0;
-            int64_t units = 0;
+            units = 0;
             int pos = -1;
             bool prev_ok = false;
             const uint8_t *cd = code.data() + base + f0;
@@ -1272,18 +1283,51 @@ struct SynthCall {
             return len;
         };
         if (reuse) target_units = D.cut_hint_target;
+        // THE SKEW.  With one round of runs, the first half of the grid's workgroups are the first to arrive on their CUs and
+        // the second half join them as each CU's second workgroup -- and the waves of the second arrivals run slower for the
+        // whole launch (measured per wave, tools/wave_times.sh: identical runs take 600 k cycles in wave slot 0 of their SIMD,
+        // 647 k in slot 1; priorities set with s_setprio do not change it), so with equal work the early half idles at the end
+        // while the late half finishes at half occupancy.  Runs that start in the first half of the batch's WORK -- they are
+        // the first half of the grid -- are therefore cut 2 % heavier, the others as much lighter (tools/try_cut_skew.sh:
+        // configs[4] 0.283 -> 0.278 ms at 20 per mille, worse again from 40 on).
+        static const int skew_permille = [] { const char *e = getenv("VPZ_CUT_SKEW"); return e ? std::max(0, atoi(e)) : 25; }();
+        int64_t heavy_work = reuse ? D.cut_hint_heavy : -1;
+        if (batches && !reuse && single_round && use_dual && skew_permille > 0 && R >= 16) {  // (short runs: nothing to skew by)
+            heavy_work = total_units * (1000 + skew_permille) / 2000;
+            D.cut_prefix.resize((size_t)D.n_streams);
+            int64_t acc = 0;
+            for (int st_i = 0; st_i < D.n_streams; ++st_i) {
+                D.cut_prefix[(size_t)st_i] = acc;
+                acc += D.s_units[(size_t)st_i];
+            }
+        }
+        if (heavy_work >= 0 && D.cut_prefix.size() != (size_t)D.n_streams) heavy_work = -1;
+        // (all-long batches only: with short blocks in runs of equal length a frame more is not 3 % more -- configs[2] lost 2 %)
+        // (group mode -- 6 channels, two workgroups of 8 waves per CU -- does not respond to it: configs[3] 0.323 either way)
+        const bool skew_frames = !batches && !any_short && single_round && use_dual && skew_permille > 0 && R >= 24 &&
+                                 R + 1 <= r_max && D.run_length_override <= 0;
+        const int64_t heavy_frames = total_frames * (R + 1) / (2 * (int64_t)R);  // the first half of the frames' work at R + 1 each
+        // the target of the run of stream `st_i` that starts `before` cost units into its stream
+        auto target_at = [&](int st_i, int64_t before, int64_t target) -> int64_t {
+            if (heavy_work < 0) return target;
+            const int64_t sk = target * skew_permille / 1000;
+            return D.cut_prefix[(size_t)st_i] + before < heavy_work ? target + sk : target - sk;
+        };
         if (batches && run_slots > 0 && !reuse) {
             // runs of equal cost do not pack as evenly as runs of equal length (and every stream ends with a partial
             // one): a few more runs than the rounds hold would put a nearly empty round behind them -- count, and give
             // every run a little more until they fit
-            for (int tries = 0; tries < 6 && target_units / 8 < r_max; ++tries) {
+            auto runs_with = [&](int64_t target) -> int64_t {
                 std::vector<int64_t> part(parties, 0);
                 auto count = [&](int c) {
                     int lo, hi;
                     stream_range(c, lo, hi);
                     int64_t n = 0;
-                    for (int s = lo; s < hi; ++s)
-                        for (int f0 = 0, cnt = (int)D.s_cnt[s]; f0 < cnt; ++n) f0 += run_length(D.s_base[s], f0, cnt, target_units);
+                    for (int s = lo; s < hi; ++s) {
+                        int64_t before = 0, u = 0;
+                        for (int f0 = 0, cnt = (int)D.s_cnt[s]; f0 < cnt; ++n, before += u)
+                            f0 += run_length(D.s_base[s], f0, cnt, target_at(s, before, target), u);
+                    }
                     part[c] = n;
                 };
                 if (parties > 1) host_failed |= !pool->run(count); else count(0);
@@ -1291,13 +1335,24 @@ struct SynthCall {
                 for (int64_t v : part) n_total += v;
                 if (getenv("VPZ_HOST_PROFILE"))
                     fprintf(stderr, "[vpz host] run cutting: R %d, target %lld eighths, %lld runs for %lld slots\n", R,
-                            (long long)target_units, (long long)n_total, (long long)run_slots);
-                if (n_total <= run_slots) break;
+                            (long long)target, (long long)n_total, (long long)run_slots);
+                return n_total;
+            };
+            // in steps of half a pass until the runs fit, then back in eighths: the lightest runs that still fit (a launch
+            // takes as long as its heaviest run; half a pass is 2 % of one)
+            bool fits = false;
+            for (int tries = 0; tries < 6 && target_units / 8 < r_max; ++tries) {
+                if ((fits = runs_with(target_units) <= run_slots)) break;
                 target_units += 4;
+            }
+            if (fits && target_units > 8 * (int64_t)R) {
+                for (int64_t t = target_units - 3; t < target_units; ++t)
+                    if (runs_with(t) <= run_slots) { target_units = t; break; }
             }
             D.cut_hint_R = R;
             D.cut_hint_slots = run_slots;
             D.cut_hint_target = target_units;
+            D.cut_hint_heavy = heavy_work;
             D.cut_hint_frames = total_frames;
             D.cut_hint_streams = D.n_streams;
         }
@@ -1311,7 +1366,7 @@ struct SynthCall {
               // subtract bases)
               int64_t pk_in_range = 0;
               for (int s = s_lo; s < s_hi; ++s) pk_in_range += D.s_cnt[s];
-              mine.reserve((size_t)(pk_in_range / std::max(1, R - 1)) + (size_t)(s_hi - s_lo) + 1);
+              mine.reserve((size_t)(pk_in_range / min_run_frames) + (size_t)(s_hi - s_lo) + 1);
           }
           for (int s = s_lo; s < s_hi; ++s) {
             const int cnt = (int)D.s_cnt[s], base = (int)D.s_base[s];
@@ -1324,8 +1379,11 @@ struct SynthCall {
                     prev_ok = ok;
                 }
             }
-            for (int f0 = 0; f0 < cnt;) {
-                const int len = batches ? run_length(base, f0, cnt, target_units) : std::min(R, cnt - f0);
+            int64_t before = 0, run_units = 0;
+            for (int f0 = 0; f0 < cnt; before += run_units) {
+                // (runs of equal LENGTH: the skew is a frame more in the first half of the frames, a frame less in the second)
+                const int len = batches ? run_length(base, f0, cnt, target_at(s, before, target_units), run_units)
+                                        : std::min(R + (skew_frames ? ((int64_t)base + f0 < heavy_frames ? 1 : -1) : 0), cnt - f0);
                 RunDesc r{};
                 r.first = base + f0;
                 r.count = len;
