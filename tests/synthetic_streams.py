@@ -140,6 +140,27 @@ def three_channels_chained(seed=7):
     return vw.Stream(3, 22050, 9, 10, books, [f_short, f_long], [r_short, r_long], maps, [(0, 0), (1, 1)]), rng
 
 
+def _many_channels(seed, channels, coupling):
+    rng = np.random.default_rng(seed)
+    books = []
+    f_short = _floor1(rng, books, 128, 4, 2)
+    f_long = _floor1(rng, books, 1024, 7, 3)
+    r_short = _residue(rng, books, 2, channels * 128, 16, 3, 2, [(2, 1, 9), (4, 1, 81)])
+    r_long = _residue(rng, books, 2, channels * 1024, 32, 4, 3, [(2, 1, 49), (4, 2, 12), (8, 1, 300)])
+    maps = [vw.Mapping(channels, coupling, [0] * channels, [0], [0]), vw.Mapping(channels, coupling, [0] * channels, [1], [1])]
+    return vw.Stream(channels, 48000, 8, 11, books, [f_short, f_long], [r_short, r_long], maps, [(0, 0), (1, 1)]), rng
+
+
+def five_channels(seed=8):
+    """5 channels (an odd count: Residue2 vectors of 5 floats per bin), coupling (0,1) and (3,4), 256/2048."""
+    return _many_channels(seed, 5, [(0, 1), (3, 4)])
+
+
+def ten_channels(seed=9):
+    """10 channels -- more than a workgroup holds: the separate coupling pass --, coupling (0,1), (2,3), (8,9), 256/2048."""
+    return _many_channels(seed, 10, [(0, 1), (2, 3), (8, 9)])
+
+
 def four_channels_quad(seed=6):
     """4 channels, coupling (0,1) and (2,3), residue 2, 256/2048."""
     rng = np.random.default_rng(seed)
@@ -155,7 +176,8 @@ def four_channels_quad(seed=6):
 
 ALL = {"mono_floor1_res1": mono_floor1_res1, "stereo_coupled_res2": stereo_coupled_res2,
        "three_channels_two_submaps": three_channels_two_submaps, "stereo_floor0": stereo_floor0,
-       "six_channels_51": six_channels_51, "four_channels_quad": four_channels_quad, "three_channels_chained": three_channels_chained}
+       "six_channels_51": six_channels_51, "four_channels_quad": four_channels_quad, "three_channels_chained": three_channels_chained,
+       "five_channels": five_channels, "ten_channels": ten_channels}
 
 
 def random_stream(seed):

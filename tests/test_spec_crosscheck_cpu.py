@@ -87,7 +87,7 @@ def test_oracle_pcm_matches_the_specification_derived_synthesis(front, oracle, n
 
 # (block sizes of 256 and up: the reference's transform is not the IMDCT for N = 64 / 128 -- quirk q1, Mdct.cs:202-209 -- and the
 # oracle follows the reference there)
-SYNTHETIC = ["stereo_coupled_res2", "three_channels_chained", "four_channels_quad", "six_channels_51"]
+SYNTHETIC = ["stereo_coupled_res2", "three_channels_chained", "four_channels_quad", "five_channels", "six_channels_51", "ten_channels"]
 
 
 @pytest.mark.parametrize("name", SYNTHETIC)

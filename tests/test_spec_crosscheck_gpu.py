@@ -71,7 +71,8 @@ def test_gpu_pcm_matches_the_specification_derived_synthesis(ctx, name):
 
 
 @pytest.mark.parametrize("layout", ["planar", "interleaved"])
-@pytest.mark.parametrize("name", ["stereo_coupled_res2", "three_channels_chained", "four_channels_quad", "six_channels_51"])
+@pytest.mark.parametrize("name", ["stereo_coupled_res2", "three_channels_chained", "four_channels_quad", "five_channels", "six_channels_51",
+                                  "ten_channels"])
 def test_gpu_matches_the_specification_on_synthetic_multichannel_streams(ctx, name, layout):
     """... and the same for what the fixtures do not hold (they are mono and stereo): 3 / 4 / 6 channels from the spec-based
     writer -- group mode with real Residue2 vectors, the libvorbis 5.1 coupling (0,2), (3,4), chained steps, silent channels
