@@ -101,3 +101,13 @@ def test_gpu_matches_the_specification_on_synthetic_multichannel_streams(ctx, na
     d = float(np.abs(got.astype(np.float64) - want).max())
     assert peak > 0.05 and d <= 1e-5 * max(1.0, peak), (name, d, peak)
     dec.close()
+    if layout == "interleaved":
+        # ... and as the 16-bit samples of the store epilogue, clipping on (the reference's own acceptance criterion)
+        dec = Decoder(ctx, C_, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings, clip_samples=True)
+        out16 = np.zeros(C_ * cap, dtype=np.int16)
+        w = dec.synth_raw(pk, res, posts, counts, out16, None, cap, capi.OUT_INTERLEAVED_S16, 0, capi.MEM_HOST)
+        n = int(w[0])
+        assert n == want.shape[1]
+        got16 = out16[: n * C_].reshape(n, C_).T.astype(np.int64)
+        assert np.abs(got16 - to_s16(np.clip(want, -0.99999994, 0.99999994))).max() <= 1, name
+        dec.close()
