@@ -523,6 +523,7 @@ struct Residue {
                 if (cascade[j] & (1 << k)) books[j][k] = book_nums[acc++];
         }
         max_stages = maxstage;
+        class_dim = cb.dimensions;
         decode_map.assign((size_t)partvals * cb.dimensions, 0);
         for (int j = 0; j < partvals; ++j) {
             int val = j, mult = partvals / classifications;
@@ -538,12 +539,25 @@ struct Residue {
 
     // per (classification, stage): the value book, or -1 (flattened `books`: one load in the partition loop)
     std::vector<int16_t> stage_book;
+    // per (class word, stage): which of the word's partitions have a book at that stage (bit k: partition k of the word).
+    // Later stages code few partitions: the loop below visits those instead of asking every partition of every stage.
+    std::vector<uint32_t> word_stage_mask;
+    int class_dim = 0;  // dimensions of the class book (partitions per class word); the masks exist for <= 32
     void finish_setup()
     {
         stage_book.assign((size_t)classifications * 8, -1);
         for (int j = 0; j < classifications; ++j)
             for (size_t k = 0; k < books[j].size() && k < 8; ++k)
                 if (cascade[j] & (1 << k)) stage_book[(size_t)j * 8 + k] = books[j][k];
+        word_stage_mask.clear();
+        if (class_dim >= 1 && class_dim <= 32) {
+            const size_t words = decode_map.size() / (size_t)class_dim;
+            word_stage_mask.assign(words * 8, 0u);
+            for (size_t w = 0; w < words; ++w)
+                for (int k = 0; k < class_dim; ++k)
+                    for (int st = 0; st < 8; ++st)
+                        if (stage_book[(size_t)decode_map[w * class_dim + k] * 8 + st] >= 0) word_stage_mask[w * 8 + st] |= 1u << k;
+        }
     }
 
     // Residue1.WriteVectors (Residue1.cs:12-34) for a partition that lies inside the channel with room for a last
@@ -682,6 +696,27 @@ struct Residue {
                             break;
                         }
                     }
+                }
+                if (count == 1 && partition_idx < partition_count && !do_not_decode[0] && !word_stage_mask.empty() && stage < 8) {
+                    // one channel (every Residue2 packet): only the partitions of this word that have a book at this stage,
+                    // in their order -- the bit stream is read exactly as by the loop below
+                    const int cw = part_word_cache[(size_t)entry_idx];
+                    const int left = partition_count - partition_idx;
+                    uint32_t m = word_stage_mask[(size_t)cw * 8 + stage];
+                    if (left < dim) m &= (1u << left) - 1u;
+                    while (m) {
+                        const int dim_idx = __builtin_ctz(m);
+                        m &= m - 1;
+                        const int idx = decode_map[(size_t)cw * dim + dim_idx];
+                        const Codebook &book = cbs[stage_book[(size_t)idx * 8 + stage]];
+                        if (write_vectors(book, p, buffer, stride, b + (partition_idx + dim_idx) * partition_size)) {
+                            partition_idx = partition_count;
+                            stage = max_stages;
+                            break;
+                        }
+                    }
+                    if (partition_idx < partition_count) partition_idx += left < dim ? left : dim;
+                    continue;
                 }
                 for (int dim_idx = 0; partition_idx < partition_count && dim_idx < dim; ++dim_idx, ++partition_idx) {
                     int offset = b + partition_idx * partition_size;
