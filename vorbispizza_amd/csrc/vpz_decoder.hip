@@ -118,8 +118,10 @@ struct Decoder {
     int64_t cut_hint_slots = 0, cut_hint_target = 0, cut_hint_frames = -1, cut_hint_runs = 0;
     int cut_hint_streams = -1;
     int64_t cut_hint_heavy = -1;             // runs that start below this cost position get the heavier target (cut_runs: THE SKEW)
-    std::vector<int64_t> s_units;            // cost of each stream's packets in this call (cut_runs), then
-    std::vector<int64_t> cut_prefix;         // ... the cost of all streams in front of each one
+    struct CutSeg { int32_t stream, off, cnt; };  // packets [s_base[stream] + off, + cnt): what one thread cuts into runs
+    std::vector<CutSeg> cut_segs;            // the streams of a call, long ones of a batch of few streams in pieces (cut_runs)
+    std::vector<int64_t> s_units;            // cost of each segment's packets in this call (cut_runs), then
+    std::vector<int64_t> cut_prefix;         // ... the cost of all segments in front of each one
     size_t zero_copy_max = 8u << 20;         // arenas up to this size are read in place by the kernels (VPZ_ZERO_COPY_MAX;
                                              // half a million packets, 1.5 MB: 2.42 -> 2.35 ms against the copy)
     std::vector<int32_t> mapping_steps_off;  // per mapping: offset into d_steps (pairs*2), -1 none
@@ -1157,14 +1159,31 @@ struct SynthCall {
         // length -- the kernel still batches what it finds in them -- rather than spend a millisecond of host time)
         HostPool *pool = static_cast<HostPool *>(ctx->host_pool);
         const bool wide = pool && D.n_streams >= 2 * pool->parties();
+        // (... or, with short blocks to batch, is walked in pieces: 65 536 frames of ONE stream cut by cost are a millisecond on one
+        // thread and 40 us on sixteen once the cut hint applies -- and worth 12 % of the kernel's time, configs[2])
+        const bool split = pool && !wide && pool->parties() > 1 && total_frames > 4096;
         const bool batches = compact && (use_dual || (use_group && any_floor)) && any_short &&
                              !synth_needs_general(D.size0, D.size1) && D.size0 == 256 && D.size1 != 256 && !D.generic &&
-                             (wide || total_frames <= 4096) && !(D.ablate & 128);
+                             (wide || total_frames <= 4096 || split) && !(D.ablate & 128);
         cut_by_cost = batches;
-        const int parties = (batches && wide) ? pool->parties() : 1;
-        auto stream_range = [&](int c, int &lo, int &hi) {
-            lo = (int)((int64_t)D.n_streams * c / parties);
-            hi = (int)((int64_t)D.n_streams * (c + 1) / parties);
+        const int parties = (batches && (wide || split)) ? pool->parties() : 1;
+        // what a thread cuts is a SEGMENT: a stream, or -- few streams, many packets -- a piece of one (runs do not cross
+        // segments; the first run of a piece inside a stream recomputes its predecessor like any run that is not a stream's first)
+        std::vector<Decoder::CutSeg> &segs = D.cut_segs;
+        segs.clear();
+        for (int st_i = 0; st_i < D.n_streams; ++st_i) {
+            const int64_t cnt = D.s_cnt[st_i];
+            int pieces = 1;
+            if (batches && split) pieces = (int)std::max<int64_t>(1, std::min<int64_t>(cnt / 1024, (cnt * 4 * parties + total_frames - 1) / total_frames));
+            for (int k = 0; k < pieces; ++k) {
+                const int64_t a = cnt * k / pieces, b = cnt * (k + 1) / pieces;
+                segs.push_back(Decoder::CutSeg{st_i, (int32_t)a, (int32_t)(b - a)});
+            }
+        }
+        const int n_segs = (int)segs.size();
+        auto seg_range = [&](int c, int &lo, int &hi) {
+            lo = (int)((int64_t)n_segs * c / parties);
+            hi = (int)((int64_t)n_segs * (c + 1) / parties);
         };
         auto joins_batch = [&](int64_t p, bool prev_in_run_ok, bool &ok) -> bool {  // does packet p ride with its predecessor?
             ok = false;
@@ -1204,18 +1223,18 @@ struct SynthCall {
                                !(packets[p - 1].flags & VPZ_PKT_BLOCK_FLAG)) ? 4 : 0));
         };
         if (batches && code.size() < (size_t)total_frames) code.resize((size_t)total_frames);
-        if (batches) D.s_units.assign((size_t)D.n_streams, 0);
+        if (batches) D.s_units.assign((size_t)n_segs, 0);
         if (batches && !reuse) {
             std::vector<int64_t> part(parties, 0);
             auto count = [&](int c) {
                 int lo, hi;
-                stream_range(c, lo, hi);
+                seg_range(c, lo, hi);
                 int64_t units = 0;
                 for (int s = lo; s < hi; ++s) {
                     int pos = -1;
                     bool prev_ok = false;
                     int64_t mine = 0;
-                    for (int64_t p = D.s_base[s], e = D.s_base[s] + D.s_cnt[s]; p < e; ++p) {
+                    for (int64_t p = D.s_base[segs[s].stream] + segs[s].off, e = p + segs[s].cnt; p < e; ++p) {
                         bool ok;
                         const bool link = joins_batch(p, prev_ok, ok);
                         code[(size_t)p] = packet_code(p, ok);
@@ -1294,14 +1313,14 @@ struct SynthCall {
         int64_t heavy_work = reuse ? D.cut_hint_heavy : -1;
         if (batches && !reuse && single_round && use_dual && skew_permille > 0 && R >= 16) {  // (short runs: nothing to skew by)
             heavy_work = total_units * (1000 + skew_permille) / 2000;
-            D.cut_prefix.resize((size_t)D.n_streams);
+            D.cut_prefix.resize((size_t)n_segs);
             int64_t acc = 0;
-            for (int st_i = 0; st_i < D.n_streams; ++st_i) {
+            for (int st_i = 0; st_i < n_segs; ++st_i) {
                 D.cut_prefix[(size_t)st_i] = acc;
                 acc += D.s_units[(size_t)st_i];
             }
         }
-        if (heavy_work >= 0 && D.cut_prefix.size() != (size_t)D.n_streams) heavy_work = -1;
+        if (heavy_work >= 0 && D.cut_prefix.size() != (size_t)n_segs) heavy_work = -1;
         // (all-long batches only: with short blocks in runs of equal length a frame more is not 3 % more -- configs[2] lost 2 %)
         // (group mode -- 6 channels, two workgroups of 8 waves per CU -- does not respond to it: configs[3] 0.323 either way)
         const bool skew_frames = !batches && !any_short && single_round && use_dual && skew_permille > 0 && R >= 24 &&
@@ -1321,12 +1340,13 @@ struct SynthCall {
                 std::vector<int64_t> part(parties, 0);
                 auto count = [&](int c) {
                     int lo, hi;
-                    stream_range(c, lo, hi);
+                    seg_range(c, lo, hi);
                     int64_t n = 0;
                     for (int s = lo; s < hi; ++s) {
                         int64_t before = 0, u = 0;
-                        for (int f0 = 0, cnt = (int)D.s_cnt[s]; f0 < cnt; ++n, before += u)
-                            f0 += run_length(D.s_base[s], f0, cnt, target_at(s, before, target), u);
+                        const int64_t seg_base = D.s_base[segs[s].stream] + segs[s].off;
+                        for (int f0 = 0, cnt = segs[s].cnt; f0 < cnt; ++n, before += u)
+                            f0 += run_length(seg_base, f0, cnt, target_at(s, before, target), u);
                     }
                     part[c] = n;
                 };
@@ -1359,18 +1379,20 @@ struct SynthCall {
         std::vector<std::vector<RunDesc>> cut(parties);
         auto cut_streams = [&](int c) {
           int s_lo, s_hi;
-          stream_range(c, s_lo, s_hi);
+          seg_range(c, s_lo, s_hi);
           std::vector<RunDesc> &mine = cut[c];
           if (parties > 1) {
               // (a stream without packets in this call keeps s_base = s_cnt = 0: count the range's packets, never
               // subtract bases)
               int64_t pk_in_range = 0;
-              for (int s = s_lo; s < s_hi; ++s) pk_in_range += D.s_cnt[s];
+              for (int g = s_lo; g < s_hi; ++g) pk_in_range += segs[g].cnt;
               mine.reserve((size_t)(pk_in_range / min_run_frames) + (size_t)(s_hi - s_lo) + 1);
           }
-          for (int s = s_lo; s < s_hi; ++s) {
-            const int cnt = (int)D.s_cnt[s], base = (int)D.s_base[s];
-            if (reuse) {  // (the codes of this stream's packets, skipped with the counting pass)
+          for (int g = s_lo; g < s_hi; ++g) {
+            const int s = segs[g].stream, seg_off = segs[g].off;
+            const int cnt = segs[g].cnt, base = (int)D.s_base[s] + seg_off;  // (f0 below counts from the segment's start)
+            const int stream_cnt = (int)D.s_cnt[s];
+            if (reuse) {  // (the codes of this segment's packets, skipped with the counting pass)
                 bool prev_ok = false;
                 for (int64_t p = base, e = (int64_t)base + cnt; p < e; ++p) {
                     bool ok;
@@ -1382,19 +1404,19 @@ struct SynthCall {
             int64_t before = 0, run_units = 0;
             for (int f0 = 0; f0 < cnt; before += run_units) {
                 // (runs of equal LENGTH: the skew is a frame more in the first half of the frames, a frame less in the second)
-                const int len = batches ? run_length(base, f0, cnt, target_at(s, before, target_units), run_units)
+                const int len = batches ? run_length(base, f0, cnt, target_at(g, before, target_units), run_units)
                                         : std::min(R + (skew_frames ? ((int64_t)base + f0 < heavy_frames ? 1 : -1) : 0), cnt - f0);
                 RunDesc r{};
                 r.first = base + f0;
                 r.count = len;
                 r.stream = s;
-                if (f0 == 0) {
+                if (seg_off + f0 == 0) {
                     r.pre_kind = started_with_prev[s] ? kPreState : kPreNone;
                     r.prev_long = started_prev_long[s];
                 } else {
                     r.pre_kind = kPreRecompute;
                 }
-                const bool last = f0 + len >= cnt;
+                const bool last = seg_off + f0 + len >= stream_cnt;
                 if (last) r.flags |= kRunSaveState;
                 r.clip_epoch = D.states[s].clip_epoch;
                 r.state_slot = D.states[s].state_slot;
