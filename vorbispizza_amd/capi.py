@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvorbispizza_synth.so")
+# (VPZ_LIB_DIR: another build of the two libraries, for A/B runs of two builds on one GPU box -- tools/ab_builds.sh)
+LIB_PATH = os.path.join(os.environ.get("VPZ_LIB_DIR") or os.path.join(_HERE, "lib"), "libvorbispizza_synth.so")
 
 OK = 0
 E_INVALID_ARG, E_UNSUPPORTED, E_HIP, E_NOMEM, E_WINDOW_MISMATCH, E_NO_DEVICE, E_CAPACITY = -1, -2, -3, -4, -5, -6, -7

@@ -407,23 +407,62 @@ __device__ __forceinline__ float tail_at(const float *tail, int q, int pn4)
 // (`lpb`: lanes per block = block size / 32: 64 for 2048, 32 / 16 for 1024 / 512, 8 for 256; a block smaller than
 // 2048 is transformed by every lane group of the wave at once, the first group's copy is the one used)
 // (packed two points to a register: byte 0 / 1 = point 2j, byte 2 / 3 = point 2j + 1)
+// All eight reads are issued before the first one is used: left to itself the compiler read them in pairs with an
+// `s_waitcnt lgkmcnt(0)` behind each pair -- four LDS round trips in a row per channel (profiles/r4_isa_*.txt).
 __device__ __forceinline__ void load_floor_indices(uint32_t (&fy)[4], const uint8_t *row, int lpb, int lane)
 {
     const uint16_t *s = reinterpret_cast<const uint16_t *>(row);
     const int k0 = lane & (lpb - 1);
     const int st = lpb;
+    uint32_t t[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fy[j] = (uint32_t)s[k0 + st * (2 * j)] | ((uint32_t)s[k0 + st * (2 * j + 1)] << 16);
+    for (int m = 0; m < 8; ++m) t[m] = s[k0 + st * m];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fy[j] = t[2 * j] | (t[2 * j + 1] << 16);
 }
-// Floor1.Apply's multiply (Floor1.cs:383,395) on the lane's 8 points
+// Floor1.Apply's multiply (Floor1.cs:383,395) on the lane's 8 points: the sixteen table values first (independent LDS
+// reads, all in flight together), then the sixteen products
 __device__ __forceinline__ void apply_floor(float2 (&x)[8], const uint32_t (&fy)[4], const float *s_db)
 {
+    float t[16];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const uint32_t v = fy[m >> 1] >> (16 * (m & 1));
-        x[m].x *= s_db[v & 0xFFu];
-        x[m].y *= s_db[(v >> 8) & 0xFFu];
+        t[2 * m] = s_db[v & 0xFFu];
+        t[2 * m + 1] = s_db[(v >> 8) & 0xFFu];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        x[m].x *= t[2 * m];
+        x[m].y *= t[2 * m + 1];
+    }
+}
+
+// Highest point k = k0 + lpb * m (bins 2k, 2k + 1) of the wave's spectrum that holds a non-zero bin, -1 if there is none:
+// bins [2 * (top + 1), n) are zero (the residue ends below N/2 in real streams) and need no curve.  lpb: lanes that hold
+// distinct points (64 for a 2048 block, 8 for a 256 one: every lane group holds the same block).  Per lane the highest of its
+// eight points with a bit set outside the sign (three vector instructions per point; -0.0 counts as zero, as `!= 0.0f` has
+// it; a NaN counts as a value), then one maximum over the wave in the cross-lane data path -- where sixteen ballots, each
+// examined by the scalar unit, took 250 instructions per stereo pass (profiles/r4_isa_*.txt).
+__device__ __forceinline__ int spectrum_top(const float2 (&x)[8], int lpb, int lane)
+{
+    int t = -1;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const float u = __uint_as_float(__float_as_uint(x[m].x) | __float_as_uint(x[m].y));
+        t = __builtin_amdgcn_classf(u, 0x39F) ? m : t;  // every class but +-0
+    }
+    int key = t < 0 ? -1 : t * lpb + (lane & (lpb - 1));
+    const int lowest = (int)0x80000000;
+    key = max(key, __builtin_amdgcn_update_dpp(lowest, key, 0x111, 0xF, 0xF, false));  // row_shr:1
+    key = max(key, __builtin_amdgcn_update_dpp(lowest, key, 0x112, 0xF, 0xF, false));  // row_shr:2
+    key = max(key, __builtin_amdgcn_update_dpp(lowest, key, 0x114, 0xF, 0xF, false));  // row_shr:4
+    key = max(key, __builtin_amdgcn_update_dpp(lowest, key, 0x118, 0xF, 0xF, false));  // row_shr:8
+    key = max(key, __builtin_amdgcn_update_dpp(lowest, key, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3
+    key = max(key, __builtin_amdgcn_update_dpp(lowest, key, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(key, 63);
 }
 
 // Builds h of one channel-block into the wave-private LDS buffer `hbuf`:

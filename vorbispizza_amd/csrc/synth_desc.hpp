@@ -115,6 +115,18 @@ struct FloorDev {
     uint32_t sorted[64];
 };
 
+// The tuning switches of the fused kernels (VPZ_SYNTH_ABLATE, VPZ_GROUP_DMA) exist in tuning builds only
+// (VPZ_EXTRA_HIPCC_FLAGS=-DVPZ_TUNING): in the product every test of them folds away at compile time.  They used to be
+// read from the kernel arguments inside the frame loop -- scalar loads whose `s_waitcnt lgkmcnt(0)` drains the wave's LDS
+// queue as well (profiles/r4_isa_*.txt).
+#ifdef VPZ_TUNING
+#define VPZ_ABLATE(a) ((a).ablate)
+#define VPZ_GROUP_DMA(a) ((a).group_dma != 0)
+#else
+#define VPZ_ABLATE(a) 0
+#define VPZ_GROUP_DMA(a) false
+#endif
+
 struct SynthArgs {
     const FrameDesc *frames;    // explicit descriptors (nullptr when every run is compact)
     const uint8_t *cflags;      // compact runs: [frame] flag byte, [frame] mapping index,
@@ -151,7 +163,9 @@ struct SynthArgs {
     int32_t s16;                // PCM as int16 (`(int)(x * 32768f)` clamped) instead of float32
     int32_t clip;
     int32_t *clipped;           // [stream] sticky HasClipped
-    int32_t ablate;             // tuning only (VPZ_SYNTH_ABLATE; wrong results, right timing): 1 no window / overlap-add / stores, 2 no
+    int32_t no_batch;           // 1: one short block per pass (the host sets it when the runs were not cut by cost -- in runs of
+                                // equal LENGTH the ones rich in short blocks would be done early -- or for VPZ_NO_BATCH=1)
+    int32_t ablate;             // TUNING BUILDS ONLY (-DVPZ_TUNING; VPZ_SYNTH_ABLATE; wrong results, right timing): 1 no window / overlap-add / stores, 2 no
                                 // transform, 4 no input loads, 8 no curve, 16 no coupling, 32 no staging (group mode) / no stores
                                 // but the arithmetic (stereo path), 64 render every bin (group mode) / prologue only (stereo path),
                                 // 128 no batches of short blocks (also set by the host when runs were not cut by cost); stereo

@@ -130,20 +130,6 @@ __device__ __forceinline__ bool render_floor_indices_fast_x2(uint8_t *out0, uint
     return true;
 }
 
-// highest bin pair below which a spectrum has non-zero values: bins [2 * (top + 1), n) are zero (the residue ends below
-// N/2 in real streams) and need no curve.  lpb: lanes that hold distinct points (64 for a 2048 block, 8 for a 256 one).
-__device__ __forceinline__ int spectrum_top(const float2 (&x)[8], int lpb)
-{
-    const unsigned long long group0 = lpb >= 64 ? ~0ull : ((1ull << lpb) - 1ull);
-    int top = -1;
-#pragma unroll
-    for (int m = 7; m >= 0; --m) {
-        const unsigned long long b = __ballot(x[m].x != 0.0f || x[m].y != 0.0f) & group0;
-        if (top < 0 && b != 0) top = lpb * m + 63 - __clzll(b);
-    }
-    return top;
-}
-
 // kIlvIn : every packet of the batch is the Residue2-interleaved vector [bin][2] (else: every packet planar [2][bin])
 // kOut   : 0 planar output, 1 interleaved
 // kExp: tuning experiments, A/B on one box through VPZ_DUAL_EXP (none at the moment; DESIGN.md 4.7 lists what was tried)
@@ -250,7 +236,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             const bool after_long = a.size1 == 2048 && prev_end == 1472 && prev_stop == 1600;
             const bool base_ok = lane < n && lane >= -fi0 && a.size0 == 256 && a.size1 != 256 && !(cf & 1) && !(cf & kCfSkip) &&
                                  has_prev && out_count == 128 && left_start == 0 && (after_short || after_long) &&
-                                 !(a.ablate & 128);
+                                 !a.no_batch;
             const bool base_prev = __shfl_up((int)base_ok, 1) != 0 && lane > 0 && after_short;
             const bool brk = !(base_ok && base_prev && mp == pmp && (cf & kCfNoFloor) == pnf);
             const unsigned long long mask_brk = __ballot(brk);
@@ -307,7 +293,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         }
     }
     int iters = run.count - fi0 - (int)__popcll(__ballot(batch_member));
-    if (a.ablate & 64) iters = 0;  // (tuning only: the kernel's prologue and nothing else)
+    if (VPZ_ABLATE(a) & 64) iters = 0;  // (tuning only: the kernel's prologue and nothing else)
     __builtin_amdgcn_wave_barrier();
     auto frame_from = [&](const uint4 lo, const uint4 hi) -> FrameDesc {  // a descriptor's two LDS words into SGPRs
         FrameDesc fd;
@@ -426,7 +412,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         {
             const bool has_next = fin < run.count;
             fd_next = frame_at(has_next ? fin : fi);
-            valid_next = has_next && !(fd_next.flags & kFrameDrain) && !(a.ablate & 4);  // (4: tuning only, no input loads)
+            valid_next = has_next && !(fd_next.flags & kFrameDrain) && !(VPZ_ABLATE(a) & 4);  // (4: tuning only, no input loads)
             prefetch(fd_next, valid_next, na, nb, cpna, cpnb);
             stwnext = steps_word(fd_next, valid_next);
         }
@@ -461,7 +447,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 }
             }
             // ---- inverse coupling, steps in reverse order (Mapping.cs:166-172); a stereo step is (0, 1) or (1, 0)
-            if (!(fd.flags & kFrameNoFloor) && !(a.ablate & 16)) {
+            if (!(fd.flags & kFrameNoFloor) && !(VPZ_ABLATE(a) & 16)) {
                 const int n_steps = (int)((fd.flags >> kFrameStepsShift) & 0xFF);
                 const uint8_t *st = s_steps + 2 * (fd.flags >> kFrameStepsOffShift);
                 const unsigned long long stw = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.y) << 32) |
@@ -491,22 +477,22 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                     silentR = cntR == 0;
                     const int lpb = is_long ? 64 : 8;
                     const int n = nblk >> 1;
-                    const int nrL = (silentL || (a.ablate & 512)) ? 0 : 2 * (spectrum_top(xL, lpb) + 1);
-                    const int nrR = (silentR || (a.ablate & 512)) ? 0 : 2 * (spectrum_top(xR, lpb) + 1);
+                    const int nrL = (silentL || (VPZ_ABLATE(a) & 512)) ? 0 : 2 * (spectrum_top(xL, lpb, ln) + 1);
+                    const int nrR = (silentR || (VPZ_ABLATE(a) & 512)) ? 0 : 2 * (spectrum_top(xR, lpb, ln) + 1);
                     const int pa = ln < cntL ? cpa : 0, pb = ln < cntR ? cpb : 0;
-                    if ((nrL > 0 || nrR > 0) && !(a.ablate & 8)) {
-                        if (!render_floor_indices_fast_x2(rowL, rowR, auxL, auxR, n, nrL, nrR, pa, pb, cntL, cntR, ln)) {
+                    if ((nrL > 0 || nrR > 0) && !(VPZ_ABLATE(a) & 8)) {
+                        if (!render_floor_indices_fast_x2(rowL, rowR, auxL, auxR, n, nrL, nrR, pa, pb, cntL, cntR, ln)) {  // [census: cold]
                             if (nrL > 0) render_floor_indices<32>(rowL, auxL, n, nrL, pa, cntL, ln);
                             if (nrR > 0) render_floor_indices<32>(rowR, auxR, n, nrR, pb, cntR, ln);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
-                    if (!(a.ablate & 256)) {
+                    if (!(VPZ_ABLATE(a) & 256)) {
                     load_floor_indices(fyL, rowL, lpb, ln);
                     load_floor_indices(fyR, rowR, lpb, ln);
                     }
                     __builtin_amdgcn_wave_barrier();
-                } else {
+                } else {  // [census: cold]
                     // the curves of the pass's blocks, 128 bytes each, block by block (both channels side by side); their
                     // posts are asked for here together
                     int cps[8][2];
@@ -543,13 +529,13 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                     __builtin_amdgcn_wave_barrier();
                 }
                 VPZ_STAMP(2);  // curves
-                if (!(a.ablate & 256)) {
+                if (!(VPZ_ABLATE(a) & 256)) {
                 apply_floor(xL, fyL, s_db);
                 apply_floor(xR, fyR, s_db);
                 }
             }
             // ---- the two transforms, side by side
-            if (a.ablate & 2) {
+            if (VPZ_ABLATE(a) & 2) {  // [census: cold]
                 // (tuning only: the spectra as they are)
                 float2 *h2L = reinterpret_cast<float2 *>(hL), *h2R = reinterpret_cast<float2 *>(hR);
 #pragma unroll
@@ -561,7 +547,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             }
             // the reference does not transform a silent channel, it clears the block (Mapping.cs:190-194): all +0.0,
             // where the transform of zeros (times a curve left over in the row) leaves zeros of both signs or worse
-            if (__any(silentL || silentR)) {
+            if (__any(silentL || silentR)) {  // [census: cold]
                 __builtin_amdgcn_wave_barrier();
                 float2 *h2L = reinterpret_cast<float2 *>(hL), *h2R = reinterpret_cast<float2 *>(hR);
                 if (is_long) {
@@ -597,7 +583,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         const bool aligned = kInterleavedOut ? (reinterpret_cast<uintptr_t>(row_i) & 15) == 0
                                              : ((reinterpret_cast<uintptr_t>(row_l) | reinterpret_cast<uintptr_t>(row_r)) & (kS16 ? 7 : 15)) == 0;
         auto emit4 = [&](int g, float l0, float l1, float l2, float l3, float r0, float r1, float r2, float r3) {
-            if (a.ablate & 32) {  // (tuning only: the arithmetic without the stores)
+            if (VPZ_ABLATE(a) & 32) {  // (tuning only: the arithmetic without the stores)
                 clip_peak = fmaxf(clip_peak, fmaxf(fmaxf(l0 + r0, l1 + r1), fmaxf(l2 + r2, l3 + r3)));
                 return;
             }
@@ -638,9 +624,9 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         const float4 *tL4 = reinterpret_cast<const float4 *>(tailL), *tR4 = reinterpret_cast<const float4 *>(tailR);
         int lf = lane;
         asm volatile("" : "+v"(lf));  // (no address of the epilogue may be computed ahead of the frame loop)
-        if (a.ablate & 1) {
+        if (VPZ_ABLATE(a) & 1) {
             // (tuning only: no window / overlap-add / stores)
-        } else if (batch && fi >= 0) {
+        } else if (batch && fi >= 0) {  // [census: cold]
             // ---- a batch of short blocks: 128 * bsz contiguous samples.  Sample i of block f is y_f[i] over the previous
             // block's y[128 + i] (both windows short): y_f[i] = -h_f[63 - i] (i < 64), h_f[i - 64] otherwise; the partner
             // is hp[i] (i < 64), hp[127 - i] otherwise, hp = the upper half of the previous block's h -- the block before
@@ -707,7 +693,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                               ola(hr.z, wl.z, pr.y, wr.y), ola(hr.w, wl.w, pr.x, wr.x));
                     }
                 }
-            } else if (vec) {
+            } else if (vec) {  // [census: cold]
                 // any other aligned geometry, branch-free: lanes past the end clamp their reads and skip only the store;
                 // samples past the overlap take weights (1, 0)
                 const float4 *s4 = reinterpret_cast<const float4 *>(slope);
@@ -736,7 +722,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                     if (lv) emit4(g, l0, l1, l2, l3, r0, r1, r2, r3);
                 }
             } else {
-                for (int i = lf; i < fd.out_count; i += 64) {
+                for (int i = lf; i < fd.out_count; i += 64) {  // [census: cold]
                     float l, r;
                     if (drain) {
                         l = tail_at(tailL, fd.prev_end + i, prev_n4);
@@ -756,7 +742,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         }
         VPZ_STAMP(5);  // window + overlap-add + stores
         // ---- keep what a later block can overlap with: y[N/2 .. N) lives in the upper half of h
-        if (!drain && !(a.ablate & 1024)) {
+        if (!drain && !(VPZ_ABLATE(a) & 1024)) {
             __builtin_amdgcn_wave_barrier();
             if (is_long) {
                 const float4 *sl = reinterpret_cast<const float4 *>(hL + 512), *sr = reinterpret_cast<const float4 *>(hR + 512);

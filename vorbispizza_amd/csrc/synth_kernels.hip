@@ -703,7 +703,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             const int hh = (size_of(fd.flags) >> 1) * (kBatchShort ? (int)((fd.flags >> kFrameBatchShift) & 7u) + 1 : 1);
             const bool shared_input = fd.flags & kFrameInterleaved;
             const float *src = a.spec + fd.spec_off + (shared_input ? 0 : (int64_t)ch * hh);
-            const bool regs = valid && !(shared_input && (a.group_dma || (a.ablate & (2048 | 4096))));  // (the packet comes by LDS-DMA)
+            const bool regs = valid && !(shared_input && (VPZ_GROUP_DMA(a) || (VPZ_ABLATE(a) & (2048 | 4096))));  // (the packet comes by LDS-DMA)
             load_group_share(x, regs ? src : a.inv_db, shared_input ? 64 * ch : 0, shared_input ? 64 * C : 64,
                              regs ? ((shared_input ? C * hh : hh) >> 2) : 1, lane);
         } else {
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             const bool after_long = a.size1 == 2048 && prev_end == 1472 && prev_stop == 1600;
             const bool base_ok = lane < n && lane >= -fi0 && a.size0 == 256 && !(cf & 1) && (cf & kCfInterleaved) &&
                                  !(cf & (kCfNoFloor | kCfSkip)) && has_prev && out_count == 128 && left_start == 0 &&
-                                 (after_short || after_long) && !(a.ablate & 128);
+                                 (after_short || after_long) && !a.no_batch;
             const bool base_prev = __shfl_up((int)base_ok, 1) != 0 && lane > 0 && after_short;
             const bool brk = !(base_ok && base_prev && mp == pmp);  // this frame does not continue its predecessor's streak
             const unsigned long long mask_brk = __ballot(brk);
@@ -873,16 +873,10 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     // residue ends below N/2; low-bitrate streams use a small part of it), and a zero times any table entry is zero.
     auto render_curve = [&](const FrameDesc &f, int cp, int m, const float2 (&x)[8], uint32_t (&fy)[4]) {
         const int lpb = lpb_of(f.flags);
-        const unsigned long long group0 = lpb >= 64 ? ~0ull : ((1ull << lpb) - 1ull);  // lanes that hold distinct points
-        int top = -1;  // highest point k = k0 + lpb * m with a non-zero bin (wave-uniform)
-#pragma unroll
-        for (int m = 7; m >= 0; --m) {
-            const unsigned long long b = __ballot(x[m].x != 0.0f || x[m].y != 0.0f) & group0;
-            if (top < 0 && b != 0) top = lpb * m + 63 - __clzll(b);
-        }
+        const int top = spectrum_top(x, lpb, lane);  // highest point k = k0 + lpb * m with a non-zero bin (wave-uniform)
         const int n = size_of(f.flags) >> 1;
         int n_render = 2 * (top + 1);
-        if (a.ablate & 64) n_render = n;
+        if (VPZ_ABLATE(a) & 64) n_render = n;
         cp = lane < m ? cp : 0;  // lanes below the record's post count hold a post
         if (n_render > 0 &&
             !render_floor_indices_fast(reinterpret_cast<uint8_t *>(hcur), reinterpret_cast<int *>(hcur) + 256, n, n_render, cp, m, lane))
@@ -911,7 +905,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         {
             const bool has_next = fin < run.count;  // (a wave that idles reads a stale descriptor; nothing of it is used)
             fd_next = frame_at(has_next ? fin : fi);
-            prefetch(fd_next, fin - fi0, has_next && !(fd_next.flags & kFrameDrain) && !(a.ablate & 4), xnext, cpnext, cntnext,
+            prefetch(fd_next, fin - fi0, has_next && !(fd_next.flags & kFrameDrain) && !(VPZ_ABLATE(a) & 4), xnext, cpnext, cntnext,
                      exnext);
             if (kGroup) stwnext = steps_word(fd_next, has_next && !(fd_next.flags & kFrameDrain));
         }
@@ -930,10 +924,10 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             const bool stage = build;  // every packet goes through the rows (see load_group_share)
             __syncthreads();  // every wave of the group is done with its row (previous block emitted)
             VPZ_STAMP(1);  // first barrier
-            if (stage && !(a.ablate & 32)) {
-                if ((fd.flags & kFrameInterleaved) && (a.ablate & 4096)) {
+            if (stage && !(VPZ_ABLATE(a) & 32)) {
+                if ((fd.flags & kFrameInterleaved) && (VPZ_ABLATE(a) & 4096)) {
                     stage_by_lds_dma_gather(a.spec + fd.spec_off, hcur, C, nstage >> 1, ch, lane);
-                } else if ((fd.flags & kFrameInterleaved) && (a.group_dma || (a.ablate & 2048))) {
+                } else if ((fd.flags & kFrameInterleaved) && (VPZ_GROUP_DMA(a) || (VPZ_ABLATE(a) & 2048))) {
                     stage_by_lds_dma(a.spec + fd.spec_off, s_work[gw0], C, nstage >> 1, ch, lane);
                 } else if (fd.flags & kFrameInterleaved) {
                     stage_interleaved(xcur, s_work[gw0], C, div_magic, nstage >> 1, ch, lane);
@@ -955,8 +949,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             auto step_byte = [&](int k) -> uint32_t { return n_steps <= 4 ? (uint32_t)(stw >> (8 * k)) & 0xFFu : (uint32_t)st[k]; };
             // (group_dma) the packet lies in the rows as it came: every wave takes its channel out of it, its own coupling step
             // applied on the way; the barrier(s) below then stand between the last pick-up and the first transform
-            const bool in_place = stage && a.group_dma && (fd.flags & kFrameInterleaved);
-            if (in_place && (exec || batch)) {
+            const bool in_place = stage && VPZ_GROUP_DMA(a) && (fd.flags & kFrameInterleaved);
+            if (in_place && (exec || batch)) {  // [census: cold]
                 int partner = -1;
                 bool is_mag = false;
                 for (int k = 0; k < n_steps; ++k) {
@@ -964,15 +958,15 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     if (sm == ch) { partner = sa; is_mag = true; }
                     else if (sa == ch) { partner = sm; }
                 }
-                if (a.ablate & 16) partner = -1;
+                if (VPZ_ABLATE(a) & 16) partner = -1;
                 int lb = lane;
                 asm volatile("" : "+v"(lb));  // (frame-invariant LDS addresses: keep them inside the iteration)
                 const int lpb = batch ? 8 : lpb_of(fd.flags);
                 pickup_interleaved(xcur, s_work[gw0], C, ch, partner, is_mag, batch ? (lb >> 3) * 64 + (lb & 7) : (lb & (lpb - 1)), lpb);
             }
-            const int n_levels = a.group_dma ? max(a.max_steps, 1) : a.max_steps;
+            const int n_levels = VPZ_GROUP_DMA(a) ? max(a.max_steps, 1) : a.max_steps;
             for (int lvl = 0; lvl < n_levels; ++lvl) {
-                if (stage && !in_place && !(a.ablate & 16)) {
+                if (stage && !in_place && !(VPZ_ABLATE(a) & 16)) {
                     bool first = true;
                     while (sidx >= 0 && (first || !(step_byte(2 * sidx) & 0x80))) {
                         float4 *pm = reinterpret_cast<float4 *>(s_work[gw0 + (step_byte(2 * sidx) & 0x7F)]);
@@ -995,7 +989,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             VPZ_STAMP(3);  // coupling levels + barriers
             if (in_place) {
                 // (already in xcur)
-            } else if (batch) {  // lane group g takes block g of the batch: points l + 8 m of its 64
+            } else if (batch) {  // lane group g takes block g of the batch: points l + 8 m of its 64  [census: cold]
                 const float2 *row2 = reinterpret_cast<const float2 *>(hcur);
                 int lb = lane;
                 asm volatile("" : "+v"(lb));
@@ -1007,7 +1001,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         }
         // ---- the curve, right before the row is needed for the transform
         bool batch_silent = false;  // this lane's block of a batch is a silent channel's
-        if (kBatchShort && batch) {
+        if (kBatchShort && batch) {  // [census: cold]
             // the curves of the batch's blocks, one after the other, 128 bytes each (the row is free: every lane holds its
             // spectrum); their posts are asked for here, together -- the one exposed memory round trip of the pass (asked for at
             // the top of the pass they would be eight more live registers across the staging: the kernel spills)
@@ -1031,7 +1025,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 #pragma unroll
                             for (int m = 0; m < 8; ++m) xcur[m] = make_float2(0.0f, 0.0f);
                         }
-                    } else if (!(a.ablate & 8)) {
+                    } else if (!(VPZ_ABLATE(a) & 8)) {
                         const int cp = lb < cns[f] ? cps[f] : 0;
                         uint8_t *dstc = reinterpret_cast<uint8_t *>(hcur) + 128 * f;
                         if (!render_floor_indices_fast(dstc, reinterpret_cast<int *>(hcur) + 256, 128, 128, cp, cns[f], lane))
@@ -1043,7 +1037,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             __builtin_amdgcn_wave_barrier();
             load_floor_indices(fycur, reinterpret_cast<const uint8_t *>(hcur) + 128 * (lb >> 3), 8, lane);
             __builtin_amdgcn_wave_barrier();
-        } else if (kHasFloor && exec && !(fd.flags & kFrameNoFloor) && !(a.ablate & 8)) {
+        } else if (kHasFloor && exec && !(fd.flags & kFrameNoFloor) && !(VPZ_ABLATE(a) & 8)) {
             render_curve(fd, cpcur, cntcur, xcur, fycur);
         }
         VPZ_STAMP(4);  // channel pick-up + curve
@@ -1053,14 +1047,14 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             // an opaque lane id keeps them inside the iteration that uses them.
             int ln = lane;
             asm volatile("" : "+v"(ln));
-            if (!exec) {
+            if (!exec) {  // [census: cold]
                 // Mapping.cs:190-194: the channel is silent, its whole block is zero
                 for (int i = lane; i < 2 * n4; i += 64) hcur[i] = 0.0f;
-            } else if (a.ablate & 2) {
+            } else if (VPZ_ABLATE(a) & 2) {  // [census: cold]
                 float2 *h2 = reinterpret_cast<float2 *>(hcur);
 #pragma unroll
                 for (int m = 0; m < 8; ++m) h2[lane + 64 * m] = xcur[m];
-            } else if (kGeneral) {
+            } else if (kGeneral) {  // [census: cold]
                 // tables of this frame's size: the long set keeps the global layout, the short set is compacted
                 const bool use_long = (fd.flags & kFrameLong) || a.size0 == a.size1;
                 const float2 *tw = use_long ? s_twL : s_twS;
@@ -1099,7 +1093,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         constexpr bool kCoop = kGroup && kOut != 0;  // interleaved output written by the group's waves together
         float o[4][4];      // the 16 samples of a long-after-long frame, or of a batch of short ones
         bool coop = false;  // ... wait in `o` for the cooperative store (uniform over the group's waves)
-        if (kBatchShort && batch && !(a.ablate & 1)) {
+        if (kBatchShort && batch && !(VPZ_ABLATE(a) & 1)) {  // [census: cold]
             // ---- a batch of short blocks: 128 * bsz contiguous samples.  Sample i of block f is y_f[i] over the previous
             // block's y[128 + i] (StreamDecoder.cs:782-789 with both windows short): y_f[i] = -h_f[63 - i] (i < 64),
             // h_f[i - 64] otherwise; the partner is hp[i] (i < 64), hp[127 - i] otherwise, hp = the upper half of the
@@ -1166,7 +1160,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     }
                 }
             }
-        } else if (live && fi >= 0 && fd.out_count > 0 && !(a.ablate & 1)) {
+        } else if (live && fi >= 0 && fd.out_count > 0 && !(VPZ_ABLATE(a) & 1)) {
             // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 573-591)
             // equal block sizes share one slope table (s_slope0 only holds a 128-entry short slope)
             const float *slope = ((fd.flags & kFrameSlope1) || a.size0 == a.size1) ? s_slope1 : s_slope0;
@@ -1245,7 +1239,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                                    ola(hr.z, wl.z, pr.y, wr.y), ola(hr.w, wl.w, pr.x, wr.x));
                     }
                 }
-            } else if (vec_pair) {
+            } else if (vec_pair) {  // [census: cold]
                 // any other aligned geometry: the branch-free form below, for both channels, over this wave's
                 // half of the float4 groups
                 const float4 *s4 = reinterpret_cast<const float4 *>(slope);
@@ -1314,7 +1308,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (!kInterleaved) store4(lf + 64 * r, o[r][0], o[r][1], o[r][2], o[r][3]);
-            } else if (!kPair && vec) {
+            } else if (!kPair && vec) {  // [census: cold]
                 // branch-free: lanes past the end clamp their reads and skip only the store; samples
                 // past the overlap take weights (1, 0)
                 const float4 *h4 = reinterpret_cast<const float4 *>(hcur);
@@ -1363,7 +1357,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             } else {
                 int l0 = lane;
                 asm volatile("" : "+v"(l0));  // (rare path: its addresses must not be computed ahead of the frame loop)
-                for (int i = l0; i < fd.out_count; i += 64) {
+                for (int i = l0; i < fd.out_count; i += 64) {  // [census: cold]
                     float v;
                     if (drain) {
                         v = tail_at(tail, fd.prev_end + i, prev_n4);
@@ -1385,7 +1379,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         if (kPair) __syncthreads();  // the partner is done reading this wave's block and tail
         if (live && !drain) {
             // keep what a later block can overlap with: y[N/2 .. N) lives in the upper half of h
-            if (kGeneral && !is_long) {
+            if (kGeneral && !is_long) {  // [census: cold]
                 for (int i = lane; i < n4; i += 64) tail[i] = hcur[n4 + i];
             } else if (is_long) {
                 const float4 *src = reinterpret_cast<const float4 *>(hcur + 512);

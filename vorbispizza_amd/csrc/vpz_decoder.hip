@@ -1790,7 +1790,8 @@ struct SynthCall {
         a.s16 = out_s16 ? 1 : 0;
         a.clip = D.clip;
         a.clipped = D.d_clipped;
-        a.ablate = D.ablate | (cut_by_cost ? 0 : 128);
+        a.no_batch = ((D.ablate & 128) || !cut_by_cost) ? 1 : 0;
+        a.ablate = D.ablate;
         a.stamps = nullptr;
 #if defined(VPZ_STAMPS) || defined(VPZ_WAVE_TIMES)
         static unsigned long long *d_stamps = nullptr;

@@ -9,7 +9,8 @@ import numpy as np
 from . import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvorbispizza_host.so")
+# (VPZ_LIB_DIR: another build of the two libraries, for A/B runs of two builds on one GPU box -- tools/ab_builds.sh)
+LIB_PATH = os.path.join(os.environ.get("VPZ_LIB_DIR") or os.path.join(_HERE, "lib"), "libvorbispizza_host.so")
 _lib = None
 
 
