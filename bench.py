@@ -146,9 +146,13 @@ def build_synth_ola(torch, device, frames=FRAMES, all_long=False):
     return pk, residue, samples, int(offs[-1])
 
 
-def build_floor6(torch, device, frames=16384):
+FLOOR6_RESIDUE_END = 410  # configs[3]: the residue's `_end` in bins per channel (a Residue2 over 6 channels with end = 2460)
+
+
+def build_floor6(torch, device, frames=16384, declare_support=True):
     """BASELINE configs[3]: 6 channels, Residue2-interleaved residue zero above a cutoff, coupling
-    (0,1),(2,3), 29-post Floor1 rendered on the GPU, N = 2048."""
+    (0,1),(2,3), 29-post Floor1 rendered on the GPU, N = 2048.  declare_support: the mapping carries the residue's support
+    (ABI v4, `residue_end`: what the setup header of such a stream says), so the zeros above it are not loaded."""
     import helpers
     from vorbispizza_amd import capi, make_packets
     C6 = 6
@@ -159,7 +163,7 @@ def build_floor6(torch, device, frames=16384):
     pk["residue_offset"] = np.arange(frames, dtype=np.int64) * (1024 * C6)
     g = torch.Generator(device=device).manual_seed(6)
     res = torch.round(torch.randn((frames, 1024, C6), generator=g, device=device) * 4.0)
-    res[:, 410:, :] = 0  # ~60 % zeros above the cutoff bin (end < N/2)
+    res[:, FLOOR6_RESIDUE_END:, :] = 0  # ~60 % zeros above the cutoff bin (end < N/2)
     posts = np.zeros((frames * C6, 64), dtype=np.int16)
     posts[:, 0] = rng.integers(20, 60, size=frames * C6)
     posts[:, 1] = rng.integers(10, 40, size=frames * C6)
@@ -169,6 +173,8 @@ def build_floor6(torch, device, frames=16384):
     counts = np.full(frames * C6, 29, dtype=np.uint8)
     floors = [(helpers.LONG_XLIST, 2)]
     mappings = [{"coupling": [(0, 1), (2, 3)], "channel_floor": [0] * C6}]
+    if declare_support:
+        mappings[0].update(residue_begin=(0, 0), residue_end=(128, FLOOR6_RESIDUE_END))
     return pk, res.reshape(-1).contiguous(), torch.from_numpy(posts).to(device), torch.from_numpy(counts).to(device), \
         floors, mappings, (frames - 1) * 1024
 
@@ -591,11 +597,28 @@ def main():
             dec = Decoder(ctx, 6, 256, 2048, floors=floors, mappings=mappings)
             dt, _ = time_decoder(ctx, dec, torch, pk, res6, posts, counts, samples6, 6, 40, 3)
             byt = 4 * res6.numel() + 4 * samples6 * 6 + posts.numel() * 2
+            # ... and with the bytes the declared support leaves to read: the lower half of every vector (the kernels work in
+            # halves of a block; the support ends at bin FLOOR6_RESIDUE_END of 1024)
+            byt_needed = byt - 4 * res6.numel() // 2
             extras["configs[3] 6ch Residue2-interleaved + coupling + Floor1 on GPU, N=2048, %d frames" % args.extras_frames6] = {
                 "Msamples_per_s": round(samples6 * 6 / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "bytes_required_with_declared_support": byt_needed,
+                "required_GBps": round(byt_needed / dt / 1e9, 1),
+                "frac_of_8TBps_required_bytes": round(byt_needed / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "2 kernels (Floor1 unwrap; fused de-interleave + coupling + floor + IMDCT + OLA); whole call; "
-                        "best of 3 loops of 40 calls"}
+                        "best of 3 loops of 40 calls.  The mapping declares the residue's support (ABI v4 residue_end = %d of "
+                        "1024 bins): the upper half of every vector is neither loaded nor staged nor de-coupled; algorithmic_* "
+                        "counts the full vectors as rounds 1-3 did, *_required the bytes that have to move" % FLOOR6_RESIDUE_END}
+            # the same workload with the support NOT declared (what ABI v3 could say): every zero loaded and multiplied
+            pk_n, res_n, posts_n, counts_n, floors_n, mappings_n, _ = build_floor6(torch, device, args.extras_frames6, declare_support=False)
+            dec_n = Decoder(ctx, 6, 256, 2048, floors=floors_n, mappings=mappings_n)
+            dt_n, _ = time_decoder(ctx, dec_n, torch, pk_n, res_n, posts_n, counts_n, samples6, 6, 40, 3)
+            extras["configs[3] with the residue's support not declared (ABI v3 accounting)"] = {
+                "Msamples_per_s": round(samples6 * 6 / dt_n / 1e6, 1), "ms_per_step": round(dt_n * 1e3, 3),
+                "algorithmic_GBps": round(byt / dt_n / 1e9, 1), "frac_of_8TBps": round(byt / dt_n / 1e9 / HBM_PEAK_GBS, 4)}
+            dec_n.close()
+            del res_n, posts_n, counts_n
             # ... and as `ReadSamples(Span<float>)` hands a 5.1 stream over: interleaved (IStreamDecoder.cs:126)
             dt, _ = time_decoder(ctx, dec, torch, pk, res6, posts, counts, samples6, 6, 40, 3, layout=capi.OUT_INTERLEAVED)
             extras["configs[3] with interleaved output (the six waves of a packet write it together)"] = {

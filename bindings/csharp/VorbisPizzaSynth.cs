@@ -1,4 +1,4 @@
-// P/Invoke binding of include/vorbispizza_synth.h (ABI version 3) for the reference host.
+// P/Invoke binding of include/vorbispizza_synth.h (ABI version 4) for the reference host.
 //
 // To be added on the reference side as NVorbis/Native/VorbisPizzaSynth.cs.  The style is the one the repository
 // already uses for libvorbisfile (NVorbis.Tests/Bindings/Vorbisfile.cs:43-107: DllImport + Cdecl, LayoutKind.Sequential
@@ -15,7 +15,7 @@ namespace NVorbis.Native
     internal static unsafe class VorbisPizzaSynth
     {
         private const string Lib = "vorbispizza_synth";              // libvorbispizza_synth.so
-        public const int AbiVersion = 3;
+        public const int AbiVersion = 4;
 
         // status codes (vorbispizza_synth.h), mapped to exceptions by ThrowOnError below the way
         // NativeDecoder.cs:145-161 maps OV_*
@@ -52,6 +52,13 @@ namespace NVorbis.Native
             public fixed byte CouplingMagnitude[256];
             public fixed byte CouplingAngle[256];
             public fixed byte ChannelFloor[256];     // _submapFloor[_mux[ch]] per channel
+            // ABI v4: the residue's support per block size ([0] Size0, [1] Size1), in bins of one channel -- what
+            // Residue0.Decode clamps itself to (Residue0.cs:122-125: Math.Min(_begin, halfSize) .. Math.Min(_end, halfSize));
+            // smallest begin / largest end over the mapping's submaps; a Residue2's range divided by its channel count
+            // (rounded outward).  End 0 = not stated (the whole block).  Residue0 needs `internal int Begin => _begin;
+            // internal int End => _end;` for the host to fill these in.
+            public fixed int ResidueBegin[2];
+            public fixed int ResidueEnd[2];
         }
 
         [StructLayout(LayoutKind.Sequential)]

@@ -27,10 +27,13 @@
 extern "C" {
 #endif
 
-#define VPZ_ABI_VERSION 3   /* 2: s16 output layouts, VPZ_PKT_RESYNC, vpz_decoder_set_position; structs unchanged
+#define VPZ_ABI_VERSION 4   /* 2: s16 output layouts, VPZ_PKT_RESYNC, vpz_decoder_set_position; structs unchanged
                                3: vpz_decoder_synth takes the extents of its input buffers (residue_floats, n_records) and
                                   reports a window mismatch per packet (vpz_decoder_last_packet_status) instead of failing
-                                  the batch; structs unchanged */
+                                  the batch; structs unchanged
+                               4: vpz_mapping_config carries the residue's support (residue_begin / residue_end, what
+                                  Residue0.cs:122-125 clamps every decode to): the kernels neither load nor de-couple nor
+                                  floor-multiply the bins the setup header says are zero.  The struct grew by 16 bytes */
 
 /* ---- status codes (negative like the OV_* codes, Vorbisfile.cs:10-24) ---- */
 #define VPZ_OK                 0
@@ -128,6 +131,17 @@ typedef struct vpz_mapping_config {       /* Mapping.cs:11-15 */
     uint8_t coupling_magnitude[VPZ_MAX_COUPLING];
     uint8_t coupling_angle[VPZ_MAX_COUPLING];
     uint8_t channel_floor[VPZ_MAX_CHANNELS + 1]; /* _submapFloor[_mux[ch]] per channel */
+    /* The residue's SUPPORT, per block size ([0]: block_size0, [1]: block_size1), in bins of one channel: every packet of
+     * this mapping has residue[bin] == +0.0 for bin < residue_begin or bin >= residue_end, in every channel.  It is a
+     * setup-header product: a residue decodes into [min(_begin, n/2), min(_end, n/2)) and nowhere else (Residue0.cs:122-125;
+     * the buffer was cleared before, Mapping.cs:117), so the host fills in the smallest begin and the largest end over the
+     * mapping's submaps (`_submapResidue`, Mapping.cs:13) -- for a type-2 residue, whose vector interleaves the submap's
+     * channels (Residue2.cs:31-34), its [begin, end) divided by that channel count, rounded outward.  The library then
+     * does not load, de-couple or floor-multiply bins beyond the support (it works in steps of blocksize/16 bins); what
+     * the buffer holds there is not looked at.  residue_end == 0 means "not stated": the whole block.  Values above
+     * blocksize/2 are clamped; begin > end is VPZ_E_INVALID_ARG.  VPZ_PKT_NO_FLOOR packets have no mapping: whole block. */
+    int32_t residue_begin[2];
+    int32_t residue_end[2];
 } vpz_mapping_config;
 
 typedef struct vpz_stream_config {

@@ -71,7 +71,7 @@ def test_host_library_headers_are_exported_and_plain_c(capi, tmp_path):
 
 def test_abi_version_and_error_strings(capi):
     L = capi.lib()
-    assert L.vpz_abi_version() == 3
+    assert L.vpz_abi_version() == 4
     assert L.vpz_error_string(0) == b"ok"
     for code in range(-7, 0):
         assert L.vpz_error_string(code) not in (b"ok", b"unknown status")
@@ -80,7 +80,7 @@ def test_abi_version_and_error_strings(capi):
 def test_struct_layouts_match_header(capi):
     assert C.sizeof(capi.Packet) == 24
     assert C.sizeof(capi.Floor1Config) == 4 * (2 + 65)
-    assert C.sizeof(capi.MappingConfig) == 4 + 256 + 256 + 256
+    assert C.sizeof(capi.MappingConfig) == 4 + 256 + 256 + 256 + 16  # (ABI v4: residue_begin[2], residue_end[2])
 
 
 def test_no_cpu_fallback(capi):

@@ -7,7 +7,7 @@
 
 The translation unit is compiled for the device only with `-S -gline-tables-only` (line tables do not change the code:
 the instruction count is the same with and without), so every instruction carries its source position WITH its inlining
-chain.  The frame loop is the outermost loop of the kernel (largest back edge).  An instruction belongs to the PHASE
+chain.  The frame loop is the kernel's `for (it < iters)` loop: every instruction whose call site lies in its source range.  An instruction belongs to the PHASE
 whose VPZ_STAMP interval holds the outermost position of its chain that lies in the kernel's own body (the call site in
 the loop), and to the helper FUNCTION of its innermost position.
 
@@ -306,9 +306,15 @@ def main():
     hot_listing = []
     pend = {"vm": [], "lgkm": []}
     waits = []
-    for idx in range(lo, hi + 1):
+    for idx in range(len(insts)):
         ins = insts[idx]
         phase, fn, cold = attribute(ins)
+        # the loop's instructions by SOURCE position (the compiler lays some of the loop's blocks out behind its back edge);
+        # code without a position in the kernel body belongs to the loop if it lies inside it
+        if phase.startswith("(no position") and not lo <= idx <= hi:
+            continue
+        if phase.startswith("(ahead") or phase.startswith("(behind"):
+            continue
         cls = classify(ins["op"])
         if cold:
             cold_tot[cls] += 1

@@ -35,7 +35,8 @@ class MappingConfig(C.Structure):
     _fields_ = [("coupling_steps", C.c_int32),
                 ("coupling_magnitude", C.c_uint8 * MAX_COUPLING),
                 ("coupling_angle", C.c_uint8 * MAX_COUPLING),
-                ("channel_floor", C.c_uint8 * (MAX_CHANNELS + 1))]
+                ("channel_floor", C.c_uint8 * (MAX_CHANNELS + 1)),
+                ("residue_begin", C.c_int32 * 2), ("residue_end", C.c_int32 * 2)]
 
 
 class StreamConfig(C.Structure):
@@ -236,7 +237,9 @@ class Decoder:
     def __init__(self, ctx, channels, block_size0, block_size1, floors=(), mappings=(), n_streams=1,
                  clip_samples=False):
         """floors: [(x_list, multiplier)] for a type-1 floor or {"order":, "rate":, "bark_map_size":, "amp_bits":,
-        "amp_ofs":} for a type-0 floor; mappings: [{"coupling": [(mag, ang)], "channel_floor": [..]}]"""
+        "amp_ofs":} for a type-0 floor; mappings: [{"coupling": [(mag, ang)], "channel_floor": [..],
+        "residue_begin": (short, long), "residue_end": (short, long)}] -- the last two optional (ABI v4: the residue's
+        support in bins per channel; 0 / absent = the whole block)"""
         self.ctx = ctx
         self.channels, self.size0, self.size1, self.n_streams = channels, block_size0, block_size1, n_streams
         fl = (Floor1Config * max(1, len(floors)))()
@@ -264,6 +267,9 @@ class Decoder:
                 mp[i].coupling_angle[j] = ang
             for c, f in enumerate(m.get("channel_floor", [0] * channels)):
                 mp[i].channel_floor[c] = f
+            for b in range(2):
+                mp[i].residue_begin[b] = int(m.get("residue_begin", (0, 0))[b])
+                mp[i].residue_end[b] = int(m.get("residue_end", (0, 0))[b])
         cfg = StreamConfig(channels, block_size0, block_size1, len(floors), fl, len(mappings), mp,
                            1 if clip_samples else 0, ftypes, fl0)
         self._h = _vp()
@@ -324,7 +330,8 @@ class Decoder:
         self.ctx._check(lib().vpz_decoder_last_packet_status(self._h, _ptr(out), n_packets, None))
         return out
 
-    def synth(self, packets, residue, posts=None, post_counts=None, out_layout=OUT_PLANAR, capacity=None):
+    def synth(self, packets, residue, posts=None, post_counts=None, out_layout=OUT_PLANAR, capacity=None,
+              on_mismatch="raise"):
         """Host-memory convenience: returns a list (per stream) of PCM arrays, [channels, samples]
         for OUT_PLANAR or [samples, channels] for OUT_INTERLEAVED (int16 arrays for the _S16 layouts)."""
         packets = np.ascontiguousarray(packets, dtype=PACKET_DTYPE)
@@ -342,7 +349,7 @@ class Decoder:
         out = np.zeros(self.n_streams * C_ * capacity, dtype=np.int16 if s16 else np.float32)
         offs = np.arange(self.n_streams, dtype=np.int64) * (C_ * capacity)
         written = self.synth_raw(packets, residue, posts, post_counts, out, offs, capacity, out_layout,
-                                 capacity, MEM_HOST)
+                                 capacity, MEM_HOST, on_mismatch=on_mismatch)
         res = []
         for s in range(self.n_streams):
             blk = out[offs[s]: offs[s] + C_ * capacity]

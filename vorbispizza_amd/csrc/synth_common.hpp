@@ -423,14 +423,27 @@ __device__ __forceinline__ void load_floor_indices(uint32_t (&fy)[4], const uint
 }
 // Floor1.Apply's multiply (Floor1.cs:383,395) on the lane's 8 points: the sixteen table values first (independent LDS
 // reads, all in flight together), then the sixteen products
-__device__ __forceinline__ void apply_floor(float2 (&x)[8], const uint32_t (&fy)[4], const float *s_db)
+// upper (wave-uniform): false when the upper half of the block lies beyond the residue's support (ABI v4) -- its bins are
+// +0.0 and stay +0.0 under any table entry: neither looked up nor multiplied
+__device__ __forceinline__ void apply_floor(float2 (&x)[8], const uint32_t (&fy)[4], const float *s_db, bool upper = true)
 {
     float t[16];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < 4; ++m) {
         const uint32_t v = fy[m >> 1] >> (16 * (m & 1));
         t[2 * m] = s_db[v & 0xFFu];
         t[2 * m + 1] = s_db[(v >> 8) & 0xFFu];
+    }
+    if (upper) {
+#pragma unroll
+        for (int m = 4; m < 8; ++m) {
+            const uint32_t v = fy[m >> 1] >> (16 * (m & 1));
+            t[2 * m] = s_db[v & 0xFFu];
+            t[2 * m + 1] = s_db[(v >> 8) & 0xFFu];
+        }
+    } else {
+#pragma unroll
+        for (int m = 8; m < 16; ++m) t[m] = 1.0f;
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -472,7 +485,7 @@ __device__ __forceinline__ void build_block(uint32_t fd_flags, int lane, float2 
                                             float *hbuf, const float2 *s_twL, const float2 *s_twAB,
                                             const float2 *s_twBC, const float2 *s_twS, const float *s_db)
 {
-    if (kHasFloor && !(fd_flags & kFrameNoFloor)) apply_floor(x, fy, s_db);
+    if (kHasFloor && !(fd_flags & kFrameNoFloor)) apply_floor(x, fy, s_db, ((fd_flags >> kFrameSkipShift) & kFrameSkipMask) < 4);
     if (kLong) {
         imdct2048_wave(x, reinterpret_cast<float2 *>(hbuf), s_twL, s_twAB, s_twBC, lane);
     } else {
@@ -482,13 +495,21 @@ __device__ __forceinline__ void build_block(uint32_t fd_flags, int lane, float2 
 }
 
 // this wave's channel of a planar packet: (X[2k], X[2k+1]) for the lane's 8 points (global memory or an LDS row)
-__device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base, int lpb, int lane)
+// upper == false: the upper half of the row was not staged (ABI v4: beyond the residue's support) -- its points are +0.0
+__device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base, int lpb, int lane, bool upper = true)
 {
     const float2 *s = reinterpret_cast<const float2 *>(base);
     const int k0 = lane & (lpb - 1);
     const int st = lpb;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) x[m] = s[k0 + st * m];
+    for (int m = 0; m < 4; ++m) x[m] = s[k0 + st * m];
+    if (upper) {
+#pragma unroll
+        for (int m = 4; m < 8; ++m) x[m] = s[k0 + st * m];
+    } else {
+#pragma unroll
+        for (int m = 4; m < 8; ++m) x[m] = make_float2(0.0f, 0.0f);
+    }
 }
 
 }  // namespace vpz

@@ -20,7 +20,16 @@ constexpr uint32_t kFrameInterleaved = 16u;  // spec_off addresses the Residue2 
 constexpr int kFrameBatchShift = 5;          // bits 5..7: this frame heads a batch of (value + 1) consecutive short blocks
                                              // that one pass synthesises (set by the kernel's own run builder only)
 constexpr int kFrameStepsShift = 8;          // bits 8..15: coupling steps of the packet's mapping
-constexpr int kFrameStepsOffShift = 16;      // bits 16..31: first step (pair index) in the steps table
+constexpr int kFrameStepsOffShift = 16;      // bits 16..23: first step (pair index, < kGroupMaxStepPairs) in the steps table
+constexpr uint32_t kFrameStepsOffMask = 0xFFu;
+// bits 24..27: how many of the block's eight point groups (group m = bins [m * blocksize/16, (m + 1) * blocksize/16): the lane's
+// m-th point in every transform layout) lie wholly beyond the residue's support (ABI v4, vpz_mapping_config.residue_end) -- their
+// bins are +0.0 by the setup header's word and are neither loaded (group mode) nor de-coupled nor floor-multiplied.  0..8.
+constexpr int kFrameSkipShift = 24;
+constexpr uint32_t kFrameSkipMask = 0xFu;
+// per-mapping word (SynthArgs.map_bits): steps count / offset as in the frame flags, the skip of a long block in bits 24..27,
+// of a short block in bits 28..31
+constexpr int kMapSkipShortShift = 28;
 constexpr int kGroupMaxChannels = 8;         // channels that fit one workgroup of 8 waves
 constexpr int kGroupMaxStepPairs = 128;      // coupling steps (pairs) of all mappings staged in LDS
 

@@ -221,7 +221,10 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         int out_count = has_prev ? max(0, (int)g.right_start - (int)g.left_start) : 0;
         uint32_t fl = ((cf & 1) ? kFrameLong : 0u) | (g.left_use_size1 ? kFrameSlope1 : 0u) |
                       ((cf & kCfNoFloor) ? kFrameNoFloor : 0u);
-        if (!(cf & kCfNoFloor)) fl |= a.map_bits[mp];
+        if (!(cf & kCfNoFloor)) {  // the mapping's coupling steps and what its setup header says about the residue's support
+            const uint32_t mb = a.map_bits[mp];
+            fl |= (mb & 0x00FFFF00u) | ((((cf & 1) ? mb >> kFrameSkipShift : mb >> kMapSkipShortShift) & kFrameSkipMask) << kFrameSkipShift);
+        }
         if (cf & kCfSkip) { fl = kFrameDrain; out_count = 0; }
         if ((run.flags & kRunLastTrimmed) && lane == n - 1) { out_count = run.last_out_count; left_start = run.last_left_start; }
         // Batches of SHORT blocks: a short block costs a pass most of what a long one costs (the 256-point transform
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     };
     // the first four coupling steps of a frame's mapping, read a frame ahead like the input
     auto steps_word = [&](const FrameDesc &fd, bool valid) -> uint2 {
-        const uint32_t off = valid ? 2u * (fd.flags >> kFrameStepsOffShift) : 0u;
+        const uint32_t off = valid ? 2u * ((fd.flags >> kFrameStepsOffShift) & kFrameStepsOffMask) : 0u;
         return *reinterpret_cast<const uint2 *>(s_steps + (off < 2u * kGroupMaxStepPairs ? off : 0u));
     };
 
@@ -430,6 +433,9 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         const int n4 = is_long ? 512 : 64;
         const bool no_floor = !kHasFloor || (fd.flags & kFrameNoFloor) || a.ccount == nullptr;
         const int slot = fi - fi0;
+        // ABI v4: point groups m >= 8 - skip lie beyond the residue's support -- zeros by the setup header's word (their loads
+        // stay: the vector is in memory with its zeros; what is saved is the arithmetic).  Halves are all this path looks at.
+        const bool upper = ((fd.flags >> kFrameSkipShift) & kFrameSkipMask) < 4;
 
         if (!drain) {
             int ln = lane;
@@ -449,17 +455,26 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             // ---- inverse coupling, steps in reverse order (Mapping.cs:166-172); a stereo step is (0, 1) or (1, 0)
             if (!(fd.flags & kFrameNoFloor) && !(VPZ_ABLATE(a) & 16)) {
                 const int n_steps = (int)((fd.flags >> kFrameStepsShift) & 0xFF);
-                const uint8_t *st = s_steps + 2 * (fd.flags >> kFrameStepsOffShift);
+                const uint8_t *st = s_steps + 2 * ((fd.flags >> kFrameStepsOffShift) & kFrameStepsOffMask);
                 const unsigned long long stw = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.y) << 32) |
                                                (uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.x);
                 for (int i = n_steps - 1; i >= 0; --i) {
                     const uint32_t mag = (n_steps <= 4 ? (uint32_t)(stw >> (16 * i)) : (uint32_t)st[2 * i]) & 0x7Fu;
+                    // (the upper half of the points only if the residue's support reaches it: zeros de-couple to zeros)
                     if (mag == 0) {
 #pragma unroll
-                        for (int m = 0; m < 8; ++m) { couple(xL[m].x, xR[m].x); couple(xL[m].y, xR[m].y); }
+                        for (int m = 0; m < 4; ++m) { couple(xL[m].x, xR[m].x); couple(xL[m].y, xR[m].y); }
+                        if (upper) {
+#pragma unroll
+                            for (int m = 4; m < 8; ++m) { couple(xL[m].x, xR[m].x); couple(xL[m].y, xR[m].y); }
+                        }
                     } else {
 #pragma unroll
-                        for (int m = 0; m < 8; ++m) { couple(xR[m].x, xL[m].x); couple(xR[m].y, xL[m].y); }
+                        for (int m = 0; m < 4; ++m) { couple(xR[m].x, xL[m].x); couple(xR[m].y, xL[m].y); }
+                        if (upper) {
+#pragma unroll
+                            for (int m = 4; m < 8; ++m) { couple(xR[m].x, xL[m].x); couple(xR[m].y, xL[m].y); }
+                        }
                     }
                 }
             }
@@ -530,8 +545,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 }
                 VPZ_STAMP(2);  // curves
                 if (!(VPZ_ABLATE(a) & 256)) {
-                apply_floor(xL, fyL, s_db);
-                apply_floor(xR, fyR, s_db);
+                apply_floor(xL, fyL, s_db, upper);
+                apply_floor(xR, fyR, s_db, upper);
                 }
             }
             // ---- the two transforms, side by side

@@ -370,8 +370,10 @@ __device__ __forceinline__ void load_group_share(float2 (&x)[8], const float *sr
 
 // ... and the de-interleave (Residue2.cs:42-51) into the group's LDS rows: element e = bin * C + channel goes to
 // rows[channel][bin].  `magic` = ceil(2^18 / C): e / C == (e * magic) >> 18 for every e < 8192, C <= 8.
+// upper == false (a 2048 block whose residue's support ends in the lower half, ABI v4): only the first two pieces of every lane
+// hold data -- pieces 64 w + 64 C j, j < 2, are exactly the lower half of every channel's row
 __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *rows, int C, uint32_t magic, int half,
-                                                  int w, int lane)
+                                                  int w, int lane, bool upper = true)
 {
     const int total4 = (C * half) >> 2;
     // The LDS addresses below do not depend on the frame: left alone, the compiler computes them once before the
@@ -385,7 +387,7 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int q = q0 + 128 * j;
-            if (full || q < total4) {
+            if ((full && (upper || j < 2)) || (!full && q < total4)) {
                 reinterpret_cast<float2 *>(rows)[q] = make_float2(x[2 * j].x, x[2 * j + 1].x);
                 reinterpret_cast<float2 *>(rows + kWaveBufFloats)[q] = make_float2(x[2 * j].y, x[2 * j + 1].y);
             }
@@ -395,15 +397,22 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
     // piece j holds elements 4*q0 + 256*C*j + i: the SAME channel as element 4*q0 + i, 256*j bins further on -- one
     // division per i, and the four pieces differ by a constant offset
     if (full) {
+        float *dst[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t e = 4u * (uint32_t)q0 + (uint32_t)i;
             const uint32_t bin = __umul24(e, magic) >> 18;  // (24-bit multiplies are full rate, 32-bit ones a quarter)
             const uint32_t c = e - __umul24(bin, (uint32_t)C);
-            float *dst = rows + __umul24(c, (uint32_t)kWaveBufFloats) + bin;
+            dst[i] = rows + __umul24(c, (uint32_t)kWaveBufFloats) + bin;
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                dst[256 * j] = (i & 2) ? ((i & 1) ? x[2 * j + 1].y : x[2 * j + 1].x) : ((i & 1) ? x[2 * j].y : x[2 * j].x);
+        for (int j = 0; j < 4; ++j) {
+            if (j < 2 || upper) {
+                dst[0][256 * j] = x[2 * j].x;
+                dst[1][256 * j] = x[2 * j].y;
+                dst[2][256 * j] = x[2 * j + 1].x;
+                dst[3][256 * j] = x[2 * j + 1].y;
+            }
         }
         return;
     }
@@ -491,13 +500,13 @@ __device__ __forceinline__ void stage_by_lds_dma_gather(const float *src, float 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__device__ __forceinline__ void stage_planar(const float2 (&x)[8], float *row, int half, int lane)
+__device__ __forceinline__ void stage_planar(const float2 (&x)[8], float *row, int half, int lane, bool upper = true)
 {
     asm volatile("" : "+v"(lane));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q = lane + 64 * j;
-        if (half == 1024 || q < (half >> 2))  // (a long block has every piece: one wave-uniform test, no lane mask)
+        if ((half == 1024 && (upper || j < 2)) || (half != 1024 && q < (half >> 2)))  // (a long block has every piece: one wave-uniform test, no lane mask)
             reinterpret_cast<float4 *>(row)[q] = make_float4(x[2 * j].x, x[2 * j].y, x[2 * j + 1].x, x[2 * j + 1].y);
     }
 }
@@ -688,13 +697,24 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     // boundary), read a frame ahead like the input: the step loop then runs out of scalar registers instead of three
     // dependent LDS round trips per step (step byte -> row address -> data)
     auto steps_word = [&](const FrameDesc &fd, bool valid) -> uint2 {
-        const uint32_t off = valid ? 2u * (fd.flags >> kFrameStepsOffShift) : 0u;
+        const uint32_t off = valid ? 2u * ((fd.flags >> kFrameStepsOffShift) & kFrameStepsOffMask) : 0u;
         return *reinterpret_cast<const uint2 *>(s_steps + (off < 2u * kGroupMaxStepPairs ? off : 0u));
     };
     // Everything below is UNCONDITIONAL -- a frame that needs no input (none follows, a drain, a silent channel) reads
     // a few bytes of a table that always exists (the inverse dB table) instead: a load under a condition leaves the
     // compiler with a merge of "loaded" and "not loaded" registers, which it resolves with copies right behind the loads, and the copies wait
     // for the data.  That put the full memory latency in front of every frame of every variant with a floor.
+    // ABI v4: does the residue's support reach the upper half of a frame's block?  If not (vpz_mapping_config.residue_end at or
+    // below a quarter of the block size), the upper half is zeros by the setup header's word: in group mode a 2048 block's upper
+    // half is neither loaded nor staged nor de-coupled, and nowhere is it looked up in the floor table or multiplied.  (Halves:
+    // every decision is wave-uniform and the same in every wave of a group; a finer step would buy real streams nothing -- their
+    // residues end in the top eighth of the block.)
+    auto upper_of = [&](uint32_t flags) -> bool { return ((flags >> kFrameSkipShift) & kFrameSkipMask) < 4; };
+    // ... and the 16-byte pieces of the packet there are to load then: half of them (whole wave-loads either way)
+    auto support_pieces = [&](uint32_t flags, int vec_channels, int hh) -> int {
+        const int total = (vec_channels * hh) >> 2;
+        return (!kGeneral && (flags & kFrameLong) && hh == 1024 && !upper_of(flags)) ? total >> 1 : total;
+    };
     auto prefetch = [&](const FrameDesc &fd, int slot, bool valid, float2 (&x)[8], int &cp, int &cnt, bool &ex) {
         cnt = valid ? __builtin_amdgcn_readlane(cc_run, slot) : 0;  // active posts of this wave's channel (0: silent)
         ex = valid && (a.ccount == nullptr || (fd.flags & kFrameNoFloor) || cnt != 0);
@@ -705,7 +725,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             const float *src = a.spec + fd.spec_off + (shared_input ? 0 : (int64_t)ch * hh);
             const bool regs = valid && !(shared_input && (VPZ_GROUP_DMA(a) || (VPZ_ABLATE(a) & (2048 | 4096))));  // (the packet comes by LDS-DMA)
             load_group_share(x, regs ? src : a.inv_db, shared_input ? 64 * ch : 0, shared_input ? 64 * C : 64,
-                             regs ? ((shared_input ? C * hh : hh) >> 2) : 1, lane);
+                             regs ? support_pieces(fd.flags, shared_input ? C : 1, hh) : 1, lane);
         } else {
             load_spectrum(x, ex ? spectrum_of(fd) : a.inv_db, ex ? lpb_of(fd.flags) : 1, lane);
         }
@@ -733,7 +753,10 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         uint32_t fl = ((cf & 1) ? kFrameLong : 0u) | (g.left_use_size1 ? kFrameSlope1 : 0u) |
                       ((cf & kCfNoFloor) ? kFrameNoFloor : 0u);
         if (cf & kCfInterleaved) fl |= kFrameInterleaved;
-        if (!(cf & kCfNoFloor)) fl |= a.map_bits[mp];
+        if (!(cf & kCfNoFloor)) {  // the mapping's coupling steps and what its setup header says about the residue's support
+            const uint32_t mb = a.map_bits[mp];
+            fl |= (mb & 0x00FFFF00u) | ((((cf & 1) ? mb >> kFrameSkipShift : mb >> kMapSkipShortShift) & kFrameSkipMask) << kFrameSkipShift);
+        }
         if (cf & kCfSkip) { fl = kFrameDrain; out_count = 0; }
         if ((run.flags & kRunLastTrimmed) && lane == n - 1) { out_count = run.last_out_count; left_start = run.last_left_start; }
         // Batches of SHORT blocks (group mode, 256 / 2048 kernel): a short block costs a pass 70 % of what a long one
@@ -922,6 +945,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         // ---- group mode: the packet goes through the group's LDS rows (de-interleave, inverse coupling)
         if (kGroup) {
             const bool stage = build;  // every packet goes through the rows (see load_group_share)
+            // (ABI v4) a 2048 block whose residue ends in the lower half: only that half goes through the rows
+            const bool stage_upper = kGeneral || batch || !is_long || upper_of(fd.flags);
             __syncthreads();  // every wave of the group is done with its row (previous block emitted)
             VPZ_STAMP(1);  // first barrier
             if (stage && !(VPZ_ABLATE(a) & 32)) {
@@ -930,9 +955,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 } else if ((fd.flags & kFrameInterleaved) && (VPZ_GROUP_DMA(a) || (VPZ_ABLATE(a) & 2048))) {
                     stage_by_lds_dma(a.spec + fd.spec_off, s_work[gw0], C, nstage >> 1, ch, lane);
                 } else if (fd.flags & kFrameInterleaved) {
-                    stage_interleaved(xcur, s_work[gw0], C, div_magic, nstage >> 1, ch, lane);
+                    stage_interleaved(xcur, s_work[gw0], C, div_magic, nstage >> 1, ch, lane, stage_upper);
                 } else {
-                    stage_planar(xcur, hcur, nblk >> 1, lane);
+                    stage_planar(xcur, hcur, nblk >> 1, lane, stage_upper);
                 }
             }
             __syncthreads();
@@ -942,7 +967,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             // that a workgroup barrier is needed between levels only -- (0,1),(2,3) of a 5.1 mapping run together
             const int n_steps = (int)((fd.flags >> kFrameStepsShift) & 0xFF);
             int sidx = n_steps - 1;
-            const uint8_t *st = s_steps + 2 * (fd.flags >> kFrameStepsOffShift);
+            const uint8_t *st = s_steps + 2 * ((fd.flags >> kFrameStepsOffShift) & kFrameStepsOffMask);
             const unsigned long long stw = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.y) << 32) |
                                            (uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.x);
             // byte k of the mapping's steps: out of the prefetched word while the mapping has at most four
@@ -971,7 +996,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     while (sidx >= 0 && (first || !(step_byte(2 * sidx) & 0x80))) {
                         float4 *pm = reinterpret_cast<float4 *>(s_work[gw0 + (step_byte(2 * sidx) & 0x7F)]);
                         float4 *pa = reinterpret_cast<float4 *>(s_work[gw0 + step_byte(2 * sidx + 1)]);
-                        for (int g = lane + 64 * ch; g < (nstage >> 3); g += 64 * C) {
+                        for (int g = lane + 64 * ch; g < (stage_upper ? nstage >> 3 : nstage >> 4); g += 64 * C) {
                             float4 m4 = pm[g], a4 = pa[g];
                             couple(m4.x, a4.x);
                             couple(m4.y, a4.y);
@@ -996,7 +1021,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 #pragma unroll
                 for (int m = 0; m < 8; ++m) xcur[m] = row2[(lb >> 3) * 64 + (lb & 7) + 8 * m];
             } else if (stage && exec) {
-                load_spectrum(xcur, hcur, lpb_of(fd.flags), lane);
+                load_spectrum(xcur, hcur, lpb_of(fd.flags), lane, stage_upper);
             }
         }
         // ---- the curve, right before the row is needed for the transform
@@ -1060,7 +1085,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 const float2 *tw = use_long ? s_twL : s_twS;
                 const float2 *ab = use_long ? s_twL + kFastTwABOffset : s_twS + 256;
                 const float2 *bc = use_long ? s_twL + kFastTwBCOffset : s_twS + 512;
-                if (kHasFloor && !(fd.flags & kFrameNoFloor)) apply_floor(xcur, fycur, s_db);
+                if (kHasFloor && !(fd.flags & kFrameNoFloor)) apply_floor(xcur, fycur, s_db, upper_of(fd.flags));
                 float2 *h2 = reinterpret_cast<float2 *>(hcur);
                 if (nblk == 2048) imdct2048_wave(xcur, h2, tw, ab, bc, ln);
                 else if (nblk == 1024) imdct_mid_wave<4>(xcur, h2, tw, ab, bc, ln);

@@ -125,6 +125,7 @@ struct Decoder {
     size_t zero_copy_max = 8u << 20;         // arenas up to this size are read in place by the kernels (VPZ_ZERO_COPY_MAX;
                                              // half a million packets, 1.5 MB: 2.42 -> 2.35 ms against the copy)
     std::vector<int32_t> mapping_steps_off;  // per mapping: offset into d_steps (pairs*2), -1 none
+    std::vector<uint8_t> mapping_skip[2];    // per mapping and block size: point groups (of 8) beyond the residue's support (ABI v4)
     DevBuf b_curve, b_temp, b_cposts, b_ccount;
     // group mode of synth_kernel (channels of a packet share a workgroup; de-interleave + coupling in LDS)
     bool group_ok = false;       // channel count, step tables and floor types allow it
@@ -332,7 +333,21 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         for (int ch = 0; ch < D.channels && rc == VPZ_OK; ++ch)
             if (D.floors.size() && mc.channel_floor[ch] >= D.floors.size()) rc = VPZ_E_INVALID_ARG;
         D.max_steps = std::max(D.max_steps, (int)mc.coupling_steps);
+        // the residue's support (ABI v4; Residue0.cs:122-125): whole point groups of blocksize/16 bins beyond residue_end
+        // are skipped.  (residue_begin is validated and kept for the record: real streams begin at bin 0.)
+        for (int b = 0; b < 2 && rc == VPZ_OK; ++b) {
+            const int half = (b ? D.size1 : D.size0) / 2;
+            const int begin = mc.residue_begin[b], end_raw = mc.residue_end[b];
+            if (begin < 0 || end_raw < 0 || (end_raw != 0 && begin > end_raw)) { rc = VPZ_E_INVALID_ARG; break; }
+            const int end = end_raw == 0 ? half : std::min(end_raw, half);
+            const int per_group = std::max(1, half / 8);
+            const int groups = std::min(8, (end + per_group - 1) / per_group);
+            D.mapping_skip[b].push_back((uint8_t)(half >= 8 ? 8 - groups : 0));
+        }
     }
+    if (const char *e = getenv("VPZ_NO_SUPPORT"))  // A/B tests: ignore the declared support (load and multiply the zeros)
+        if (atoi(e))
+            for (int b = 0; b < 2; ++b) std::fill(D.mapping_skip[b].begin(), D.mapping_skip[b].end(), (uint8_t)0);
     // group mode applies a mapping's steps in reverse order with a workgroup barrier only where a step touches a
     // channel an earlier step of the same LEVEL touched: mark those steps, count the levels
     std::vector<uint8_t> steps_lvl = steps;
@@ -395,6 +410,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         if ((D.group_ok || D.dual_ok) && n > 0)
             map_bits[m] = ((uint32_t)n << kFrameStepsShift) |
                           ((uint32_t)(D.mapping_steps_off[m] / 2) << kFrameStepsOffShift);
+        map_bits[m] |= ((uint32_t)D.mapping_skip[1][m] << kFrameSkipShift) | ((uint32_t)D.mapping_skip[0][m] << kMapSkipShortShift);
         for (int ch = 0; ch < D.channels; ++ch)
             if (!D.floor_types.empty() && D.floor_types[D.mappings[m].channel_floor[ch]] == 0) D.mapping_uses_floor0[m] = 1;
     }
@@ -649,6 +665,7 @@ struct SynthCall {
                 f |= ((uint32_t)steps << kFrameStepsShift) |
                      ((uint32_t)(D.mapping_steps_off[pk.mapping] / 2) << kFrameStepsOffShift);
         }
+        if (!no_floor) f |= (uint32_t)D.mapping_skip[bf ? 1 : 0][pk.mapping] << kFrameSkipShift;
         return f;
     }
 
@@ -1475,7 +1492,7 @@ struct SynthCall {
     {
         if (!need_coupling || use_group || use_dual) return;
         // the separate pass hands planar, de-coupled spectra over: the frames lose their group-mode bits
-        for (size_t fi = 0; fi < n_frames; ++fi) frames[fi].flags &= 0xFu;
+        for (size_t fi = 0; fi < n_frames; ++fi) frames[fi].flags &= 0xFu | (kFrameSkipMask << kFrameSkipShift);
         const size_t cps = coupling_packet_size();
         cpk = arena_alloc<uint8_t>(*A, cps * n_frames);
         for (size_t fi = 0; fi < n_frames; ++fi) {

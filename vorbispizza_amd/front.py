@@ -117,7 +117,8 @@ class OggVorbisFile:
 
     Attributes mirror what StreamDecoder holds after LoadStreamHeader / LoadBooks
     (StreamDecoder.cs:213-321): channels, sample_rate, block sizes, floors [(x_list, multiplier)],
-    mappings [{"coupling": [(mag, ang)], "channel_floor": [...]}]."""
+    mappings [{"coupling": [(mag, ang)], "channel_floor": [...], "residue_begin": (short, long), "residue_end": (short, long)}]
+    (the last two: the residue's support per block size, ABI v4)."""
 
     def __init__(self, path_or_bytes, stream_index=0):
         data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
@@ -153,7 +154,8 @@ class OggVorbisFile:
             lib().vpzh_get_mapping(self._h, i, C.byref(m))
             self.mappings.append({
                 "coupling": [(m.coupling_magnitude[j], m.coupling_angle[j]) for j in range(m.coupling_steps)],
-                "channel_floor": list(m.channel_floor[: self.channels])})
+                "channel_floor": list(m.channel_floor[: self.channels]),
+                "residue_begin": tuple(m.residue_begin), "residue_end": tuple(m.residue_end)})
         self.residue_types = [lib().vpzh_get_residue_type(self._h, i) for i in range(info.residue_count)]
 
     @property

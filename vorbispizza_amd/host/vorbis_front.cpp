@@ -1390,6 +1390,31 @@ int vpzh_get_mapping(vpzh_stream *s, int index, vpz_mapping_config *out)
         out->coupling_angle[i] = m.coupling_angle[i];
     }
     for (int c = 0; c < s->channels && c <= VPZ_MAX_CHANNELS; ++c) out->channel_floor[c] = m.submap_floor[m.mux[c]];
+    // The residue's support (ABI v4): a residue decodes into [min(_begin, n), min(_end, n)) of its vector and nowhere else
+    // (Residue0.cs:122-125), n = blocksize/2 for types 0 / 1 and blocksize/2 * (channels of the submap) for type 2, whose vector
+    // interleaves them (Residue2.cs:31-34): bin = index / channels.  Smallest begin and largest end over the submaps -- the
+    // reference reuses one decode buffer for every submap without clearing it (Mapping.cs:132-163), so a later submap's
+    // channels can carry an earlier one's values: the union covers that too.
+    const int sizes[2] = {s->size0, s->size1};
+    for (int b = 0; b < 2; ++b) {
+        const int half = sizes[b] / 2;
+        int lo = half, hi = 0;
+        for (size_t i = 0; i < m.submap_residue.size(); ++i) {
+            int count = 0;
+            for (int c = 0; c < s->channels; ++c) count += m.mux[c] == (int)i;
+            if (count == 0 || m.submap_residue[i] >= s->residues.size()) continue;
+            const Residue &r = s->residues[m.submap_residue[i]];
+            const int64_t n = r.type == 2 ? (int64_t)half * count : half;
+            const int64_t rb = std::min<int64_t>(r.begin, n), re = std::min<int64_t>(r.end, n);
+            if (re <= rb) continue;
+            const int per = r.type == 2 ? count : 1;
+            lo = std::min(lo, (int)(rb / per));
+            hi = std::max(hi, (int)((re + per - 1) / per));
+        }
+        if (hi <= lo) { lo = 0; hi = 1; }  // (no residue reaches this block size: one bin stands for "nothing", 0 would say "not stated")
+        out->residue_begin[b] = lo;
+        out->residue_end[b] = std::min(hi, half);
+    }
     return VPZH_OK;
 }
 

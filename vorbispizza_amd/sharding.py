@@ -55,8 +55,12 @@ def merge_setups(setups):
             remap.append(index[k])
         bases.append(len(mappings))
         for m in mps:
-            mappings.append({"coupling": [tuple(p) for p in m["coupling"]],
-                             "channel_floor": [remap[f] for f in m["channel_floor"]]})
+            merged = {"coupling": [tuple(p) for p in m["coupling"]],
+                      "channel_floor": [remap[f] for f in m["channel_floor"]]}
+            for k in ("residue_begin", "residue_end"):  # (ABI v4: the residue's support travels with its mapping)
+                if k in m:
+                    merged[k] = tuple(m[k])
+            mappings.append(merged)
     if len(mappings) > 256:
         raise ValueError("merge_setups: more than 256 mappings do not fit a packet's mapping index")
     return floors, mappings, bases
