@@ -87,24 +87,28 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
                          int64_t *residue_floats_used, float *f0_amp, float *f0_coeff, int32_t f0_stride);
 
 /* Many containers at once -- what a host that transcodes a library of files does: opens and entropy-decodes `n` in-memory
- * containers (first logical stream of each) on `threads` host threads (0: as many as the machine reports), one stream at a
+ * containers (first logical stream of each) on `threads` host threads (0: vpzh_default_threads), one stream at a
  * time per thread, the reference's model of one decoder per stream.  Stream k writes its packets at packets + packet_base[k]
  * (records of posts / post_counts at packet_base[k] * channels), its residue at residue + residue_base[k]; its packets carry
  * stream id stream_id0 + k and residue offsets relative to residue + residue_origin (the start of the buffer a later
  * vpz_decoder_synth call is given).  The caller sizes the slices from a vpzh_get_info of each distinct file and says how much
  * room each has (packet_room[k] packets, residue_room[k] floats): a container that holds more is refused (VPZH_E_ARG, nothing of
- * it written; the other streams are still decoded).  All streams must have the same channel count.  failed_packets (may be
+ * it written; the other streams are still decoded).  All streams must have `channels` channels -- the post records of the batch are
+ * laid out for that count: a container with another one is refused the same way (done[k] = -1).  threads 0: vpzh_default_threads().  failed_packets (may be
  * NULL): packets whose decode failed (see vpzh_decode_failures).  Type-0 floor data is not collected here. */
-int vpzh_decode_many(int32_t n, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
+int vpzh_decode_many(int32_t n, int32_t channels, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
                      const int64_t *packet_base, const int64_t *packet_room, const int64_t *residue_base,
                      const int64_t *residue_room, int64_t residue_origin, vpz_packet *packets, float *residue, int16_t *posts,
                      uint8_t *post_counts, int64_t *failed_packets);
+
+/* The cores this process may run on (affinity mask) divided by LOCAL_WORLD_SIZE (processes per node under torchrun), >= 1. */
+int vpzh_default_threads(void);
 
 /* The same with a progress report, for a caller that hands finished streams on (to vpz_decoder_synth) while the rest is still
  * being decoded: done[k] (caller-zeroed, n entries) becomes 1 once stream k's slices are complete, -1 if it was refused or
  * failed to open; streams are taken in index order, one per thread at a time.  The flags are stored with release semantics --
  * read them from another thread, see non-zero, then read the slices. */
-int vpzh_decode_many_progress(int32_t n, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
+int vpzh_decode_many_progress(int32_t n, int32_t channels, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
                               const int64_t *packet_base, const int64_t *packet_room, const int64_t *residue_base,
                               const int64_t *residue_room, int64_t residue_origin, vpz_packet *packets, float *residue,
                               int16_t *posts, uint8_t *post_counts, int64_t *failed_packets, int32_t *done);

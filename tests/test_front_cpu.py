@@ -262,6 +262,40 @@ def test_decode_many_equals_one_stream_at_a_time():
     assert list(done) == [-1, 1]
 
 
+def test_decode_many_refuses_a_container_with_another_channel_count():
+    """The batch's post records are laid out for ONE channel count: a 6-channel file that slips into a stereo batch -- with few
+    enough packets and residue to pass both room checks -- would write its records past the caller's arrays (untrusted file
+    contents).  It is refused before anything is written; the streams next to it are decoded."""
+    import synthetic_streams as ss
+    from vorbispizza_amd import capi, front
+    stereo = open(os.path.join(GOLDEN, "3test.ogg"), "rb").read()
+    f = front.OggVorbisFile(stereo)
+    n, rf = f.audio_packets, f.info.residue_floats
+    stream, rng = ss.ALL["six_channels_51"]()
+    six, _ = stream.build(rng, 6)
+    g = front.OggVorbisFile(six)
+    assert g.channels == 6 and g.audio_packets <= n and g.info.residue_floats <= rf  # (it WOULD pass the room checks)
+    C_ = 2
+    pk = capi.make_packets(3 * n)
+    res = np.full(3 * rf, 7.0, dtype=np.float32)
+    guard = 4096
+    posts = np.full((3 * n * C_ + guard, 64), -3, dtype=np.int16)
+    counts = np.full(3 * n * C_ + guard, 200, dtype=np.uint8)
+    arrays = [np.frombuffer(stereo, dtype=np.uint8), np.frombuffer(bytes(six), dtype=np.uint8), np.frombuffer(stereo, dtype=np.uint8)]
+    done = np.zeros(3, dtype=np.int32)
+    with pytest.raises(front.FrontError):
+        front.decode_many(arrays, [0, n, 2 * n], [0, rf, 2 * rf], pk, res, posts[: 3 * n * C_], counts[: 3 * n * C_], threads=2,
+                          done=done, channels=C_)
+    assert list(done) == [1, -1, 1]
+    assert (res[rf: 2 * rf] == 7.0).all() and (counts[n * C_: 2 * n * C_] == 200).all() and (posts[n * C_: 2 * n * C_] == -3).all()
+    assert (counts[3 * n * C_:] == 200).all() and (posts[3 * n * C_:] == -3).all()  # nothing beyond the arrays
+    assert (pk["stream"][:n] == 0).all() and (pk["stream"][2 * n:] == 2).all()
+    # a channel count out of range is an argument error
+    with pytest.raises(front.FrontError):
+        front.decode_many(arrays[:1], [0], [0], pk, res, posts, counts, threads=1, channels=0)
+    assert front.lib().vpzh_default_threads() >= 1
+
+
 def test_decode_many_progress_lets_another_thread_take_finished_streams():
     """The pipeline bench.py's end-to-end leg runs: one thread inside vpzh_decode_many_progress, another one watching the
     flags and picking streams up in order as they complete -- what it picks up is final."""

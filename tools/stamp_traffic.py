@@ -23,7 +23,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAMP = os.path.join(ROOT, "profiles", "traffic_stamp.json")
 FUSED_SOURCES = ["vorbispizza_amd/csrc/synth_dual.hip", "vorbispizza_amd/csrc/synth_common.hpp",
-                 "vorbispizza_amd/csrc/imdct_core.hpp", "vorbispizza_amd/csrc/synth_desc.hpp"]
+                 "vorbispizza_amd/csrc/imdct_core.hpp", "vorbispizza_amd/csrc/synth_desc.hpp",
+                 # (the run cutting decides how many blocks a launch recomputes: a change there changes the bytes moved)
+                 "vorbispizza_amd/csrc/vpz_decoder.hip"]
 WORKLOADS = {
     # key: (command after the interpreter, kernel-name substrings, sources, algorithmic bytes or None = parse the log)
     "headline": (["bench.py", "--steps", "5", "--no-extras", "--no-cpu-baseline"], ["imdct2048_kernel"],

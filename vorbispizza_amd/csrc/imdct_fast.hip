@@ -307,12 +307,12 @@ static int grid_for(int64_t work_groups, int resident)
 }
 
 hipError_t launch_imdct_fast_2048(const float *spectra, float *out, int64_t count,
-                                  const float2 *tw, int num_cu, hipStream_t stream, const int64_t *src_off,
+                                  const float2 *tw, Context *ctx, hipStream_t stream, const int64_t *src_off,
                                   const int64_t *dst_off)
 {
     if (count <= 0) return hipSuccess;
-    static int resident = 0;
-    if (!resident) resident = resident_groups(imdct2048_kernel<false>, num_cu);
+    int &resident = ctx->resident[kResident2048];  // (per context: the contexts of one process may sit on different devices)
+    if (!resident) resident = resident_groups(imdct2048_kernel<false>, ctx->num_cu);
     int grid = grid_for((count + kWavesPerGroup - 1) / kWavesPerGroup, resident);
     if (src_off && dst_off)
         hipLaunchKernelGGL(imdct2048_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, spectra, out, (long)count, tw,
@@ -324,12 +324,12 @@ hipError_t launch_imdct_fast_2048(const float *spectra, float *out, int64_t coun
 }
 
 hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count,
-                                 const float2 *tw, int num_cu, hipStream_t stream, const int64_t *src_off,
+                                 const float2 *tw, Context *ctx, hipStream_t stream, const int64_t *src_off,
                                  const int64_t *dst_off)
 {
     if (count <= 0) return hipSuccess;
-    static int resident = 0;
-    if (!resident) resident = resident_groups(imdct256_kernel<false>, num_cu);
+    int &resident = ctx->resident[kResident256];  // (per context: the contexts of one process may sit on different devices)
+    if (!resident) resident = resident_groups(imdct256_kernel<false>, ctx->num_cu);
     int64_t per_group = kWavesPerGroup * 8;
     int grid = grid_for((count + per_group - 1) / per_group, resident);
     if (src_off && dst_off)
@@ -341,43 +341,43 @@ hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count
     return hipGetLastError();
 }
 
-hipError_t launch_imdct_fast_4096(const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
+hipError_t launch_imdct_fast_4096(const float *spectra, float *out, int64_t count, const float2 *tw, Context *ctx,
                                   hipStream_t stream, const int64_t *src_off, const int64_t *dst_off)
 {
     if (count <= 0) return hipSuccess;
-    static int resident = 0;
-    if (!resident) resident = resident_groups(imdct4096_kernel, num_cu);
+    int &resident = ctx->resident[kResident4096];  // (per context: the contexts of one process may sit on different devices)
+    if (!resident) resident = resident_groups(imdct4096_kernel, ctx->num_cu);
     const int grid = grid_for((count + kWavesPerGroup - 1) / kWavesPerGroup, resident);
     hipLaunchKernelGGL(imdct4096_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out, (long)count, tw, src_off,
                        dst_off);
     return hipGetLastError();
 }
 
-hipError_t launch_imdct_fast_8192(const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
+hipError_t launch_imdct_fast_8192(const float *spectra, float *out, int64_t count, const float2 *tw, Context *ctx,
                                   hipStream_t stream, const int64_t *src_off, const int64_t *dst_off)
 {
     if (count <= 0) return hipSuccess;
-    static int resident = 0;
-    if (!resident) resident = resident_groups(imdct8192_kernel, num_cu);
+    int &resident = ctx->resident[kResident8192];  // (per context: the contexts of one process may sit on different devices)
+    if (!resident) resident = resident_groups(imdct8192_kernel, ctx->num_cu);
     const int grid = grid_for((count + kWavesPerGroup - 1) / kWavesPerGroup, resident);
     hipLaunchKernelGGL(imdct8192_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out, (long)count, tw, src_off,
                        dst_off);
     return hipGetLastError();
 }
 
-hipError_t launch_imdct_fast_mid(int n, const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
+hipError_t launch_imdct_fast_mid(int n, const float *spectra, float *out, int64_t count, const float2 *tw, Context *ctx,
                                  hipStream_t stream, const int64_t *src_off, const int64_t *dst_off)
 {
     if (count <= 0) return hipSuccess;
     if (n == 512) {
-        static int resident = 0;
-        if (!resident) resident = resident_groups(imdct_mid_kernel<2>, num_cu);
+        int &resident = ctx->resident[kResident512];  // (per context: the contexts of one process may sit on different devices)
+        if (!resident) resident = resident_groups(imdct_mid_kernel<2>, ctx->num_cu);
         const int64_t per_group = kWavesPerGroup * 4;
         hipLaunchKernelGGL(imdct_mid_kernel<2>, dim3(grid_for((count + per_group - 1) / per_group, resident)),
                            dim3(kThreads), 0, stream, spectra, out, (long)count, tw, src_off, dst_off);
     } else if (n == 1024) {
-        static int resident = 0;
-        if (!resident) resident = resident_groups(imdct_mid_kernel<4>, num_cu);
+        int &resident = ctx->resident[kResident1024];  // (per context: the contexts of one process may sit on different devices)
+        if (!resident) resident = resident_groups(imdct_mid_kernel<4>, ctx->num_cu);
         const int64_t per_group = kWavesPerGroup * 2;
         hipLaunchKernelGGL(imdct_mid_kernel<4>, dim3(grid_for((count + per_group - 1) / per_group, resident)),
                            dim3(kThreads), 0, stream, spectra, out, (long)count, tw, src_off, dst_off);

@@ -387,15 +387,15 @@ int vpz_imdct_batch(vpz_context *c, int n, int64_t count, const float *spectra, 
     hipError_t e;
     const bool fast = (mode == VPZ_IMDCT_FAST) && t->d_fast != nullptr;
     if (fast && n == 2048)
-        e = vpz::launch_imdct_fast_2048(d_in, d_out, count, t->d_fast, ctx->num_cu, ctx->stream);
+        e = vpz::launch_imdct_fast_2048(d_in, d_out, count, t->d_fast, ctx, ctx->stream);
     else if (fast && n == 256)
-        e = vpz::launch_imdct_fast_256(d_in, d_out, count, t->d_fast, ctx->num_cu, ctx->stream);
+        e = vpz::launch_imdct_fast_256(d_in, d_out, count, t->d_fast, ctx, ctx->stream);
     else if (fast && (n == 512 || n == 1024))
-        e = vpz::launch_imdct_fast_mid(n, d_in, d_out, count, t->d_fast, ctx->num_cu, ctx->stream);
+        e = vpz::launch_imdct_fast_mid(n, d_in, d_out, count, t->d_fast, ctx, ctx->stream);
     else if (fast && n == 4096)
-        e = vpz::launch_imdct_fast_4096(d_in, d_out, count, t->d_fast, ctx->num_cu, ctx->stream);
+        e = vpz::launch_imdct_fast_4096(d_in, d_out, count, t->d_fast, ctx, ctx->stream);
     else if (fast && n == 8192)
-        e = vpz::launch_imdct_fast_8192(d_in, d_out, count, t->d_fast, ctx->num_cu, ctx->stream);
+        e = vpz::launch_imdct_fast_8192(d_in, d_out, count, t->d_fast, ctx, ctx->stream);
     else
         e = vpz::launch_imdct_exact(n, t->ld, d_in, d_out, count, t->d_A, t->d_B, t->d_C, t->d_bitrev,
                                     ctx->num_cu, ctx->stream);

@@ -149,6 +149,7 @@ struct Decoder {
     PacketInfo packet_info[8];  // Mode.GetPacketInfo by (block | prev << 1 | next << 2) == vpz_packet.flags & 7
     int run_length_override = 0;
     int ablate = 0;  // VPZ_SYNTH_ABLATE, tuning experiments only
+    bool no_early_upload = false;  // VPZ_NO_EARLY_UPLOAD=1 (A/B tests): a host-memory call's H2D copies stay behind its host pass
     std::vector<int32_t> packet_samples;  // per packet of the last synth call
     std::vector<int64_t> mismatch_packets;  // packets of the last synth call that failed the window check (skipped)
 };
@@ -182,10 +183,16 @@ static int arena_begin(Context *ctx, PinnedArena &A, size_t need)
     return VPZ_OK;
 }
 
+// Carves `count` objects out of the call's arena.  open_arena sizes the arena for everything a call can ask for; should a
+// request not fit after all, the arena is marked overflown -- the pointer returned then addresses a small spare block of
+// ordinary memory that absorbs nothing but keeps the caller's next store harmless when count == 0 -- and the call fails with
+// VPZ_E_NOMEM at its next check (SynthCall::arena_ok) instead of writing beyond the allocation.
+struct ArenaOverflow {};
 template <typename T>
 static T *arena_alloc(PinnedArena &A, size_t count)
 {
     A.used = (A.used + 63) & ~(size_t)63;
+    if (A.used > A.cap || sizeof(T) * count > A.cap - A.used) throw ArenaOverflow();
     T *p = reinterpret_cast<T *>(A.base + A.used);
     A.used += sizeof(T) * count;
     return p;
@@ -303,6 +310,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         if (atoi(e)) D.ablate |= 128;
     }
     if (const char *e = getenv("VPZ_HOST_THREADS")) D.host_threads = atoi(e);
+    if (const char *e = getenv("VPZ_NO_EARLY_UPLOAD")) D.no_early_upload = atoi(e) != 0;
     if (const char *e = getenv("VPZ_PAR_MIN_PACKETS")) D.par_min_packets = atoll(e);
 
     int rc = VPZ_OK;
@@ -639,7 +647,7 @@ struct SynthCall {
         // (runs hold >= 3 frames unless VPZ_RUN_LENGTH says otherwise: see cut_runs)
         size_t need = (sizeof(FrameDesc) + (D.run_length_override > 0 ? sizeof(RunDesc) : sizeof(RunDesc) / 2) + 2 +
                        coupling_packet_size()) * np +
-                      sizeof(RunDesc) * ((size_t)D.n_streams + 1) + (have_posts ? (size_t)n_rec : 0) +
+                      sizeof(RunDesc) * ((size_t)D.n_streams + 1 + 4 * 64) + (have_posts ? (size_t)n_rec : 0) +  // (+ the pieces of long streams)
                       sizeof(int64_t) * (size_t)D.n_streams + 4096;
         if (has_floor0_type) need += floor0_rec_size() * (size_t)n_rec + 64;
         if (D.generic)
@@ -1293,9 +1301,9 @@ struct SynthCall {
         // (... and the lighter half of a skewed cut holds that much less: see THE SKEW below)
         static const int skew_cap_permille = [] { const char *e = getenv("VPZ_CUT_SKEW"); return e ? std::max(0, atoi(e)) : 25; }();
         const int min_run_frames = std::max(1, R - 1 - ((skew_cap_permille > 0 && R >= 16) ? R * skew_cap_permille / 1000 + 2 : 0));
-        runs_cap = (size_t)(total_frames / min_run_frames) + (size_t)D.n_streams + 1;
-        runs = arena_alloc<RunDesc>(*A, runs_cap);
-        if (A->used > A->cap) { host_failed = true; return; }  // (open_arena's budget is R >= 4 runs: never, but never silently)
+        // (every segment -- a stream, or a piece of a long one -- ends with a partial run)
+        runs_cap = (size_t)(total_frames / min_run_frames) + (size_t)std::max(n_segs, D.n_streams) + 1;
+        runs = arena_alloc<RunDesc>(*A, runs_cap);  // (throws ArenaOverflow -> VPZ_E_NOMEM: open_arena's budget is R >= 4 runs)
         if (D.generic) return;
         int64_t target_units = 8 * (int64_t)R;
         // one run of a frame: as many frames from f0 on as the cost target (and the descriptor area) allow
@@ -1461,7 +1469,8 @@ struct SynthCall {
                     }
                 }
                 if (parties > 1) mine.push_back(r);
-                else runs[n_runs++] = r;
+                else if (n_runs < runs_cap) runs[n_runs++] = r;
+                else { host_failed = true; return; }
                 f0 += len;
             }
           }
@@ -1470,6 +1479,7 @@ struct SynthCall {
             host_failed |= !pool->run(cut_streams);
             if (host_failed) { n_runs = 0; return; }
             for (const std::vector<RunDesc> &v : cut) {
+                if (n_runs + v.size() > runs_cap) { host_failed = true; n_runs = 0; return; }  // (never silently into what follows)
                 memcpy(runs + n_runs, v.data(), v.size() * sizeof(RunDesc));
                 n_runs += v.size();
             }
@@ -1742,15 +1752,15 @@ struct SynthCall {
             // schedule (64 and 128 must take it: quirk q1)
             auto imdct_gathered = [&](int n, BlockTables *t, int64_t cnt, const int64_t *so, const int64_t *dof) {
                 if (n == 4096 && t->d_fast)
-                    return launch_imdct_fast_4096(d_temp, d_y, cnt, t->d_fast, ctx->num_cu, ctx->stream, so, dof);
+                    return launch_imdct_fast_4096(d_temp, d_y, cnt, t->d_fast, ctx, ctx->stream, so, dof);
                 if (n == 8192 && t->d_fast)
-                    return launch_imdct_fast_8192(d_temp, d_y, cnt, t->d_fast, ctx->num_cu, ctx->stream, so, dof);
+                    return launch_imdct_fast_8192(d_temp, d_y, cnt, t->d_fast, ctx, ctx->stream, so, dof);
                 if (n == 2048 && t->d_fast)
-                    return launch_imdct_fast_2048(d_temp, d_y, cnt, t->d_fast, ctx->num_cu, ctx->stream, so, dof);
+                    return launch_imdct_fast_2048(d_temp, d_y, cnt, t->d_fast, ctx, ctx->stream, so, dof);
                 if (n == 256 && t->d_fast)
-                    return launch_imdct_fast_256(d_temp, d_y, cnt, t->d_fast, ctx->num_cu, ctx->stream, so, dof);
+                    return launch_imdct_fast_256(d_temp, d_y, cnt, t->d_fast, ctx, ctx->stream, so, dof);
                 if ((n == 512 || n == 1024) && t->d_fast)
-                    return launch_imdct_fast_mid(n, d_temp, d_y, cnt, t->d_fast, ctx->num_cu, ctx->stream, so, dof);
+                    return launch_imdct_fast_mid(n, d_temp, d_y, cnt, t->d_fast, ctx, ctx->stream, so, dof);
                 return launch_imdct_exact(n, t->ld, d_temp, d_y, cnt, t->d_A, t->d_B, t->d_C, t->d_bitrev, ctx->num_cu,
                                           ctx->stream, so, dof);
             };
@@ -1929,8 +1939,7 @@ static int synth_impl(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
             if ((call.early_residue || call.early_posts) && !completed) (void)hipStreamSynchronize(ctx->stream);
         }
     } early_guard{ctx, call};
-    static const bool no_early = getenv("VPZ_NO_EARLY_UPLOAD") != nullptr;  // A/B tests
-    if (!no_early && (rc = call.stage_inputs_early(residue_floats, n_records)) != VPZ_OK) return rc;
+    if (!D.no_early_upload && (rc = call.stage_inputs_early(residue_floats, n_records)) != VPZ_OK) return rc;
     if ((rc = call.open_arena()) != VPZ_OK) return rc;
     const auto t_arena = tick();
     rc = call.run_state_machine_parallel(samples_written);
@@ -1990,6 +1999,8 @@ int vpz_decoder_synth(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     try {
         return synth_impl(d, n_packets, packets, residue, residue_floats, posts, post_counts, n_records, mem_space, pcm_out,
                           stream_out_offset, stream_out_capacity, out_layout, channel_stride, samples_written);
+    } catch (const ArenaOverflow &) {
+        return set_error(d->impl.ctx, VPZ_E_NOMEM, "vpz_decoder_synth: the descriptor arena is too small for this batch");
     } catch (const std::bad_alloc &) {
         return set_error(d->impl.ctx, VPZ_E_NOMEM, "vpz_decoder_synth: host allocation failed");
     } catch (...) {

@@ -47,7 +47,11 @@ struct Context {
     // fork-join pool of the host-side state machine (host_pool.hpp), created by the first large synth batch
     void *host_pool = nullptr;
     void (*host_pool_free)(void *) = nullptr;
+    // persistent grids of the IMDCT kernels on THIS context's device (workgroups the chip keeps resident), filled by the first
+    // launch of each; per context, not per process: a host with several GPUs holds one context per device
+    int resident[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+enum { kResident2048 = 0, kResident256, kResident4096, kResident8192, kResident512, kResident1024 };
 
 int set_error(Context *ctx, int status, const char *what, hipError_t e = hipSuccess);
 int get_tables(Context *ctx, int n, BlockTables **out);
@@ -63,17 +67,17 @@ int ensure_stage(Context *ctx, void **buf, size_t *have, size_t need);
 // spectra [count][n/2] -> out [count][n], device pointers, asynchronous on `stream`.
 // optional gather lists (float offsets of each block's spectrum / output) serve the three-pass decoder path
 hipError_t launch_imdct_fast_2048(const float *spectra, float *out, int64_t count,
-                                  const float2 *tw, int num_cu, hipStream_t stream,
+                                  const float2 *tw, Context *ctx, hipStream_t stream,
                                   const int64_t *src_off = nullptr, const int64_t *dst_off = nullptr);
 hipError_t launch_imdct_fast_256(const float *spectra, float *out, int64_t count,
-                                 const float2 *tw, int num_cu, hipStream_t stream,
+                                 const float2 *tw, Context *ctx, hipStream_t stream,
                                  const int64_t *src_off = nullptr, const int64_t *dst_off = nullptr);
 // N = 4096; optional gather lists (float offsets of each block's spectrum / output) for the three-pass decoder path
-hipError_t launch_imdct_fast_4096(const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
+hipError_t launch_imdct_fast_4096(const float *spectra, float *out, int64_t count, const float2 *tw, Context *ctx,
                                   hipStream_t stream, const int64_t *src_off = nullptr, const int64_t *dst_off = nullptr);
-hipError_t launch_imdct_fast_8192(const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
+hipError_t launch_imdct_fast_8192(const float *spectra, float *out, int64_t count, const float2 *tw, Context *ctx,
                                   hipStream_t stream, const int64_t *src_off = nullptr, const int64_t *dst_off = nullptr);
-hipError_t launch_imdct_fast_mid(int n, const float *spectra, float *out, int64_t count, const float2 *tw, int num_cu,
+hipError_t launch_imdct_fast_mid(int n, const float *spectra, float *out, int64_t count, const float2 *tw, Context *ctx,
                                  hipStream_t stream, const int64_t *src_off = nullptr,
                                  const int64_t *dst_off = nullptr);  // n = 512 or 1024
 hipError_t launch_imdct_exact(int n, int ld, const float *spectra, float *out, int64_t count,

@@ -65,12 +65,14 @@ def lib():
         L.vpzh_decode_range.argtypes = [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int64, vp, vp, vp, vp,
                                         C.POINTER(C.c_int64)]
         L.vpzh_decode_range.restype = C.c_int
-        L.vpzh_decode_many.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp,
+        L.vpzh_decode_many.argtypes = [C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp,
                                        C.POINTER(C.c_int64)]
         L.vpzh_decode_many.restype = C.c_int
-        L.vpzh_decode_many_progress.argtypes = [C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int64, vp, vp, vp,
+        L.vpzh_decode_many_progress.argtypes = [C.c_int32, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp, C.c_int64, vp, vp, vp,
                                                 vp, C.POINTER(C.c_int64), vp]
         L.vpzh_decode_many_progress.restype = C.c_int
+        L.vpzh_default_threads.argtypes = []
+        L.vpzh_default_threads.restype = C.c_int
         L.vpzh_decode_failures.argtypes = [vp, C.POINTER(C.c_int64)]
         L.vpzh_decode_failures.restype = C.c_int64
         # VorbisReader mirror (include/vorbispizza_reader.h)
@@ -230,14 +232,17 @@ class OggVorbisFile:
 
 
 def decode_many(datas, packet_base, residue_base, packets, residue, posts, counts, threads=0, stream_id0=0, residue_origin=0,
-                packet_room=None, residue_room=None, done=None):
+                packet_room=None, residue_room=None, done=None, channels=None):
     """vpzh_decode_many: opens and entropy-decodes the containers `datas` (numpy uint8 arrays) on `threads` host threads of
     the library's own (no Python in the loop, the GIL is released for the whole call), stream k into packets[packet_base[k]:],
     residue[residue_base[k]:], posts / counts at record packet_base[k] * channels.  packet_room / residue_room: what each slice
     holds (default: up to the next stream's base, or the end of the array).  done (optional, zeroed int32 array of len(datas)):
     vpzh_decode_many_progress -- entry k turns 1 (-1: refused) when stream k is complete, so that another thread can hand
-    finished streams on while this call is still running.  Returns the number of packets that failed."""
+    finished streams on while this call is still running.  channels: what the batch arrays are laid out for (default: what
+    the shape of `posts` says); a container with another count is refused.  Returns the number of packets that failed."""
     n = len(datas)
+    if channels is None:
+        channels = max(1, posts.size // (64 * max(1, len(packets))))
     ptrs = (C.c_void_p * n)(*[d.ctypes.data for d in datas])
     sizes = (C.c_uint64 * n)(*[d.size for d in datas])
     pb = np.ascontiguousarray(packet_base, dtype=np.int64)
@@ -255,12 +260,12 @@ def decode_many(datas, packet_base, residue_base, packets, residue, posts, count
     failed = C.c_int64(0)
     if done is not None:
         assert done.dtype == np.int32 and done.size >= n and done.flags["C_CONTIGUOUS"]
-        rc = lib().vpzh_decode_many_progress(n, ptrs, sizes, int(threads), int(stream_id0), pb.ctypes.data, pr.ctypes.data,
+        rc = lib().vpzh_decode_many_progress(n, int(channels), ptrs, sizes, int(threads), int(stream_id0), pb.ctypes.data, pr.ctypes.data,
                                              rb.ctypes.data, rr.ctypes.data, int(residue_origin), packets.ctypes.data,
                                              residue.ctypes.data, posts.ctypes.data, counts.ctypes.data, C.byref(failed),
                                              done.ctypes.data)
     else:
-        rc = lib().vpzh_decode_many(n, ptrs, sizes, int(threads), int(stream_id0), pb.ctypes.data, pr.ctypes.data, rb.ctypes.data,
+        rc = lib().vpzh_decode_many(n, int(channels), ptrs, sizes, int(threads), int(stream_id0), pb.ctypes.data, pr.ctypes.data, rb.ctypes.data,
                                     rr.ctypes.data, int(residue_origin), packets.ctypes.data, residue.ctypes.data,
                                     posts.ctypes.data, counts.ctypes.data, C.byref(failed))
     if rc != 0:

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <sched.h>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -1468,26 +1469,37 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
     return VPZH_OK;
 }
 
-int vpzh_decode_many(int32_t n, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
+// Threads a call uses when the caller does not say: the cores this process may run on (its affinity mask, not the machine's
+// count), divided among the processes torchrun started on this node -- the rule of the synthesis library's host pool.
+int vpzh_default_threads(void)
+{
+    cpu_set_t set;
+    int n = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+    if (const char *lw = getenv("LOCAL_WORLD_SIZE")) n /= std::max(1, atoi(lw));
+    return std::max(1, n);
+}
+
+int vpzh_decode_many(int32_t n, int32_t channels, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
                      const int64_t *packet_base, const int64_t *packet_room, const int64_t *residue_base,
                      const int64_t *residue_room, int64_t residue_origin, vpz_packet *packets, float *residue, int16_t *posts,
                      uint8_t *post_counts, int64_t *failed_packets)
 {
-    return vpzh_decode_many_progress(n, data, size, threads, stream_id0, packet_base, packet_room, residue_base, residue_room,
+    return vpzh_decode_many_progress(n, channels, data, size, threads, stream_id0, packet_base, packet_room, residue_base, residue_room,
                                      residue_origin, packets, residue, posts, post_counts, failed_packets, nullptr);
 }
 
-int vpzh_decode_many_progress(int32_t n, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
+int vpzh_decode_many_progress(int32_t n, int32_t channels, const uint8_t *const *data, const uint64_t *size, int32_t threads, int32_t stream_id0,
                               const int64_t *packet_base, const int64_t *packet_room, const int64_t *residue_base,
                               const int64_t *residue_room, int64_t residue_origin, vpz_packet *packets, float *residue,
                               int16_t *posts, uint8_t *post_counts, int64_t *failed_packets, int32_t *done)
 {
-    if (n < 0 || (n > 0 && (!data || !size || !packet_base || !packet_room || !residue_base || !residue_room || !packets ||
-                            !residue || !posts || !post_counts)))
+    if (n < 0 || channels < 1 || channels > VPZ_MAX_CHANNELS ||
+        (n > 0 && (!data || !size || !packet_base || !packet_room || !residue_base || !residue_room || !packets || !residue ||
+                   !posts || !post_counts)))
         return VPZH_E_ARG;
     if (failed_packets) *failed_packets = 0;
     if (n == 0) return VPZH_OK;
-    int workers = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    int workers = threads > 0 ? threads : vpzh_default_threads();
     workers = std::max(1, std::min(workers, (int)n));
     std::atomic<int32_t> next{0};
     std::atomic<int64_t> failed{0};
@@ -1499,17 +1511,25 @@ int vpzh_decode_many_progress(int32_t n, const uint8_t *const *data, const uint6
             const int32_t k = next.fetch_add(1, std::memory_order_relaxed);
             if (k >= n) return;
             vpzh_stream *s = nullptr;
-            int rc = vpzh_open_memory(data[k], size[k], &s);
-            // (the slices were sized by the caller from a probe of the file: a container that holds more than its slice has
-            // room for is refused, nothing of it is written)
-            if (rc == VPZH_OK && ((int64_t)s->audio.size() > packet_room[k] || s->residue_floats > residue_room[k])) rc = VPZH_E_ARG;
-            if (rc == VPZH_OK) {
-                const size_t C = (size_t)s->channels;
-                const int64_t pb = packet_base[k];
-                rc = vpzh_decode_range_ex(s, 0, (int64_t)s->audio.size(), stream_id0 + k, residue_base[k] - residue_origin,
-                                          packets + pb, residue + residue_base[k], posts + (size_t)pb * 64 * C,
-                                          post_counts + (size_t)pb * C, nullptr, nullptr, nullptr, 0);
-                failed.fetch_add(s->decode_failures, std::memory_order_relaxed);
+            int rc = VPZH_E_ARG;
+            try {  // (a worker's exception -- bad_alloc -- must not end the process: it costs the stream)
+                rc = vpzh_open_memory(data[k], size[k], &s);
+                // (the slices were sized by the caller from a probe of the file: a container that holds more than its slice has
+                // room for is refused, nothing of it is written)
+                if (rc == VPZH_OK && ((int64_t)s->audio.size() > packet_room[k] || s->residue_floats > residue_room[k])) rc = VPZH_E_ARG;
+                // ... and so is one with another channel count than the batch was laid out for: its post records would land
+                // at packet_base * 64 * ITS channel count, beyond the records the caller sized (untrusted file contents)
+                if (rc == VPZH_OK && s->channels != channels) rc = VPZH_E_ARG;
+                if (rc == VPZH_OK) {
+                    const size_t C = (size_t)channels;
+                    const int64_t pb = packet_base[k];
+                    rc = vpzh_decode_range_ex(s, 0, (int64_t)s->audio.size(), stream_id0 + k, residue_base[k] - residue_origin,
+                                              packets + pb, residue + residue_base[k], posts + (size_t)pb * 64 * C,
+                                              post_counts + (size_t)pb * C, nullptr, nullptr, nullptr, 0);
+                    failed.fetch_add(s->decode_failures, std::memory_order_relaxed);
+                }
+            } catch (...) {
+                rc = VPZH_E_INVALID_DATA;
             }
             if (rc != VPZH_OK) status.store(rc, std::memory_order_relaxed);
             if (s) vpzh_close(s);
