@@ -59,17 +59,54 @@ def pmc_traffic_bytes(workload="headline"):
         return None
 
 
-def host_threads(cap=16):
-    """Host threads of ONE rank (CPU baseline, entropy-decode pool): the cores this process may run on, divided by the
-    ranks torchrun started on this node (LOCAL_WORLD_SIZE) -- eight ranks must not each claim the whole node, that would
-    oversubscribe exactly the end-to-end figure the 8-GPU run reports -- and never more than `cap`.  The C++ host pool
-    of the library divides the same way (vpz_decoder.hip, run_state_machine_parallel)."""
+HOST_THREADS_CAP = None  # --host-threads N: an explicit cap (none by default: every core the process may run on is used)
+
+
+def cpu_quota():
+    """CPUs' worth of CPU time the container may use (cgroup cpu.max / cfs quota), or None when there is no quota."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, -(-int(q) // int(p)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, -(-q // p))
+    except (OSError, ValueError):
+        return None
+
+
+def cores_available():
+    """CPUs this process may use: its affinity mask, capped by the container's CPU-time quota (a 256-core host that gives the
+    job 16 CPUs' worth shows 256 cores in the mask; more runnable threads than the quota only thrash inside it) -- what the
+    box gives the job, not what the machine has.  The library's pools count the same way (vpzh_default_threads)."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
-    return max(1, min(cap, n // local_world))
+    q = cpu_quota()
+    return min(n, q) if q else n
+
+
+def host_threads(whole_node=False):
+    """Host threads of ONE rank (CPU baselines, entropy-decode pool): the cores this process may run on, divided by the
+    ranks torchrun started on this node (LOCAL_WORLD_SIZE) -- eight ranks must not each claim the whole node, that would
+    oversubscribe exactly the end-to-end figure the 8-GPU run reports.  whole_node: the single-process legs, which run
+    while the other ranks wait at a barrier, take every core.  No silent cap (rounds 1-3 stopped at 16): --host-threads
+    sets one explicitly.  The library's own pools divide the same way (vpzh_default_threads)."""
+    n = cores_available()
+    local_world = 1 if whole_node else max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    n = max(1, n // local_world)
+    return min(n, HOST_THREADS_CAP) if HOST_THREADS_CAP else n
+
+
+def host_report(threads):
+    """What every CPU-side figure of the line says about the host it ran on (north_star: "core count stated")."""
+    return {"cores_available": cores_available(), "threads_used": threads, "cpu_quota": cpu_quota(),
+            "cores_in_affinity_mask": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "local_world_size": max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)),
+            "machine_cores": os.cpu_count()}
 
 
 def cpu_baseline_imdct(seconds_1thread=4.0, seconds_all=8.0):
@@ -112,11 +149,91 @@ def cpu_baseline_imdct(seconds_1thread=4.0, seconds_all=8.0):
     rate_all = blocks * (N // 2) / wall / 1e6
     return {
         "value": round(rate_all, 2), "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "cores_available": cores_available(), "threads_used": threads, "machine_cores": os.cpu_count(), "cpu_quota": cpu_quota(),
         "value_1thread": round(rate1, 2),
         "sample": "oracle Mdct.Reverse restatement (gcc -O2 -ffp-contract=off, scalar), N=2048: %d channel-blocks on "
                   "1 thread in %.1f s, then %d channel-blocks on %d threads in %.1f s"
                   % (r1[0][0], r1[0][1], blocks, threads, wall),
     }
+
+
+def cpu_baseline_fused(which, seconds=1.0, reps=3):
+    """The restated reference (oracle, C, scalar, Mdct tables warm) on the FUSED workloads, beside the GPU figures of
+    configs[2] / [3] / [4] and north_star's line: every thread pushes its own copy of a bounded sample of the workload through
+    oracle.FlooredStream (orc_synth_stream_floored: Residue2 de-interleave, inverse coupling, Floor1, IMDCT, window + overlap-add,
+    store) until its deadline; 1 thread and every core the rank may use, `reps` repetitions each, the median counts."""
+    import helpers
+    import oracle
+    from vorbispizza_amd import capi, make_packets
+    threads = host_threads()
+
+    def sample(i):
+        rng = np.random.default_rng(1000 + i)
+        if which in ("configs2", "north_star_line"):
+            frames = 1024
+            flags = helpers.markov_block_flags(frames, seed=3 + i)
+            if which == "north_star_line":
+                flags = np.full(frames, capi.PKT_BLOCK_FLAG | capi.PKT_PREV_FLAG | capi.PKT_NEXT_FLAG, dtype=np.uint8)
+            halves = np.where(flags & 1, 1024, 128).astype(np.int64)
+            pk = make_packets(frames)
+            pk["flags"] = flags | capi.PKT_NO_FLOOR
+            pk["granule"] = -1
+            pk["residue_offset"] = np.concatenate([[0], np.cumsum(halves * CHANNELS)[:-1]])
+            res = (rng.standard_normal(int((halves * CHANNELS).sum())) * 2.0 ** -8).astype(np.float32)
+            return [oracle.FlooredStream(CHANNELS, 256, 2048, pk, res, None, None)]
+        if which == "configs3":
+            frames, C6 = 192, 6
+            pk = make_packets(frames)
+            pk["flags"] = capi.PKT_BLOCK_FLAG | capi.PKT_PREV_FLAG | capi.PKT_NEXT_FLAG | capi.PKT_INTERLEAVED
+            pk["granule"] = -1
+            pk["residue_offset"] = np.arange(frames, dtype=np.int64) * (1024 * C6)
+            res = np.round(rng.standard_normal((frames, 1024, C6)) * 4.0).astype(np.float32)
+            res[:, FLOOR6_RESIDUE_END:, :] = 0
+            posts = np.zeros((frames * C6, 64), dtype=np.int16)
+            posts[:, 0] = rng.integers(20, 60, size=frames * C6)
+            posts[:, 1] = rng.integers(10, 40, size=frames * C6)
+            v = rng.integers(0, 10, size=(frames * C6, 27))
+            v[rng.random(v.shape) < 0.35] = 0
+            posts[:, 2:29] = v
+            counts = np.full(frames * C6, 29, dtype=np.uint8)
+            return [oracle.FlooredStream(C6, 256, 2048, pk, res.reshape(-1), posts, counts, floors=[(helpers.LONG_XLIST, 2)],
+                                         mappings=[{"coupling": [(0, 1), (2, 3)], "channel_floor": [0] * C6}])]
+        from vorbispizza_amd.front import OggVorbisFile
+        out = []
+        for name, _ in REAL_FIXTURES:  # configs[4]: the two real stereo fixtures, entropy-decoded by the front end
+            f = OggVorbisFile(os.path.join(ROOT, "tests", "golden", name))
+            pk, r, po, co = f.decode_packets()
+            out.append(oracle.FlooredStream(f.channels, f.block_size0, f.block_size1, pk, r, po, co, floors=f.floors, mappings=f.mappings))
+        return out
+
+    work = [sample(i) for i in range(threads)]
+
+    def worker(streams, deadline, result, idx):
+        done = 0
+        while time.perf_counter() < deadline:
+            for st in streams:
+                done += st.run() * st.channels
+        result[idx] = done
+
+    def rate(n_threads):
+        res = [0] * n_threads
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=worker, args=(work[i], t0 + seconds, res, i)) for i in range(n_threads)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        return sum(res) / (time.perf_counter() - t0) / 1e6
+
+    r1 = sorted(rate(1) for _ in range(reps))[reps // 2]
+    ra = sorted(rate(threads) for _ in range(reps))[reps // 2]
+    return {"Msamples_per_s_1thread": round(r1, 2), "Msamples_per_s_all_threads": round(ra, 2), "kind": "port",
+            "cores_available": cores_available(), "threads_used": threads, "repetitions": reps,
+            "sample": "oracle restatement (orc_synth_stream_floored, gcc -O2 -ffp-contract=off, scalar, Mdct tables warm), median of "
+                      "%d runs of %.1f s; per thread: %s" % (reps, seconds, {
+                          "configs2": "1024 frames of the mixed 256/2048 stereo sequence", "north_star_line": "1024 all-long stereo frames",
+                          "configs3": "192 frames of the 6-channel Residue2 + coupling + Floor1 workload",
+                          "configs4": "3test.ogg + issue6test.ogg, decoded spectra"}[which])}
 
 
 def build_synth_ola(torch, device, frames=FRAMES, all_long=False):
@@ -413,6 +530,130 @@ def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2, 
     return total, best
 
 
+def dispatcher_whole_job(torch, device_ids, threads, s16=False, repeats=3, streams=None, checksum=True):
+    """configs[4]'s whole job -- 1024 stereo streams, container bytes in host memory -> interleaved PCM in (page-locked) host
+    memory -- through the in-process multi-device dispatcher of libvorbispizza_host.so (include/vorbispizza_multi.h): ONE
+    process, one context group per entry of device_ids, streams partitioned contiguously (stream s plays fixture s % 2, as in
+    the per-process job), no collective.  Returns a dict for the bench line; the checksum is the per-process job's."""
+    from vorbispizza_amd import multi, sharding
+    streams = TOTAL_REAL_STREAMS if streams is None else streams
+    raws = [np.frombuffer(open(os.path.join(ROOT, "tests", "golden", name), "rb").read(), dtype=np.uint8) for name, _ in REAL_FIXTURES]
+    caps1 = [smp + 2048 for _, smp in REAL_FIXTURES]
+    datas = [raws[i % 2] for i in range(streams)]
+    caps = np.array([caps1[i % 2] for i in range(streams)], dtype=np.int64)
+    sizes = caps * 2
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    pcm = torch.empty(int(sizes.sum()), dtype=torch.int16 if s16 else torch.float32, pin_memory=True).numpy()
+    d = multi.Dispatcher(device_ids, host_threads=threads, streams_per_call=16, contexts_per_device=2)
+    best = None
+    try:
+        for _ in range(repeats):
+            results, stats = d.decode_library(datas, pcm, offs, caps, s16=s16)
+            assert (results["status"] == 0).all(), "dispatcher: a stream failed: %s" % d.last_error()
+            assert all(int(results["samples"][i]) == REAL_FIXTURES[i % 2][1] for i in range(streams)), "sample counts"
+            if best is None or stats.wall_s < best[0]:
+                n = len(device_ids)
+                best = (stats.wall_s, [round(stats.device_wall_s[g] * 1e3, 2) for g in range(min(n, 16))],
+                        [round(stats.device_decode_s[g] * 1e3, 2) for g in range(min(n, 16))],
+                        [round(stats.device_synth_s[g] * 1e3, 2) for g in range(min(n, 16))],
+                        [int(stats.device_streams[g]) for g in range(min(n, 16))], stats.threads_per_device)
+    finally:
+        d.close()
+    tot = int(results["samples"].sum()) * 2
+    out = {"Msamples_per_s": round(tot / best[0] / 1e6, 1), "wall_ms": round(best[0] * 1e3, 2), "devices": list(device_ids),
+           "per_device_ms": {"wall": best[1], "until_last_stream_entropy_decoded": best[2], "summed_synth_calls": best[3]},
+           "streams_per_device": best[4], "host": dict(host_report(threads), decode_threads_per_device=best[5]),
+           "pcm": "int16" if s16 else "float32", "collectives_on_the_data_path": 0, "samples_total": tot}
+    if checksum and not s16:
+        sums = []
+        for i in range(streams):
+            smp = int(results["samples"][i])
+            sums.append(int(pcm[offs[i]: offs[i] + smp * 2].view(np.int32).sum(dtype=np.int64)))
+        out["pcm_checksum"] = "%016x" % sharding.combine_stream_checksums(sums)
+    del pcm
+    return out
+
+
+def main_single_process(args):
+    """bench.py --gpus N --single-process: the alternative launcher -- ONE process, N devices, no torchrun, no
+    torch.distributed.  The contract workload (configs[1]) runs as N host threads, one vpz_context and one batch per device,
+    started together and timed from the first launch to the last completion (the in-process form of "barrier, K steps,
+    max over ranks"); the 1024-stream job runs through the in-process dispatcher.  Prints one JSON line of the same shape."""
+    import torch
+    import __graft_entry__ as ge
+    ge.build()
+    from vorbispizza_amd import Context, capi
+    n_dev = args.gpus
+    have = torch.cuda.device_count()
+    rehearsal = os.environ.get("VPZ_BENCH_REHEARSAL") == "1"  # every context on device 0 (a one-GPU box)
+    if n_dev > have and not rehearsal:
+        raise SystemExit("--gpus %d: only %d device(s) visible (VPZ_BENCH_REHEARSAL=1 puts every context on device 0)" % (n_dev, have))
+    ids = [0] * n_dev if rehearsal else list(range(n_dev))
+    count = FRAMES * CHANNELS
+    ctxs, ins, outs = [], [], []
+    for r, dev in enumerate(ids):
+        device = torch.device("cuda", dev)
+        g = torch.Generator(device=device).manual_seed(2048 + r)
+        ins.append(torch.randn((count, N // 2), generator=g, device=device, dtype=torch.float32) * 2.0 ** -8)
+        outs.append(torch.empty((count, N), device=device, dtype=torch.float32))
+        ctxs.append(Context(dev))
+    for dev in set(ids):
+        torch.cuda.synchronize(dev)
+    start = threading.Barrier(n_dev + 1)
+    done = threading.Barrier(n_dev + 1)
+    kernel_ms = [0.0] * n_dev
+
+    def lane(r):
+        for _ in range(args.warmup):
+            ctxs[r].imdct_batch(ins[r], N, capi.IMDCT_FAST, out=outs[r])
+        ctxs[r].synchronize()
+        start.wait()
+        ctxs[r].timer_start()
+        for _ in range(args.steps):
+            ctxs[r].imdct_batch(ins[r], N, capi.IMDCT_FAST, out=outs[r])
+        kernel_ms[r] = ctxs[r].timer_stop() / args.steps
+        ctxs[r].synchronize()
+        done.wait()
+
+    ths = [threading.Thread(target=lane, args=(r,)) for r in range(n_dev)]
+    for t in ths:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    done.wait()
+    elapsed = time.perf_counter() - t0
+    for t in ths:
+        t.join()
+    value = n_dev * count * (N // 2) * args.steps / elapsed / 1e6
+    alg_bytes = count * (4 * (N // 2) + 4 * N)
+    achieved = alg_bytes / (max(kernel_ms) * 1e-3) / 1e9
+    result = {
+        "metric": "decoded PCM Msamples/s (batched stereo N=2048)", "value": round(value, 1), "unit": "Msamples/s",
+        "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "launcher": "single process: one host thread + one vpz_context per device (bench.py --single-process)",
+        "config": {"workload": "BASELINE configs[1]: batched long-block IMDCT (Mdct.Reverse semantics), N=2048, 2 ch, "
+                               "65536 frames = 131072 channel-blocks per GPU, spectra N(0, 2^-8) device-resident",
+                   "channel_blocks_per_gpu": count, "block_size": N, "sharding": "independent batch per GPU, no collective",
+                   "devices": ids},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_bytes(), "kernel": "imdct2048_kernel",
+                     "kernel_ms": round(max(kernel_ms), 4), "kernel_ms_per_device": [round(k, 4) for k in kernel_ms],
+                     "algorithmic_bytes_per_launch": alg_bytes},
+    }
+    del ins, outs
+    for c in ctxs:
+        c.close()
+    torch.cuda.empty_cache()
+    if not args.no_extras:
+        thr = host_threads(whole_node=True)
+        result["extra_workloads"] = {
+            "configs[4] whole job in ONE process: 1024 real stereo streams through the in-process dispatcher "
+            "(vpzm_decode_library), %d device(s), float32 PCM" % n_dev: dispatcher_whole_job(torch, ids, thr),
+            "... with 16-bit PCM": dispatcher_whole_job(torch, ids, thr, s16=True)}
+    print(json.dumps(result))
+
+
 def cpu_plumbing_2test():
     """BASELINE configs[0]: TestFiles/2test.ogg decoded on the CPU only (front end + oracle)."""
     import helpers
@@ -457,6 +698,15 @@ def time_decoder(ctx, dec, torch, pk, residue, posts, counts, samples, channels,
         ctx.synchronize()
         dt = (time.perf_counter() - t0) / steps
         best = dt if best is None else min(best, dt)
+    # the GPU time of every call on its own (HIP events on the library's stream around ONE call): what the spread of a fixed
+    # batch is -- the run cutting must land on one cut for it, call after call
+    us = []
+    for _ in range(steps):
+        ctx.timer_start()
+        step()
+        us.append(ctx.timer_stop() * 1e3)
+    time_decoder.last_spread = {"kernel_us_min": round(min(us), 1), "kernel_us_mean": round(sum(us) / len(us), 1),
+                                "kernel_us_max": round(max(us), 1), "calls": len(us)}
     return best, out
 
 
@@ -469,7 +719,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras-frames", type=int, default=FRAMES, help="frames of the configs[2] side measurement")
     ap.add_argument("--extras-frames6", type=int, default=16384, help="frames of the configs[3] side measurement")
+    ap.add_argument("--host-threads", type=int, default=0, help="explicit cap on the host threads of a rank (default: every "
+                    "core the process may run on, divided by LOCAL_WORLD_SIZE)")
+    ap.add_argument("--single-process", action="store_true", help="alternative launcher: ONE process drives --gpus N devices "
+                    "(one host thread + one context per device, the in-process dispatcher for the 1024-stream job) instead of "
+                    "one process per GPU under torchrun")
     args = ap.parse_args()
+    global HOST_THREADS_CAP
+    HOST_THREADS_CAP = args.host_threads if args.host_threads > 0 else None
+    if args.single_process:
+        return main_single_process(args)
 
     import torch
     import __graft_entry__ as ge
@@ -575,7 +834,9 @@ def main():
                              "traffic": pmc_traffic_bytes("north_star_line") if args.extras_frames == FRAMES else None,
                              "kernel": "synth_dual_kernel<false, false, 0, false> (stereo fast path, no floor, planar in / out)",
                              "bytes_per_sample": round(byt / (samples * CHANNELS), 3)},
-                "note": "whole vpz_decoder_synth call incl. the host state machine; 8 B per sample; best of 3 loops of 40 calls"}
+                "gpu_time_per_call": time_decoder.last_spread,
+                "note": "whole vpz_decoder_synth call incl. the host state machine; 8 B per sample; best of 3 loops of 40 calls",
+                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_fused("north_star_line")}
             dec.close()
             del residue
             torch.cuda.empty_cache()
@@ -588,6 +849,8 @@ def main():
                 "Msamples_per_s": round(samples * CHANNELS / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes": byt, "traffic": pmc_traffic_bytes("configs2") if args.extras_frames == FRAMES else None,
+                "gpu_time_per_call": time_decoder.last_spread,
+                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_fused("configs2"),
                 "note": "whole vpz_decoder_synth call incl. the host state machine; best of 3 loops of 40 calls"}
             dec.close()
             del residue
@@ -606,6 +869,8 @@ def main():
                 "bytes_required_with_declared_support": byt_needed,
                 "required_GBps": round(byt_needed / dt / 1e9, 1),
                 "frac_of_8TBps_required_bytes": round(byt_needed / dt / 1e9 / HBM_PEAK_GBS, 4),
+                "gpu_time_per_call": time_decoder.last_spread,
+                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_fused("configs3"),
                 "note": "2 kernels (Floor1 unwrap; fused de-interleave + coupling + floor + IMDCT + OLA); whole call; "
                         "best of 3 loops of 40 calls.  The mapping declares the residue's support (ABI v4 residue_end = %d of "
                         "1024 bins): the upper half of every vector is neither loaded nor staged nor de-coupled; algorithmic_* "
@@ -634,6 +899,7 @@ def main():
                 "Msamples_per_s": round(tot / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
                 "algorithmic_GBps": round(8 * tot / dt / 1e9, 1), "frac_of_8TBps": round(8 * tot / dt / 1e9 / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes": 8 * tot, "traffic": pmc_traffic_bytes("configs4_share"),
+                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_fused("configs4"),
                 "cpu_entropy_decode_s_for_128_streams_1thread": round(t_front, 3),
                 "end_to_end_Msamples_per_s_incl_cpu_entropy_decode_1thread": round(tot / (dt + t_front) / 1e6, 2),
                 "note": "one decoder over both fixtures' setups (sharding.merge_setups); GPU stage = Floor1 unwrap + the stereo "
@@ -642,7 +908,7 @@ def main():
             tot_e, (t_all, t_dec, t_syn) = end_to_end_real_streams(ctx, torch, 64, thr)
             extras["configs[4] end to end, one GPU's share: 128 real stereo streams, container bytes in host memory "
                    "-> interleaved PCM in host memory"] = {
-                "Msamples_per_s": round(tot_e / t_all / 1e6, 1), "host_threads": thr,
+                "Msamples_per_s": round(tot_e / t_all / 1e6, 1), "host_threads": thr, "host": host_report(thr),
                 "cpu_open_and_entropy_decode_wall_ms": round(t_dec * 1e3, 2),
                 "synth_host_memory_calls_ms_incl_h2d_d2h": round(t_syn * 1e3, 2),
                 "note": "sub-batches of 16 streams on 2 contexts: synth calls overlap the entropy decode of later sub-batches "
@@ -698,13 +964,32 @@ def main():
                             "s16_end_to_end_wall": [round(r[3], 2) for r in rank_ms],
                             "s16_cpu_open_and_entropy_decode_wall": [round(r[4], 2) for r in rank_ms],
                             "s16_synth_host_memory_calls": [round(r[5], 2) for r in rank_ms]},
-            "host_threads_per_rank": thr, "samples_total": tot, "samples_per_rank": per_rank,
+            "host_threads_per_rank": thr, "host": host_report(thr), "samples_total": tot, "samples_per_rank": per_rank,
             "streams_per_rank": [sharding.shard_range(TOTAL_REAL_STREAMS, world, r)[1] -
                                  sharding.shard_range(TOTAL_REAL_STREAMS, world, r)[0] for r in range(world)],
             "pcm_checksum": "%016x" % job_sum, "checksum_equals_single_stream_decode": job_sum == expect,
             "scaling": "strong (1024 streams in total)", "collectives_on_the_data_path": 0,
             "note": "GPU stage: decoded spectra device-resident, best of 3 loops of 5 steps (barrier before, max over ranks after each); end to end: container "
                     "bytes in host memory -> PCM in host memory incl. CPU entropy decode, best of 3 per rank, max over ranks"}
+    if not args.no_extras:
+        # ---------------- the same job in ONE process: rank 0 drives all `world` devices through the in-process dispatcher
+        # (include/vorbispizza_multi.h) while the other ranks wait -- both launchers' curves from one driver run
+        if distributed:
+            sharding.barrier()
+        if rank == 0:
+            ids = [0] * world if rehearsal else list(range(world))
+            thr_all = host_threads(whole_node=True)
+            try:
+                one = dispatcher_whole_job(torch, ids, thr_all)
+                one16 = dispatcher_whole_job(torch, ids, thr_all, s16=True, checksum=False)
+                one["checksum_equals_the_per_process_job"] = one.get("pcm_checksum") == "%016x" % job_sum
+                extras["configs[4] whole job in ONE process: the in-process multi-device dispatcher (vpzm_decode_library), "
+                       "%d device(s), container bytes -> float32 PCM in host memory" % world] = one
+                extras["... with 16-bit PCM"] = one16
+            except Exception as e:  # (the leg is an extra: its failure must not cost the contract line)
+                extras["configs[4] whole job in ONE process: FAILED"] = repr(e)
+        if distributed:
+            sharding.barrier()
     if rank == 0 and extras:
         result["extra_workloads"] = extras
     ctx.close()

@@ -106,6 +106,8 @@ namespace NVorbis.Native
 
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_device_alloc(ContextHandle ctx, ulong bytes, out IntPtr devPtr);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_device_free(ContextHandle ctx, IntPtr devPtr);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_host_alloc(ContextHandle ctx, ulong bytes, out IntPtr hostPtr);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_host_free(ContextHandle ctx, IntPtr hostPtr);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_memcpy_h2d(ContextHandle ctx, IntPtr devDst, void* hostSrc, ulong bytes);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_memcpy_d2h(ContextHandle ctx, void* hostDst, IntPtr devSrc, ulong bytes);
 

@@ -101,7 +101,8 @@ int vpzh_decode_many(int32_t n, int32_t channels, const uint8_t *const *data, co
                      const int64_t *residue_room, int64_t residue_origin, vpz_packet *packets, float *residue, int16_t *posts,
                      uint8_t *post_counts, int64_t *failed_packets);
 
-/* The cores this process may run on (affinity mask) divided by LOCAL_WORLD_SIZE (processes per node under torchrun), >= 1. */
+/* The CPUs this process may use -- its affinity mask, capped by the container's CPU-time quota (cgroup cpu.max) -- divided by
+ * LOCAL_WORLD_SIZE (processes per node under torchrun), >= 1. */
 int vpzh_default_threads(void);
 
 /* The same with a progress report, for a caller that hands finished streams on (to vpz_decoder_synth) while the rest is still

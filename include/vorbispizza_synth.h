@@ -84,6 +84,10 @@ int vpz_context_timer_stop(vpz_context *ctx, float *elapsed_ms);
 /* Device memory helpers so a host without its own HIP binding can keep batches resident. */
 int vpz_device_alloc(vpz_context *ctx, uint64_t bytes, void **dev_ptr);
 int vpz_device_free(vpz_context *ctx, void *dev_ptr);
+/* Page-locked host memory (ABI v4): VPZ_MEM_HOST calls copy from / to it at the link's full rate and asynchronously; any
+ * other host memory works too, through the runtime's staging.  Usable from every context of the process. */
+int vpz_host_alloc(vpz_context *ctx, uint64_t bytes, void **host_ptr);
+int vpz_host_free(vpz_context *ctx, void *host_ptr);
 int vpz_memcpy_h2d(vpz_context *ctx, void *dev_dst, const void *host_src, uint64_t bytes);
 int vpz_memcpy_d2h(vpz_context *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
 

@@ -117,6 +117,10 @@ def lib():
         L.orc_synth_stream_planar.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long, u8p, f32p, f32p,
                                               C.c_long, C.c_int]
         L.orc_synth_stream_planar.restype = C.c_long
+        i64p, i16p = C.POINTER(C.c_int64), C.POINTER(C.c_int16)
+        L.orc_synth_stream_floored.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long, u8p, u8p, i64p, i64p, f32p,
+                                               C.POINTER(Floor1), i32p, u8p, u8p, i32p, i16p, u8p, f32p, C.c_long, C.c_int]
+        L.orc_synth_stream_floored.restype = C.c_long
         _lib = L
     return _lib
 
@@ -246,3 +250,54 @@ def synth_stream_planar(channels, size0, size1, flags, spectra, clip=False):
     if total < 0:
         raise RuntimeError("inconsistent window flags (StreamDecoder.cs:777-778 would throw)")
     return pcm[:, :total].copy()
+
+
+class FlooredStream:
+    """The arguments of orc_synth_stream_floored for ONE stream's packets in the batch-array form the C ABI takes
+    (packets: numpy record array with flags / mapping / granule / residue_offset; residue float32; posts int16 [records, 64];
+    counts uint8 [records]; floors [(x_list, multiplier)]; mappings [{"coupling": [(mag, ang)], "channel_floor": [...]}]).
+    run() pushes the packets through the restated Mapping.DecodePacket tail + StreamDecoder in C (Mdct tables warm) and
+    returns the samples per channel; .pcm holds them (planar).  bench.py's CPU baseline of the fused workloads calls run()
+    from several threads on separate instances (ctypes releases the GIL)."""
+
+    def __init__(self, channels, size0, size1, packets, residue, posts, counts, floors=(), mappings=(), clip=False):
+        self.channels, self.size0, self.size1, self.clip = channels, size0, size1, int(clip)
+        self.n = len(packets)
+        self.flags = np.ascontiguousarray(packets["flags"], dtype=np.uint8)
+        self.mapping = np.ascontiguousarray(packets["mapping"], dtype=np.uint8)
+        self.granule = np.ascontiguousarray(packets["granule"], dtype=np.int64)
+        self.offsets = np.ascontiguousarray(packets["residue_offset"], dtype=np.int64)
+        self.residue = np.ascontiguousarray(residue, dtype=np.float32)
+        recs = max(1, self.n * channels)
+        self.posts = np.zeros((recs, 64), dtype=np.int16) if posts is None else np.ascontiguousarray(posts, dtype=np.int16)
+        self.counts = np.zeros(recs, dtype=np.uint8) if counts is None else np.ascontiguousarray(counts, dtype=np.uint8)
+        fl = [floor1_init(x, m) for x, m in floors] or [floor1_init([0, 128], 1)]
+        self.floors = (Floor1 * len(fl))(*fl)
+        nm = max(1, len(mappings))
+        self.foc = np.zeros(nm * channels, dtype=np.int32)
+        mag, ang, off = [], [], [0]
+        for i, m in enumerate(mappings):
+            self.foc[i * channels:(i + 1) * channels] = m.get("channel_floor", [0] * channels)
+            for a, b in m.get("coupling", []):
+                mag.append(a)
+                ang.append(b)
+            off.append(len(mag))
+        while len(off) < nm + 1:
+            off.append(len(mag))
+        self.mag = np.array(mag or [0], dtype=np.uint8)
+        self.ang = np.array(ang or [0], dtype=np.uint8)
+        self.off = np.array(off, dtype=np.int32)
+        self.cap = self.n * (size1 // 2) + size1
+        self.pcm = np.zeros((channels, self.cap), dtype=np.float32)
+        self.total = 0
+
+    def run(self):
+        u8p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int)
+        i64p, i16p = C.POINTER(C.c_int64), C.POINTER(C.c_int16)
+        self.total = lib().orc_synth_stream_floored(
+            self.channels, self.size0, self.size1, self.n, self.flags.ctypes.data_as(u8p), self.mapping.ctypes.data_as(u8p),
+            self.granule.ctypes.data_as(i64p), self.offsets.ctypes.data_as(i64p), _fp(self.residue), self.floors,
+            self.foc.ctypes.data_as(i32p), self.mag.ctypes.data_as(u8p), self.ang.ctypes.data_as(u8p),
+            self.off.ctypes.data_as(i32p), self.posts.ctypes.data_as(i16p), self.counts.ctypes.data_as(u8p), _fp(self.pcm),
+            self.cap, self.clip)
+        return self.total

@@ -1048,3 +1048,81 @@ long orc_synth_stream_planar(int channels, int size0, int size1, long frames, co
     orc_stream_destroy(s);
     return total;
 }
+
+/* ------------------------------------------------------------------ a floored stream, packet by packet, in C
+ * bench.py's CPU baseline of the FUSED workloads (configs[2]/[3]/[4] of BASELINE.json): the packets of ONE stream as the
+ * CPU stage leaves them at Mapping.cs:163 go through Residue2's de-interleave (Residue2.cs:42-51), the tail of
+ * Mapping.DecodePacket (Mapping.cs:166-195: orc_apply_coupling in reverse step order, orc_floor1_apply + orc_mdct_reverse
+ * per channel, or a cleared half block for a silent one), ReadNextPacket / OverlapBuffers (StreamDecoder.cs:640-694, 764-791)
+ * and StoreContiguous, exactly as tests/helpers.py drives the same functions from Python -- with the Mdct tables warm
+ * (the reference caches them per block size, Mdct.cs:13,23-27; orc_mapping_synth builds them per call).
+ * flags[p]: bits 0..2 window flags, 0x08 EOS, 0x10 not decoded, 0x20 residue is the interleaved Residue2 vector,
+ * 0x40 already floored (no coupling, no floor).  Mapping m: floor of channel c = floor_of_channel[m * channels + c],
+ * coupling steps [coupling_off[m], coupling_off[m + 1]).  Returns samples per channel written (planar, pcm_stride). */
+long orc_synth_stream_floored(int channels, int size0, int size1, long n_packets, const uint8_t *flags,
+                              const uint8_t *mapping, const int64_t *granule, const int64_t *residue_offset,
+                              const float *residue, const orc_floor1 *floors, const int *floor_of_channel,
+                              const uint8_t *coupling_mag, const uint8_t *coupling_ang, const int *coupling_off,
+                              const int16_t *posts, const uint8_t *post_count, float *pcm, long pcm_stride, int clip)
+{
+    orc_stream *s = orc_stream_create(channels, size0, size1);
+    orc_mdct *m0 = orc_mdct_create(size0), *m1 = orc_mdct_create(size1);
+    float *buf2 = (float *)malloc(sizeof(float) * (size_t)size1);
+    int *ip = (int *)malloc(sizeof(int) * 64);
+    long p, total = 0;
+    int ch, i;
+    for (p = 0; p < n_packets; ++p) {
+        const int f = flags[p];
+        const int bf = f & 1, pf = (f >> 1) & 1, nf = (f >> 2) & 1, eos = (f >> 3) & 1;
+        const int bs = bf ? size1 : size0, half = bs / 2;
+        orc_packet_info info;
+        int avail;
+        if (f & 0x10) { /* DecodeNextPacket returned null (StreamDecoder.cs:758-761) */
+            orc_stream_read_next_packet(s, 0, NULL, -1, eos);
+            continue;
+        }
+        {
+            float *cur = orc_stream_next_buffer(s);
+            const float *src = residue + residue_offset[p];
+            const int m = mapping[p];
+            orc_get_packet_info(size0, size1, bf, pf, nf, &info);
+            for (ch = 0; ch < channels; ++ch) memset(cur + (size_t)ch * (size_t)size1, 0, sizeof(float) * (size_t)size1); /* Mapping.cs:117 */
+            if (f & 0x20) {
+                orc_residue2_deinterleave(src, half, channels, cur, size1);
+            } else {
+                for (ch = 0; ch < channels; ++ch)
+                    memcpy(cur + (size_t)ch * (size_t)size1, src + (size_t)ch * (size_t)half, sizeof(float) * (size_t)half);
+            }
+            if (f & 0x40) {
+                for (ch = 0; ch < channels; ++ch) orc_mdct_reverse(bf ? m1 : m0, cur + (size_t)ch * (size_t)size1, buf2);
+            } else {
+                for (i = coupling_off[m + 1] - 1; i >= coupling_off[m]; --i) /* Mapping.cs:166-172 */
+                    orc_apply_coupling(cur + (size_t)coupling_mag[i] * (size_t)size1, cur + (size_t)coupling_ang[i] * (size_t)size1, half, 1);
+                for (ch = 0; ch < channels; ++ch) { /* :180-195 */
+                    float *span = cur + (size_t)ch * (size_t)size1;
+                    const long rec = p * channels + ch;
+                    if (post_count[rec] > 0) {
+                        int k;
+                        for (k = 0; k < 64; ++k) ip[k] = posts[rec * 64 + k];
+                        orc_floor1_apply(&floors[floor_of_channel[m * channels + ch]], ip, post_count[rec], bs, span);
+                        orc_mdct_reverse(bf ? m1 : m0, span, buf2);
+                    } else {
+                        memset(span, 0, sizeof(float) * (size_t)half);
+                    }
+                }
+            }
+        }
+        if (orc_stream_read_next_packet(s, 1, &info, granule ? granule[p] : -1, eos) < 0) continue; /* :777-778 throws: that Read is lost */
+        avail = orc_stream_available(s);
+        if (avail > 0) {
+            orc_stream_store(s, pcm, total, avail, pcm_stride, 0, clip);
+            total += avail;
+        }
+    }
+    free(ip);
+    free(buf2);
+    orc_mdct_destroy(m0);
+    orc_mdct_destroy(m1);
+    orc_stream_destroy(s);
+    return total;
+}

@@ -146,6 +146,14 @@ int64_t orc_stream_position(const orc_stream *s);
 long orc_synth_stream_planar(int channels, int size0, int size1, long frames, const uint8_t *flags,
                              const float *spectra, float *pcm, long pcm_stride, int clip);
 
+/* One stream's packets through the restated Mapping.DecodePacket tail + StreamDecoder, in C, with the Mdct tables warm:
+ * bench.py's CPU baseline of the fused workloads.  See the definition for the argument layout. */
+long orc_synth_stream_floored(int channels, int size0, int size1, long n_packets, const uint8_t *flags,
+                              const uint8_t *mapping, const int64_t *granule, const int64_t *residue_offset,
+                              const float *residue, const orc_floor1 *floors, const int *floor_of_channel,
+                              const uint8_t *coupling_mag, const uint8_t *coupling_ang, const int *coupling_off,
+                              const int16_t *posts, const uint8_t *post_count, float *pcm, long pcm_stride, int clip);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,159 @@
+"""The in-process multi-device dispatcher (include/vorbispizza_multi.h, host/vorbis_multi.cpp): ONE process, one context
+group per device, streams partitioned contiguously, no collective (VorbisReader.cs:56-85: one reader,
+N independent StreamDecoders).  On a one-GPU box the N-device path is exercised with N groups on device 0: the PCM must be
+bit-equal to what one group produces and to the stream-by-stream decode, whatever the partition."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import __graft_entry__ as ge
+    ge.build()
+    from vorbispizza_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def single_stream_pcm(ctx, raw, s16=False):
+    """interleaved PCM of one container through the plain ABI: front end + one decoder + one synth call"""
+    from vorbispizza_amd import Decoder, capi
+    from vorbispizza_amd.front import OggVorbisFile
+    f = OggVorbisFile(raw)
+    pk, res, posts, counts = f.decode_packets()
+    dec = Decoder(ctx, f.channels, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings)
+    if f.floor0_data is not None:
+        dec.set_floor0_data(*f.floor0_data)
+    out = dec.synth(pk, res, posts, counts, out_layout=capi.OUT_INTERLEAVED_S16 if s16 else capi.OUT_INTERLEAVED,
+                    on_mismatch="ignore")[0]
+    dec.close()
+    return out
+
+
+def library(kinds, n):
+    raws = [open(os.path.join(GOLDEN, k), "rb").read() for k in kinds]
+    return [raws[i % len(raws)] for i in range(n)]
+
+
+def run_dispatcher(device_ids, raws, s16=False, capacity_slack=2048, **opt):
+    from vorbispizza_amd import multi
+    from vorbispizza_amd.front import OggVorbisFile
+    infos = {}
+    for r in set(raws):
+        f = OggVorbisFile(r)
+        infos[r] = (f.channels, int(f.total_samples))
+    caps = np.array([infos[r][1] + capacity_slack for r in raws], dtype=np.int64)
+    sizes = np.array([c * infos[r][0] for c, r in zip(caps, raws)], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    pcm = np.full(int(sizes.sum()), 7, dtype=np.int16) if s16 else np.full(int(sizes.sum()), np.float32(7.0), dtype=np.float32)
+    datas = [np.frombuffer(r, dtype=np.uint8) for r in raws]
+    d = multi.Dispatcher(device_ids, **opt)
+    try:
+        results, stats = d.decode_library(datas, pcm, offs, caps, s16=s16)
+    finally:
+        d.close()
+    return pcm, offs, results, stats, infos
+
+
+@pytest.mark.parametrize("groups", [1, 2, 4])
+@pytest.mark.parametrize("s16", [False, True])
+def test_partitioned_library_equals_the_stream_by_stream_decode(ctx, groups, s16):
+    raws = library(("3test.ogg", "issue6test.ogg", "2test.ogg", "1test.ogg"), 22)
+    pcm, offs, results, stats, infos = run_dispatcher([0] * groups, raws, s16=s16, host_threads=6, streams_per_call=4)
+    refs = {r: single_stream_pcm(ctx, r, s16=s16) for r in set(raws)}
+    for k, r in enumerate(raws):
+        ref = refs[r]
+        C_ = infos[r][0]
+        assert results["status"][k] == 0 and results["channels"][k] == C_
+        assert results["samples"][k] == ref.shape[0] <= infos[r][1]  # (issue6test.ogg's last packet is skipped: 63 samples short)
+        got = pcm[offs[k]: offs[k] + ref.shape[0] * C_].reshape(-1, C_)
+        assert np.array_equal(got.view(np.uint16 if s16 else np.uint32), ref.view(np.uint16 if s16 else np.uint32)), (k, groups)
+        # stream k -> group k * groups / n (shard_range)
+        lo = [len(raws) * g // groups for g in range(groups + 1)]
+        assert lo[results["device_slot"][k]] <= k < lo[results["device_slot"][k] + 1]
+    assert sum(stats.device_streams[g] for g in range(groups)) == len(raws)
+    assert sum(stats.device_samples[g] for g in range(groups)) == sum(int(results["samples"][k]) * infos[r][0] for k, r in enumerate(raws))
+    assert stats.wall_s > 0 and all(stats.device_wall_s[g] > 0 for g in range(groups))
+    # issue6test.ogg's trailing packet fails the window check (StreamDecoder.cs:777-778): a per-stream count, not a failure
+    name = open(os.path.join(GOLDEN, "issue6test.ogg"), "rb").read()
+    assert all(results["skipped_packets"][k] == (1 if r == name else 0) for k, r in enumerate(raws))
+
+
+def test_partition_does_not_change_a_single_bit(ctx):
+    """... and the whole PCM array of the job is the same for 1, 2, 3 and 5 groups, any sub-batch size, any thread count."""
+    raws = library(("3test.ogg", "issue6test.ogg"), 17)
+    base = run_dispatcher([0], raws, host_threads=4, streams_per_call=16)
+    for groups, spc, thr, ctxs in ((2, 3, 2, 1), (3, 16, 8, 2), (5, 1, 3, 3)):
+        other = run_dispatcher([0] * groups, raws, host_threads=thr, streams_per_call=spc, contexts_per_device=ctxs)
+        assert np.array_equal(base[0].view(np.uint32), other[0].view(np.uint32)), (groups, spc)
+        assert np.array_equal(base[2]["samples"], other[2]["samples"])
+
+
+def test_a_bad_container_or_a_small_area_costs_only_its_stream(ctx):
+    from vorbispizza_amd import multi
+    good = open(os.path.join(GOLDEN, "3test.ogg"), "rb").read()
+    raws = [good, b"not an ogg file at all" * 10, good, good[: len(good) // 3], good]
+    from vorbispizza_amd.front import OggVorbisFile
+    f = OggVorbisFile(good)
+    n_s, C_ = int(f.total_samples), f.channels
+    caps = np.array([n_s + 64, n_s + 64, 1000, n_s + 64, n_s + 64], dtype=np.int64)  # stream 2: area too small
+    offs = (np.arange(5, dtype=np.int64) * (n_s + 64) * C_)
+    pcm = np.zeros(int(5 * (n_s + 64) * C_), dtype=np.float32)
+    d = multi.Dispatcher([0, 0], host_threads=3, streams_per_call=2)
+    results, _ = d.decode_library([np.frombuffer(r, dtype=np.uint8) for r in raws], pcm, offs, caps)
+    d.close()
+    assert results["status"][0] == 0 and results["status"][4] == 0
+    assert results["status"][1] == multi.E_OPEN
+    assert results["status"][2] == multi.E_CAPACITY
+    ref = single_stream_pcm(ctx, good)
+    for k in (0, 4):
+        assert results["samples"][k] == ref.shape[0]
+        assert np.array_equal(pcm[offs[k]: offs[k] + ref.size].view(np.uint32), ref.reshape(-1).view(np.uint32))
+    # the truncated file is a valid prefix: it decodes to fewer samples (or fails to open) -- never touches its neighbours
+    assert results["status"][3] in (0, multi.E_OPEN) and results["samples"][3] < n_s
+    assert not pcm[offs[1]: offs[1] + 100].any() and not pcm[offs[2]: offs[2] + 100].any()
+
+
+def test_streams_with_different_channel_counts_and_floor_types_in_one_library(ctx):
+    import synthetic_streams as ss
+    raws = []
+    for name in ("stereo_floor0", "six_channels_51", "mono_floor1_res1", "three_channels_two_submaps"):
+        stream, rng = ss.ALL[name]()
+        ogg, _ = stream.build(rng, 30)
+        raws.append(bytes(ogg))
+    raws = raws + [open(os.path.join(GOLDEN, "3test.ogg"), "rb").read()] + raws
+    pcm, offs, results, stats, infos = run_dispatcher([0, 0, 0], raws, host_threads=4, streams_per_call=2)
+    for k, r in enumerate(raws):
+        ref = single_stream_pcm(ctx, r)
+        C_ = infos[r][0]
+        assert results["status"][k] == 0 and results["samples"][k] == ref.shape[0], k
+        got = pcm[offs[k]: offs[k] + ref.shape[0] * C_].reshape(-1, C_)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), k
+
+
+def test_a_dispatcher_is_reusable_and_says_what_it_is(ctx):
+    from vorbispizza_amd import multi
+    raws = library(("3test.ogg",), 5)
+    from vorbispizza_amd.front import OggVorbisFile
+    f = OggVorbisFile(raws[0])
+    n_s, C_ = int(f.total_samples), f.channels
+    d = multi.Dispatcher([0, 0], host_threads=2, streams_per_call=2)
+    assert multi.lib().vpzm_device_count(d._h) == 2
+    outs = []
+    for _ in range(3):
+        pcm = np.zeros(5 * (n_s + 8) * C_, dtype=np.float32)
+        res, _ = d.decode_library([np.frombuffer(r, dtype=np.uint8) for r in raws], pcm, np.arange(5, dtype=np.int64) * (n_s + 8) * C_,
+                                  np.full(5, n_s + 8, dtype=np.int64))
+        assert (res["status"] == 0).all()
+        outs.append(pcm)
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)) and np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))
+    d.close()
+    with pytest.raises(multi.MultiError):
+        multi.Dispatcher([99])  # no such device

@@ -1,4 +1,5 @@
 """CPU checks of the oracle's stream driver used by the GPU parity tests (tests/helpers.py)."""
+import os
 import numpy as np
 
 import helpers
@@ -67,3 +68,23 @@ def test_floor_and_coupling_driver_runs(oracle):
         posts, counts = helpers.random_posts(rng, helpers.LONG_XLIST, 2, 1)
         fy, _ = oracle.floor1_unwrap(f1, posts[0], int(counts[0]))
         assert fy[:29].min() >= 0 and fy[:29].max() * 2 <= 255
+
+
+def test_the_c_stream_driver_equals_the_packet_by_packet_drive(oracle):
+    """oracle.FlooredStream (orc_synth_stream_floored: one stream's packets through the restated Mapping.DecodePacket tail +
+    StreamDecoder in C, what bench.py's CPU baselines of the fused workloads time) gives the bits of helpers.oracle_decode,
+    which drives the same restated functions packet by packet: on the reference's stereo and mono fixtures (Residue2 vector,
+    coupling, EOS trim, the skipped trailing packet of issue6test.ogg) and on a synthetic 6-channel stream."""
+    import synthetic_streams as ss
+    from vorbispizza_amd.front import OggVorbisFile
+    cases = [open(os.path.join(os.path.dirname(__file__), "golden", n), "rb").read() for n in ("3test.ogg", "issue6test.ogg", "2test.ogg")]
+    stream, rng = ss.ALL["six_channels_51"]()
+    cases.append(bytes(stream.build(rng, 24)[0]))
+    for raw in cases:
+        f = OggVorbisFile(raw)
+        pk, res, posts, counts = f.decode_packets()
+        ref, _, _ = helpers.oracle_decode(oracle, f.channels, f.block_size0, f.block_size1,
+                                          helpers.packets_for_oracle(f, pk, res, posts, counts), floors=f.floors, mappings=f.mappings)
+        fs = oracle.FlooredStream(f.channels, f.block_size0, f.block_size1, pk, res, posts, counts, floors=f.floors, mappings=f.mappings)
+        assert fs.run() == ref.shape[1] > 0
+        assert np.array_equal(fs.pcm[:, :fs.total].view(np.uint32), ref.view(np.uint32))

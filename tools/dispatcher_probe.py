@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""The 1024-stream job through the in-process dispatcher under several thread / slot / sub-batch settings (one GPU, N groups)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import bench
+from vorbispizza_amd import multi
+streams = int(os.environ.get("STREAMS", "1024"))
+raws = [np.frombuffer(open(os.path.join(ROOT, "tests", "golden", n), "rb").read(), dtype=np.uint8) for n, _ in bench.REAL_FIXTURES]
+caps1 = [smp + 2048 for _, smp in bench.REAL_FIXTURES]
+datas = [raws[i % 2] for i in range(streams)]
+caps = np.array([caps1[i % 2] for i in range(streams)], dtype=np.int64)
+offs = np.concatenate([[0], np.cumsum(caps * 2)[:-1]]).astype(np.int64)
+for s16 in (False, True):
+    pcm = torch.empty(int((caps * 2).sum()), dtype=torch.int16 if s16 else torch.float32, pin_memory=True).numpy()
+    for groups, thr, spc, ctxs, slots in [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]:
+        d = multi.Dispatcher([0] * groups, host_threads=thr, streams_per_call=spc, contexts_per_device=ctxs, slots_per_device=slots)
+        best = None
+        for _ in range(3):
+            res, st = d.decode_library(datas, pcm, offs, caps, s16=s16)
+            assert (res["status"] == 0).all()
+            if best is None or st.wall_s < best[0]:
+                best = (st.wall_s, st.device_decode_s[0], st.device_synth_s[0])
+        d.close()
+        tot = int(res["samples"].sum()) * 2
+        print("%s groups %d threads %3d streams/call %2d contexts %d slots %d: %.1f ms = %.2f Gsamples/s (decode until %.1f, synth sum %.1f)"
+              % ("s16" if s16 else "f32", groups, thr, spc, ctxs, slots, best[0] * 1e3, tot / best[0] / 1e9, best[1] * 1e3, best[2] * 1e3), flush=True)
+    del pcm

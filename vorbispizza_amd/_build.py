@@ -25,7 +25,7 @@ SOURCES = {
     "vpz_decoder.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-          "-fno-strict-aliasing"]
+          "-Wno-constant-logical-operand", "-fno-strict-aliasing"]
 
 
 def _hipcc():
@@ -52,14 +52,15 @@ def build_host(force=False, verbose=False):
     """Compile the C++ host side with g++: the CPU front end (Ogg + Vorbis setup + entropy decode) and
     the VorbisReader / StreamDecoder.Read mirror, which calls the C ABI of libvorbispizza_synth.so."""
     os.makedirs(LIB_DIR, exist_ok=True)
-    srcs = [os.path.join(HOST_DIR, "vorbis_front.cpp"), os.path.join(HOST_DIR, "vorbis_reader.cpp")]
+    srcs = [os.path.join(HOST_DIR, "vorbis_front.cpp"), os.path.join(HOST_DIR, "vorbis_reader.cpp"),
+            os.path.join(HOST_DIR, "vorbis_multi.cpp")]
     inc = os.path.join(_HERE, "..", "include")
     deps = srcs + [os.path.join(inc, "vorbispizza_front.h"), os.path.join(inc, "vorbispizza_reader.h"),
-                   os.path.join(inc, "vorbispizza_synth.h"), LIB_PATH]
+                   os.path.join(inc, "vorbispizza_multi.h"), os.path.join(inc, "vorbispizza_synth.h"), LIB_PATH]
     stale = force or not os.path.exists(HOST_LIB_PATH) or any(
         os.path.exists(d) and os.path.getmtime(d) > os.path.getmtime(HOST_LIB_PATH) for d in deps)
     if stale:
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-pthread",
                "-o", HOST_LIB_PATH] + srcs + ["-L" + LIB_DIR, "-lvorbispizza_synth", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -71,6 +71,8 @@ _SIGNATURES = [
     ("vpz_context_timer_stop", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("vpz_device_alloc", C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
     ("vpz_device_free", C.c_int, [_vp, _vp]),
+    ("vpz_host_alloc", C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
+    ("vpz_host_free", C.c_int, [_vp, _vp]),
     ("vpz_memcpy_h2d", C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     ("vpz_memcpy_d2h", C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     ("vpz_imdct_batch", C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, C.c_int, C.c_int]),

@@ -330,6 +330,27 @@ int vpz_device_alloc(vpz_context *c, uint64_t bytes, void **dev_ptr)
     return VPZ_OK;
 }
 
+// page-locked host memory: what a host-memory synth call copies from / to at the link's full rate (pageable memory goes
+// through the runtime's own staging buffers)
+int vpz_host_alloc(vpz_context *c, uint64_t bytes, void **host_ptr)
+{
+    if (!c || !host_ptr) return VPZ_E_INVALID_ARG;
+    *host_ptr = nullptr;
+    VPZ_HIP_TRY(&c->impl, hipSetDevice(c->impl.device));
+    hipError_t e = hipHostMalloc(host_ptr, bytes ? bytes : 1, hipHostMallocPortable);
+    if (e != hipSuccess) return vpz::set_error(&c->impl, VPZ_E_NOMEM, "hipHostMalloc", e);
+    return VPZ_OK;
+}
+
+int vpz_host_free(vpz_context *c, void *host_ptr)
+{
+    if (!c) return VPZ_E_INVALID_ARG;
+    if (!host_ptr) return VPZ_OK;
+    VPZ_HIP_TRY(&c->impl, hipSetDevice(c->impl.device));
+    VPZ_HIP_TRY(&c->impl, hipHostFree(host_ptr));
+    return VPZ_OK;
+}
+
 int vpz_device_free(vpz_context *c, void *dev_ptr)
 {
     if (!c) return VPZ_E_INVALID_ARG;

@@ -1495,6 +1495,11 @@ struct SynthCall {
             return;
         }
         if (batches && !reuse) D.cut_hint_runs = (int64_t)n_runs;
+        if (getenv("VPZ_HOST_PROFILE"))
+            fprintf(stderr, "[vpz host] cut: %s, by %s, R %d, target %lld eighths, %zu runs for %lld slots, %d segments on %d threads, heavy below %lld, "
+                            "hint (frames %lld, runs %lld)\n", reuse ? "hint reused" : "fitted", batches ? "cost" : "length", R,
+                    (long long)target_units, n_runs, (long long)run_slots, n_segs, parties, (long long)heavy_work,
+                    (long long)D.cut_hint_frames, (long long)D.cut_hint_runs);
     }
 
     // coupling packets: de-interleave + inverse coupling into a planar temp laid out in frame order

@@ -1475,6 +1475,22 @@ int vpzh_default_threads(void)
 {
     cpu_set_t set;
     int n = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+    // ... of which a container may be allowed less CPU TIME than its affinity mask shows cores (cgroup quota: a 256-core
+    // host that gives the job 16 CPUs' worth -- 256 runnable threads would only thrash inside that share)
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(h, "%lld", &period) != 1) period = 0;
+            fclose(h);
+        }
+    }
+    if (quota > 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
     if (const char *lw = getenv("LOCAL_WORLD_SIZE")) n /= std::max(1, atoi(lw));
     return std::max(1, n);
 }
