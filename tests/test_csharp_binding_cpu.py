@@ -31,7 +31,7 @@ def c_kind(decl):
     base = [t for t in base if t]
     ty = base[0] if len(base) == 1 else " ".join(base[:-1])  # drop the parameter name
     return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "float": "f32", "void": "void",
-            "uint8_t": "u8", "uint16_t": "u16", "int16_t": "i16"}[ty]
+            "uint8_t": "u8", "uint16_t": "u16", "int16_t": "i16", "double": "f64"}[ty]
 
 
 def cs_kind(decl):
@@ -45,7 +45,7 @@ def cs_kind(decl):
     if ty in ("IntPtr", "ContextHandle", "DecoderHandle"):
         return "ptr"
     return {"int": "i32", "long": "i64", "ulong": "u64", "float": "f32", "void": "void", "byte": "u8", "short": "i16",
-            "ushort": "u16"}[ty]
+            "ushort": "u16", "double": "f64"}[ty]
 
 
 def c_functions(header, prefix):
@@ -208,3 +208,42 @@ def test_batch_class_passes_extents_and_reads_the_per_packet_status():
     assert len([a for a in call.split(",")]) == 15
     assert "_residueUsed" in call and "_count * _channels" in call
     assert "vpz_decoder_last_packet_status" in text and "EWindowMismatch" not in text
+
+
+def test_the_multi_device_binding_matches_its_header():
+    """bindings/csharp/VorbisPizzaMulti.cs against include/vorbispizza_multi.h: every DllImport, struct and status."""
+    c = c_functions("vorbispizza_multi.h", "vpzm_")
+    path = os.path.join(CS, "VorbisPizzaMulti.cs")
+    cs = {}
+    text = strip_cs_comments(open(path).read()).replace("DispatcherHandle", "IntPtr")
+    pat = r"\[DllImport\((\w+)[^\]]*\)\]\s*(?:public|private|internal)?\s*static\s+extern\s+([\w\*]+)\s+(\w+)\s*\(([^;]*?)\)\s*;"
+    for m in re.finditer(pat, text, flags=re.S):
+        lib, ret, name, args = m.group(1), m.group(2), m.group(3), " ".join(m.group(4).split())
+        params = [] if not args else [a.strip() for a in args.split(",")]
+        cs[name] = (lib, cs_kind(ret + " x"), [cs_kind(p) for p in params])
+    assert sorted(cs) == sorted(c) and len(c) == 5
+    for name, (ret, params) in c.items():
+        lib, cs_ret, cs_params = cs[name]
+        assert lib == "Host" and cs_params == params and cs_ret == ret, (name, (ret, params), (cs_ret, cs_params))
+    assert re.search(r'Host\s*=\s*"vorbispizza_host"', open(path).read())
+    cstructs, defines = c_structs("vorbispizza_multi.h")
+    css = cs_structs_with_doubles(path)
+    pairs = {"vpzm_options": "Options", "vpzm_stream_result": "StreamResult", "vpzm_stats": "Stats"}
+    assert sorted(cstructs) == sorted(pairs)
+    for cname, csname in pairs.items():
+        cf, sf = cstructs[cname], css[csname]
+        assert len(cf) == len(sf), (cname, cf, sf)
+        for (n0, k0, a0), (n1, k1, a1) in zip(cf, sf):
+            assert norm(n0) == norm(n1) and k0 == k1 and a0 == a1, (cname, (n0, k0, a0), (n1, k1, a1))
+    consts = {}
+    for m in re.finditer(r"public\s+const\s+int\s+([^;]+);", strip_cs_comments(open(path).read())):
+        for part in m.group(1).split(","):
+            k, v = part.split("=")
+            consts[norm(k.strip())] = int(v.strip(), 0)
+    for name, value in defines.items():
+        if name.startswith("VPZM_"):
+            assert consts[norm(name[5:])] == value, name
+
+
+def cs_structs_with_doubles(path):
+    return cs_structs(path)

@@ -157,8 +157,12 @@ def main():
     ap.add_argument("-o", "--out")
     ap.add_argument("--tmp", default="/tmp/vpz_isa")
     ap.add_argument("--dump-loop", help="write the annotated hot path of the loop to this file")
+    ap.add_argument("--csrc", help="another copy of vorbispizza_amd/csrc to analyse (an older commit's sources, with the cold marks added)")
     args = ap.parse_args()
     unit, kernel = PRESETS[args.preset] if args.preset else (args.unit, args.kernel)
+    global CSRC
+    if args.csrc:
+        CSRC = os.path.abspath(args.csrc)
     os.makedirs(args.tmp, exist_ok=True)
     asm = compile_asm(unit, args.tmp)
     text = open(asm).read().split("\n")
