@@ -4,9 +4,17 @@
 #pragma once
 
 #include <cstdint>
+#include <type_traits>
 
 #include "imdct_core.hpp"
 #include "synth_desc.hpp"
+
+// pointers that are GLOBAL by construction (the host pass of hipcc only parses the kernels: no address spaces there)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VPZ_GLOBAL __attribute__((address_space(1)))
+#else
+#define VPZ_GLOBAL
+#endif
 
 namespace vpz {
 
@@ -350,7 +358,6 @@ __device__ __forceinline__ uint32_t pack_s16(float lo, float hi)
 // PCM leaves through pointers that are GLOBAL by construction.  The output base travels through scalar registers as two
 // integers (see out_base), which costs the compiler its knowledge of the address space: it would emit FLAT stores --
 // slower, and counted by the LDS wait counter as well.  Every PCM store goes through one of these.
-#define VPZ_GLOBAL __attribute__((address_space(1)))
 typedef uint32_t vpz_u4v __attribute__((ext_vector_type(4)));
 typedef uint32_t vpz_u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_nt(uint2 *p, uint32_t a, uint32_t b)
@@ -496,9 +503,12 @@ __device__ __forceinline__ void build_block(uint32_t fd_flags, int lane, float2 
 
 // this wave's channel of a planar packet: (X[2k], X[2k+1]) for the lane's 8 points (global memory or an LDS row)
 // upper == false: the upper half of the row was not staged (ABI v4: beyond the residue's support) -- its points are +0.0
-__device__ __forceinline__ void load_spectrum(float2 (&x)[8], const float *base, int lpb, int lane, bool upper = true)
+// (P: a pointer to float in whatever address space the caller knows it to be in -- an LDS row, or global memory)
+template <class P>
+__device__ __forceinline__ void load_spectrum(float2 (&x)[8], P base, int lpb, int lane, bool upper = true)
 {
-    const float2 *s = reinterpret_cast<const float2 *>(base);
+    using F2 = std::conditional_t<std::is_same<P, const VPZ_GLOBAL float *>::value, const VPZ_GLOBAL float2 *, const float2 *>;
+    F2 s = reinterpret_cast<F2>(base);
     const int k0 = lane & (lpb - 1);
     const int st = lpb;
 #pragma unroll

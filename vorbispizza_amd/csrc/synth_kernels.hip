@@ -354,10 +354,10 @@ __global__ __launch_bounds__(64 * kRenderWaves) void floor1_render_kernel(int n_
 // The loads are UNCONDITIONAL (pieces past the end re-read the last one; staging drops them): a load under a lane
 // condition needs a select on its result, and that select would make the wave wait for the data right here --
 // which is the one place where it must not.
-__device__ __forceinline__ void load_group_share(float2 (&x)[8], const float *src, int first, int step, int limit,
+__device__ __forceinline__ void load_group_share(float2 (&x)[8], const VPZ_GLOBAL float *src, int first, int step, int limit,
                                                  int lane)
 {
-    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    const VPZ_GLOBAL float4 *s4 = reinterpret_cast<const VPZ_GLOBAL float4 *>(src);
     asm volatile("" : "+v"(lane));  // the piece numbers are frame-invariant: keep them out of long-lived registers
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -676,19 +676,48 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     __syncthreads();
     if (!kSync && !active) return;  // (the lock-step variants keep idle waves around for their barriers)
 
-    const int half1 = a.size1 >> 1;
+    // The scalars the frame loop needs, read from the kernel arguments ONCE and parked in the lanes of a vector register:
+    // left as `a.x`, the compiler re-loads them from the argument segment inside the loop wherever it is short of scalar
+    // registers -- a scalar load per use, each followed by an `s_waitcnt lgkmcnt(0)` that drains the wave's LDS queue as well
+    // (round 3: 125 scalar loads per wave of this kernel, profiles/r3_isa_group.txt).  A lane of an opaque register comes
+    // back with one v_readlane_b32 and no wait.  Pointers come back as GLOBAL pointers (a pointer rebuilt from two integers
+    // has lost its address space: loads through it would be FLAT loads).
+    int kv = 0;
+    {
+        const unsigned long long ps = reinterpret_cast<unsigned long long>(a.spec), pi = reinterpret_cast<unsigned long long>(a.inv_db),
+                                 pc = reinterpret_cast<unsigned long long>(a.cposts), cs = (unsigned long long)a.channel_stride;
+        const int vals[14] = {a.size0, a.size1, a.clip, a.max_steps, a.channels, a.ccount == nullptr ? 1 : 0, (int)(unsigned)ps, (int)(unsigned)(ps >> 32),
+                              (int)(unsigned)pi, (int)(unsigned)(pi >> 32), (int)(unsigned)pc, (int)(unsigned)(pc >> 32), (int)(unsigned)cs, (int)(unsigned)(cs >> 32)};
+#pragma unroll
+        for (int i = 0; i < 14; ++i) kv = (int)(threadIdx.x & 63) == i ? vals[i] : kv;
+        asm volatile("" : "+v"(kv));
+    }
+    auto parked64 = [&](int i) -> unsigned long long {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(kv, i + 1) << 32) | (unsigned)__builtin_amdgcn_readlane(kv, i);
+    };
+#define k_size0 __builtin_amdgcn_readlane(kv, 0)
+#define k_size1 __builtin_amdgcn_readlane(kv, 1)
+#define k_clip __builtin_amdgcn_readlane(kv, 2)
+#define k_max_steps __builtin_amdgcn_readlane(kv, 3)
+#define k_channels __builtin_amdgcn_readlane(kv, 4)
+#define k_no_ccount __builtin_amdgcn_readlane(kv, 5)
+#define k_spec reinterpret_cast<const VPZ_GLOBAL float *>(parked64(6))
+#define k_inv_db reinterpret_cast<const VPZ_GLOBAL float *>(parked64(8))
+#define k_cposts reinterpret_cast<const VPZ_GLOBAL int32_t *>(parked64(10))
+#define k_channel_stride ((long long)parked64(12))
+    const int half1 = k_size1 >> 1;
 
     float *hcur = s_work[wave];
     float *tail = s_tail[wave];
     int prev_n4 = 0;  // n/4 of the previous block (0: none yet)
 
     // which transform a frame takes depends on its block SIZE, not on its flag (size0 may be 2048 too)
-    auto size_of = [&](uint32_t flags) -> int { return (flags & kFrameLong) ? a.size1 : a.size0; };
+    auto size_of = [&](uint32_t flags) -> int { return (flags & kFrameLong) ? k_size1 : k_size0; };
     // lanes per block of a frame; the plain variant only knows 2048 (64) and 256 (8)
     auto lpb_of = [&](uint32_t flags) -> int { return kGeneral ? (size_of(flags) >> 5) : (size_of(flags) == 2048 ? 64 : 8); };
-    auto spectrum_of = [&](const FrameDesc &fd) -> const float * {
-        const int hh = (fd.flags & kFrameLong) ? (a.size1 >> 1) : (a.size0 >> 1);
-        return a.spec + fd.spec_off + (int64_t)ch * hh;
+    auto spectrum_of = [&](const FrameDesc &fd) -> const VPZ_GLOBAL float * {
+        const int hh = (fd.flags & kFrameLong) ? (k_size1 >> 1) : (k_size0 >> 1);
+        return k_spec + fd.spec_off + (int64_t)ch * hh;
     };
     // the raw input of a frame into registers: this wave's channel, or -- for an interleaved packet in group mode --
     // this wave's share of the packet.  cp: this lane's active floor post (lane < count).
@@ -717,24 +746,24 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
     };
     auto prefetch = [&](const FrameDesc &fd, int slot, bool valid, float2 (&x)[8], int &cp, int &cnt, bool &ex) {
         cnt = valid ? __builtin_amdgcn_readlane(cc_run, slot) : 0;  // active posts of this wave's channel (0: silent)
-        ex = valid && (a.ccount == nullptr || (fd.flags & kFrameNoFloor) || cnt != 0);
+        ex = valid && (k_no_ccount || (fd.flags & kFrameNoFloor) || cnt != 0);
         if (kGroup) {
             // (a batch of short blocks: their vectors lie back to back -- one packet of batch * 128 bins)
             const int hh = (size_of(fd.flags) >> 1) * (kBatchShort ? (int)((fd.flags >> kFrameBatchShift) & 7u) + 1 : 1);
             const bool shared_input = fd.flags & kFrameInterleaved;
-            const float *src = a.spec + fd.spec_off + (shared_input ? 0 : (int64_t)ch * hh);
+            const VPZ_GLOBAL float *src = k_spec + fd.spec_off + (shared_input ? 0 : (int64_t)ch * hh);
             const bool regs = valid && !(shared_input && (VPZ_GROUP_DMA(a) || (VPZ_ABLATE(a) & (2048 | 4096))));  // (the packet comes by LDS-DMA)
-            load_group_share(x, regs ? src : a.inv_db, shared_input ? 64 * ch : 0, shared_input ? 64 * C : 64,
+            load_group_share(x, regs ? src : k_inv_db, shared_input ? 64 * ch : 0, shared_input ? 64 * C : 64,
                              regs ? support_pieces(fd.flags, shared_input ? C : 1, hh) : 1, lane);
         } else {
-            load_spectrum(x, ex ? spectrum_of(fd) : a.inv_db, ex ? lpb_of(fd.flags) : 1, lane);
+            load_spectrum(x, ex ? spectrum_of(fd) : k_inv_db, ex ? lpb_of(fd.flags) : 1, lane);
         }
         if (kHasFloor) {
             // all 64 entries of the record's row (the ones past `cnt` are dropped where the curve is rendered)
             const bool floored = ex && !(fd.flags & kFrameNoFloor);
             int l = lane;
             asm volatile("" : "+v"(l));  // keeps `cposts + lane` out of the registers that live across the frame loop
-            cp = a.cposts[(size_t)(floored ? fd.rec + ch : 0) * 64 + l];
+            cp = k_cposts[(size_t)(floored ? fd.rec + ch : 0) * 64 + l];
         }
     };
     bool batch_head = false, batch_member = false;
@@ -772,8 +801,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             // (the block before may be a short one -- its upper half overlaps -- or, for the head of a batch, a long one
             // with a short right window: the same 128 samples of overlap, further up in its tail)
             const bool after_short = prev_end == 128 && prev_stop == 256;
-            const bool after_long = a.size1 == 2048 && prev_end == 1472 && prev_stop == 1600;
-            const bool base_ok = lane < n && lane >= -fi0 && a.size0 == 256 && !(cf & 1) && (cf & kCfInterleaved) &&
+            const bool after_long = k_size1 == 2048 && prev_end == 1472 && prev_stop == 1600;
+            const bool base_ok = lane < n && lane >= -fi0 && k_size0 == 256 && !(cf & 1) && (cf & kCfInterleaved) &&
                                  !(cf & (kCfNoFloor | kCfSkip)) && has_prev && out_count == 128 && left_start == 0 &&
                                  (after_short || after_long) && !a.no_batch;
             const bool base_prev = __shfl_up((int)base_ok, 1) != 0 && lane > 0 && after_short;
@@ -795,7 +824,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             }
         }
         // residue and output offsets: exclusive prefix sums over the run's frames
-        const int half = (cf & 1) ? (a.size1 >> 1) : (a.size0 >> 1);
+        const int half = (cf & 1) ? (k_size1 >> 1) : (k_size0 >> 1);
         int spec_sz = lane < n ? C * half : 0;
         int out_sz = (lane < n && lane >= -fi0) ? out_count : 0;
         int spec_incl = spec_sz, out_incl = out_sz;
@@ -864,8 +893,8 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 
     // ---- block preceding the run: from the saved state, or recomputed as "frame -1" of the loop
     if (run.pre_kind == kPreState) {
-        const float *st = a.state_h + (size_t)run.state_slot * a.state_slot_floats + ((size_t)run.stream * a.channels + ch) * half1;
-        prev_n4 = run.prev_long ? (a.size1 >> 2) : (a.size0 >> 2);
+        const float *st = a.state_h + (size_t)run.state_slot * a.state_slot_floats + ((size_t)run.stream * k_channels + ch) * half1;
+        prev_n4 = run.prev_long ? (k_size1 >> 2) : (k_size0 >> 2);
         for (int i = lane; i < prev_n4; i += 64) tail[i] = st[i];
     }
     out_t *out_base = reinterpret_cast<out_t *>(a.out) + (a.stream_out_off ? a.stream_out_off[run.stream] : 0);
@@ -951,9 +980,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             VPZ_STAMP(1);  // first barrier
             if (stage && !(VPZ_ABLATE(a) & 32)) {
                 if ((fd.flags & kFrameInterleaved) && (VPZ_ABLATE(a) & 4096)) {
-                    stage_by_lds_dma_gather(a.spec + fd.spec_off, hcur, C, nstage >> 1, ch, lane);
+                    stage_by_lds_dma_gather((const float *)(k_spec + fd.spec_off), hcur, C, nstage >> 1, ch, lane);
                 } else if ((fd.flags & kFrameInterleaved) && (VPZ_GROUP_DMA(a) || (VPZ_ABLATE(a) & 2048))) {
-                    stage_by_lds_dma(a.spec + fd.spec_off, s_work[gw0], C, nstage >> 1, ch, lane);
+                    stage_by_lds_dma((const float *)(k_spec + fd.spec_off), s_work[gw0], C, nstage >> 1, ch, lane);
                 } else if (fd.flags & kFrameInterleaved) {
                     stage_interleaved(xcur, s_work[gw0], C, div_magic, nstage >> 1, ch, lane, stage_upper);
                 } else {
@@ -989,7 +1018,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 const int lpb = batch ? 8 : lpb_of(fd.flags);
                 pickup_interleaved(xcur, s_work[gw0], C, ch, partner, is_mag, batch ? (lb >> 3) * 64 + (lb & 7) : (lb & (lpb - 1)), lpb);
             }
-            const int n_levels = VPZ_GROUP_DMA(a) ? max(a.max_steps, 1) : a.max_steps;
+            const int n_levels = VPZ_GROUP_DMA(a) ? max(k_max_steps, 1) : k_max_steps;
             for (int lvl = 0; lvl < n_levels; ++lvl) {
                 if (stage && !in_place && !(VPZ_ABLATE(a) & 16)) {
                     bool first = true;
@@ -1038,7 +1067,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             for (int f = 0; f < 8; ++f) {
                 const int ff = f < bsz ? f : 0;
                 cns[f] = f < bsz ? __builtin_amdgcn_readlane(cc_run, slot0 + ff) : 0;
-                cps[f] = a.cposts[(size_t)(fd.rec + ff * C + ch) * 64 + lb];
+                cps[f] = k_cposts[(size_t)(fd.rec + ff * C + ch) * 64 + lb];
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1081,7 +1110,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 for (int m = 0; m < 8; ++m) h2[lane + 64 * m] = xcur[m];
             } else if (kGeneral) {  // [census: cold]
                 // tables of this frame's size: the long set keeps the global layout, the short set is compacted
-                const bool use_long = (fd.flags & kFrameLong) || a.size0 == a.size1;
+                const bool use_long = (fd.flags & kFrameLong) || k_size0 == k_size1;
                 const float2 *tw = use_long ? s_twL : s_twS;
                 const float2 *ab = use_long ? s_twL + kFastTwABOffset : s_twS + 256;
                 const float2 *bc = use_long ? s_twL + kFastTwBCOffset : s_twS + 512;
@@ -1126,9 +1155,9 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             const float4 *h4 = reinterpret_cast<const float4 *>(hcur);
             const float4 *t4 = reinterpret_cast<const float4 *>(tail);
             const float4 *s4 = reinterpret_cast<const float4 *>(s_slope0);
-            out_t *dst = kInterleaved ? out_base + fd.out_off * a.channels + ch
-                                       : out_base + (int64_t)ch * a.channel_stride + fd.out_off;
-            const int64_t ostep = kInterleaved ? a.channels : 1;
+            out_t *dst = kInterleaved ? out_base + fd.out_off * k_channels + ch
+                                       : out_base + (int64_t)ch * k_channel_stride + fd.out_off;
+            const int64_t ostep = kInterleaved ? k_channels : 1;
             const bool aligned = kInterleaved ? (reinterpret_cast<uintptr_t>(out_base + fd.out_off * C) & 15) == 0
                                               : (reinterpret_cast<uintptr_t>(dst) & (kS16 ? 7 : 15)) == 0;
             coop = kCoop && aligned;
@@ -1155,7 +1184,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 o[r][2] = ola(v.z, wl.z, t.z, wr.y);
                 o[r][3] = ola(v.w, wl.w, t.w, wr.x);
                 if (valid) {
-                    if (a.clip) clip_group(o[r][0], o[r][1], o[r][2], o[r][3], clip_peak);
+                    if (k_clip) clip_group(o[r][0], o[r][1], o[r][2], o[r][3], clip_peak);
                     if (!coop) {
                         if (aligned || kInterleaved) {
                             // (planar and aligned: one 16-byte store; interleaved and not: four at the channel stride)
@@ -1188,17 +1217,17 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         } else if (live && fi >= 0 && fd.out_count > 0 && !(VPZ_ABLATE(a) & 1)) {
             // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 573-591)
             // equal block sizes share one slope table (s_slope0 only holds a 128-entry short slope)
-            const float *slope = ((fd.flags & kFrameSlope1) || a.size0 == a.size1) ? s_slope1 : s_slope0;
+            const float *slope = ((fd.flags & kFrameSlope1) || k_size0 == k_size1) ? s_slope1 : s_slope0;
             const int plen = fd.packet_len;
-            out_t *dst = kInterleaved ? out_base + fd.out_off * a.channels + ch
-                                       : out_base + (int64_t)ch * a.channel_stride + fd.out_off;
+            out_t *dst = kInterleaved ? out_base + fd.out_off * k_channels + ch
+                                       : out_base + (int64_t)ch * k_channel_stride + fd.out_off;
             // every window boundary of the 256/2048 geometries is a multiple of 64 samples, so unless
             // an EOS trim cut the packet a float4 never straddles a mirror / overlap boundary
             // (interleaved output keeps the float4 arithmetic and scatters the four samples with the
             // channel stride; the other channels' waves fill the gaps of the same cache lines)
             const bool vec = !drain && ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0 &&
                              (kInterleaved || (reinterpret_cast<uintptr_t>(dst) & (kS16 ? 7 : 15)) == 0);
-            const int64_t ostep = kInterleaved ? a.channels : 1;
+            const int64_t ostep = kInterleaved ? k_channels : 1;
             auto store4 = [&](int g, float o0, float o1, float o2, float o3) {
                 if (kInterleaved) {
                     out_t *d = dst + (int64_t)(4 * g) * ostep;
@@ -1228,7 +1257,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             const bool vec_pair = kPair && !drain && ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0 &&
                                   (reinterpret_cast<uintptr_t>(pair_row) & 15) == 0;
             auto store_pair = [&](int g, float l0, float l1, float l2, float l3, float r0, float r1, float r2, float r3) {
-                if (a.clip) {
+                if (k_clip) {
                     clip_group(l0, l1, l2, l3, clip_peak);
                     clip_group(r0, r1, r2, r3, clip_peak);
                 }
@@ -1242,7 +1271,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 }
             };
             if (vec_pair && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 &&
-                fd.prev_end == 1024 && fd.out_count == 1024 && prev_n4 == 512 && a.size1 == 2048) {
+                fd.prev_end == 1024 && fd.out_count == 1024 && prev_n4 == 512 && k_size1 == 2048) {
                 // long after long, long windows (see the single-channel version below): channel-0's wave writes
                 // samples [0, 512) -- the negated mirror half --, channel-1's wave samples [512, 1024)
                 const float4 *s4 = reinterpret_cast<const float4 *>(s_slope1);
@@ -1293,7 +1322,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     if (lv) store_pair(g, l0, l1, l2, l3, r0, r1, r2, r3);
                 }
             } else if (!kPair && vec && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 &&
-                fd.prev_end == 1024 && fd.out_count == 1024 && prev_n4 == 512 && a.size1 == 2048) {
+                fd.prev_end == 1024 && fd.out_count == 1024 && prev_n4 == 512 && k_size1 == 2048) {
                 // long block after a long block with long windows on both sides (the steady state of
                 // every stream): the geometry is a compile-time constant -- first half of the output
                 // is the negated mirror of h[0:512) over the straight previous tail, second half is
@@ -1322,11 +1351,11 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                         o[r][3] = ola(hv.w, wl.w, pv.x, wr.x);
                     }
                     if (kInterleaved && !coop) {  // scattered stores: finish each group of four at once (short live ranges)
-                        if (a.clip) clip_group(o[r][0], o[r][1], o[r][2], o[r][3], clip_peak);
+                        if (k_clip) clip_group(o[r][0], o[r][1], o[r][2], o[r][3], clip_peak);
                         store4(g, o[r][0], o[r][1], o[r][2], o[r][3]);
                     }
                 }
-                if ((!kInterleaved || coop) && a.clip) {
+                if ((!kInterleaved || coop) && k_clip) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) clip_group(o[r][0], o[r][1], o[r][2], o[r][3], clip_peak);
                 }
@@ -1373,7 +1402,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     o1 = in ? o1 : v.y;
                     o2 = in ? o2 : v.z;
                     o3 = in ? o3 : v.w;
-                    if (a.clip) {
+                    if (k_clip) {
                         // (a lane past the end has re-computed the last group: real samples, counted twice at worst)
                         clip_group(o0, o1, o2, o3, clip_peak);
                     }
@@ -1393,7 +1422,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                             v = ola(v, slope[i], t, slope[plen - 1 - i]);
                         }
                     }
-                    if (a.clip) {
+                    if (k_clip) {
                         v = clip_track(v, clip_peak);
                     }
                     store_pcm(dst + i * ostep, kS16 ? (out_t)to_s16(v) : (out_t)v);
@@ -1449,12 +1478,23 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 
     // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
     if ((run.flags & kRunSaveState) && prev_n4 > 0) {
-        float *st = a.state_h + (size_t)(run.state_slot ^ 1) * a.state_slot_floats + ((size_t)run.stream * a.channels + ch) * half1;
+        float *st = a.state_h + (size_t)(run.state_slot ^ 1) * a.state_slot_floats + ((size_t)run.stream * k_channels + ch) * half1;
         for (int i = lane; i < prev_n4; i += 64) st[i] = tail[i];
     }
     // HasClipped is sticky until ResetDecoder: the flag holds the stream's reset epoch, so a reset costs no device work
-    if (a.clip && __any(clip_peak > 0.99999994f) && lane == 0) atomicMax(&a.clipped[run.stream], run.clip_epoch);
+    if (k_clip && __any(clip_peak > 0.99999994f) && lane == 0) atomicMax(&a.clipped[run.stream], run.clip_epoch);
 }
+
+#undef k_size0
+#undef k_size1
+#undef k_clip
+#undef k_max_steps
+#undef k_channels
+#undef k_no_ccount
+#undef k_spec
+#undef k_inv_db
+#undef k_cposts
+#undef k_channel_stride
 
 // ---------------------------------------------------------------------------------------------
 // Any-block-size path (64 .. 8192): three plain passes over HBM instead of the fused kernel --
