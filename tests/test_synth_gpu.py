@@ -485,3 +485,65 @@ def test_general_sizes_layouts_streams_and_eos(ctx, oracle, size0, size1, channe
         assert np.array_equal(inter[s], planar[s].T)
         assert dec.position(s) == pos
     dec.close()
+
+
+@pytest.mark.parametrize("order,bark", [(16, 128), (9, 100), (30, 1024), (16, 256)])
+@pytest.mark.parametrize("interleaved", [True, False])
+def test_floor0_inside_the_stereo_fast_path_equals_the_separate_floor0_pass(ctx, oracle, order, bark, interleaved):
+    """A stereo 256 / 2048 stream with type-0 floors: the stereo fast path applies the floor itself (the record's curve over
+    the bark indices from floor0_curve_kernel, looked up per bin -- Floor0.cs:188-222 multiplies a run of bins of one bark
+    index by one q), instead of planar temp + floor0_apply_kernel + the one-channel kernel (VPZ_NO_F0_FUSED=1).  Same bits;
+    and against the oracle.  Coupled, a silent channel, window switching, two calls (the overlap state crosses them)."""
+    from test_host_paths_gpu import env
+    from vorbispizza_amd import Decoder, capi, make_packets
+    rng = np.random.default_rng(order * 7 + bark)
+    frames = 36
+    flags = helpers.markov_block_flags(frames, seed=order, p_ls=0.2, p_sl=0.3)
+    f0 = {"order": order, "rate": 44100, "bark_map_size": bark, "amp_bits": 6, "amp_ofs": 100}
+    floors = [f0, f0]
+    mappings = [{"coupling": [(0, 1)], "channel_floor": [0, 0]}, {"coupling": [(0, 1)], "channel_floor": [1, 1]}]
+    pk = make_packets(frames)
+    res, amps, coeffs, opk = [], [], [], []
+    off = 0
+    for f in range(frames):
+        half = 1024 if flags[f] & 1 else 128
+        r = np.round(rng.standard_normal((2, half)) * 3.0).astype(np.float32)
+        coeff = np.zeros((2, order), dtype=np.float32)
+        amp = np.zeros(2, dtype=np.float32)
+        for c in range(2):
+            coeff[c] = np.sort(rng.uniform(0.05, 3.0, size=order)).astype(np.float32)
+            amp[c] = helpers.floor0_safe_amp(coeff[c], bark, 100.0) * rng.uniform(0.3, 1.0)
+        if f == 5:
+            amp[1] = 0.0  # a silent channel inside the coupled pair
+        pk[f]["flags"] = flags[f] | (capi.PKT_INTERLEAVED if interleaved else 0)
+        pk[f]["mapping"] = flags[f] & 1
+        pk[f]["granule"] = -1
+        pk[f]["residue_offset"] = off
+        res.append(r.T.reshape(-1) if interleaved else r.reshape(-1))
+        off += 2 * half
+        amps.append(amp)
+        coeffs.append(coeff)
+        opk.append({"flags": int(pk[f]["flags"]), "granule": -1, "mapping": int(pk[f]["mapping"]), "residue": res[-1],
+                    "posts": np.zeros((2, 64), dtype=np.int16), "post_count": (amp != 0).astype(np.uint8),
+                    "f0_amp": amp, "f0_coeff": coeff})
+    res = np.concatenate(res)
+    amps, coeffs = np.concatenate(amps), np.concatenate(coeffs)
+    posts = np.zeros((frames * 2, 64), dtype=np.int16)
+    counts = (amps != 0).astype(np.uint8)
+    outs = {}
+    for name, kv in (("fused", dict(VPZ_NO_F0_FUSED=None)), ("separate", dict(VPZ_NO_F0_FUSED=1))):
+        with env(**kv):
+            dec = Decoder(ctx, 2, 256, 2048, floors=floors, mappings=mappings)
+            parts = []
+            for a, b in ((0, 20), (20, frames)):
+                dec.set_floor0_data(amps[2 * a:2 * b], coeffs[2 * a:2 * b])
+                sub = pk[a:b].copy()
+                parts.append(dec.synth(sub, res, posts[2 * a:2 * b], counts[2 * a:2 * b], out_layout=capi.OUT_PLANAR)[0])
+            dec.close()
+        outs[name] = np.concatenate(parts, axis=1)
+    assert outs["fused"].shape == outs["separate"].shape and outs["fused"].shape[1] > 0
+    assert np.array_equal(outs["fused"].view(np.uint32), outs["separate"].view(np.uint32))
+    if bark <= 128:  # (a bark map larger than a block's half makes the reference index its w map out of range: no oracle there)
+        ref, _, _ = helpers.oracle_decode(oracle, 2, 256, 2048, opk, floors=floors, mappings=mappings)
+        assert ref.shape == outs["fused"].shape
+        assert np.abs(outs["fused"] - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))

@@ -92,7 +92,7 @@ def main():
 
     dt, w = timed(ctx, step_b)
     byt = 4 * res.numel() + 4 * samples * C_
-    print("(b) stereo, type-0 floor of order 16, %d frames (planar temp + Floor0.Apply + fused kernel): %.3f ms/call  %.1f Msamples/s  "
+    print("(b) stereo, type-0 floor of order 16, %d frames (curve per bark index + the stereo fast path; VPZ_NO_F0_FUSED=1: planar temp + Floor0.Apply + one-channel kernel): %.3f ms/call  %.1f Msamples/s  "
           "%.0f GB/s algorithmic = %.3f of 8 TB/s" % (frames, dt * 1e3, samples * C_ / dt / 1e6, byt / dt / 1e9, byt / dt / 8e12), flush=True)
     dec.close()
     del res, out

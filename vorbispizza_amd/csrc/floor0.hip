@@ -62,10 +62,91 @@ __global__ __launch_bounds__(256) void floor0_apply_kernel(const Floor0Rec *__re
             p *= p * (2.0f - w);
             q *= q * (2.0f + w);
         }
-        q = (float)((double)a / (double)(float)sqrt((double)(p + q))) - amp_ofs;
+        // (amp / sqrt(p + q) in float32, both correctly rounded -- hipcc's default for float division and square root --, which is
+        // what rounding the double-precision quotient of the double-precision root gives: 53 bits are more than 2 * 24 + 2)
+        q = a / sqrtf(p + q) - amp_ofs;
         q = (float)exp((double)(q * 0.11512925f));
         x[i] *= q;
     }
+}
+
+// The fused route (stereo fast path): Floor0's multiplier is a function of the bin's BARK INDEX only -- the reference computes
+// q for a run of bins with the same barkMap value and multiplies them all by it (Floor0.cs:188-222: `while (barkMap[++i] == k)
+// residue[i] *= q`) -- so a record's curve is bark_map_size values, not blocksize/2: this kernel evaluates them once per
+// (packet, channel) record into curve[rec][k] (the same arithmetic, per k instead of per bin), and synth_dual_kernel looks its
+// bins' values up by the bark map (floor0_multiply in synth_dual.hip).  No planar temp, no extra pass over the spectrum.
+// rec_info[rec]: floor index | 0x40 for a type-0 floor (else the record is skipped) | 0x80 long block.
+// wtab[floor * k_stride + k] = 2 cos(pi k / bark_map_size) (Floor0.cs:103-111 `SynthesizeWDelMap`): a setup-time table, filled
+// once per decoder with the expression floor0_apply_kernel evaluates per bin
+__global__ __launch_bounds__(256) void floor0_wtab_kernel(const Floor0Dev *__restrict__ floors, int k_stride, float *__restrict__ wtab)
+{
+    const Floor0Dev f = floors[blockIdx.x];
+    if (f.bark_map_size <= 0) return;
+    const float wdel = (float)(3.14159265358979323846 / (double)f.bark_map_size);
+    for (int k = threadIdx.x; k < f.bark_map_size && k < k_stride; k += 256)
+        wtab[(size_t)blockIdx.x * k_stride + k] = 2.0f * (float)cos((double)(wdel * (float)k));
+}
+
+hipError_t launch_floor0_wtab(const void *floors, int n_floors, int k_stride, float *wtab, hipStream_t stream)
+{
+    if (n_floors <= 0) return hipSuccess;
+    hipLaunchKernelGGL(floor0_wtab_kernel, dim3(n_floors), dim3(256), 0, stream, static_cast<const Floor0Dev *>(floors), k_stride, wtab);
+    return hipGetLastError();
+}
+
+// One WAVEFRONT per record, four records per workgroup (a workgroup per record -- 256 threads for 256 values -- ran at the
+// dispatcher's workgroup rate: 65 536 of them took 175 us, of arithmetic there is little).
+constexpr int kCurveWaves = 4;
+__global__ __launch_bounds__(64 * kCurveWaves) void floor0_curve_kernel(int n_rec, const uint8_t *__restrict__ rec_info,
+                                                                       const Floor0Dev *__restrict__ floors, const float *__restrict__ amp,
+                                                                       const float *__restrict__ coeff, int coeff_stride, int k_stride,
+                                                                       const float *__restrict__ wtab, float *__restrict__ curve)
+{
+    __shared__ float s_c_all[kCurveWaves][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *s_c = s_c_all[wave];
+    const int rec = blockIdx.x * kCurveWaves + wave;
+    if (rec >= n_rec) return;
+    const uint8_t info = rec_info[rec];
+    if (!(info & 0x40)) return;
+    const Floor0Dev f = floors[info & 0x3F];
+    const float a = amp[rec];
+    if (a <= 0.0f) return;  // (ExecuteChannel false: the channel's block is zeros, nobody reads its curve)
+    for (int j = lane; j < f.order; j += 64)
+        s_c[j] = 2.0f * (float)cos((double)coeff[(size_t)rec * coeff_stride + j]);
+    __builtin_amdgcn_wave_barrier();
+    const float amp_ofs = (float)f.amp_ofs;
+    const float *wt = wtab + (size_t)(info & 0x3F) * k_stride;
+    for (int k = lane; k < f.bark_map_size && k < k_stride; k += 64) {
+        float p = .5f, q = .5f;
+        const float w = wt[k];
+        int j;
+        for (j = 1; j < f.order; j += 2) {
+            q *= w - s_c[j - 1];
+            p *= w - s_c[j];
+        }
+        if (j == f.order) {  // odd order
+            q *= w - s_c[j - 1];
+            p *= p * (4.0f - w * w);
+            q *= q;
+        } else {
+            p *= p * (2.0f - w);
+            q *= q * (2.0f + w);
+        }
+        // (amp / sqrt(p + q) in float32, both correctly rounded -- hipcc's default for float division and square root --, which is
+        // what rounding the double-precision quotient of the double-precision root gives: 53 bits are more than 2 * 24 + 2)
+        q = a / sqrtf(p + q) - amp_ofs;
+        curve[(size_t)rec * k_stride + k] = (float)exp((double)(q * 0.11512925f));
+    }
+}
+
+hipError_t launch_floor0_curves(int n_rec, const uint8_t *rec_info, const void *floors, const float *amp, const float *coeff,
+                                int coeff_stride, int k_stride, const float *wtab, float *curve, hipStream_t stream)
+{
+    if (n_rec <= 0) return hipSuccess;
+    hipLaunchKernelGGL(floor0_curve_kernel, dim3((n_rec + kCurveWaves - 1) / kCurveWaves), dim3(64 * kCurveWaves), 0, stream, n_rec, rec_info,
+                       static_cast<const Floor0Dev *>(floors), amp, coeff, coeff_stride, k_stride, wtab, curve);
+    return hipGetLastError();
 }
 
 hipError_t launch_floor0_apply(const void *recs, int n_recs, const void *floors, const int32_t *bark_maps,

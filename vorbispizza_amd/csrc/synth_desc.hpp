@@ -25,12 +25,24 @@ constexpr uint32_t kFrameStepsOffMask = 0xFFu;
 // bits 24..27: how many of the block's eight point groups (group m = bins [m * blocksize/16, (m + 1) * blocksize/16): the lane's
 // m-th point in every transform layout) lie wholly beyond the residue's support (ABI v4, vpz_mapping_config.residue_end) -- their
 // bins are +0.0 by the setup header's word and are neither loaded (group mode) nor de-coupled nor floor-multiplied.  0..8.
+// bit 28: the steady state of every stream -- a 2048 block after a 2048 block with long windows on both sides: PacketInfo
+// LeftStart 0, the overlap 1024 samples from position 1024 of the previous block, 1024 samples out, the size1 slope.  Settled
+// once where the descriptor is built (one lane per frame, or the host), so that the frame loop tests one bit instead of eight
+// fields (40 scalar instructions per pass, profiles/r4_isa_*.txt).
+constexpr uint32_t kFrameSteady = 1u << 28;
+__host__ __device__ inline bool frame_is_steady(uint32_t flags, int size1, int left_start, int packet_len, int prev_end, int out_count)
+{
+    return size1 == 2048 && (flags & kFrameLong) && (flags & kFrameSlope1) && !(flags & kFrameDrain) && left_start == 0 &&
+           packet_len == 1024 && prev_end == 1024 && out_count == 1024;
+}
 constexpr int kFrameSkipShift = 24;
 constexpr uint32_t kFrameSkipMask = 0xFu;
 // per-mapping word (SynthArgs.map_bits): steps count / offset as in the frame flags, the skip of a long block in bits 24..27,
 // of a short block in bits 28..31
 constexpr int kMapSkipShortShift = 28;
 constexpr int kGroupMaxChannels = 8;         // channels that fit one workgroup of 8 waves
+constexpr int kFloor0Marker = 255;           // active-post count of a record whose floor is type 0 and is applied by the fused kernel
+constexpr int kFloor0MaxBark = 1024;         // bark_map_size the fused route takes (the curve sits in a wave's LDS row)
 constexpr int kGroupMaxStepPairs = 128;      // coupling steps (pairs) of all mappings staged in LDS
 
 struct FrameDesc {        // 32 bytes: staged per run into LDS by the wavefront that owns the run
@@ -158,6 +170,14 @@ struct SynthArgs {
     int32_t group_dma;          // group mode: an interleaved packet lands in the group's rows AS IT IS ([bin][C], LDS-DMA) and every
                                 // wave picks its channel up with the inverse coupling applied in registers (even channel
                                 // counts, no channel in more than one step of any mapping)
+    // type-0 floors in the stereo fast path (a record whose post count is kFloor0Marker): the record's curve over the bark
+    // indices, curve[rec * f0_stride + k] (floor0_curve_kernel), and per (floor, block size) the bark index of every bin in the
+    // order a lane holds its bins: f0_bark[(floor * 2 + long) * 1024 + lane * 16 + 2 * m + e] = barkMap[2 * (lane + 64 m) + e]
+    // for a 2048 block, lane < 8 and bin 2 * (lane + 8 m) + e for a 256 one
+    const float *f0_curve;
+    const uint16_t *f0_bark;
+    int32_t f0_stride;
+    int32_t f0_reserved;
     const float *inv_db;        // 256 floats
     float *state_h;             // [2][stream][channel][size1/2]: two copies -- a run that starts from the saved state reads
                                 // copy RunDesc.state_slot, the run that ends its stream's batch writes the OTHER one (the

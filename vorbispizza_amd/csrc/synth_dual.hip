@@ -130,6 +130,33 @@ __device__ __forceinline__ bool render_floor_indices_fast_x2(uint8_t *out0, uint
     return true;
 }
 
+// Floor0.Apply (Floor0.cs:164-225) inside the pass: the record's curve over the bark indices (floor0_curve_kernel) is staged in
+// the wave's LDS row, and every bin is multiplied by the value of ITS bark index -- the reference multiplies a run of bins with
+// the same barkMap value by one q (:221-222), i.e. q is a function of the index.  bark: this (floor, block size)'s indices in the
+// order a lane holds its bins (SynthArgs.f0_bark), 16 per lane.
+__device__ __forceinline__ void floor0_multiply(float2 (&x)[8], float *row, const float *curve, int k_count, const uint16_t *bark,
+                                                int lpb, int lane)
+{
+    const uint4 *b4 = reinterpret_cast<const uint4 *>(bark + (lane & (lpb - 1)) * 16);
+    const uint4 b0 = b4[0], b1 = b4[1];
+    for (int i = lane; i < k_count; i += 64) row[i] = curve[i];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t w[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float t[16];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        t[2 * m] = row[w[m] & 0xFFFFu];
+        t[2 * m + 1] = row[w[m] >> 16];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        x[m].x *= t[2 * m];
+        x[m].y *= t[2 * m + 1];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // kIlvIn : every packet of the batch is the Residue2-interleaved vector [bin][2] (else: every packet planar [2][bin])
 // kOut   : 0 planar output, 1 interleaved
 // kExp: tuning experiments, A/B on one box through VPZ_DUAL_EXP (none at the moment; DESIGN.md 4.7 lists what was tried)
@@ -273,8 +300,10 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             lo.x = (uint32_t)spec_off; lo.y = (uint32_t)((uint64_t)spec_off >> 32);
             lo.z = (uint32_t)out_off; lo.w = (uint32_t)((uint64_t)out_off >> 32);
             hi.x = (uint32_t)(run.rec_base + lane * 2);
-            hi.y = (uint32_t)left_start | ((uint32_t)(has_prev && !(cf & kCfSkip) ? prev_stop - prev_end : 0) << 16);
-            hi.z = (uint32_t)((has_prev && !(cf & kCfSkip)) ? prev_end : 0) | ((uint32_t)out_count << 16);
+            const int plen_d = (has_prev && !(cf & kCfSkip)) ? prev_stop - prev_end : 0, pend_d = (has_prev && !(cf & kCfSkip)) ? prev_end : 0;
+            hi.y = (uint32_t)left_start | ((uint32_t)plen_d << 16);
+            hi.z = (uint32_t)pend_d | ((uint32_t)out_count << 16);
+            if (frame_is_steady(fl, a.size1, left_start, plen_d, pend_d, out_count)) fl |= kFrameSteady;
             hi.w = fl;
             s_desc[wave][2 * lane] = lo;
             s_desc[wave][2 * lane + 1] = hi;
@@ -453,7 +482,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 }
             }
             // ---- inverse coupling, steps in reverse order (Mapping.cs:166-172); a stereo step is (0, 1) or (1, 0)
-            if (!(fd.flags & kFrameNoFloor) && !(VPZ_ABLATE(a) & 16)) {
+            if (kHasFloor && !(fd.flags & kFrameNoFloor) && !(VPZ_ABLATE(a) & 16)) {  // (a batch without floors has no coupling either)
                 const int n_steps = (int)((fd.flags >> kFrameStepsShift) & 0xFF);
                 const uint8_t *st = s_steps + 2 * ((fd.flags >> kFrameStepsOffShift) & kFrameStepsOffMask);
                 const unsigned long long stw = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)stwcur.y) << 32) |
@@ -481,6 +510,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             VPZ_STAMP(1);  // unpack + coupling
             // ---- Floor1 curves x spectra (Floor1.cs:222-268), silence (Mapping.cs:190-194)
             bool silentL = false, silentR = false;  // per lane: this lane's block of the pass is a silent channel's
+            bool f0L = false, f0R = false;          // (wave-uniform) the channel's floor is type 0
             if (!no_floor) {
                 uint8_t *rowL = reinterpret_cast<uint8_t *>(hL), *rowR = reinterpret_cast<uint8_t *>(hR);
                 int *auxL = reinterpret_cast<int *>(hL) + 256, *auxR = reinterpret_cast<int *>(hR) + 256;
@@ -492,8 +522,10 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                     silentR = cntR == 0;
                     const int lpb = is_long ? 64 : 8;
                     const int n = nblk >> 1;
-                    const int nrL = (silentL || (VPZ_ABLATE(a) & 512)) ? 0 : 2 * (spectrum_top(xL, lpb, ln) + 1);
-                    const int nrR = (silentR || (VPZ_ABLATE(a) & 512)) ? 0 : 2 * (spectrum_top(xR, lpb, ln) + 1);
+                    f0L = cntL == kFloor0Marker;  // (type-0 floors: no curve to render, see floor0_multiply below)
+                    f0R = cntR == kFloor0Marker;
+                    const int nrL = (silentL || f0L || (VPZ_ABLATE(a) & 512)) ? 0 : 2 * (spectrum_top(xL, lpb, ln) + 1);
+                    const int nrR = (silentR || f0R || (VPZ_ABLATE(a) & 512)) ? 0 : 2 * (spectrum_top(xR, lpb, ln) + 1);
                     const int pa = ln < cntL ? cpa : 0, pb = ln < cntR ? cpb : 0;
                     if ((nrL > 0 || nrR > 0) && !(VPZ_ABLATE(a) & 8)) {
                         if (!render_floor_indices_fast_x2(rowL, rowR, auxL, auxR, n, nrL, nrR, pa, pb, cntL, cntR, ln)) {  // [census: cold]
@@ -545,8 +577,18 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 }
                 VPZ_STAMP(2);  // curves
                 if (!(VPZ_ABLATE(a) & 256)) {
-                apply_floor(xL, fyL, s_db, upper);
-                apply_floor(xR, fyR, s_db, upper);
+                if (!f0L) apply_floor(xL, fyL, s_db, upper);
+                if (!f0R) apply_floor(xR, fyR, s_db, upper);
+                if (f0L || f0R) {  // [census: cold]
+                    const int lpb0 = is_long ? 64 : 8;
+                    const int kc = min(a.f0_stride, kFloor0MaxBark);
+                    if (f0L)
+                        floor0_multiply(xL, hL, a.f0_curve + (size_t)fd.rec * a.f0_stride, kc,
+                                        a.f0_bark + ((size_t)__builtin_amdgcn_readlane(cpa, 0) * 2 + (is_long ? 1 : 0)) * 1024, lpb0, ln);
+                    if (f0R)
+                        floor0_multiply(xR, hR, a.f0_curve + (size_t)(fd.rec + 1) * a.f0_stride, kc,
+                                        a.f0_bark + ((size_t)__builtin_amdgcn_readlane(cpb, 0) * 2 + (is_long ? 1 : 0)) * 1024, lpb0, ln);
+                }
                 }
             }
             // ---- the two transforms, side by side
@@ -686,8 +728,15 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             // every window boundary of the 256 / 2048 geometries is a multiple of 64 samples, so unless an EOS trim cut the
             // packet a group of four samples never straddles a mirror / overlap boundary
             const bool vec = !drain && aligned && ((fd.out_count | fd.left_start | plen | fd.prev_end) & 3) == 0;
+            // (the descriptor carries the steady state as ONE bit too -- kFrameSteady --, and testing that bit instead of the fields
+            // is SLOWER: north_star's line 0.236-0.241 ms with the field tests, 0.245-0.261 with the bit, alternating on one box;
+            // -DVPZ_DUAL_STEADY_BIT builds the bit test)
+#ifdef VPZ_DUAL_STEADY_BIT
+            if ((fd.flags & kFrameSteady) && aligned && prev_n4 == 512) {
+#else
             if (vec && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 && fd.prev_end == 1024 &&
                 fd.out_count == 1024 && prev_n4 == 512 && a.size1 == 2048) {
+#endif
                 // long after long with long windows on both sides (the steady state of every stream): first half of the
                 // output = negated mirror of h[0:512) over the straight previous tail, second half = h[0:512) straight over
                 // the mirrored tail; the window values are read once for both channels

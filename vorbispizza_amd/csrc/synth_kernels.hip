@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64 * kUnwrapWaves) void floor1_unwrap_kernel(int n_
                                                           const FloorDev *__restrict__ g_floors, int n_floors,
                                                           int32_t *__restrict__ cposts, uint8_t *__restrict__ ccount,
                                                           int16_t *__restrict__ dbg_y, uint8_t *__restrict__ dbg_f,
-                                                          unsigned long long *stamps)
+                                                          unsigned long long *stamps, int f0_fused)
 {
 #ifdef VPZ_STAMPS
     unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -216,9 +216,14 @@ __global__ __launch_bounds__(64 * kUnwrapWaves) void floor1_unwrap_kernel(int n_
     int count = 0;
     if (my_count != 0) {
         int32_t *row = cposts + (size_t)rec * 64;  // this lane's record: one 256-byte row, front to back
-        if (info & 0x40) {  // type-0 floor: already applied, the curve is 1.0
-            s_out[0] = 255 << 16;
-            count = 1;
+        if (info & 0x40) {
+            if (f0_fused) {  // type-0 floor applied by the stereo fast path itself: the marker, and which floor it is
+                s_out[0] = info & 0x3F;
+                count = kFloor0Marker;
+            } else {  // type-0 floor already applied (floor0_apply_kernel on the planar temp): the curve is 1.0
+                s_out[0] = 255 << 16;
+                count = 1;
+            }
         } else {
             const int fi = info & 0x3F;
             const FloorDev &f = kFloorsInLds ? s_floors[fi] : g_floors[fi];  // (folds to one address space)
@@ -572,6 +577,15 @@ __device__ __forceinline__ void emit_interleaved_rows(const float *rows, void *o
 // Floor: the wave renders its channel's curve (Floor1.cs:236-262, 372-397) from the record's active posts into its
 //       LDS row as one table index per bin, right before the row is needed for anything else.
 // kS16: PCM leaves as 16-bit samples (to_s16) instead of float32; offsets and strides count samples either way.
+// The steady state of a stream (2048 after 2048, long windows): tested field by field here.  The descriptor carries it as ONE
+// bit too (kFrameSteady, which the stereo fast path tests) -- measured in this kernel, the bit test is SLOWER: configs[3] 0.265 ms
+// with the eight field tests, 0.274 with the bit (three alternating rounds on one box, profiles/r4_ab_steady_bit.txt): the
+// compiler folds the geometry it has just compared into the branch's address arithmetic.  -DVPZ_GROUP_STEADY_BIT: the bit.
+#ifdef VPZ_GROUP_STEADY_BIT
+#define VPZ_STEADY(fd) ((fd).flags & kFrameSteady)
+#else
+#define VPZ_STEADY(fd) (is_long && ((fd).flags & kFrameSlope1) && (fd).left_start == 0 && plen == 1024 && (fd).prev_end == 1024 && (fd).out_count == 1024 && k_size1 == 2048)
+#endif
 template <bool kHasFloor, int kOut, bool kGeneral, bool kGroup, bool kS16>
 __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
 {
@@ -840,8 +854,10 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
             lo.x = (uint32_t)spec_off; lo.y = (uint32_t)((uint64_t)spec_off >> 32);
             lo.z = (uint32_t)out_off; lo.w = (uint32_t)((uint64_t)out_off >> 32);
             hi.x = (uint32_t)(run.rec_base + lane * C);
-            hi.y = (uint32_t)left_start | ((uint32_t)(has_prev && !(cf & kCfSkip) ? prev_stop - prev_end : 0) << 16);
-            hi.z = (uint32_t)((has_prev && !(cf & kCfSkip)) ? prev_end : 0) | ((uint32_t)out_count << 16);
+            const int plen_d = (has_prev && !(cf & kCfSkip)) ? prev_stop - prev_end : 0, pend_d = (has_prev && !(cf & kCfSkip)) ? prev_end : 0;
+            hi.y = (uint32_t)left_start | ((uint32_t)plen_d << 16);
+            hi.z = (uint32_t)pend_d | ((uint32_t)out_count << 16);
+            if (frame_is_steady(fl, a.size1, left_start, plen_d, pend_d, out_count)) fl |= kFrameSteady;
             hi.w = fl;
             s_desc[wave][2 * lane] = lo;
             s_desc[wave][2 * lane + 1] = hi;
@@ -1270,8 +1286,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     store_pcm4(d + 1, make_float4(l2, r2, l3, r3));
                 }
             };
-            if (vec_pair && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 &&
-                fd.prev_end == 1024 && fd.out_count == 1024 && prev_n4 == 512 && k_size1 == 2048) {
+            if (vec_pair && VPZ_STEADY(fd) && prev_n4 == 512) {
                 // long after long, long windows (see the single-channel version below): channel-0's wave writes
                 // samples [0, 512) -- the negated mirror half --, channel-1's wave samples [512, 1024)
                 const float4 *s4 = reinterpret_cast<const float4 *>(s_slope1);
@@ -1321,8 +1336,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     const float r2 = in ? ola(vr.z, wl.z, qr.z, wr.y) : vr.z, r3 = in ? ola(vr.w, wl.w, qr.w, wr.x) : vr.w;
                     if (lv) store_pair(g, l0, l1, l2, l3, r0, r1, r2, r3);
                 }
-            } else if (!kPair && vec && is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && plen == 1024 &&
-                fd.prev_end == 1024 && fd.out_count == 1024 && prev_n4 == 512 && k_size1 == 2048) {
+            } else if (!kPair && vec && VPZ_STEADY(fd) && prev_n4 == 512) {
                 // long block after a long block with long windows on both sides (the steady state of
                 // every stream): the geometry is a compile-time constant -- first half of the output
                 // is the negated mirror of h[0:512) over the straight previous tail, second half is
@@ -1596,7 +1610,7 @@ __global__ __launch_bounds__(256) void generic_save_state_kernel(const GenericFr
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *post_counts, const uint8_t *rec_info,
                                 const FloorDev *floors, int n_floors, int32_t *cposts, uint8_t *ccount, int16_t *dbg_y,
-                                uint8_t *dbg_f, hipStream_t stream)
+                                uint8_t *dbg_f, hipStream_t stream, int f0_fused)
 {
     if (n_rec <= 0) return hipSuccess;
     unsigned long long *stamps = nullptr;
@@ -1608,10 +1622,10 @@ hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *
 #endif
     if (n_floors <= kPrepFloorsInLds)
         hipLaunchKernelGGL(floor1_unwrap_kernel<true>, dim3((n_rec + kUnwrapRecs * kUnwrapWaves - 1) / (kUnwrapRecs * kUnwrapWaves)), dim3(64 * kUnwrapWaves), 0, stream, n_rec, posts,
-                           post_counts, rec_info, floors, n_floors, cposts, ccount, dbg_y, dbg_f, stamps);
+                           post_counts, rec_info, floors, n_floors, cposts, ccount, dbg_y, dbg_f, stamps, f0_fused);
     else
         hipLaunchKernelGGL(floor1_unwrap_kernel<false>, dim3((n_rec + kUnwrapRecs * kUnwrapWaves - 1) / (kUnwrapRecs * kUnwrapWaves)), dim3(64 * kUnwrapWaves), 0, stream, n_rec, posts,
-                           post_counts, rec_info, floors, n_floors, cposts, ccount, dbg_y, dbg_f, stamps);
+                           post_counts, rec_info, floors, n_floors, cposts, ccount, dbg_y, dbg_f, stamps, f0_fused);
 #ifdef VPZ_STAMPS
     {
         unsigned long long h[16];

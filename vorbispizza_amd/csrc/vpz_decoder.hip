@@ -19,7 +19,10 @@ namespace vpz {
 
 hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *post_counts, const uint8_t *rec_info,
                                 const FloorDev *floors, int n_floors, int32_t *cposts, uint8_t *ccount, int16_t *dbg_y,
-                                uint8_t *dbg_f, hipStream_t stream);
+                                uint8_t *dbg_f, hipStream_t stream, int f0_fused = 0);
+hipError_t launch_floor0_curves(int n_rec, const uint8_t *rec_info, const void *floors, const float *amp, const float *coeff,
+                                int coeff_stride, int k_stride, const float *wtab, float *curve, hipStream_t stream);
+hipError_t launch_floor0_wtab(const void *floors, int n_floors, int k_stride, float *wtab, hipStream_t stream);
 hipError_t launch_floor1_render(int n_rec, const int32_t *cposts, const uint8_t *ccount, const uint8_t *rec_info,
                                 int half0, int half1, uint8_t *curve_y, hipStream_t stream);
 hipError_t launch_coupling(const void *pkts, int n_pkts, const uint8_t *steps, int channels,
@@ -143,6 +146,13 @@ struct Decoder {
     std::vector<vpz_floor0_config> floors0;
     void *d_floors0 = nullptr;
     int32_t *d_bark_maps = nullptr;
+    // type-0 floors inside the stereo fast path (floor0_curve_kernel + floor0_multiply): possible when every type-0 floor's
+    // bark map has at most kFloor0MaxBark entries; f0_k = the largest of them (row length of the per-record curves)
+    bool f0_fused = false;
+    int f0_k = 0;
+    uint16_t *d_f0_bark = nullptr;   // [floor][short / long][1024]: bark index of every bin in lane order (SynthArgs.f0_bark)
+    float *d_f0_w = nullptr;         // [floor][f0_k]: 2 cos(pi k / bark_map_size), Floor0's wMap (floor0_wtab_kernel)
+    DevBuf b_f0curve;
     DevBuf b_in_amp, b_in_coeff;
     const float *f0_amp = nullptr, *f0_coeff = nullptr;
     int32_t f0_stride = 0;
@@ -385,8 +395,17 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         D.group_ok = synth_group_supported(D.channels) && !D.generic && !has_floor0 && D.max_steps <= 255 &&
                      D.n_step_pairs <= kGroupMaxStepPairs && !(no_group && atoi(no_group));
         const char *no_dual = getenv("VPZ_NO_DUAL");
-        D.dual_ok = synth_dual_supported(D.channels, D.size0, D.size1) && !D.generic && !has_floor0 && D.max_steps <= 255 &&
+        // (type-0 floors ride in the stereo fast path when their bark maps fit a wave's LDS row; VPZ_NO_F0_FUSED=1: the old route)
+        const char *no_f0 = getenv("VPZ_NO_F0_FUSED");
+        D.f0_fused = has_floor0 && !(no_f0 && atoi(no_f0));
+        for (size_t i = 0; i < D.floors0.size() && rc == VPZ_OK; ++i)
+            if (D.floor_types[i] == 0) {
+                if (D.floors0[i].bark_map_size < 1 || D.floors0[i].bark_map_size > kFloor0MaxBark) D.f0_fused = false;
+                D.f0_k = std::max(D.f0_k, (int)D.floors0[i].bark_map_size);
+            }
+        D.dual_ok = synth_dual_supported(D.channels, D.size0, D.size1) && !D.generic && (!has_floor0 || D.f0_fused) && D.max_steps <= 255 &&
                     D.n_step_pairs <= kGroupMaxStepPairs && !(no_dual && atoi(no_dual));
+        D.f0_fused = D.f0_fused && D.dual_ok;
         // every channel in at most one step of its mapping (then a mapping has one level, and a wave can apply its own step
         // to the pair of values it reads): the packet may stay interleaved in LDS
         bool single_step = true;
@@ -449,6 +468,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     if (e == hipSuccess) {
         // Floor0 ctor tables (Floor0.cs:82-95): one bark map per block size, n+1 ints, last bin left at 0
         std::vector<int32_t> maps;
+        std::vector<uint16_t> f0_bark;
         std::vector<char> devs(floor0_dev_size() * std::max<size_t>(1, D.floors0.size()), 0);
         bool any0 = false;
         for (size_t i = 0; i < D.floors0.size(); ++i) {
@@ -473,12 +493,34 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
                 maps.insert(maps.end(), m.begin(), m.end());
             }
             fill_floor0_dev(devs.data() + i * floor0_dev_size(), f0.order, f0.bark_map_size, f0.amp_ofs, off[0], off[1]);
+            if (D.f0_fused) {  // the same maps in the order a lane of the stereo fast path holds its bins (SynthArgs.f0_bark)
+                if (f0_bark.size() < (D.floors0.size() * 2) * 1024) f0_bark.assign((D.floors0.size() * 2) * 1024, 0);
+                for (int b = 0; b < 2; ++b) {
+                    const int n = halves[b], lpb = n / 16;
+                    if (n != 128 && n != 1024) continue;
+                    const int32_t *mp = maps.data() + off[b];
+                    uint16_t *T = f0_bark.data() + (i * 2 + (size_t)b) * 1024;
+                    for (int l = 0; l < lpb; ++l)
+                        for (int mm = 0; mm < 8; ++mm)
+                            for (int e2 = 0; e2 < 2; ++e2) {
+                                const int v = mp[2 * (l + lpb * mm) + e2];
+                                T[l * 16 + 2 * mm + e2] = (uint16_t)std::min(std::max(v, 0), D.f0_k - 1);
+                            }
+                }
+            }
         }
         if (any0) {
             e = hipMalloc(&D.d_floors0, devs.size());
             if (e == hipSuccess) e = hipMemcpy(D.d_floors0, devs.data(), devs.size(), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMalloc((void **)&D.d_bark_maps, sizeof(int32_t) * maps.size());
             if (e == hipSuccess) e = hipMemcpy(D.d_bark_maps, maps.data(), sizeof(int32_t) * maps.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess && D.f0_fused && !f0_bark.empty()) {
+                e = hipMalloc((void **)&D.d_f0_bark, sizeof(uint16_t) * f0_bark.size());
+                if (e == hipSuccess) e = hipMemcpy(D.d_f0_bark, f0_bark.data(), sizeof(uint16_t) * f0_bark.size(), hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMalloc((void **)&D.d_f0_w, sizeof(float) * D.floors0.size() * (size_t)D.f0_k);
+                if (e == hipSuccess) e = launch_floor0_wtab(D.d_floors0, (int)D.floors0.size(), D.f0_k, D.d_f0_w, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            }
         }
     }
     if (e != hipSuccess) {
@@ -497,7 +539,9 @@ void vpz_decoder_destroy(vpz_decoder *d)
         (void)hipSetDevice(D.ctx->device);
         (void)hipStreamSynchronize(D.ctx->stream);
     }
-    DevBuf *bufs[] = {&D.b_in_amp, &D.b_in_coeff, &D.b_ybuf, &D.b_curve, &D.b_temp, &D.b_cposts, &D.b_ccount, &D.b_in_res, &D.b_in_posts,
+    if (D.d_f0_bark) (void)hipFree(D.d_f0_bark);
+    if (D.d_f0_w) (void)hipFree(D.d_f0_w);
+    DevBuf *bufs[] = {&D.b_f0curve, &D.b_in_amp, &D.b_in_coeff, &D.b_ybuf, &D.b_curve, &D.b_temp, &D.b_cposts, &D.b_ccount, &D.b_in_res, &D.b_in_posts,
                       &D.b_in_counts, &D.b_out, &D.arenas[0].dev, &D.arenas[1].dev};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -629,7 +673,7 @@ struct SynthCall {
     // layout is a template parameter) and start where its loads are aligned: 16 bytes for the Residue2 vector, 8 for planar.
     bool dual_usable() const
     {
-        if (!D.dual_ok || any_floor0 || (ilv_seen && planar_seen)) return false;
+        if (!D.dual_ok || (any_floor0 && !D.f0_fused) || (ilv_seen && planar_seen)) return false;
         const bool dev_ok = mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & (ilv_seen ? 15 : 7)) == 0;
         return dev_ok && (ilv_seen ? group_align_ok : align2_ok);
     }
@@ -842,7 +886,8 @@ struct SynthCall {
         // back residues and a batch the fused kernel takes as it is (no planar temp, no type-0 floor pass)
         const bool group_usable = D.group_ok && group_align_ok &&
                                   (mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
-        compact = all_dense && !D.generic && !any_floor0 && !D.no_compact && (!need_coupling || group_usable || dual_usable());
+        compact = all_dense && !D.generic && (!any_floor0 || (D.f0_fused && dual_usable())) && !D.no_compact &&
+                  (!need_coupling || group_usable || dual_usable());
         if (compact) {
             cflags = arena_alloc<uint8_t>(*A, (size_t)n_packets);
             cmap = arena_alloc<uint8_t>(*A, (size_t)n_packets);
@@ -919,6 +964,7 @@ struct SynthCall {
                         fd.spec_off = pk.residue_offset;
                     }
                     fd.out_off = run;
+                    if (frame_is_steady(fd.flags, D.size1, fd.left_start, fd.packet_len, fd.prev_end, fd.out_count)) fd.flags |= kFrameSteady;
                     frames[p] = fd;
                 }
                 run += psamples[p];
@@ -997,6 +1043,7 @@ struct SynthCall {
                     if (!compact) {
                         frames[L].out_count = (uint16_t)cnt;
                         frames[L].left_start = (uint16_t)start;
+                        frames[L].flags &= ~kFrameSteady;  // (an EOS trim changed the geometry)
                     }
                 }
                 if (pk.granule != -1 && !has_pos) {  // :459-463 at the last packet itself
@@ -1152,6 +1199,7 @@ struct SynthCall {
             else planar_seen = true;
             if (pk.residue_offset & 3) group_align_ok = false;  // group mode reads every packet in 16-byte pieces
             if (pk.residue_offset & 1) align2_ok = false;
+            if (frame_is_steady(fd.flags, D.size1, fd.left_start, fd.packet_len, fd.prev_end, fd.out_count)) fd.flags |= kFrameSteady;
             frames[s_base[pk.stream] + s_cnt[pk.stream]++] = fd;
         }
         for (int s = 0; s < D.n_streams; ++s)
@@ -1187,7 +1235,7 @@ struct SynthCall {
         // (... or, with short blocks to batch, is walked in pieces: 65 536 frames of ONE stream cut by cost are a millisecond on one
         // thread and 40 us on sixteen once the cut hint applies -- and worth 12 % of the kernel's time, configs[2])
         const bool split = pool && !wide && pool->parties() > 1 && total_frames > 4096;
-        const bool batches = compact && (use_dual || (use_group && any_floor)) && any_short &&
+        const bool batches = compact && !any_floor0 && (use_dual || (use_group && any_floor)) && any_short &&
                              !synth_needs_general(D.size0, D.size1) && D.size0 == 256 && D.size1 != 256 && !D.generic &&
                              (wide || total_frames <= 4096 || split) && !(D.ablate & 128);
         cut_by_cost = batches;
@@ -1507,7 +1555,7 @@ struct SynthCall {
     {
         if (!need_coupling || use_group || use_dual) return;
         // the separate pass hands planar, de-coupled spectra over: the frames lose their group-mode bits
-        for (size_t fi = 0; fi < n_frames; ++fi) frames[fi].flags &= 0xFu | (kFrameSkipMask << kFrameSkipShift);
+        for (size_t fi = 0; fi < n_frames; ++fi) frames[fi].flags &= 0xFu | (kFrameSkipMask << kFrameSkipShift) | kFrameSteady;
         const size_t cps = coupling_packet_size();
         cpk = arena_alloc<uint8_t>(*A, cps * n_frames);
         for (size_t fi = 0; fi < n_frames; ++fi) {
@@ -1529,6 +1577,12 @@ struct SynthCall {
     int build_floor0_records()
     {
         if (!any_floor0) return VPZ_OK;
+        if (use_dual) {  // (the stereo fast path applies type-0 floors itself: floor0_curve_kernel works from the per-record info)
+            if (!D.f0_amp || !D.f0_coeff || D.f0_stride < 1)
+                return set_error(ctx, VPZ_E_INVALID_ARG,
+                                 "vpz_decoder_synth: type-0 floors need vpz_decoder_set_floor0_data before the call");
+            return VPZ_OK;
+        }
         if (!D.f0_amp || !D.f0_coeff || D.f0_stride < 1)
             return set_error(ctx, VPZ_E_INVALID_ARG,
                              "vpz_decoder_synth: type-0 floors need vpz_decoder_set_floor0_data before the call");
@@ -1694,6 +1748,7 @@ struct SynthCall {
         }
         if (need_coupling && !use_group && !use_dual && (rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK)
             return rc;
+        if (any_floor0 && use_dual && (rc = grow(ctx, D.b_f0curve, sizeof(float) * (size_t)n_rec * (size_t)D.f0_k)) != VPZ_OK) return rc;
         if (any_floor) {
             if ((rc = grow(ctx, D.b_cposts, sizeof(int32_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
             if ((rc = grow(ctx, D.b_ccount, (size_t)n_rec)) != VPZ_OK) return rc;
@@ -1730,15 +1785,21 @@ struct SynthCall {
         const int32_t *d_cposts = static_cast<const int32_t *>(D.b_cposts.p);
         const uint8_t *d_ccount = static_cast<const uint8_t *>(D.b_ccount.p);
         if (any_floor) {  // Floor1.UnwrapPosts and the choice of the posts a line is drawn to, per channel record
+            const bool f0_fused = any_floor0 && use_dual;
             hipError_t e = launch_floor1_unwrap((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(dev(rec_floor)),
                                                 D.d_floors, (int)D.floors.size(), static_cast<int32_t *>(D.b_cposts.p),
-                                                static_cast<uint8_t *>(D.b_ccount.p), nullptr, nullptr, ctx->stream);
+                                                static_cast<uint8_t *>(D.b_ccount.p), nullptr, nullptr, ctx->stream, f0_fused ? 1 : 0);
+            if (e == hipSuccess && f0_fused) {  // the records' Floor0 curves over their bark indices (Floor0.cs:188-219)
+                e = launch_floor0_curves((int)n_rec, static_cast<uint8_t *>(dev(rec_floor)), D.d_floors0, d_amp, d_coeff, D.f0_stride,
+                                         D.f0_k, D.d_f0_w, static_cast<float *>(D.b_f0curve.p), ctx->stream);
+                D.f0_amp = D.f0_coeff = nullptr;  // consumed
+            }
             if (e == hipSuccess && D.generic)  // the three-pass path reads the curve from memory
                 e = launch_floor1_render((int)n_rec, d_cposts, d_ccount, static_cast<uint8_t *>(dev(rec_floor)), half0,
                                          half1, static_cast<uint8_t *>(D.b_curve.p), ctx->stream);
             if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor1 unwrap kernel launch", e);
         }
-        if (any_floor0) {  // Floor0.Apply in place on the temp (rare; Floor0.cs:164-225)
+        if (any_floor0 && !use_dual) {  // Floor0.Apply in place on the temp (rare; Floor0.cs:164-225)
             hipError_t e = launch_floor0_apply(dev(f0recs), n_f0, D.d_floors0, D.d_bark_maps, d_amp, d_coeff, D.f0_stride,
                                                static_cast<float *>(D.b_temp.p), ctx->stream);
             if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "floor0 kernel launch", e);
@@ -1809,6 +1870,9 @@ struct SynthCall {
         a.group = use_group ? 1 : 0;
         a.group_dma = (use_group && D.group_dma) ? 1 : 0;
         a.inv_db = ctx->d_inv_db;
+        a.f0_curve = static_cast<const float *>(D.b_f0curve.p);
+        a.f0_bark = D.d_f0_bark;
+        a.f0_stride = D.f0_k;
         a.state_h = D.d_state_h;
         a.state_slot_floats = (int64_t)D.n_streams * C * half1;
         a.tw_long = D.t1->d_fast;
@@ -1822,7 +1886,7 @@ struct SynthCall {
         a.s16 = out_s16 ? 1 : 0;
         a.clip = D.clip;
         a.clipped = D.d_clipped;
-        a.no_batch = ((D.ablate & 128) || !cut_by_cost) ? 1 : 0;
+        a.no_batch = ((D.ablate & 128) || !cut_by_cost || any_floor0) ? 1 : 0;
         a.ablate = D.ablate;
         a.stamps = nullptr;
 #if defined(VPZ_STAMPS) || defined(VPZ_WAVE_TIMES)
