@@ -21,7 +21,8 @@ hipError_t launch_floor1_unwrap(int n_rec, const int16_t *posts, const uint8_t *
                                 const FloorDev *floors, int n_floors, int32_t *cposts, uint8_t *ccount, int16_t *dbg_y,
                                 uint8_t *dbg_f, hipStream_t stream, int f0_fused = 0);
 hipError_t launch_floor0_curves(int n_rec, const uint8_t *rec_info, const void *floors, const float *amp, const float *coeff,
-                                int coeff_stride, int k_stride, const float *wtab, float *curve, hipStream_t stream);
+                                int coeff_stride, int k_stride, const float *wtab, float *curve, const uint8_t *post_counts,
+                                uint8_t *ccount, int32_t *cposts, hipStream_t stream);
 hipError_t launch_floor0_wtab(const void *floors, int n_floors, int k_stride, float *wtab, hipStream_t stream);
 hipError_t launch_floor1_render(int n_rec, const int32_t *cposts, const uint8_t *ccount, const uint8_t *rec_info,
                                 int half0, int half1, uint8_t *curve_y, hipStream_t stream);
@@ -149,6 +150,7 @@ struct Decoder {
     // type-0 floors inside the stereo fast path (floor0_curve_kernel + floor0_multiply): possible when every type-0 floor's
     // bark map has at most kFloor0MaxBark entries; f0_k = the largest of them (row length of the per-record curves)
     bool f0_fused = false;
+    bool has_floor1 = false;  // some floor of the setup is of type 1
     int f0_k = 0;
     uint16_t *d_f0_bark = nullptr;   // [floor][short / long][1024]: bark index of every bin in lane order (SynthArgs.f0_bark)
     float *d_f0_w = nullptr;         // [floor][f0_k]: 2 cos(pi k / bark_map_size), Floor0's wMap (floor0_wtab_kernel)
@@ -391,6 +393,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     {
         bool has_floor0 = false;
         for (uint8_t t : D.floor_types) has_floor0 |= (t == 0);
+        for (uint8_t t : D.floor_types) D.has_floor1 |= (t != 0);
         const char *no_group = getenv("VPZ_NO_GROUP");  // tuning / A-B tests: force the separate coupling pass
         D.group_ok = synth_group_supported(D.channels) && !D.generic && !has_floor0 && D.max_steps <= 255 &&
                      D.n_step_pairs <= kGroupMaxStepPairs && !(no_group && atoi(no_group));
@@ -403,6 +406,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
                 if (D.floors0[i].bark_map_size < 1 || D.floors0[i].bark_map_size > kFloor0MaxBark) D.f0_fused = false;
                 D.f0_k = std::max(D.f0_k, (int)D.floors0[i].bark_map_size);
             }
+        D.f0_k = (D.f0_k + 255) & ~255;  // (rows of whole 256-value rounds: floor0_curve_kernel stores a round without asking)
         D.dual_ok = synth_dual_supported(D.channels, D.size0, D.size1) && !D.generic && (!has_floor0 || D.f0_fused) && D.max_steps <= 255 &&
                     D.n_step_pairs <= kGroupMaxStepPairs && !(no_dual && atoi(no_dual));
         D.f0_fused = D.f0_fused && D.dual_ok;
@@ -1786,12 +1790,16 @@ struct SynthCall {
         const uint8_t *d_ccount = static_cast<const uint8_t *>(D.b_ccount.p);
         if (any_floor) {  // Floor1.UnwrapPosts and the choice of the posts a line is drawn to, per channel record
             const bool f0_fused = any_floor0 && use_dual;
-            hipError_t e = launch_floor1_unwrap((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(dev(rec_floor)),
-                                                D.d_floors, (int)D.floors.size(), static_cast<int32_t *>(D.b_cposts.p),
-                                                static_cast<uint8_t *>(D.b_ccount.p), nullptr, nullptr, ctx->stream, f0_fused ? 1 : 0);
+            // (a decoder whose floors are all of type 0 has nothing to unwrap: the curve kernel leaves the records' markers itself)
+            hipError_t e = hipSuccess;
+            if (!(f0_fused && !D.has_floor1))
+                e = launch_floor1_unwrap((int)n_rec, d_posts, d_counts, static_cast<uint8_t *>(dev(rec_floor)), D.d_floors,
+                                         (int)D.floors.size(), static_cast<int32_t *>(D.b_cposts.p),
+                                         static_cast<uint8_t *>(D.b_ccount.p), nullptr, nullptr, ctx->stream, f0_fused ? 1 : 0);
             if (e == hipSuccess && f0_fused) {  // the records' Floor0 curves over their bark indices (Floor0.cs:188-219)
                 e = launch_floor0_curves((int)n_rec, static_cast<uint8_t *>(dev(rec_floor)), D.d_floors0, d_amp, d_coeff, D.f0_stride,
-                                         D.f0_k, D.d_f0_w, static_cast<float *>(D.b_f0curve.p), ctx->stream);
+                                         D.f0_k, D.d_f0_w, static_cast<float *>(D.b_f0curve.p), d_counts,
+                                         static_cast<uint8_t *>(D.b_ccount.p), static_cast<int32_t *>(D.b_cposts.p), ctx->stream);
                 D.f0_amp = D.f0_coeff = nullptr;  // consumed
             }
             if (e == hipSuccess && D.generic)  // the three-pass path reads the curve from memory
