@@ -381,8 +381,11 @@ def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, 
             dec.reset(-1)
             # (issue6test.ogg's trailing empty packet fails the window check -- StreamDecoder.cs:777-778 throws out of that
             # one Read --: a per-packet status since ABI v3, the call and every stream's PCM are valid)
-            w = dec.synth_raw(pk, res, posts, counts, out, offs, cap, capi.OUT_INTERLEAVED, 0, capi.MEM_DEVICE,
-                              on_mismatch="ignore")
+            # (VPZ_BENCH_REAL_LAYOUT=planar: an A/B switch for tools/, never the bench's default -- the reference's ReadSamples(Span<float>)
+            # delivers interleaved samples)
+            planar = os.environ.get("VPZ_BENCH_REAL_LAYOUT") == "planar"
+            w = dec.synth_raw(pk, res, posts, counts, out, offs, cap, capi.OUT_PLANAR if planar else capi.OUT_INTERLEAVED,
+                              cap if planar else 0, capi.MEM_DEVICE, on_mismatch="ignore")
             assert [int(v) for v in w] == samples, "sample counts"
             assert dec.last_mismatches() == sum(1 for v in samples if v == REAL_FIXTURES[1][1]), "skipped packets"
 
