@@ -103,7 +103,28 @@ def brace_block_end(lines, start):
     """Index of the line that closes the brace block opened on lines[start] (the last `{` of that line)."""
     depth = 0
     opened = False
+    # (preprocessor alternatives: `#ifdef X / if (a) { / #else / if (b) { / #endif` opens ONE block -- only the branch a build
+    # without -D switches compiles is counted: the #else branch of an #ifdef, the first branch of an #ifndef)
+    active = [True]
     for k in range(start, len(lines)):
+        pp = lines[k].strip()
+        if pp.startswith("#ifdef") or (pp.startswith("#if ") and "defined" in pp and "!defined" not in pp):
+            active.append(False)
+            continue
+        if pp.startswith("#ifndef") or pp.startswith("#if"):
+            active.append(True)
+            continue
+        if pp.startswith("#else") and len(active) > 1:
+            active[-1] = not active[-1]
+            continue
+        if pp.startswith("#elif") and len(active) > 1:
+            active[-1] = False
+            continue
+        if pp.startswith("#endif") and len(active) > 1:
+            active.pop()
+            continue
+        if not all(active):
+            continue
         code = re.sub(r'//.*', "", lines[k])
         if k == start:  # the block is the one the LAST `{` of the opening line opens (`} else if (...) {`)
             code = code[code.rfind("{"):]

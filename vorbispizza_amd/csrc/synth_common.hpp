@@ -375,6 +375,20 @@ __device__ __forceinline__ void store_pcm4(float4 *p, float4 v)
     vpz_f4v t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, (VPZ_GLOBAL vpz_f4v *)reinterpret_cast<vpz_f4v *>(p));
 }
+// Two adjacent 16-byte pieces per lane (interleaved stereo float32: L R L R | L R L R): two store instructions, each covering HALF of
+// every 32-byte sector the wave writes.  As non-temporal stores the halves reach memory separately (rocprofv3 WRITE_SIZE: 510 MB
+// for 428 MB of PCM on the configs[4] share, profiles/r4_pmc_write_layouts.txt); as plain stores they meet in the L2 first.
+__device__ __forceinline__ void store_pcm4_pair(float4 *p, float4 v0, float4 v1)
+{
+    vpz_f4v t0 = {v0.x, v0.y, v0.z, v0.w}, t1 = {v1.x, v1.y, v1.z, v1.w};
+#ifdef VPZ_PAIR_STORES_NT
+    __builtin_nontemporal_store(t0, (VPZ_GLOBAL vpz_f4v *)reinterpret_cast<vpz_f4v *>(p));
+    __builtin_nontemporal_store(t1, (VPZ_GLOBAL vpz_f4v *)reinterpret_cast<vpz_f4v *>(p) + 1);
+#else
+    *((VPZ_GLOBAL vpz_f4v *)reinterpret_cast<vpz_f4v *>(p)) = t0;
+    *((VPZ_GLOBAL vpz_f4v *)reinterpret_cast<vpz_f4v *>(p) + 1) = t1;
+#endif
+}
 template <class T>
 __device__ __forceinline__ void store_pcm(T *p, T v) { *(VPZ_GLOBAL T *)p = v; }
 

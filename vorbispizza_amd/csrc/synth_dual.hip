@@ -652,9 +652,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 if (kS16) {
                     store_nt(reinterpret_cast<uint4 *>(row_i) + g, pack_s16(l0, r0), pack_s16(l1, r1), pack_s16(l2, r2), pack_s16(l3, r3));
                 } else {
-                    float4 *d = reinterpret_cast<float4 *>(row_i) + 2 * g;
-                    store_pcm4(d, make_float4(l0, r0, l1, r1));
-                    store_pcm4(d + 1, make_float4(l2, r2, l3, r3));
+                    store_pcm4_pair(reinterpret_cast<float4 *>(row_i) + 2 * g, make_float4(l0, r0, l1, r1), make_float4(l2, r2, l3, r3));
                 }
             } else if (kS16) {
                 store_nt(reinterpret_cast<uint2 *>(row_l) + g, pack_s16(l0, l1), pack_s16(l2, l3));
