@@ -701,15 +701,22 @@ def time_decoder(ctx, dec, torch, pk, residue, posts, counts, samples, channels,
         ctx.synchronize()
         dt = (time.perf_counter() - t0) / steps
         best = dt if best is None else min(best, dt)
-    # the GPU time of every call on its own (HIP events on the library's stream around ONE call): what the spread of a fixed
-    # batch is -- the run cutting must land on one cut for it, call after call
-    us = []
-    for _ in range(steps):
-        ctx.timer_start()
+    # The device time of every call of a back-to-back sequence: one HIP event on the LIBRARY's stream (wrapped as a torch external
+    # stream -- an event recorded on torch's own stream would not see the kernels) behind every call, nothing synchronised in
+    # between; consecutive events are one call's kernels plus the gap to the next call's.  What the spread of a fixed batch is:
+    # the run cutting lands on one cut for it, call after call (VPZ_HOST_PROFILE=1 logs it), the rest is the device's.
+    ext = torch.cuda.ExternalStream(int(ctx.stream), device=residue.device)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 2)]
+    step()
+    evs[0].record(ext)
+    for i in range(steps + 1):
         step()
-        us.append(ctx.timer_stop() * 1e3)
-    time_decoder.last_spread = {"kernel_us_min": round(min(us), 1), "kernel_us_mean": round(sum(us) / len(us), 1),
-                                "kernel_us_max": round(max(us), 1), "calls": len(us)}
+        evs[i + 1].record(ext)
+    ctx.synchronize()
+    us = [evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(1, steps + 1)]  # (the first interval holds the queue's start-up)
+    time_decoder.last_spread = {"device_us_per_call_min": round(min(us), 1), "device_us_per_call_mean": round(sum(us) / len(us), 1),
+                                "device_us_per_call_max": round(max(us), 1), "max_over_min": round(max(us) / min(us), 3),
+                                "calls": len(us), "how": "HIP events on the library's stream behind each of consecutive calls"}
     return best, out
 
 

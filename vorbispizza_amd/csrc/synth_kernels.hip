@@ -1281,9 +1281,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                     store_nt(reinterpret_cast<uint4 *>(pair_row) + g, pack_s16(l0, r0), pack_s16(l1, r1), pack_s16(l2, r2),
                              pack_s16(l3, r3));
                 } else {
-                    float4 *d = reinterpret_cast<float4 *>(pair_row) + 2 * g;
-                    store_pcm4(d, make_float4(l0, r0, l1, r1));
-                    store_pcm4(d + 1, make_float4(l2, r2, l3, r3));
+                    store_pcm4_pair(reinterpret_cast<float4 *>(pair_row) + 2 * g, make_float4(l0, r0, l1, r1), make_float4(l2, r2, l3, r3));
                 }
             };
             if (vec_pair && VPZ_STEADY(fd) && prev_n4 == 512) {
