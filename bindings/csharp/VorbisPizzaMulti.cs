@@ -21,9 +21,9 @@ namespace NVorbis.Native
         {
             public int HostThreads;         // entropy-decode threads over all devices (0: the CPUs the process may use)
             public int StreamsPerCall;      // streams per vpz_decoder_synth call (0: 16)
-            public int ContextsPerDevice;   // contexts / issuing threads per device (0: 2)
+            public int ContextsPerDevice;   // contexts / issuing threads per device (0: 4 with 8 or more host threads per device, else 2)
             public int ClipSamples;         // StreamDecoder.ClipSamples
-            public int SlotsPerDevice;      // sub-batches in flight per device (0: 2 * contexts + 2)
+            public int SlotsPerDevice;      // sub-batches in flight per device (0: 4 * contexts + 4)
             public fixed int Reserved[3];
         }
 

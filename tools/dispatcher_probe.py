@@ -19,7 +19,7 @@ for s16 in (False, True):
         best = None
         for _ in range(3):
             res, st = d.decode_library(datas, pcm, offs, caps, s16=s16)
-            assert (res["status"] == 0).all()
+            assert (res["status"] == 0).all() or os.environ.get("VPZM_NO_SYNTH")
             if best is None or st.wall_s < best[0]:
                 best = (st.wall_s, st.device_decode_s[0], st.device_synth_s[0])
         d.close()

@@ -478,7 +478,6 @@ struct Residue {
     std::vector<uint8_t> cascade;
     std::vector<std::vector<uint8_t>> books;  // per class: book per stage (empty: null)
     std::vector<int> decode_map;
-    std::vector<int> part_word_cache;
 
     void read(BitReader &p, int type_, const std::vector<Codebook> &cbs)
     {
@@ -668,8 +667,9 @@ struct Residue {
     }
 
     // Residue0.Decode :117-206.  buffer: `count` channels at stride `stride`.
+    // (part_word_cache: the caller's scratch -- a Residue belongs to a setup that many streams share, so it is not written here)
     void decode(BitReader &p, const std::vector<uint8_t> &do_not_decode, int block_size, float *buffer, int stride,
-                const std::vector<Codebook> &cbs)
+                const std::vector<Codebook> &cbs, std::vector<int> &part_word_cache) const
     {
         int half = block_size / 2;
         int b = begin < half ? begin : half;
@@ -831,8 +831,9 @@ uint32_t crc_update(uint32_t crc, const uint8_t *d, size_t n)
 // What the setup header of a stream unpacks into (StreamDecoder.cs:262-321): codebooks with their decode tables, floors,
 // residues, mappings, modes.  Files that come out of one encoder at one setting carry byte-identical setup headers, and a host
 // that transcodes a library opens thousands of them: the unpacked form of the last few distinct (identification, setup)
-// header pairs is kept, and a stream whose headers match one byte for byte copies it instead of building ~40 Huffman tables
-// again (0.36 -> 0.1 ms of a 2 ms file).  VPZH_NO_SETUP_CACHE=1 switches it off.
+// header pairs is kept, and a stream whose headers match one byte for byte SHARES it (read-only; a stream's scratch is its own)
+// instead of building ~40 Huffman tables again -- no copy either: a thousand streams of one encoder decode out of one set of
+// tables that stays in the cache.  VPZH_NO_SETUP_CACHE=1 gives every stream its own.
 struct SetupBlob {
     std::vector<uint8_t> ident, setup;  // the key: both packets, compared in full
     std::vector<Codebook> books;
@@ -866,18 +867,19 @@ struct SetupCache {
                 return b;
         return nullptr;
     }
-    void insert(std::shared_ptr<const SetupBlob> b)
+    std::shared_ptr<const SetupBlob> insert(std::shared_ptr<const SetupBlob> b)
     {
-        if (!enabled) return;
+        if (!enabled) return b;
         std::lock_guard<std::mutex> lock(mu);
         for (const auto &e : entries)  // (threads that opened the same headers at the same time: one copy)
-            if (e->setup == b->setup && e->ident == b->ident) return;
+            if (e->setup == b->setup && e->ident == b->ident) return e;
         if (entries.size() < kEntries) {
-            entries.push_back(std::move(b));
+            entries.push_back(b);
         } else {
-            entries[next] = std::move(b);
+            entries[next] = b;
             next = (next + 1) % kEntries;
         }
+        return b;
     }
 };
 static SetupCache &setup_cache()
@@ -889,15 +891,10 @@ static SetupCache &setup_cache()
 struct vpzh_stream {
     std::string error;
     int channels = 0, sample_rate = 0, size0 = 0, size1 = 0;
-    std::vector<Codebook> books;
-    std::vector<Floor1> floors;          // indexed by floor number; unused entries for type-0 floors
-    std::vector<Floor0> floors0;         // same indexing; unused entries for type-1 floors
-    std::vector<uint8_t> floor_types;
-    int max_floor0_order = 0;
-    std::vector<Residue> residues;
-    std::vector<Mapping> mappings;
-    std::vector<Mode> modes;
-    int mode_field_bits = 0;
+    // the unpacked setup header (floors indexed by floor number: unused entries in `floors` for type-0 floors and in `floors0` for
+    // type-1 ones), possibly shared with other streams -- never written after parse_headers
+    std::shared_ptr<const SetupBlob> su;
+    std::vector<int> residue_scratch;    // Residue::decode's part_word_cache
     std::vector<OggPacket> audio;
     int64_t last_granule = -1;
     int pages = 0, bad_crc = 0;
@@ -1044,17 +1041,18 @@ struct vpzh_stream {
         }
         // setup, StreamDecoder.cs:262-321 -- or its unpacked form, if these very headers have been seen before
         if (std::shared_ptr<const SetupBlob> hit = setup_cache().find(pk[0].data, pk[2].data)) {
-            books = hit->books;
-            floors = hit->floors;
-            floors0 = hit->floors0;
-            floor_types = hit->floor_types;
-            max_floor0_order = hit->max_floor0_order;
-            residues = hit->residues;
-            mappings = hit->mappings;
-            modes = hit->modes;
-            mode_field_bits = hit->mode_field_bits;
+            su = std::move(hit);
             return;
         }
+        auto blob = std::make_shared<SetupBlob>();
+        std::vector<Codebook> &books = blob->books;
+        std::vector<Floor1> &floors = blob->floors;
+        std::vector<Floor0> &floors0 = blob->floors0;
+        std::vector<uint8_t> &floor_types = blob->floor_types;
+        int &max_floor0_order = blob->max_floor0_order;
+        std::vector<Residue> &residues = blob->residues;
+        std::vector<Mapping> &mappings = blob->mappings;
+        std::vector<Mode> &modes = blob->modes;
         BitReader p;
         p.init(pk[2].data.data(), pk[2].data.size());
         static const uint8_t sig[7] = {0x05, 'v', 'o', 'r', 'b', 'i', 's'};
@@ -1101,21 +1099,13 @@ struct vpzh_stream {
             if (m.mapping >= n_map) throw InvalidData("Mode header had invalid mapping index!");
         }
         if (!p.read_bit()) throw InvalidData("Book packet did not end on correct bit!");
-        mode_field_bits = ilog(n_modes - 1);
+        blob->mode_field_bits = ilog(n_modes - 1);
         if (setup_cache().enabled) {
-            auto blob = std::make_shared<SetupBlob>();
             blob->ident = pk[0].data;
             blob->setup = pk[2].data;
-            blob->books = books;
-            blob->floors = floors;
-            blob->floors0 = floors0;
-            blob->floor_types = floor_types;
-            blob->max_floor0_order = max_floor0_order;
-            blob->residues = residues;
-            blob->mappings = mappings;
-            blob->modes = modes;
-            blob->mode_field_bits = mode_field_bits;
-            setup_cache().insert(std::move(blob));
+            su = setup_cache().insert(std::move(blob));  // (the cache's copy, if another thread was first with these headers)
+        } else {
+            su = std::move(blob);
         }
     }
 
@@ -1125,9 +1115,9 @@ struct vpzh_stream {
         BitReader p;
         p.init(pk.data.data(), pk.data.size());
         if (p.read_bits(1) != 0) return 0;
-        int mode_idx = (int)p.read_bits(mode_field_bits);
-        if (mode_idx >= (int)modes.size()) return 0;
-        return (int64_t)channels * ((modes[mode_idx].block_flag ? size1 : size0) / 2);
+        int mode_idx = (int)p.read_bits(su->mode_field_bits);
+        if (mode_idx >= (int)su->modes.size()) return 0;
+        return (int64_t)channels * ((su->modes[mode_idx].block_flag ? size1 : size0) / 2);
     }
 
     // IPacketGranuleCountProvider.GetPacketGranuleCount (StreamDecoder.cs:884-913): what a packet adds to the
@@ -1137,9 +1127,9 @@ struct vpzh_stream {
         BitReader p;
         p.init(pk.data.data(), pk.data.size());
         if (p.read_bits(1) != 0) return 0;
-        const int mode_idx = (int)p.read_bits(mode_field_bits);
-        if (mode_idx >= (int)modes.size()) return 0;
-        const bool bf = modes[mode_idx].block_flag;
+        const int mode_idx = (int)p.read_bits(su->mode_field_bits);
+        if (mode_idx >= (int)su->modes.size()) return 0;
+        const bool bf = su->modes[mode_idx].block_flag;
         bool prev = true, next = true;
         if (bf) {
             prev = p.read_bit();
@@ -1174,9 +1164,9 @@ struct vpzh_stream {
         BitReader p;
         p.init(pk.data.data(), pk.data.size());
         if (p.read_bits(1) != 0) { out->flags |= VPZ_PKT_NOT_DECODED; return; }
-        int mode_idx = (int)p.read_bits(mode_field_bits);
-        if ((unsigned)mode_idx >= modes.size()) throw InvalidData("Unused mode index.");
-        const Mode &mode = modes[mode_idx];
+        int mode_idx = (int)p.read_bits(su->mode_field_bits);
+        if ((unsigned)mode_idx >= su->modes.size()) throw InvalidData("Unused mode index.");
+        const Mode &mode = su->modes[mode_idx];
         if (p.is_short) { out->flags |= VPZ_PKT_NOT_DECODED; return; }  // Mode.cs:32-36
         const int block_size = mode.block_flag ? size1 : size0;
         const int half = block_size / 2;
@@ -1187,18 +1177,18 @@ struct vpzh_stream {
         }
         out->mapping = (uint8_t)mode.mapping;
         out->granule = pk.granule;
-        const Mapping &map = mappings[mode.mapping];
+        const Mapping &map = su->mappings[mode.mapping];
 
         // floors, Mapping.cs:109-118
         std::vector<uint8_t> no_execute(channels);
         for (int ch = 0; ch < channels; ++ch) {
             const int fl = map.submap_floor[map.mux[ch]];
-            if (floor_types[fl] == 0) {  // Floor0.Unpack; ExecuteChannel = Amp != 0
+            if (su->floor_types[fl] == 0) {  // Floor0.Unpack; ExecuteChannel = Amp != 0
                 float tmp[256];
-                const float amp = floors0[fl].unpack(p, books, tmp);
+                const float amp = su->floors0[fl].unpack(p, su->books, tmp);
                 if (f0_amp) {
                     f0_amp[ch] = amp;
-                    for (int i = 0; i < f0_stride; ++i) f0_coeff[(size_t)ch * f0_stride + i] = i < floors0[fl].order ? tmp[i] : 0.f;
+                    for (int i = 0; i < f0_stride; ++i) f0_coeff[(size_t)ch * f0_stride + i] = i < su->floors0[fl].order ? tmp[i] : 0.f;
                 }
                 post_counts[ch] = amp != 0.f ? 1 : 0;
                 no_execute[ch] = amp == 0.f;
@@ -1206,7 +1196,7 @@ struct vpzh_stream {
             }
             int raw[64];
             memset(raw, 0, sizeof raw);
-            int pc = floors[fl].unpack(p, books, raw);
+            int pc = su->floors[fl].unpack(p, su->books, raw);
             if (pc > 64) pc = 64;
             post_counts[ch] = (uint8_t)pc;
             for (int i = 0; i < 64; ++i) {
@@ -1225,7 +1215,7 @@ struct vpzh_stream {
         float *dst = residue;  // planar [ch][half] unless the interleaved shortcut below is taken
         memset(dst, 0, sizeof(float) * (size_t)channels * half);
         const int submaps = (int)map.submap_residue.size();
-        if (submaps == 1 && channels > 1 && residues[map.submap_residue[0]].type == 2) {
+        if (submaps == 1 && channels > 1 && su->residues[map.submap_residue[0]].type == 2) {
             // The common stereo / multichannel case, one Residue2 submap over every channel: decode the
             // interleaved vector straight into the output and let the GPU de-interleave (Residue2.cs:42-51) --
             // same values as the general path below, without its scratch buffers.
@@ -1237,7 +1227,7 @@ struct vpzh_stream {
             if (all_mux0) {
                 if (any) {
                     one_flag.assign(1, 0);
-                    residues[map.submap_residue[0]].decode(p, one_flag, block_size * channels, dst, half * channels, books);
+                    su->residues[map.submap_residue[0]].decode(p, one_flag, block_size * channels, dst, half * channels, su->books, residue_scratch);
                 }
                 // (a packet whose channels are all silent is zeros in either layout: it keeps the stream's layout, so that
                 // a batch has ONE input layout and the back end's fast paths -- whose loads are unconditional -- take it)
@@ -1252,7 +1242,7 @@ struct vpzh_stream {
             std::vector<int> members;
             for (int j = 0; j < channels; ++j)
                 if (map.mux[j] == i) { dnd.push_back(no_execute[j]); members.push_back(j); }
-            Residue &res = residues[map.submap_residue[i]];
+            const Residue &res = su->residues[map.submap_residue[i]];
             const int count = (int)dnd.size();
             if (res.type == 2) {  // Residue2.cs:12-52
                 bool any = false;
@@ -1262,7 +1252,7 @@ struct vpzh_stream {
                 } else {
                     std::vector<float> tmp((size_t)half * count, 0.f);
                     std::vector<uint8_t> one(1, 0);
-                    res.decode(p, one, block_size * count, tmp.data(), half * count, books);
+                    res.decode(p, one, block_size * count, tmp.data(), half * count, su->books, residue_scratch);
                     if (submaps == 1 && count == channels && channels > 1) {
                         // hand the Residue2 vector over as it is: the GPU de-interleaves (Residue2.cs:42-51)
                         memcpy(dst, tmp.data(), sizeof(float) * (size_t)half * channels);
@@ -1277,7 +1267,7 @@ struct vpzh_stream {
                     }
                 }
             } else {
-                res.decode(p, dnd, block_size, decode_buffer.data(), block_size, books);
+                res.decode(p, dnd, block_size, decode_buffer.data(), block_size, su->books, residue_scratch);
             }
             for (int k = 0; k < count; ++k)
                 memcpy(dst + (size_t)members[k] * half, &decode_buffer[(size_t)k * block_size], sizeof(float) * half);
@@ -1334,11 +1324,11 @@ int vpzh_get_info(vpzh_stream *s, vpzh_info *info)
     info->sample_rate = s->sample_rate;
     info->block_size0 = s->size0;
     info->block_size1 = s->size1;
-    info->floor_count = (int32_t)s->floors.size();
-    info->residue_count = (int32_t)s->residues.size();
-    info->mapping_count = (int32_t)s->mappings.size();
-    info->mode_count = (int32_t)s->modes.size();
-    info->codebook_count = (int32_t)s->books.size();
+    info->floor_count = (int32_t)s->su->floors.size();
+    info->residue_count = (int32_t)s->su->residues.size();
+    info->mapping_count = (int32_t)s->su->mappings.size();
+    info->mode_count = (int32_t)s->su->modes.size();
+    info->codebook_count = (int32_t)s->su->books.size();
     info->audio_packets = (int64_t)s->audio.size();
     info->last_granule = s->last_granule;
     info->residue_floats = s->residue_floats;
@@ -1350,14 +1340,14 @@ int vpzh_get_info(vpzh_stream *s, vpzh_info *info)
 
 int vpzh_get_floor_type(vpzh_stream *s, int index)
 {
-    if (!s || index < 0 || index >= (int)s->floor_types.size()) return VPZH_E_ARG;
-    return s->floor_types[index];
+    if (!s || index < 0 || index >= (int)s->su->floor_types.size()) return VPZH_E_ARG;
+    return s->su->floor_types[index];
 }
 
 int vpzh_get_floor0(vpzh_stream *s, int index, vpz_floor0_config *out)
 {
-    if (!s || !out || index < 0 || index >= (int)s->floors0.size() || s->floor_types[index] != 0) return VPZH_E_ARG;
-    const Floor0 &f = s->floors0[index];
+    if (!s || !out || index < 0 || index >= (int)s->su->floors0.size() || s->su->floor_types[index] != 0) return VPZH_E_ARG;
+    const Floor0 &f = s->su->floors0[index];
     out->order = f.order;
     out->rate = f.rate;
     out->bark_map_size = f.bark_map_size;
@@ -1366,12 +1356,12 @@ int vpzh_get_floor0(vpzh_stream *s, int index, vpz_floor0_config *out)
     return VPZH_OK;
 }
 
-int vpzh_max_floor0_order(vpzh_stream *s) { return s ? s->max_floor0_order : 0; }
+int vpzh_max_floor0_order(vpzh_stream *s) { return s ? s->su->max_floor0_order : 0; }
 
 int vpzh_get_floor1(vpzh_stream *s, int index, vpz_floor1_config *out)
 {
-    if (!s || !out || index < 0 || index >= (int)s->floors.size() || s->floor_types[index] != 1) return VPZH_E_ARG;
-    const Floor1 &f = s->floors[index];
+    if (!s || !out || index < 0 || index >= (int)s->su->floors.size() || s->su->floor_types[index] != 1) return VPZH_E_ARG;
+    const Floor1 &f = s->su->floors[index];
     memset(out, 0, sizeof *out);
     if (f.x_list.size() > VPZ_POSTS_STRIDE) return VPZH_E_INVALID_DATA;  // `Posts = new int[64]`, Floor1.cs:17
     out->x_count = (int32_t)f.x_list.size();
@@ -1382,8 +1372,8 @@ int vpzh_get_floor1(vpzh_stream *s, int index, vpz_floor1_config *out)
 
 int vpzh_get_mapping(vpzh_stream *s, int index, vpz_mapping_config *out)
 {
-    if (!s || !out || index < 0 || index >= (int)s->mappings.size()) return VPZH_E_ARG;
-    const Mapping &m = s->mappings[index];
+    if (!s || !out || index < 0 || index >= (int)s->su->mappings.size()) return VPZH_E_ARG;
+    const Mapping &m = s->su->mappings[index];
     memset(out, 0, sizeof *out);
     out->coupling_steps = (int32_t)m.coupling_angle.size();
     for (size_t i = 0; i < m.coupling_angle.size(); ++i) {
@@ -1403,8 +1393,8 @@ int vpzh_get_mapping(vpzh_stream *s, int index, vpz_mapping_config *out)
         for (size_t i = 0; i < m.submap_residue.size(); ++i) {
             int count = 0;
             for (int c = 0; c < s->channels; ++c) count += m.mux[c] == (int)i;
-            if (count == 0 || m.submap_residue[i] >= s->residues.size()) continue;
-            const Residue &r = s->residues[m.submap_residue[i]];
+            if (count == 0 || m.submap_residue[i] >= s->su->residues.size()) continue;
+            const Residue &r = s->su->residues[m.submap_residue[i]];
             const int64_t n = r.type == 2 ? (int64_t)half * count : half;
             const int64_t rb = std::min<int64_t>(r.begin, n), re = std::min<int64_t>(r.end, n);
             if (re <= rb) continue;
@@ -1421,8 +1411,8 @@ int vpzh_get_mapping(vpzh_stream *s, int index, vpz_mapping_config *out)
 
 int vpzh_get_residue_type(vpzh_stream *s, int index)
 {
-    if (!s || index < 0 || index >= (int)s->residues.size()) return VPZH_E_ARG;
-    return s->residues[index].type;
+    if (!s || index < 0 || index >= (int)s->su->residues.size()) return VPZH_E_ARG;
+    return s->su->residues[index].type;
 }
 
 int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
@@ -1432,7 +1422,7 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
     if (!s || !packets || !residue || !posts || !post_counts || first < 0 || count < 0 ||
         first + count > (int64_t)s->audio.size())
         return VPZH_E_ARG;
-    if (f0_amp && (!f0_coeff || f0_stride < s->max_floor0_order)) return VPZH_E_ARG;
+    if (f0_amp && (!f0_coeff || f0_stride < s->su->max_floor0_order)) return VPZH_E_ARG;
     s->decode_failures = 0;
     s->first_failed_packet = -1;
     int64_t off = 0;

@@ -472,7 +472,8 @@ struct GroupRun {
         }
         int rc = VPZ_OK;
         const auto t0 = Clock::now();
-        if (any && n_pk > 0) {
+        static const bool no_synth = getenv("VPZM_NO_SYNTH") != nullptr;  // (diagnosis: the decode side of the pipeline alone)
+        if (any && n_pk > 0 && !no_synth) {
             vpz_decoder *dec = decoder_for(L, sb.setup);
             if (!dec) rc = VPZ_E_NOMEM;
             // the decoder is re-used for new streams: back to what a StreamDecoder is after ProcessHeaderPackets
@@ -573,9 +574,14 @@ int vpzm_create(const int32_t *device_ids, int32_t n_devices, const vpzm_options
     if (opt) m->opt = *opt;
     if (m->opt.host_threads <= 0) m->opt.host_threads = vpzh_default_threads();
     if (m->opt.streams_per_call <= 0) m->opt.streams_per_call = 16;
-    if (m->opt.contexts_per_device <= 0) m->opt.contexts_per_device = 2;
+    // (one GPU, 16 CPUs, 1 024 streams, 16-bit PCM, slots = 4 * contexts + 4: 2 contexts 90 ms, 3: 84 ms, 4: 78 ms -- a host-memory
+    // synth call is upload, kernels, download in a row, and only other contexts' calls fill the link's other direction and the
+    // device meanwhile.  Every context is an issuing thread that waits in hipStreamSynchronize, so few host threads get few)
+    if (m->opt.contexts_per_device <= 0) m->opt.contexts_per_device = m->opt.host_threads / n_devices >= 8 ? 4 : 2;
     if (m->opt.contexts_per_device > 8) m->opt.contexts_per_device = 8;
-    if (m->opt.slots_per_device <= 0) m->opt.slots_per_device = 2 * m->opt.contexts_per_device + 2;  // (4 -> 6: 143 -> 120 ms for 1024 streams)
+    // (one GPU, 16 CPUs, 1 024 streams, 16-bit PCM: 6 slots 114 ms, 12 slots 101 ms, 24 slots 104 ms -- with few slots the decode of
+    // sub-batch b + slots waits for the synth call of sub-batch b)
+    if (m->opt.slots_per_device <= 0) m->opt.slots_per_device = 4 * m->opt.contexts_per_device + 4;
     if (m->opt.slots_per_device < m->opt.contexts_per_device + 1) m->opt.slots_per_device = m->opt.contexts_per_device + 1;
     m->groups.resize((size_t)n_devices);
     int rc = VPZM_OK;
