@@ -377,8 +377,21 @@ __device__ __forceinline__ void load_group_share(float2 (&x)[8], const VPZ_GLOBA
 // rows[channel][bin].  `magic` = ceil(2^18 / C): e / C == (e * magic) >> 18 for every e < 8192, C <= 8.
 // upper == false (a 2048 block whose residue's support ends in the lower half, ABI v4): only the first two pieces of every lane
 // hold data -- pieces 64 w + 64 C j, j < 2, are exactly the lower half of every channel's row
+// `pre`: for a 2048 block, the four row positions (floats from `rows`) of a lane's elements 4 q0 + i -- they do not depend on the
+// frame, the kernel computes them once per run (stage_positions) and keeps exactly these four registers across the loop
+__device__ __forceinline__ void stage_positions(int (&pre)[4], int C, uint32_t magic, int w, int lane)
+{
+    const int q0 = lane + 64 * w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t e = 4u * (uint32_t)q0 + (uint32_t)i;
+        const uint32_t bin = __umul24(e, magic) >> 18;  // (24-bit multiplies are full rate, 32-bit ones a quarter)
+        const uint32_t c = e - __umul24(bin, (uint32_t)C);
+        pre[i] = (int)(__umul24(c, (uint32_t)kWaveBufFloats) + bin);
+    }
+}
 __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *rows, int C, uint32_t magic, int half,
-                                                  int w, int lane, bool upper = true)
+                                                  int w, int lane, bool upper, const int (&pre)[4])
 {
     const int total4 = (C * half) >> 2;
     // The LDS addresses below do not depend on the frame: left alone, the compiler computes them once before the
@@ -404,12 +417,7 @@ __device__ __forceinline__ void stage_interleaved(const float2 (&x)[8], float *r
     if (full) {
         float *dst[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t e = 4u * (uint32_t)q0 + (uint32_t)i;
-            const uint32_t bin = __umul24(e, magic) >> 18;  // (24-bit multiplies are full rate, 32-bit ones a quarter)
-            const uint32_t c = e - __umul24(bin, (uint32_t)C);
-            dst[i] = rows + __umul24(c, (uint32_t)kWaveBufFloats) + bin;
-        }
+        for (int i = 0; i < 4; ++i) dst[i] = rows + pre[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (j < 2 || upper) {
@@ -954,6 +962,12 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         load_floor_indices(fy, reinterpret_cast<const uint8_t *>(hcur), lpb, lane);
         __builtin_amdgcn_wave_barrier();
     };
+    int stage_pre[4] = {0, 0, 0, 0};
+    if (kGroup) {
+        stage_positions(stage_pre, C, div_magic, ch, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(stage_pre[i]));  // (kept, not recomputed: four registers for 30 instructions a frame)
+    }
     uint32_t fycur[4];
 #ifdef VPZ_STAMPS
     unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1000,7 +1014,7 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 } else if ((fd.flags & kFrameInterleaved) && (VPZ_GROUP_DMA(a) || (VPZ_ABLATE(a) & 2048))) {
                     stage_by_lds_dma((const float *)(k_spec + fd.spec_off), s_work[gw0], C, nstage >> 1, ch, lane);
                 } else if (fd.flags & kFrameInterleaved) {
-                    stage_interleaved(xcur, s_work[gw0], C, div_magic, nstage >> 1, ch, lane, stage_upper);
+                    stage_interleaved(xcur, s_work[gw0], C, div_magic, nstage >> 1, ch, lane, stage_upper, stage_pre);
                 } else {
                     stage_planar(xcur, hcur, nblk >> 1, lane, stage_upper);
                 }
