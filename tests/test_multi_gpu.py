@@ -157,3 +157,24 @@ def test_a_dispatcher_is_reusable_and_says_what_it_is(ctx):
     d.close()
     with pytest.raises(multi.MultiError):
         multi.Dispatcher([99])  # no such device
+
+
+def test_more_setups_than_a_context_keeps_decoders_for(ctx):
+    """A context keeps the decoders of its last 8 setups (vorbis_multi.cpp: kDecodersPerContext): a library of 12 stereo streams with
+    12 different setup headers, decoded twice on ONE context -- decoders are created, evicted and created again, the PCM stays that of
+    the stream-by-stream decode."""
+    import synthetic_streams as ss
+    raws = []
+    for seed in range(100, 112):
+        stream, rng = ss.stereo_coupled_res2(seed=seed)
+        ogg, _ = stream.build(rng, 12)
+        raws.append(bytes(ogg))
+    assert len(set(raws)) == 12
+    raws = raws + raws
+    pcm, offs, results, stats, infos = run_dispatcher([0], raws, host_threads=3, streams_per_call=1, contexts_per_device=1)
+    for k, r in enumerate(raws):
+        ref = single_stream_pcm(ctx, r)
+        C_ = infos[r][0]
+        assert results["status"][k] == 0 and results["samples"][k] == ref.shape[0], k
+        got = pcm[offs[k]: offs[k] + ref.shape[0] * C_].reshape(-1, C_)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), k

@@ -398,6 +398,12 @@ struct GroupRun {
             m->fail(std::string("vpz_decoder_create: ") + vpz_context_last_error(L.ctx));
             return nullptr;
         }
+        // (a library of files from many encoders: a context keeps the decoders of the last few setups, not of every one it has seen)
+        constexpr size_t kDecodersPerContext = 8;
+        if (L.decs.size() >= kDecodersPerContext) {
+            vpz_decoder_destroy(L.decs.front().second);
+            L.decs.erase(L.decs.begin());
+        }
         L.decs.emplace_back(st, dec);
         return dec;
     }
