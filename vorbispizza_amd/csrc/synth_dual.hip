@@ -845,9 +845,11 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         if (run_idx < (1 << 16)) {  // this wave's own record (VPZ_STAMPS_DUMP)
             unsigned long long *rec = a.stamps + 16 + 16 * (size_t)run_idx;
             for (int k = 0; k < 9; ++k) rec[k] = t_acc[k];
+#ifdef VPZ_WAVE_TIMES
             rec[2] = wt_long; rec[3] = wt_short; rec[4] = wt_batch; rec[5] = wt_members;  // passes by kind, blocks in batches
-        rec[6] = (unsigned long long)run.pre_kind;
-        rec[9] = (unsigned long long)iters;
+#endif
+            rec[6] = (unsigned long long)run.pre_kind;
+            rec[9] = (unsigned long long)iters;
             rec[10] = n_long_frames;
         }
     }
