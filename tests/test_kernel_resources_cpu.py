@@ -53,3 +53,22 @@ def test_stereo_fast_path_instantiations_and_their_budget(kernels):
         assert k["vgprs"] <= 256, k["name"]                   # 2 waves per SIMD: 512 / 2
         assert k["lds"] <= 80 * 1024, (k["name"], k["lds"])   # two 4-wave workgroups per CU (160 KiB)
         assert k.get("occupancy", 2) >= 2, k["name"]
+
+
+@pytest.mark.parametrize("flags", [["-DVPZ_STAMPS"], ["-DVPZ_WAVE_TIMES"], ["-DVPZ_TUNING"], ["-DVPZ_STAMPS", "-DVPZ_WAVE_TIMES", "-DVPZ_TUNING"],
+                                   ["-DVPZ_DUAL_STEADY_BIT", "-DVPZ_GROUP_STEADY_BIT", "-DVPZ_PAIR_STORES_NT"]])
+def test_the_diagnostic_builds_still_parse(flags):
+    """The build switches of the fused kernels (phase stamps, wave clocks, tuning switches, the alternatives kept for A/B runs) are
+    compiled only when somebody needs them -- and rot unseen: a syntax-only device pass of the three translation units per set."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    from vorbispizza_amd import _build
+    hipcc = _build._hipcc()
+    if not (shutil.which(hipcc) or os.path.exists(hipcc)):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "vorbispizza_amd", "csrc")
+    for unit in ("synth_dual.hip", "synth_kernels.hip", "floor0.hip"):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "--cuda-device-only", "-Wno-unused-function",
+                            "-I", csrc, "-I", os.path.join(ROOT, "include")] + flags + [os.path.join(csrc, unit)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (unit, flags, r.stderr[-2000:])
