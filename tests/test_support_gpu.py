@@ -66,7 +66,10 @@ def test_group_mode_does_not_look_beyond_the_support(ctx, channels):
     """Group mode neither loads nor stages the upper half of a 2048 block whose support ends in the lower one: NaNs there
     do not reach the PCM.  (The stereo fast path reads the whole vector -- it saves the arithmetic, not the loads -- so it
     is held to the zero-filled vector only.)"""
+    import os
     from vorbispizza_amd import capi
+    if os.environ.get("VPZ_NO_SUPPORT", "0") not in ("", "0"):
+        pytest.skip("the decoder is told to ignore the declared support (tools/suite_under_switches.sh)")
     n_streams, frames, ends = 5, 40, (128, 400)
     pk, res, posts, counts = stream_major_batch(n_streams, frames, channels, seed=91 + channels, floor=True, interleaved=True,
                                                 p_ls=0.1, p_sl=0.3, silent_prob=0.0)

@@ -18,16 +18,18 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--which", default="both")
     ap.add_argument("--copies", type=int, default=64, help="streams of each fixture for --which real")
+    ap.add_argument("--layout", default="planar", help="PCM layout of the ola / olalong workloads: planar (the bench's) or interleaved")
     args = ap.parse_args()
     import torch
     import bench
-    from vorbispizza_amd import Context, Decoder
+    from vorbispizza_amd import Context, Decoder, capi
+    layout = capi.OUT_INTERLEAVED if args.layout == "interleaved" else None
     ctx = Context(0)
     dev = torch.device("cuda", 0)
     if args.which in ("both", "ola"):
         pk, residue, samples, res_floats = bench.build_synth_ola(torch, dev, args.frames)
         dec = Decoder(ctx, 2, 256, 2048)
-        dt, _ = bench.time_decoder(ctx, dec, torch, pk, residue, None, None, samples, 2, args.steps, 2)
+        dt, _ = bench.time_decoder(ctx, dec, torch, pk, residue, None, None, samples, 2, args.steps, 2, layout=layout)
         byt = 4 * res_floats + 4 * samples * 2
         print("configs[2]: %.3f ms/call  %.1f Msamples/s  %.0f GB/s algorithmic (whole call); algorithmic bytes %d"
               % (dt * 1e3, samples * 2 / dt / 1e6, byt / dt / 1e9, byt))
@@ -36,7 +38,7 @@ def main():
     if args.which == "olalong":  # north_star's literal line: all-long stereo IMDCT + window + OLA through the fused kernel
         pk, residue, samples, res_floats = bench.build_synth_ola(torch, dev, args.frames, all_long=True)
         dec = Decoder(ctx, 2, 256, 2048)
-        dt, _ = bench.time_decoder(ctx, dec, torch, pk, residue, None, None, samples, 2, args.steps, 2)
+        dt, _ = bench.time_decoder(ctx, dec, torch, pk, residue, None, None, samples, 2, args.steps, 2, layout=layout)
         byt = 4 * res_floats + 4 * samples * 2
         print("north_star line: %.3f ms/call  %.1f Msamples/s  %.0f GB/s algorithmic (whole call); algorithmic bytes %d"
               % (dt * 1e3, samples * 2 / dt / 1e6, byt / dt / 1e9, byt))
