@@ -370,15 +370,31 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     // table): a load under a condition would make the wave wait for it right behind the load (see synth_kernel).
     // Points of a lane: k = lane + 64 m for a 2048 block; for 256 blocks lane group g = lane >> 3 takes block g of the
     // pass (block 0 again where the pass has fewer), k = (lane & 7) + 8 m.
+    // The pointers a pass needs once -- the spectra, the inverse dB table (what a frame without input reads), the active posts -- would
+    // be re-loaded from the argument segment once per pass (scalar registers are short; an s_load's wait drains the LDS queue with
+    // it): parked in the lanes of a vector register, fetched with v_readlane_b32 (see synth_kernel).
+    int kv = 0;
+    {
+        const uint64_t sp = reinterpret_cast<uint64_t>(a.spec), db = reinterpret_cast<uint64_t>(a.inv_db);
+        const uint64_t cpp = a.cposts != nullptr ? reinterpret_cast<uint64_t>(a.cposts) : db;
+        const int vals[8] = {(int)(uint32_t)sp, (int)(uint32_t)(sp >> 32), (int)(uint32_t)db, (int)(uint32_t)(db >> 32),
+                             (int)(uint32_t)cpp, (int)(uint32_t)(cpp >> 32), a.cposts != nullptr ? 1 : 0, a.f0_stride};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kv = lane == i ? vals[i] : kv;
+        asm volatile("" : "+v"(kv));
+    }
+    auto parked64 = [&](int i) -> uint64_t {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(kv, i + 1) << 32) | (uint32_t)__builtin_amdgcn_readlane(kv, i);
+    };
     auto prefetch = [&](const FrameDesc &fd, bool valid, float2 (&va)[8], float2 (&vb)[8], int &cpa, int &cpb) {
         const bool is_long = size_of(fd.flags) == 2048;
         const int bsz = (int)((fd.flags >> kFrameBatchShift) & 7u) + 1;
         int l = lane;
         asm volatile("" : "+v"(l));  // (frame-invariant lane arithmetic stays inside the iteration that uses it)
         const int g = l >> 3, gg = g < bsz ? g : 0;
-        const float *src = valid ? a.spec + fd.spec_off : a.inv_db;
+        const VPZ_GLOBAL float *src = valid ? (const VPZ_GLOBAL float *)parked64(0) + fd.spec_off : (const VPZ_GLOBAL float *)parked64(2);
         if (kIlvIn) {
-            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            const VPZ_GLOBAL float4 *s4 = (const VPZ_GLOBAL float4 *)src;
             const int base = !valid ? 0 : (is_long ? l : 64 * gg + (l & 7));
             const int step = !valid ? 0 : (is_long ? 64 : 8);
 #pragma unroll
@@ -388,7 +404,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 vb[m] = make_float2(v.z, v.w);
             }
         } else {
-            const float2 *s2 = reinterpret_cast<const float2 *>(src);
+            const VPZ_GLOBAL float2 *s2 = (const VPZ_GLOBAL float2 *)src;
             // block gg of the pass: its L row at + gg * 2 * 128 floats, its R row half a packet further on
             const int base = !valid ? 0 : (is_long ? l : 128 * gg + (l & 7));
             const int step = !valid ? 0 : (is_long ? 64 : 8);
@@ -400,8 +416,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             }
         }
         if (kHasFloor) {
-            const bool floored = valid && !(fd.flags & kFrameNoFloor) && a.cposts != nullptr;
-            const int32_t *cp = a.cposts != nullptr ? a.cposts : reinterpret_cast<const int32_t *>(a.inv_db);
+            const bool floored = valid && !(fd.flags & kFrameNoFloor) && __builtin_amdgcn_readlane(kv, 6) != 0;  // (a.cposts != nullptr)
+            const VPZ_GLOBAL int32_t *cp = (const VPZ_GLOBAL int32_t *)parked64(4);  // (the posts, or the table's head)
             const size_t rec = floored ? (size_t)fd.rec : 0;
             cpa = cp[rec * 64 + l];
             cpb = cp[(floored ? rec + 1 : 0) * 64 + l];
@@ -581,12 +597,13 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 if (!f0R) apply_floor(xR, fyR, s_db, upper);
                 if (f0L || f0R) {  // [census: cold]
                     const int lpb0 = is_long ? 64 : 8;
-                    const int kc = min(a.f0_stride, kFloor0MaxBark);
+                    const int f0s = __builtin_amdgcn_readlane(kv, 7);  // (a.f0_stride)
+                    const int kc = min(f0s, kFloor0MaxBark);
                     if (f0L)
-                        floor0_multiply(xL, hL, a.f0_curve + (size_t)fd.rec * a.f0_stride, kc,
+                        floor0_multiply(xL, hL, a.f0_curve + (size_t)fd.rec * f0s, kc,
                                         a.f0_bark + ((size_t)__builtin_amdgcn_readlane(cpa, 0) * 2 + (is_long ? 1 : 0)) * 1024, lpb0, ln);
                     if (f0R)
-                        floor0_multiply(xR, hR, a.f0_curve + (size_t)(fd.rec + 1) * a.f0_stride, kc,
+                        floor0_multiply(xR, hR, a.f0_curve + (size_t)(fd.rec + 1) * f0s, kc,
                                         a.f0_bark + ((size_t)__builtin_amdgcn_readlane(cpb, 0) * 2 + (is_long ? 1 : 0)) * 1024, lpb0, ln);
                 }
                 }
