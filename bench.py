@@ -547,7 +547,7 @@ def dispatcher_whole_job(torch, device_ids, threads, s16=False, repeats=3, strea
     sizes = caps * 2
     offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
     pcm = torch.empty(int(sizes.sum()), dtype=torch.int16 if s16 else torch.float32, pin_memory=True).numpy()
-    d = multi.Dispatcher(device_ids, host_threads=threads, streams_per_call=16, contexts_per_device=2)
+    d = multi.Dispatcher(device_ids, host_threads=threads)  # (the library's defaults: 16 streams per call, 4 contexts with 8+ threads per device)
     best = None
     try:
         for _ in range(repeats):
