@@ -784,8 +784,12 @@ struct Mode {  // Mode.cs:12-28
     int mapping = 0;
 };
 
+// (the payload lies in the stream's one `payload` buffer: a vector per packet was ~700 heap blocks per stream, allocated by the thread
+// that opens the container and -- in the multi-device dispatcher -- freed by the one that decodes it, i.e. through the allocator's
+// cross-thread path, 16 threads at a time)
 struct OggPacket {
-    std::vector<uint8_t> data;
+    const uint8_t *data = nullptr;
+    size_t size = 0;
     int64_t granule = -1;
     bool eos = false;
     bool resync = false;   // VorbisPacket.IsResync: the page that completes the packet was found after lost sync
@@ -857,13 +861,13 @@ struct SetupCache {
         const char *e = getenv("VPZH_NO_SETUP_CACHE");
         enabled = !(e && atoi(e));
     }
-    std::shared_ptr<const SetupBlob> find(const std::vector<uint8_t> &ident, const std::vector<uint8_t> &setup)
+    std::shared_ptr<const SetupBlob> find(const uint8_t *ident, size_t n_ident, const uint8_t *setup, size_t n_setup)
     {
         if (!enabled) return nullptr;
         std::lock_guard<std::mutex> lock(mu);
         for (const auto &b : entries)
-            if (b->setup.size() == setup.size() && b->ident.size() == ident.size() &&
-                memcmp(b->setup.data(), setup.data(), setup.size()) == 0 && memcmp(b->ident.data(), ident.data(), ident.size()) == 0)
+            if (b->setup.size() == n_setup && b->ident.size() == n_ident && memcmp(b->setup.data(), setup, n_setup) == 0 &&
+                memcmp(b->ident.data(), ident, n_ident) == 0)
                 return b;
         return nullptr;
     }
@@ -894,6 +898,7 @@ struct vpzh_stream {
     // the unpacked setup header (floors indexed by floor number: unused entries in `floors` for type-0 floors and in `floors0` for
     // type-1 ones), possibly shared with other streams -- never written after parse_headers
     std::shared_ptr<const SetupBlob> su;
+    std::vector<uint8_t> payload;        // every packet's bytes, back to back (OggPacket::data points in here)
     std::vector<int> residue_scratch;    // Residue::decode's part_word_cache
     std::vector<OggPacket> audio;
     int64_t last_granule = -1;
@@ -908,6 +913,15 @@ struct vpzh_stream {
     bool demux(const uint8_t *d, size_t size, std::vector<OggPacket> &packets, int want = 0)
     {
         crc_init();
+        payload.clear();
+        payload.reserve(size + 8);  // (every packet's bytes come out of the container once: never reallocated, pointers stay)
+        auto keep = [&](const uint8_t *a, size_t na, const uint8_t *b, size_t nb) -> const uint8_t * {
+            const size_t at = payload.size();
+            if (at + na + nb > payload.capacity()) throw InvalidData("container payload larger than the container");
+            payload.insert(payload.end(), a, a + na);
+            payload.insert(payload.end(), b, b + nb);
+            return payload.data() + at;
+        };
         size_t pos = 0;
         bool have_serial = false, finished = false;
         uint32_t serial = 0;
@@ -976,8 +990,8 @@ struct vpzh_stream {
                     OggPacket pk;
                     if (packet_idx == 0 && first_is_continuation) {
                         if (pending_valid) {
-                            pk.data = pending;
-                            pk.data.insert(pk.data.end(), data + off, data + off + cur);
+                            pk.data = keep(pending.data(), pending.size(), data + off, cur);
+                            pk.size = pending.size() + cur;
                         } else {
                             // The tail of a packet whose head was lost.  The reference's sequential reader hands this
                             // piece to the decoder as a packet of its own (flagged IsResync); it is known garbage, so
@@ -988,7 +1002,8 @@ struct vpzh_stream {
                         pending.clear();
                         pending_valid = false;
                     } else {
-                        pk.data.assign(data + off, data + off + cur);
+                        pk.data = keep(nullptr, 0, data + off, cur);
+                        pk.size = cur;
                     }
                     // GranulePosition only on the last packet of the page (PacketProvider.cs:515-530)
                     pk.granule = (packet_idx == packet_count - 1) ? granule : -1;
@@ -1022,7 +1037,7 @@ struct vpzh_stream {
         // identification, StreamDecoder.cs:213-240
         {
             BitReader p;
-            p.init(pk[0].data.data(), pk[0].data.size());
+            p.init(pk[0].data, pk[0].size);
             static const uint8_t sig[11] = {0x01, 'v', 'o', 'r', 'b', 'i', 's', 0, 0, 0, 0};
             for (uint8_t c : sig) if (p.read_bits(8) != c) throw InvalidData("not a Vorbis identification header");
             channels = (int)p.read_bits(8);
@@ -1035,12 +1050,12 @@ struct vpzh_stream {
         }
         {   // comments: only the signature is checked (StreamDecoder.cs:242-260)
             BitReader p;
-            p.init(pk[1].data.data(), pk[1].data.size());
+            p.init(pk[1].data, pk[1].size);
             static const uint8_t sig[7] = {0x03, 'v', 'o', 'r', 'b', 'i', 's'};
             for (uint8_t c : sig) if (p.read_bits(8) != c) throw InvalidData("not a Vorbis comment header");
         }
         // setup, StreamDecoder.cs:262-321 -- or its unpacked form, if these very headers have been seen before
-        if (std::shared_ptr<const SetupBlob> hit = setup_cache().find(pk[0].data, pk[2].data)) {
+        if (std::shared_ptr<const SetupBlob> hit = setup_cache().find(pk[0].data, pk[0].size, pk[2].data, pk[2].size)) {
             su = std::move(hit);
             return;
         }
@@ -1054,7 +1069,7 @@ struct vpzh_stream {
         std::vector<Mapping> &mappings = blob->mappings;
         std::vector<Mode> &modes = blob->modes;
         BitReader p;
-        p.init(pk[2].data.data(), pk[2].data.size());
+        p.init(pk[2].data, pk[2].size);
         static const uint8_t sig[7] = {0x05, 'v', 'o', 'r', 'b', 'i', 's'};
         for (uint8_t c : sig) if (p.read_bits(8) != c) throw InvalidData("not a Vorbis setup header");
         books.resize((size_t)p.read_bits(8) + 1);
@@ -1101,8 +1116,8 @@ struct vpzh_stream {
         if (!p.read_bit()) throw InvalidData("Book packet did not end on correct bit!");
         blob->mode_field_bits = ilog(n_modes - 1);
         if (setup_cache().enabled) {
-            blob->ident = pk[0].data;
-            blob->setup = pk[2].data;
+            blob->ident.assign(pk[0].data, pk[0].data + pk[0].size);
+            blob->setup.assign(pk[2].data, pk[2].data + pk[2].size);
             su = setup_cache().insert(std::move(blob));  // (the cache's copy, if another thread was first with these headers)
         } else {
             su = std::move(blob);
@@ -1113,7 +1128,7 @@ struct vpzh_stream {
     int64_t packet_floats(const OggPacket &pk) const
     {
         BitReader p;
-        p.init(pk.data.data(), pk.data.size());
+        p.init(pk.data, pk.size);
         if (p.read_bits(1) != 0) return 0;
         int mode_idx = (int)p.read_bits(su->mode_field_bits);
         if (mode_idx >= (int)su->modes.size()) return 0;
@@ -1125,7 +1140,7 @@ struct vpzh_stream {
     int packet_sample_count(const OggPacket &pk) const
     {
         BitReader p;
-        p.init(pk.data.data(), pk.data.size());
+        p.init(pk.data, pk.size);
         if (p.read_bits(1) != 0) return 0;
         const int mode_idx = (int)p.read_bits(su->mode_field_bits);
         if (mode_idx >= (int)su->modes.size()) return 0;
@@ -1162,7 +1177,7 @@ struct vpzh_stream {
         for (int c = 0; c < channels; ++c) post_counts[c] = 0;
         memset(posts, 0, sizeof(int16_t) * 64 * (size_t)channels);
         BitReader p;
-        p.init(pk.data.data(), pk.data.size());
+        p.init(pk.data, pk.size);
         if (p.read_bits(1) != 0) { out->flags |= VPZ_PKT_NOT_DECODED; return; }
         int mode_idx = (int)p.read_bits(su->mode_field_bits);
         if ((unsigned)mode_idx >= su->modes.size()) throw InvalidData("Unused mode index.");
