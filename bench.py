@@ -547,7 +547,9 @@ def dispatcher_whole_job(torch, device_ids, threads, s16=False, repeats=3, strea
     sizes = caps * 2
     offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
     pcm = torch.empty(int(sizes.sum()), dtype=torch.int16 if s16 else torch.float32, pin_memory=True).numpy()
-    d = multi.Dispatcher(device_ids, host_threads=threads)  # (the library's defaults: 16 streams per call, 4 contexts with 8+ threads per device)
+    # (the library's defaults: 16 streams per call, 4 contexts with 8+ threads per device; `threads` None: its own count of decode
+    # threads -- the CPUs the process may use plus one per context)
+    d = multi.Dispatcher(device_ids, host_threads=threads or 0)
     best = None
     try:
         for _ in range(repeats):
@@ -565,7 +567,8 @@ def dispatcher_whole_job(torch, device_ids, threads, s16=False, repeats=3, strea
     tot = int(results["samples"].sum()) * 2
     out = {"Msamples_per_s": round(tot / best[0] / 1e6, 1), "wall_ms": round(best[0] * 1e3, 2), "devices": list(device_ids),
            "per_device_ms": {"wall": best[1], "until_last_stream_entropy_decoded": best[2], "summed_synth_calls": best[3]},
-           "streams_per_device": best[4], "host": dict(host_report(threads), decode_threads_per_device=best[5]),
+           "streams_per_device": best[4],
+           "host": dict(host_report(threads if threads else host_threads(whole_node=True)), decode_threads_per_device=best[5]),
            "pcm": "int16" if s16 else "float32", "collectives_on_the_data_path": 0, "samples_total": tot}
     if checksum and not s16:
         sums = []
@@ -649,7 +652,7 @@ def main_single_process(args):
         c.close()
     torch.cuda.empty_cache()
     if not args.no_extras:
-        thr = host_threads(whole_node=True)
+        thr = host_threads(whole_node=True) if HOST_THREADS_CAP else None  # (None: the dispatcher's own count)
         result["extra_workloads"] = {
             "configs[4] whole job in ONE process: 1024 real stereo streams through the in-process dispatcher "
             "(vpzm_decode_library), %d device(s), float32 PCM" % n_dev: dispatcher_whole_job(torch, ids, thr),
@@ -990,8 +993,10 @@ def main():
             ids = [0] * world if rehearsal else list(range(world))
             thr_all = host_threads(whole_node=True)
             try:
-                one = dispatcher_whole_job(torch, ids, thr_all)
-                one16 = dispatcher_whole_job(torch, ids, thr_all, s16=True, checksum=False)
+                # (no --host-threads: the dispatcher counts its decode threads itself -- the CPUs this process may use plus one per context)
+                thr_disp = thr_all if HOST_THREADS_CAP else None
+                one = dispatcher_whole_job(torch, ids, thr_disp)
+                one16 = dispatcher_whole_job(torch, ids, thr_disp, s16=True, checksum=False)
                 one["checksum_equals_the_per_process_job"] = one.get("pcm_checksum") == "%016x" % job_sum
                 extras["configs[4] whole job in ONE process: the in-process multi-device dispatcher (vpzm_decode_library), "
                        "%d device(s), container bytes -> float32 PCM in host memory" % world] = one

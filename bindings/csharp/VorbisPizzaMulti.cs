@@ -19,7 +19,7 @@ namespace NVorbis.Native
         [StructLayout(LayoutKind.Sequential)]
         public struct Options
         {
-            public int HostThreads;         // entropy-decode threads over all devices (0: the CPUs the process may use)
+            public int HostThreads;         // entropy-decode threads over all devices (0: the CPUs the process may use, plus one per context)
             public int StreamsPerCall;      // streams per vpz_decoder_synth call (0: 16)
             public int ContextsPerDevice;   // contexts / issuing threads per device (0: 4 with 8 or more host threads per device, else 2)
             public int ClipSamples;         // StreamDecoder.ClipSamples

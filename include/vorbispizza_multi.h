@@ -40,7 +40,7 @@ extern "C" {
 typedef struct vpzm_dispatcher vpzm_dispatcher;
 
 typedef struct vpzm_options {
-    int32_t host_threads;         /* entropy-decode threads over ALL devices (0: vpzh_default_threads()); each device gets its share */
+    int32_t host_threads;         /* entropy-decode threads over ALL devices (0: vpzh_default_threads() plus one per context -- the issuing threads mostly wait); each device gets its share */
     int32_t streams_per_call;     /* streams per vpz_decoder_synth call (0: 16) */
     int32_t contexts_per_device;  /* contexts -- HIP streams, issuing threads -- that take a device's calls in turn (0: 4 when the device has 8 or more host threads, else 2) */
     int32_t clip_samples;         /* StreamDecoder.ClipSamples (VorbisReader sets it to true, VorbisReader.cs:71) */

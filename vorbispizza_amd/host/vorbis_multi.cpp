@@ -143,6 +143,7 @@ struct Job {  // one stream of the library inside its group
 
 struct Sub {  // streams of one setup that ride in one vpz_decoder_synth call
     int setup = 0;
+    std::shared_ptr<Setup> st;           // (its own reference: `setups` grows under the group's mutex while sub-batches are worked on outside it)
     std::vector<int> members;            // indices into jobs
     std::vector<int64_t> pbase, rbase;   // where each member's packets / residue start in the slot's arrays
     int64_t n_packets = 0, res_floats = 0;
@@ -262,6 +263,7 @@ struct GroupRun {
             for (size_t s0 = 0; s0 < v.size(); s0 += (size_t)S) {
                 Sub sb;
                 sb.setup = (int)q;
+                sb.st = setups[q];
                 for (size_t j = s0; j < std::min(v.size(), s0 + (size_t)S); ++j) {
                     const Job &J = jobs[(size_t)v[j]];
                     sb.members.push_back(v[j]);
@@ -282,11 +284,12 @@ struct GroupRun {
         ++waves_planned;
     }
 
-    bool prep_slot(size_t b)  // (called with `mu` released; one thread prepares a given sub-batch)
+    // (the functions below run with `mu` RELEASED: they get their sub-batch by reference -- a deque's elements stay where they are, but
+    // indexing `subs` / `setups` while plan_wave appends to them is a race)
+    bool prep_slot(size_t b, Sub &sb)  // (one thread prepares a given sub-batch)
     {
-        Sub &sb = subs[b];
         Slot &sl = G.slots[b % G.slots.size()];
-        const Setup &st = *setups[(size_t)sb.setup];
+        const Setup &st = *sb.st;
         const size_t C = (size_t)st.info.channels, rec = (size_t)sb.n_packets * C;
         vpz_context *ctx = G.lanes[0].ctx;
         bool ok = grow(ctx, sl.packets, sl.cap_packets, (size_t)sb.n_packets) && grow(ctx, sl.residue, sl.cap_residue, (size_t)sb.res_floats) &&
@@ -296,13 +299,12 @@ struct GroupRun {
         return ok;
     }
 
-    void decode_member(size_t b, int j)
+    void decode_member(size_t b, Sub &sb, int j)
     {
-        Sub &sb = subs[b];
         Job &J = jobs[(size_t)sb.members[(size_t)j]];
         if (J.status == VPZM_OK) {
             Slot &sl = G.slots[b % G.slots.size()];
-            const Setup &st = *setups[(size_t)sb.setup];
+            const Setup &st = *sb.st;
             const size_t C = (size_t)st.info.channels;
             const int64_t pb = sb.pbase[(size_t)j], rb = sb.rbase[(size_t)j];
             int rc = VPZH_E_ARG;
@@ -334,7 +336,7 @@ struct GroupRun {
                 if (sb.prepped) {
                     const int j = tasks[next_task++].second;
                     lk.unlock();
-                    decode_member(b, j);
+                    decode_member(b, sb, j);
                     lk.lock();
                     if (++sb.decoded == (int)sb.members.size()) cv.notify_all();
                     continue;
@@ -342,7 +344,7 @@ struct GroupRun {
                 if (!sb.prepping && (b < B || subs[b - B].synth_done)) {  // its slot is free: get the arrays ready
                     sb.prepping = true;
                     lk.unlock();
-                    const bool ok = prep_slot(b);
+                    const bool ok = prep_slot(b, sb);
                     lk.lock();
                     if (!ok) {
                         for (int mi : sb.members) jobs[(size_t)mi].status = VPZM_E_SYNTH;
@@ -377,9 +379,8 @@ struct GroupRun {
     size_t done_decoding() const { return std::min(next_task + skipped_streams, jobs.size()); }
     size_t skipped_streams = 0;  // (streams that never become a decode task: failed to open, no packets, area too small)
 
-    vpz_decoder *decoder_for(Lane &L, int setup)
+    vpz_decoder *decoder_for(Lane &L, const std::shared_ptr<Setup> &st)
     {
-        const std::shared_ptr<Setup> &st = setups[(size_t)setup];
         for (auto &p : L.decs)
             if (p.first->same(*st)) return p.second;
         vpz_stream_config cfg{};
@@ -413,6 +414,7 @@ struct GroupRun {
     {
         for (;;) {
             size_t b;
+            Sub *sp = nullptr;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 for (;;) {
@@ -422,19 +424,19 @@ struct GroupRun {
                 }
                 b = next_synth++;
                 cv.wait(lk, [&] { return subs[b].decoded == (int)subs[b].members.size(); });
+                sp = &subs[b];
             }
-            synth_sub(L, b);
+            synth_sub(L, b, *sp);
         }
     }
 
-    void synth_sub(Lane &L, size_t b)
+    void synth_sub(Lane &L, size_t b, Sub &sb)
     {
         const int S = m->opt.streams_per_call;
         std::vector<int64_t> offs((size_t)S), written((size_t)S);
         std::vector<int32_t> status;
-        Sub &sb = subs[b];
         Slot &sl = G.slots[b % G.slots.size()];
-        const Setup &st = *setups[(size_t)sb.setup];
+        const Setup &st = *sb.st;
         const int C = st.info.channels;
         bool any = false, all_ok = true;
         int64_t cap = INT64_MAX, base = INT64_MAX;
@@ -480,7 +482,7 @@ struct GroupRun {
         const auto t0 = Clock::now();
         static const bool no_synth = getenv("VPZM_NO_SYNTH") != nullptr;  // (diagnosis: the decode side of the pipeline alone)
         if (any && n_pk > 0 && !no_synth) {
-            vpz_decoder *dec = decoder_for(L, sb.setup);
+            vpz_decoder *dec = decoder_for(L, sb.st);
             if (!dec) rc = VPZ_E_NOMEM;
             // the decoder is re-used for new streams: back to what a StreamDecoder is after ProcessHeaderPackets
             // (`_currentPosition = 0; _hasPosition = true`, StreamDecoder.cs:165-168) -- a bare reset would leave the position to be
@@ -541,13 +543,13 @@ struct GroupRun {
             for (size_t i = 0; i < jobs.size(); ++i) open_one(i);
             for (int w = 0; w < (int)wave_left.size(); ++w) plan_wave(w);
             for (size_t b = 0; b < subs.size(); ++b) {
-                if (!prep_slot(b)) {
+                if (!prep_slot(b, subs[b])) {
                     for (int mi : subs[b].members) jobs[(size_t)mi].status = VPZM_E_SYNTH;
                     m->fail("vpzm_decode_library: page-locked batch arrays could not be allocated");
                 }
-                for (size_t j = 0; j < subs[b].members.size(); ++j) decode_member(b, (int)j);
+                for (size_t j = 0; j < subs[b].members.size(); ++j) decode_member(b, subs[b], (int)j);
                 subs[b].decoded = (int)subs[b].members.size();
-                synth_sub(G.lanes[0], b);
+                synth_sub(G.lanes[0], b, subs[b]);
             }
             t_decode = seconds_since(t_begin);
         } else {
@@ -578,7 +580,8 @@ int vpzm_create(const int32_t *device_ids, int32_t n_devices, const vpzm_options
     std::unique_ptr<vpzm_dispatcher> m(new (std::nothrow) vpzm_dispatcher());
     if (!m) return VPZM_E_NOMEM;
     if (opt) m->opt = *opt;
-    if (m->opt.host_threads <= 0) m->opt.host_threads = vpzh_default_threads();
+    const bool threads_by_default = m->opt.host_threads <= 0;
+    if (threads_by_default) m->opt.host_threads = vpzh_default_threads();
     if (m->opt.streams_per_call <= 0) m->opt.streams_per_call = 16;
     // (one GPU, 16 CPUs, 1 024 streams, 16-bit PCM, slots = 4 * contexts + 4: 2 contexts 90 ms, 3: 84 ms, 4: 78 ms -- a host-memory
     // synth call is upload, kernels, download in a row, and only other contexts' calls fill the link's other direction and the
@@ -587,6 +590,9 @@ int vpzm_create(const int32_t *device_ids, int32_t n_devices, const vpzm_options
     if (m->opt.contexts_per_device > 8) m->opt.contexts_per_device = 8;
     // (one GPU, 16 CPUs, 1 024 streams, 16-bit PCM: 6 slots 114 ms, 12 slots 101 ms, 24 slots 104 ms -- with few slots the decode of
     // sub-batch b + slots waits for the synth call of sub-batch b)
+    // (the default number of decode threads: the CPUs the process may use PLUS one per issuing thread -- an issuer spends its time waiting
+    // for its stream, and on 16 CPUs 20 decode threads beat 16: 74-76 ms against 76-83 for the 1 024-stream job)
+    if (threads_by_default) m->opt.host_threads += n_devices * m->opt.contexts_per_device;
     if (m->opt.slots_per_device <= 0) m->opt.slots_per_device = 4 * m->opt.contexts_per_device + 4;
     if (m->opt.slots_per_device < m->opt.contexts_per_device + 1) m->opt.slots_per_device = m->opt.contexts_per_device + 1;
     m->groups.resize((size_t)n_devices);
