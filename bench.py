@@ -994,7 +994,8 @@ def main():
             thr_all = host_threads(whole_node=True)
             try:
                 # (no --host-threads: the dispatcher counts its decode threads itself -- the CPUs this process may use plus one per context)
-                thr_disp = thr_all if HOST_THREADS_CAP else None
+                # (under torchrun the library's own count is this RANK's share of the CPUs: the whole node's is passed instead)
+                thr_disp = thr_all if (HOST_THREADS_CAP or world > 1) else None
                 one = dispatcher_whole_job(torch, ids, thr_disp)
                 one16 = dispatcher_whole_job(torch, ids, thr_disp, s16=True, checksum=False)
                 one["checksum_equals_the_per_process_job"] = one.get("pcm_checksum") == "%016x" % job_sum
