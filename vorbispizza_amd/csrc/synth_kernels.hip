@@ -962,8 +962,11 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
         load_floor_indices(fy, reinterpret_cast<const uint8_t *>(hcur), lpb, lane);
         __builtin_amdgcn_wave_barrier();
     };
+    // (kept across the loop where the instantiation has the registers -- planar output, 112 of 128; the interleaved-output ones are
+    // at the limit and would spill: they compute the positions per frame, as every instantiation did before)
+    constexpr bool kKeepStagePositions = kGroup && kOut == 0;
     int stage_pre[4] = {0, 0, 0, 0};
-    if (kGroup) {
+    if (kKeepStagePositions) {
         stage_positions(stage_pre, C, div_magic, ch, lane);
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(stage_pre[i]));  // (kept, not recomputed: four registers for 30 instructions a frame)
@@ -1014,6 +1017,11 @@ __global__ __launch_bounds__(kSynthThreads, 4) void synth_kernel(SynthArgs a)
                 } else if ((fd.flags & kFrameInterleaved) && (VPZ_GROUP_DMA(a) || (VPZ_ABLATE(a) & 2048))) {
                     stage_by_lds_dma((const float *)(k_spec + fd.spec_off), s_work[gw0], C, nstage >> 1, ch, lane);
                 } else if (fd.flags & kFrameInterleaved) {
+                    if (!kKeepStagePositions) {
+                        int lo = lane;
+                        asm volatile("" : "+v"(lo));  // (per frame here: an opaque lane id keeps the compiler from hoisting them after all)
+                        stage_positions(stage_pre, C, div_magic, ch, lo);
+                    }
                     stage_interleaved(xcur, s_work[gw0], C, div_magic, nstage >> 1, ch, lane, stage_upper, stage_pre);
                 } else {
                     stage_planar(xcur, hcur, nblk >> 1, lane, stage_upper);
