@@ -24,7 +24,8 @@ namespace NVorbis.Native
             public int ContextsPerDevice;   // contexts / issuing threads per device (0: 4 with 8 or more host threads per device, else 2)
             public int ClipSamples;         // StreamDecoder.ClipSamples
             public int SlotsPerDevice;      // sub-batches in flight per device (0: 4 * contexts + 4)
-            public fixed int Reserved[3];
+            public int FloatResidue;        // 0: integral residues cross the link as int16 (same values, half the bytes); non-zero: always float32
+            public fixed int Reserved[2];
         }
 
         [StructLayout(LayoutKind.Sequential)]

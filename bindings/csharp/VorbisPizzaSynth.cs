@@ -1,4 +1,4 @@
-// P/Invoke binding of include/vorbispizza_synth.h (ABI version 4) for the reference host.
+// P/Invoke binding of include/vorbispizza_synth.h (ABI version 5) for the reference host.
 //
 // To be added on the reference side as NVorbis/Native/VorbisPizzaSynth.cs.  The style is the one the repository
 // already uses for libvorbisfile (NVorbis.Tests/Bindings/Vorbisfile.cs:43-107: DllImport + Cdecl, LayoutKind.Sequential
@@ -15,13 +15,14 @@ namespace NVorbis.Native
     internal static unsafe class VorbisPizzaSynth
     {
         private const string Lib = "vorbispizza_synth";              // libvorbispizza_synth.so
-        public const int AbiVersion = 4;
+        public const int AbiVersion = 5;
 
         // status codes (vorbispizza_synth.h), mapped to exceptions by ThrowOnError below the way
         // NativeDecoder.cs:145-161 maps OV_*
         public const int Ok = 0, EInvalidArg = -1, EUnsupported = -2, EHip = -3, ENoMem = -4, EWindowMismatch = -5,
                          ENoDevice = -6, ECapacity = -7;
         public const int MemHost = 0, MemDevice = 1;
+        public const int ResidueF32 = 0, ResidueI16 = 1;             // vpz_decoder_set_residue_format (ABI v5)
         public const int OutInterleaved = 0, OutPlanar = 1, OutInterleavedS16 = 2, OutPlanarS16 = 3;
         public const int ImdctFast = 0, ImdctExact = 1;
         public const int PostsStride = 64;                            // Floor1.Data.Posts = new int[64], Floor1.cs:17
@@ -138,6 +139,9 @@ namespace NVorbis.Native
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_decoder_has_clipped(DecoderHandle decoder, int stream, out int hasClipped);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_decoder_position(DecoderHandle decoder, int stream, out long position);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_decoder_set_position(DecoderHandle decoder, int stream, long position);
+        // ABI v5: `residue` of the following synth calls is short* (the same values as 16-bit integers: exact for integral residues --
+        // every libvorbis stream --, half the bytes over the host link); ResidueF32 switches back
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_decoder_set_residue_format(DecoderHandle decoder, int format);
 
         /// <summary>Status code to the exception the reference throws for the same condition.</summary>
         public static void ThrowOnError(int status, ContextHandle? ctx, string what)

@@ -86,6 +86,17 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
                          vpz_packet *packets, float *residue, int16_t *posts, uint8_t *post_counts,
                          int64_t *residue_floats_used, float *f0_amp, float *f0_coeff, int32_t f0_stride);
 
+/* The residue as 16-bit integers.  A residue value is a sum of at most one codebook value per cascade stage; libvorbis' residue books
+ * are integer lattices, so for its streams every value is a (small) integer, the same in float32 and in int16 -- and half the bytes on
+ * their way to the device (vpz_decoder_set_residue_format(VPZ_RESIDUE_I16)).  vpzh_residue_is_integral: 1 when the setup header
+ * guarantees it (every residue value book holds integers only, the worst-case sum stays below 2^15), else 0.
+ * vpzh_decode_range_i16: vpzh_decode_range_ex with `residue` as int16 values (offsets and counts in VALUES); VPZH_E_ARG for a stream
+ * whose residue is not integral. */
+int vpzh_residue_is_integral(vpzh_stream *s);
+int vpzh_decode_range_i16(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
+                          vpz_packet *packets, int16_t *residue, int16_t *posts, uint8_t *post_counts,
+                          int64_t *residue_values_used, float *f0_amp, float *f0_coeff, int32_t f0_stride);
+
 /* Many containers at once -- what a host that transcodes a library of files does: opens and entropy-decodes `n` in-memory
  * containers (first logical stream of each) on `threads` host threads (0: vpzh_default_threads), one stream at a
  * time per thread, the reference's model of one decoder per stream.  Stream k writes its packets at packets + packet_base[k]

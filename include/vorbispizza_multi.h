@@ -45,7 +45,8 @@ typedef struct vpzm_options {
     int32_t contexts_per_device;  /* contexts -- HIP streams, issuing threads -- that take a device's calls in turn (0: 4 when the device has 8 or more host threads, else 2) */
     int32_t clip_samples;         /* StreamDecoder.ClipSamples (VorbisReader sets it to true, VorbisReader.cs:71) */
     int32_t slots_per_device;     /* sub-batches in flight per device: decoded or being decoded ahead of their synth call (0: 4 * contexts + 4; about 70 MB of page-locked memory each for stereo streams of a few seconds -- with fewer the entropy decode waits for synth calls) */
-    int32_t reserved[3];
+    int32_t float_residue;        /* 0 (default): the residue of streams whose setup header guarantees 16-bit integers (vpzh_residue_is_integral: every libvorbis stream) crosses the host link as int16 -- the same values at half the bytes; non-zero: always float32 */
+    int32_t reserved[2];
 } vpzm_options;
 
 /* One context group per entry of device_ids (an id may appear more than once: several groups on one GPU, which is how a

@@ -27,13 +27,14 @@
 extern "C" {
 #endif
 
-#define VPZ_ABI_VERSION 4   /* 2: s16 output layouts, VPZ_PKT_RESYNC, vpz_decoder_set_position; structs unchanged
+#define VPZ_ABI_VERSION 5   /* 2: s16 output layouts, VPZ_PKT_RESYNC, vpz_decoder_set_position; structs unchanged
                                3: vpz_decoder_synth takes the extents of its input buffers (residue_floats, n_records) and
                                   reports a window mismatch per packet (vpz_decoder_last_packet_status) instead of failing
                                   the batch; structs unchanged
                                4: vpz_mapping_config carries the residue's support (residue_begin / residue_end, what
                                   Residue0.cs:122-125 clamps every decode to): the kernels neither load nor de-couple nor
-                                  floor-multiply the bins the setup header says are zero.  The struct grew by 16 bytes */
+                                  floor-multiply the bins the setup header says are zero.  The struct grew by 16 bytes
+                               5: vpz_decoder_set_residue_format: the residue may be handed over as 16-bit integers */
 
 /* ---- status codes (negative like the OV_* codes, Vorbisfile.cs:10-24) ---- */
 #define VPZ_OK                 0
@@ -264,6 +265,16 @@ int vpz_decoder_position(vpz_decoder *dec, int32_t stream, int64_t *sample_posit
  * pick-up stays off; synth of the pre-roll packet and the target packet; vpz_decoder_set_position(stream,
  * target + samples still undelivered).  INTEGRATION.md spells the sequence out. */
 int vpz_decoder_set_position(vpz_decoder *dec, int32_t stream, int64_t sample_position);
+
+/* The element type of `residue` in the synth calls that follow (until changed).  VPZ_RESIDUE_F32 (the default): float32, what
+ * Residue*.Decode leaves in its buffer.  VPZ_RESIDUE_I16: the same values as 16-bit integers -- exact whenever every value is an
+ * integer of that range, which the entropy decoder can tell from the setup header (libvorbis' residue books are integer
+ * lattices; vpzh_residue_is_integral in vorbispizza_front.h) -- at half the bytes over the host link; the device widens them
+ * to float32 before anything else looks at them.  `residue` then points to int16_t; residue_offset, residue_floats count
+ * VALUES as before. */
+#define VPZ_RESIDUE_F32 0
+#define VPZ_RESIDUE_I16 1
+int vpz_decoder_set_residue_format(vpz_decoder *dec, int32_t format);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(os.environ.get("VPZ_LIB_DIR") or os.path.join(_HERE, "li
 OK = 0
 E_INVALID_ARG, E_UNSUPPORTED, E_HIP, E_NOMEM, E_WINDOW_MISMATCH, E_NO_DEVICE, E_CAPACITY = -1, -2, -3, -4, -5, -6, -7
 MEM_HOST, MEM_DEVICE = 0, 1
+RESIDUE_F32, RESIDUE_I16 = 0, 1  # vpz_decoder_set_residue_format (ABI v5)
 IMDCT_FAST, IMDCT_EXACT = 0, 1
 OUT_INTERLEAVED, OUT_PLANAR, OUT_INTERLEAVED_S16, OUT_PLANAR_S16 = 0, 1, 2, 3
 PKT_BLOCK_FLAG, PKT_PREV_FLAG, PKT_NEXT_FLAG, PKT_EOS = 0x01, 0x02, 0x04, 0x08
@@ -87,6 +88,7 @@ _SIGNATURES = [
     ("vpz_decoder_has_clipped", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int32)]),
     ("vpz_decoder_position", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64)]),
     ("vpz_decoder_set_position", C.c_int, [_vp, C.c_int32, C.c_int64]),
+    ("vpz_decoder_set_residue_format", C.c_int, [_vp, C.c_int32]),
 ]
 # include/vorbispizza_synth_debug.h (test-only entry points, not part of the surface a C# host binds)
 _DEBUG_SIGNATURES = [
@@ -305,6 +307,10 @@ class Decoder:
         "ignore" leaves it to last_packet_status()."""
         written = np.zeros(self.n_streams, dtype=np.int64)
         packets = np.ascontiguousarray(packets, dtype=PACKET_DTYPE)
+        # ABI v5: the element type of `residue` is the array's (numpy or torch int16: VPZ_RESIDUE_I16, anything else float32)
+        want = RESIDUE_I16 if str(getattr(residue, "dtype", "")) in ("int16", "torch.int16") else RESIDUE_F32
+        if getattr(self, "residue_format", RESIDUE_F32) != want:
+            self.set_residue_format(want)
         offs = None if stream_out_offset is None else np.ascontiguousarray(stream_out_offset, dtype=np.int64)
         if mem_space == MEM_DEVICE:
             _sync_producer(residue, posts, post_counts, pcm_out)
@@ -337,7 +343,8 @@ class Decoder:
         """Host-memory convenience: returns a list (per stream) of PCM arrays, [channels, samples]
         for OUT_PLANAR or [samples, channels] for OUT_INTERLEAVED (int16 arrays for the _S16 layouts)."""
         packets = np.ascontiguousarray(packets, dtype=PACKET_DTYPE)
-        residue = np.ascontiguousarray(residue, dtype=np.float32)
+        # (int16 values -- ABI v5 -- go over as they are: synth_raw tells the decoder)
+        residue = np.ascontiguousarray(residue, dtype=np.int16 if getattr(residue, "dtype", None) == np.int16 else np.float32)
         if posts is not None:
             posts = np.ascontiguousarray(posts, dtype=np.int16)
             post_counts = np.ascontiguousarray(post_counts, dtype=np.uint8)
@@ -400,6 +407,11 @@ class Decoder:
         v = C.c_int64()
         self.ctx._check(lib().vpz_decoder_position(self._h, stream, C.byref(v)))
         return v.value
+
+    def set_residue_format(self, fmt):
+        """RESIDUE_F32 (default) or RESIDUE_I16: the element type of `residue` in the synth calls that follow (ABI v5)"""
+        self.ctx._check(lib().vpz_decoder_set_residue_format(self._h, int(fmt)))
+        self.residue_format = int(fmt)
 
     def set_position(self, position, stream=0):
         self.ctx._check(lib().vpz_decoder_set_position(self._h, stream, int(position)))

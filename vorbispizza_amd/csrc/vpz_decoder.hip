@@ -96,6 +96,41 @@ struct PinnedArena {
 struct PacketInfo {
     int length, left_use_size1, left_start, left_end, right_start, right_end;
 };
+// VPZ_RESIDUE_I16: 16-bit residue values to the float32 the synthesis kernels read (exact: every int16 is a float32).  Eight values
+// per lane and step where the source is 16-byte aligned (a staging buffer always is), one otherwise.
+__global__ __launch_bounds__(256) void widen_i16_kernel(const int16_t *__restrict__ in, float *__restrict__ out, long n)
+{
+    const long stride = (long)gridDim.x * 256 * 8;
+    if ((reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+            if (i + 8 <= n) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(in + i);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                float f[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f[2 * k] = (float)(int16_t)(w[k] & 0xFFFFu);
+                    f[2 * k + 1] = (float)(int16_t)(w[k] >> 16);
+                }
+                *reinterpret_cast<float4 *>(out + i) = make_float4(f[0], f[1], f[2], f[3]);
+                *reinterpret_cast<float4 *>(out + i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+            } else {
+                for (long j = i; j < n; ++j) out[j] = (float)in[j];
+            }
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = (float)in[i];
+    }
+}
+static hipError_t launch_widen_i16(const void *in, float *out, int64_t n, int num_cu, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    const int64_t want = (n + 256 * 8 - 1) / (256 * 8);
+    const int grid = (int)std::min<int64_t>(want, (int64_t)num_cu * 8);
+    hipLaunchKernelGGL(widen_i16_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const int16_t *>(in), out, (long)n);
+    return hipGetLastError();
+}
+
 struct Decoder {
     Context *ctx = nullptr;
     PinnedArena arenas[2];
@@ -140,6 +175,8 @@ struct Decoder {
     int host_threads = 0;        // parties of the parallel state machine (VPZ_HOST_THREADS; 0: pick)
     int64_t par_min_packets = 16384;  // batches below this take the serial state machine (VPZ_PAR_MIN_PACKETS)
     DevBuf b_in_res, b_in_posts, b_in_counts, b_out;  // VPZ_MEM_HOST staging
+    DevBuf b_in_res16;              // VPZ_RESIDUE_I16: the int16 values as they came over the link, widened into b_in_res
+    int residue_format = VPZ_RESIDUE_F32;
     DevBuf b_ybuf;                                    // any-block-size path
     bool generic = false;  // a block size outside {256, 512, 1024, 2048}: three-pass path (synth_kernels.hip)
     // type-0 floors (Floor0.cs)
@@ -545,7 +582,7 @@ void vpz_decoder_destroy(vpz_decoder *d)
     }
     if (D.d_f0_bark) (void)hipFree(D.d_f0_bark);
     if (D.d_f0_w) (void)hipFree(D.d_f0_w);
-    DevBuf *bufs[] = {&D.b_f0curve, &D.b_in_amp, &D.b_in_coeff, &D.b_ybuf, &D.b_curve, &D.b_temp, &D.b_cposts, &D.b_ccount, &D.b_in_res, &D.b_in_posts,
+    DevBuf *bufs[] = {&D.b_f0curve, &D.b_in_amp, &D.b_in_coeff, &D.b_ybuf, &D.b_curve, &D.b_temp, &D.b_cposts, &D.b_ccount, &D.b_in_res, &D.b_in_res16, &D.b_in_posts,
                       &D.b_in_counts, &D.b_out, &D.arenas[0].dev, &D.arenas[1].dev};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -678,7 +715,9 @@ struct SynthCall {
     bool dual_usable() const
     {
         if (!D.dual_ok || (any_floor0 && !D.f0_fused) || (ilv_seen && planar_seen)) return false;
-        const bool dev_ok = mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & (ilv_seen ? 15 : 7)) == 0;
+        // (int16 values are widened into the decoder's own, aligned staging buffer whatever the memory space)
+        const bool dev_ok = mem_space == VPZ_MEM_HOST || D.residue_format == VPZ_RESIDUE_I16 ||
+                            (reinterpret_cast<uintptr_t>(residue) & (ilv_seen ? 15 : 7)) == 0;
         return dev_ok && (ilv_seen ? group_align_ok : align2_ok);
     }
     bool zero_copy = false;
@@ -889,7 +928,7 @@ struct SynthCall {
         // Compact runs (two bytes per frame, descriptors built on the device) need consecutive packets with back to
         // back residues and a batch the fused kernel takes as it is (no planar temp, no type-0 floor pass)
         const bool group_usable = D.group_ok && group_align_ok &&
-                                  (mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
+                                  (mem_space == VPZ_MEM_HOST || D.residue_format == VPZ_RESIDUE_I16 || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
         compact = all_dense && !D.generic && (!any_floor0 || (D.f0_fused && dual_usable())) && !D.no_compact &&
                   (!need_coupling || group_usable || dual_usable());
         if (compact) {
@@ -1676,6 +1715,21 @@ struct SynthCall {
     // is copied: up to the highest residue a decodable packet names (>= what the state machine will use; within the extent
     // the caller stated, else nothing is started here and the call fails where it always did).  The caller's buffers are
     // read asynchronously from here on: every way out of the call synchronises (see EarlyUploadGuard).
+    // the caller's host residue into D.b_in_res: as it is, or -- VPZ_RESIDUE_I16 -- at 2 bytes a value over the link and widened there
+    int upload_residue(int64_t ext)
+    {
+        int rc;
+        if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)ext)) != VPZ_OK) return rc;
+        if (D.residue_format == VPZ_RESIDUE_I16) {
+            if ((rc = grow(ctx, D.b_in_res16, sizeof(int16_t) * (size_t)ext)) != VPZ_OK) return rc;
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res16.p, residue, sizeof(int16_t) * (size_t)ext, hipMemcpyHostToDevice, ctx->stream));
+            VPZ_HIP_TRY(ctx, launch_widen_i16(D.b_in_res16.p, static_cast<float *>(D.b_in_res.p), ext, ctx->num_cu, ctx->stream));
+        } else {
+            VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res.p, residue, sizeof(float) * (size_t)ext, hipMemcpyHostToDevice, ctx->stream));
+        }
+        return VPZ_OK;
+    }
+
     int stage_inputs_early(int64_t residue_floats, int64_t n_records)
     {
         if (mem_space != VPZ_MEM_HOST || !residue) return VPZ_OK;
@@ -1688,8 +1742,7 @@ struct SynthCall {
         }
         if (ext <= 0 || ext > residue_floats) return VPZ_OK;
         int rc;
-        if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)ext)) != VPZ_OK) return rc;
-        VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res.p, residue, sizeof(float) * (size_t)ext, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = upload_residue(ext)) != VPZ_OK) return rc;
         early_residue = true;
         early_res_extent = ext;
         if (have_posts && n_records >= n_rec && n_rec > 0) {
@@ -1712,12 +1765,13 @@ struct SynthCall {
         d_amp = D.f0_amp;
         d_coeff = D.f0_coeff;
         d_out = pcm_out;
+        if (mem_space != VPZ_MEM_HOST && D.residue_format == VPZ_RESIDUE_I16) {  // device-resident int16 values: widened into the staging buffer
+            if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)res_extent)) != VPZ_OK) return rc;
+            VPZ_HIP_TRY(ctx, launch_widen_i16(residue, static_cast<float *>(D.b_in_res.p), res_extent, ctx->num_cu, ctx->stream));
+            d_res = static_cast<const float *>(D.b_in_res.p);
+        }
         if (mem_space == VPZ_MEM_HOST) {
-            if (!(early_residue && early_res_extent >= res_extent)) {
-                if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)res_extent)) != VPZ_OK) return rc;
-                VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res.p, residue, sizeof(float) * (size_t)res_extent,
-                                                hipMemcpyHostToDevice, ctx->stream));
-            }
+            if (!(early_residue && early_res_extent >= res_extent) && (rc = upload_residue(res_extent)) != VPZ_OK) return rc;
             d_res = static_cast<const float *>(D.b_in_res.p);
             if (any_floor) {
                 if (!early_posts) {
@@ -2186,6 +2240,16 @@ int vpz_decoder_set_position(vpz_decoder *d, int32_t stream, int64_t sample_posi
     if (stream < 0 || stream >= D.n_streams) return set_error(D.ctx, VPZ_E_INVALID_ARG, "vpz_decoder_set_position: bad stream");
     D.states[stream].current_position = sample_position;
     D.states[stream].has_position = true;
+    return VPZ_OK;
+}
+
+int vpz_decoder_set_residue_format(vpz_decoder *d, int32_t format)
+{
+    if (!d) return VPZ_E_INVALID_ARG;
+    Decoder &D = d->impl;
+    if (format != VPZ_RESIDUE_F32 && format != VPZ_RESIDUE_I16)
+        return set_error(D.ctx, VPZ_E_INVALID_ARG, "vpz_decoder_set_residue_format: neither VPZ_RESIDUE_F32 nor VPZ_RESIDUE_I16");
+    D.residue_format = format;
     return VPZ_OK;
 }
 

@@ -56,6 +56,10 @@ def lib():
         L.vpzh_decode_range_ex.argtypes = [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int64, vp, vp, vp, vp,
                                            C.POINTER(C.c_int64), vp, vp, C.c_int32]
         L.vpzh_decode_range_ex.restype = C.c_int
+        L.vpzh_decode_range_i16.argtypes = L.vpzh_decode_range_ex.argtypes
+        L.vpzh_decode_range_i16.restype = C.c_int
+        L.vpzh_residue_is_integral.argtypes = [vp]
+        L.vpzh_residue_is_integral.restype = C.c_int
         L.vpzh_get_mapping.argtypes = [vp, C.c_int, C.POINTER(capi.MappingConfig)]
         L.vpzh_get_mapping.restype = C.c_int
         L.vpzh_get_residue_type.argtypes = [vp, C.c_int]
@@ -194,19 +198,26 @@ class OggVorbisFile:
     def last_error(self):
         return lib().vpzh_last_error(self._h).decode()
 
-    def decode_packets(self, stream_id=0, residue_base=0):
+    @property
+    def residue_is_integral(self):
+        """every residue value of the stream is an integer of 16 bits (decided from the setup header; vorbispizza_front.h)"""
+        return bool(lib().vpzh_residue_is_integral(self._h))
+
+    def decode_packets(self, stream_id=0, residue_base=0, int16=False):
         """Entropy-decode every audio packet.  Returns (packets, residue, posts, post_counts) in the
-        layout of vpz_decoder_synth."""
+        layout of vpz_decoder_synth; int16=True: the residue as 16-bit integers (vpzh_decode_range_i16; only for a stream whose
+        residue_is_integral)."""
         n, C_ = self.audio_packets, self.channels
         packets = capi.make_packets(n)
-        residue = np.zeros(max(1, self.info.residue_floats), dtype=np.float32)
+        residue = np.zeros(max(1, self.info.residue_floats), dtype=np.int16 if int16 else np.float32)
         posts = np.zeros((n * C_, 64), dtype=np.int16)
         counts = np.zeros(n * C_, dtype=np.uint8)
         amp = coeff = None
         if self.floor0_stride > 0:
             amp = np.zeros(n * C_, dtype=np.float32)
             coeff = np.zeros((n * C_, self.floor0_stride), dtype=np.float32)
-        rc = lib().vpzh_decode_range_ex(self._h, 0, n, stream_id, residue_base, packets.ctypes.data, residue.ctypes.data,
+        fn = lib().vpzh_decode_range_i16 if int16 else lib().vpzh_decode_range_ex
+        rc = fn(self._h, 0, n, stream_id, residue_base, packets.ctypes.data, residue.ctypes.data,
                                         posts.ctypes.data, counts.ctypes.data, None,
                                         None if amp is None else amp.ctypes.data,
                                         None if coeff is None else coeff.ctypes.data, self.floor0_stride)

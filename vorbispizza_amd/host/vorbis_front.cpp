@@ -1161,6 +1161,7 @@ struct vpzh_stream {
     std::vector<int64_t> cum_samples;
 
     std::vector<float> scratch_decode;  // per-handle scratch of decode_packet (one thread per handle)
+    std::vector<float> scratch_i16;     // a packet's residue on its way to the int16 form (vpzh_decode_range_i16)
     std::vector<uint8_t> one_flag;
 
     // StreamDecoder.DecodeNextPacket :696-762 -> Mode.Decode -> Mapping.DecodePacket :98-163
@@ -1430,11 +1431,42 @@ int vpzh_get_residue_type(vpzh_stream *s, int index)
     return s->su->residues[index].type;
 }
 
-int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
-                         vpz_packet *packets, float *residue, int16_t *posts, uint8_t *post_counts,
-                         int64_t *residue_floats_used, float *f0_amp, float *f0_coeff, int32_t f0_stride)
+// Is every residue value of this stream an integer that fits 16 bits?  A residue is a sum, per bin, of at most one codebook value per
+// cascade stage (Residue0.cs:144-205); libvorbis' residue books are integer lattices, so for its streams the answer is yes and
+// the vector can travel as int16 -- exactly: sums of integers below 2^24 are the same in float32 -- at half the bytes.  Decided
+// from the setup header alone, conservatively: every value book any residue names must hold integers only, and the worst case --
+// the largest magnitude of any of a residue's books, times its stages -- must stay below 2^15.
+static bool residue_integral(const SetupBlob &su)
 {
-    if (!s || !packets || !residue || !posts || !post_counts || first < 0 || count < 0 ||
+    for (const Residue &r : su.residues) {
+        double worst = 0.0;
+        for (size_t cl = 0; cl < r.books.size(); ++cl)
+            for (size_t st = 0; st < r.books[cl].size(); ++st) {
+                if (!(r.cascade[cl] & (1u << st))) continue;  // (no book at this stage of the class)
+                const size_t b = r.books[cl][st];
+                if (b >= su.books.size()) return false;
+                const Codebook &cb = su.books[b];
+                double mx = 0.0;
+                for (float v : cb.lookup) {
+                    if (!(v == (float)(int32_t)v) || !(fabsf(v) < 32768.0f)) return false;
+                    mx = std::max(mx, (double)fabsf(v));
+                }
+                worst = std::max(worst, mx);
+            }
+        if (worst * std::max(1, r.max_stages) >= 32768.0) return false;
+    }
+    return true;
+}
+
+int vpzh_residue_is_integral(vpzh_stream *s) { return s && s->su && residue_integral(*s->su) ? 1 : 0; }
+
+// (residue16 != nullptr: the int16 form -- every packet is decoded into the stream's float scratch and converted; a value that is not
+// an integer of 16 bits after all fails the packet, which vpzh_residue_is_integral() == 1 rules out)
+static int decode_range_impl(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
+                             vpz_packet *packets, float *residue, int16_t *residue16, int16_t *posts, uint8_t *post_counts,
+                             int64_t *residue_floats_used, float *f0_amp, float *f0_coeff, int32_t f0_stride)
+{
+    if (!s || !packets || (!residue && !residue16) || !posts || !post_counts || first < 0 || count < 0 ||
         first + count > (int64_t)s->audio.size())
         return VPZH_E_ARG;
     if (f0_amp && (!f0_coeff || f0_stride < s->su->max_floor0_order)) return VPZH_E_ARG;
@@ -1442,14 +1474,27 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
     s->first_failed_packet = -1;
     int64_t off = 0;
     const size_t C = (size_t)s->channels;
+    if (residue16) s->scratch_i16.resize((size_t)s->channels * (size_t)(s->size1 / 2));
     for (int64_t k = 0; k < count; ++k) {
         const OggPacket &pk = s->audio[(size_t)(first + k)];
         const int64_t n = s->packet_floats(pk);
         try {
-            s->decode_packet(pk, stream_id, residue_base + off, &packets[k], residue + off,
+            s->decode_packet(pk, stream_id, residue_base + off, &packets[k], residue16 ? s->scratch_i16.data() : residue + off,
                              posts + (size_t)k * 64 * C, post_counts + (size_t)k * C,
                              f0_amp ? f0_amp + (size_t)k * C : nullptr,
                              f0_coeff ? f0_coeff + (size_t)k * C * (size_t)f0_stride : nullptr, f0_stride);
+            if (residue16) {
+                const float *src = s->scratch_i16.data();
+                int16_t *dst = residue16 + off;
+                bool exact = true;
+                for (int64_t i = 0; i < n; ++i) {
+                    const float v = src[i];
+                    const int32_t q = (int32_t)v;
+                    exact &= (float)q == v && q >= -32768 && q <= 32767;
+                    dst[i] = (int16_t)q;
+                }
+                if (!exact) throw InvalidData("residue value outside the 16-bit integers");
+            }
         } catch (const std::exception &e) {
             // An exception out of DecodeNextPacket (StreamDecoder.cs:696-762: "Unused mode index.", a residue vector
             // overrun, ...) costs the reference exactly that packet: it is consumed, no decoder state has changed
@@ -1472,6 +1517,24 @@ int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t s
     }
     if (residue_floats_used) *residue_floats_used = off;
     return VPZH_OK;
+}
+
+int vpzh_decode_range_ex(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
+                         vpz_packet *packets, float *residue, int16_t *posts, uint8_t *post_counts,
+                         int64_t *residue_floats_used, float *f0_amp, float *f0_coeff, int32_t f0_stride)
+{
+    if (!residue) return VPZH_E_ARG;
+    return decode_range_impl(s, first, count, stream_id, residue_base, packets, residue, nullptr, posts, post_counts, residue_floats_used,
+                             f0_amp, f0_coeff, f0_stride);
+}
+
+int vpzh_decode_range_i16(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
+                          vpz_packet *packets, int16_t *residue, int16_t *posts, uint8_t *post_counts,
+                          int64_t *residue_values_used, float *f0_amp, float *f0_coeff, int32_t f0_stride)
+{
+    if (!residue || !s || !vpzh_residue_is_integral(s)) return VPZH_E_ARG;
+    return decode_range_impl(s, first, count, stream_id, residue_base, packets, nullptr, residue, posts, post_counts, residue_values_used,
+                             f0_amp, f0_coeff, f0_stride);
 }
 
 // Threads a call uses when the caller does not say: the cores this process may run on (its affinity mask, not the machine's

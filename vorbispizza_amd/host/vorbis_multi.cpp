@@ -41,6 +41,7 @@ struct Setup {
     std::vector<uint8_t> floor_types;
     std::vector<vpz_mapping_config> mappings;
     int f0_stride = 0;
+    bool integral = false;  // every residue value is an integer of 16 bits: the residue travels as int16 (half the link bytes)
 
     bool load(vpzh_stream *h)
     {
@@ -57,13 +58,14 @@ struct Setup {
         for (int i = 0; i < info.mapping_count; ++i)
             if (vpzh_get_mapping(h, i, &mappings[i]) != VPZH_OK) return false;
         f0_stride = vpzh_max_floor0_order(h);
+        integral = vpzh_residue_is_integral(h) != 0;
         return true;
     }
     // the same decoder serves two streams iff everything it was created from is the same
     bool same(const Setup &o) const
     {
         if (info.channels != o.info.channels || info.block_size0 != o.info.block_size0 || info.block_size1 != o.info.block_size1 ||
-            floors.size() != o.floors.size() || mappings.size() != o.mappings.size() || floor_types != o.floor_types)
+            floors.size() != o.floors.size() || mappings.size() != o.mappings.size() || floor_types != o.floor_types || integral != o.integral)
             return false;
         for (size_t i = 0; i < floors.size(); ++i) {
             if (floor_types[i] == 0) {
@@ -88,7 +90,7 @@ struct Lane {  // one context (HIP stream) of a device group and the decoders th
 
 struct Slot {  // page-locked batch arrays of one sub-batch in flight
     vpz_packet *packets = nullptr;
-    float *residue = nullptr;
+    float *residue = nullptr;            // (cap_residue floats; holds int16 values for a sub-batch whose residue travels as int16)
     int16_t *posts = nullptr;
     uint8_t *counts = nullptr;
     float *f0_amp = nullptr, *f0_coeff = nullptr;
@@ -284,6 +286,9 @@ struct GroupRun {
         ++waves_planned;
     }
 
+    // the residue of a sub-batch travels as int16 when its setup header guarantees integers (and the caller has not asked for floats)
+    bool use_i16(const Setup &st) const { return st.integral && !m->opt.float_residue; }
+
     // (the functions below run with `mu` RELEASED: they get their sub-batch by reference -- a deque's elements stay where they are, but
     // indexing `subs` / `setups` while plan_wave appends to them is a race)
     bool prep_slot(size_t b, Sub &sb)  // (one thread prepares a given sub-batch)
@@ -309,9 +314,14 @@ struct GroupRun {
             const int64_t pb = sb.pbase[(size_t)j], rb = sb.rbase[(size_t)j];
             int rc = VPZH_E_ARG;
             try {
-                rc = vpzh_decode_range_ex(J.h, 0, J.packets, j, rb, sl.packets + pb, sl.residue + rb, sl.posts + (size_t)pb * 64 * C,
-                                          sl.counts + (size_t)pb * C, nullptr, st.f0_stride ? sl.f0_amp + (size_t)pb * C : nullptr,
-                                          st.f0_stride ? sl.f0_coeff + (size_t)pb * C * (size_t)st.f0_stride : nullptr, st.f0_stride);
+                float *amp_at = st.f0_stride ? sl.f0_amp + (size_t)pb * C : nullptr;
+                float *coeff_at = st.f0_stride ? sl.f0_coeff + (size_t)pb * C * (size_t)st.f0_stride : nullptr;
+                if (use_i16(st))
+                    rc = vpzh_decode_range_i16(J.h, 0, J.packets, j, rb, sl.packets + pb, reinterpret_cast<int16_t *>(sl.residue) + rb,
+                                               sl.posts + (size_t)pb * 64 * C, sl.counts + (size_t)pb * C, nullptr, amp_at, coeff_at, st.f0_stride);
+                else
+                    rc = vpzh_decode_range_ex(J.h, 0, J.packets, j, rb, sl.packets + pb, sl.residue + rb, sl.posts + (size_t)pb * 64 * C,
+                                              sl.counts + (size_t)pb * C, nullptr, amp_at, coeff_at, st.f0_stride);
                 if (rc == VPZH_OK) results[J.k].skipped_packets += vpzh_decode_failures(J.h, nullptr);
             } catch (...) {
                 rc = VPZH_E_INVALID_DATA;
@@ -490,6 +500,7 @@ struct GroupRun {
             if (rc == VPZ_OK) rc = vpz_decoder_reset(dec, -1);
             for (int sidx = 0; sidx < S && rc == VPZ_OK; ++sidx) rc = vpz_decoder_set_position(dec, sidx, 0);
             if (rc == VPZ_OK && st.f0_stride > 0) rc = vpz_decoder_set_floor0_data(dec, sl.f0_amp, sl.f0_coeff, st.f0_stride);
+            if (rc == VPZ_OK) rc = vpz_decoder_set_residue_format(dec, use_i16(st) ? VPZ_RESIDUE_I16 : VPZ_RESIDUE_F32);
             if (rc == VPZ_OK)
                 rc = vpz_decoder_synth(dec, n_pk, sl.packets, sl.residue, sb.res_floats, sl.posts, sl.counts, n_pk * C, VPZ_MEM_HOST, out_at,
                                        offs.data(), cap, out_layout, 0, written.data());

@@ -13,7 +13,8 @@ E_OPEN, E_CAPACITY, E_SYNTH, E_SETUP = -10, -11, -12, -13
 
 class Options(C.Structure):
     _fields_ = [("host_threads", C.c_int32), ("streams_per_call", C.c_int32), ("contexts_per_device", C.c_int32),
-                ("clip_samples", C.c_int32), ("slots_per_device", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("clip_samples", C.c_int32), ("slots_per_device", C.c_int32), ("float_residue", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 class StreamResult(C.Structure):
@@ -62,9 +63,10 @@ class Dispatcher:
     """vpzm_dispatcher: one context group per entry of `device_ids` (an id may repeat: several groups on one GPU)."""
 
     def __init__(self, device_ids, host_threads=0, streams_per_call=0, contexts_per_device=0, clip_samples=False,
-                 slots_per_device=0):
+                 slots_per_device=0, float_residue=False):
         ids = (C.c_int32 * len(device_ids))(*[int(d) for d in device_ids])
-        opt = Options(host_threads, streams_per_call, contexts_per_device, 1 if clip_samples else 0, slots_per_device)
+        opt = Options(host_threads, streams_per_call, contexts_per_device, 1 if clip_samples else 0, slots_per_device,
+                      1 if float_residue else 0)
         self._h = C.c_void_p()
         rc = lib().vpzm_create(ids, len(device_ids), C.byref(opt), C.byref(self._h))
         if rc != OK:
