@@ -32,6 +32,17 @@ static int run(const std::vector<uint8_t>&d){
     int st=vpzh_max_floor0_order(s); std::vector<float> amp((size_t)info.audio_packets*info.channels+1), co((size_t)info.audio_packets*info.channels*(st>0?st:1)+1);
     int64_t used=0;
     rc=vpzh_decode_range_ex(s,0,info.audio_packets,0,0,pk.data(),res.data(),posts.data(),cnt.data(),&used,st?amp.data():nullptr,st?co.data():nullptr,st);
+    // (ABI v5) the int16 form of the same decode, where the -- possibly mutated -- setup header still promises integers: the float
+    // values must be those integers, packet for packet
+    if(rc==0 && vpzh_residue_is_integral(s)){
+      std::vector<vpz_packet> pk2(info.audio_packets); std::vector<int16_t> res16(info.residue_floats+1); int64_t used2=0;
+      int rc2=vpzh_decode_range_i16(s,0,info.audio_packets,0,0,pk2.data(),res16.data(),posts.data(),cnt.data(),&used2,st?amp.data():nullptr,st?co.data():nullptr,st);
+      if(rc2!=0 || used2!=used){ fprintf(stderr,"int16 decode differs in extent\n"); abort(); }
+      for(int64_t k=0;k<info.audio_packets;++k){
+        if((pk[k].flags&VPZ_PKT_NOT_DECODED)!=(pk2[k].flags&VPZ_PKT_NOT_DECODED)){ fprintf(stderr,"int16 decode differs in a packet's fate\n"); abort(); }
+      }
+      for(int64_t i=0;i<used;++i) if((float)res16[i]!=res[i]){ fprintf(stderr,"int16 residue differs at %lld: %d vs %g\n",(long long)i,(int)res16[i],(double)res[i]); abort(); }
+    }
     int64_t a,b; vpzh_seek(s, vpzh_total_samples(s)/2, &a,&b);
   }
   vpzh_close(s); return rc?2:0;

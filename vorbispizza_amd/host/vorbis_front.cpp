@@ -119,6 +119,11 @@ struct Codebook {
     int dimensions = 0, entries = 0, map_type = 0, max_bits = 0, prefix_bits = 0;
     std::vector<int> lengths;
     std::vector<float> lookup;
+    // the same values as 16-bit integers, when every one of them is one (bit for bit: no fraction, no -0.0, |v| < 2^15) -- else empty;
+    // entry_l1: the largest sum of magnitudes over an entry's dimensions (what one vector can add to ONE bin at most, Residue0's quirk included)
+    std::vector<int16_t> lookup_i16;
+    double entry_l1 = 0.0;
+    template <class T> const T *values() const;
     // prefix table of the first `prefix_bits` bits of a code (Huffman.cs:24-105), one 32-bit word per entry:
     // value << 6 | length, 0 = the code is longer than the table (overflow list).  4 KiB per book instead of the 16 KiB of
     // a table of nodes: the dozen books a packet touches stay in the L1 cache together.
@@ -299,6 +304,21 @@ struct Codebook {
                 }
             }
         }
+        // (ABI v5) the integer form of the table, if it has one
+        bool integral = !lookup.empty();
+        for (float v : lookup) {
+            const float back = (float)(int16_t)(int32_t)v;
+            integral = integral && fabsf(v) < 32768.0f && memcmp(&back, &v, sizeof v) == 0;
+        }
+        if (integral) {
+            lookup_i16.resize(lookup.size());
+            for (size_t i = 0; i < lookup.size(); ++i) lookup_i16[i] = (int16_t)(int32_t)lookup[i];
+        }
+        for (int idx = 0; idx < entries && dimensions > 0; ++idx) {
+            double l1 = 0.0;
+            for (int i = 0; i < dimensions; ++i) l1 += fabs((double)lookup[(size_t)idx * dimensions + i]);
+            entry_l1 = std::max(entry_l1, l1);
+        }
     }
 
     int decode_scalar(BitReader &p) const  // Codebook.cs:301-335
@@ -338,6 +358,9 @@ struct Codebook {
 // ---------------------------------------------------------------------------------------------
 // Floor1.cs:39-219
 // ---------------------------------------------------------------------------------------------
+template <> inline const float *Codebook::values<float>() const { return lookup.data(); }
+template <> inline const int16_t *Codebook::values<int16_t>() const { return lookup_i16.data(); }
+
 struct Floor1 {
     std::vector<uint8_t> partition_class, class_dimensions, class_subclasses, class_masterbooks;
     std::vector<std::vector<int>> subclass_books;
@@ -563,10 +586,12 @@ struct Residue {
     // Residue1.WriteVectors (Residue1.cs:12-34) for a partition that lies inside the channel with room for a last
     // vector that overhangs it: no per-vector bounds test, the add loop specialised for the usual dimensions.
     // Returns true when the packet ran out (Codebook.DecodeScalar == -1).
-    template <int kDim>
-    static bool write_vectors_fast(const Codebook &cb, BitReader &p, float *dst, int partition_size)
+    // T: float (what the reference accumulates, Residue*.cs) or int16_t (ABI v5: the same sums as integers -- exact when the setup
+    // header guarantees integers, residue_integral below -- written straight into the int16 vector the device is given)
+    template <int kDim, class T>
+    static bool write_vectors_fast(const Codebook &cb, BitReader &p, T *dst, int partition_size)
     {
-        const float *lookup = cb.lookup.data();
+        const T *lookup = cb.values<T>();
         const int dim = kDim ? kDim : cb.dimensions;
         int i = 0;
         // The bulk of a packet: a 64-bit window of the bit stream in a register, refilled every few symbols -- the chain
@@ -591,7 +616,7 @@ struct Residue {
                     w >>= len;
                     avail -= len;
                     pos += len;
-                    const float *lk = lookup + (size_t)(e >> 6) * dim;
+                    const T *lk = lookup + (size_t)(e >> 6) * dim;
                     if (kDim) {
 #pragma GCC unroll 8
                         for (int j = 0; j < kDim; ++j) dst[i + j] += lk[j];
@@ -607,7 +632,7 @@ struct Residue {
         for (; i < partition_size; i += dim) {
             const int entry = cb.decode_scalar(p);
             if (entry == -1) return true;
-            const float *lk = lookup + (size_t)entry * dim;
+            const T *lk = lookup + (size_t)entry * dim;
             if (kDim) {
 #pragma GCC unroll 8
                 for (int j = 0; j < kDim; ++j) dst[i + j] += lk[j];
@@ -620,7 +645,8 @@ struct Residue {
 
     // WriteVectors: Residue0.cs:208-231 (type 0, sums the entry into ONE bin: quirk q9) and
     // Residue1.cs:12-34 (types 1 and 2)
-    bool write_vectors(const Codebook &cb, BitReader &p, float *chan, int chan_len, int offset) const
+    template <class T>
+    bool write_vectors(const Codebook &cb, BitReader &p, T *chan, int chan_len, int offset) const
     {
 #ifdef VPZH_STATS
         g_vpzh_stats[cb.dimensions < 16 ? cb.dimensions : 15] += 1;
@@ -633,13 +659,13 @@ struct Residue {
             const int dim = cb.dimensions;
             const int reach = (partition_size + dim - 1) / dim * dim;  // a last vector may overhang the partition
             if (offset + reach <= chan_len) {
-                float *dst = chan + offset;
+                T *dst = chan + offset;
                 switch (dim) {
-                    case 1: return write_vectors_fast<1>(cb, p, dst, partition_size);
-                    case 2: return write_vectors_fast<2>(cb, p, dst, partition_size);
-                    case 4: return write_vectors_fast<4>(cb, p, dst, partition_size);
-                    case 8: return write_vectors_fast<8>(cb, p, dst, partition_size);
-                    default: return write_vectors_fast<0>(cb, p, dst, partition_size);
+                    case 1: return write_vectors_fast<1, T>(cb, p, dst, partition_size);
+                    case 2: return write_vectors_fast<2, T>(cb, p, dst, partition_size);
+                    case 4: return write_vectors_fast<4, T>(cb, p, dst, partition_size);
+                    case 8: return write_vectors_fast<8, T>(cb, p, dst, partition_size);
+                    default: return write_vectors_fast<0, T>(cb, p, dst, partition_size);
                 }
             }
         }
@@ -648,19 +674,19 @@ struct Residue {
             for (int step = 0; step < steps; ++step) {
                 int entry = cb.decode_scalar(p);
                 if (entry == -1) return true;
-                float r = 0;
-                const float *lk = &cb.lookup[(size_t)entry * cb.dimensions];
-                for (int d = 0; d < cb.dimensions; ++d) { volatile float t = r + lk[d]; r = t; }
-                if (offset + step < chan_len) { volatile float t = chan[offset + step] + r; chan[offset + step] = t; }
+                T r = 0;
+                const T *lk = cb.values<T>() + (size_t)entry * cb.dimensions;
+                for (int d = 0; d < cb.dimensions; ++d) { volatile T t = (T)(r + lk[d]); r = t; }  // (float: every sum rounded, as the reference's)
+                if (offset + step < chan_len) { volatile T t = (T)(chan[offset + step] + r); chan[offset + step] = t; }
             }
             return false;
         }
         for (int i = 0; i < partition_size;) {
             int entry = cb.decode_scalar(p);
             if (entry == -1) return true;
-            const float *lk = &cb.lookup[(size_t)entry * cb.dimensions];
+            const T *lk = cb.values<T>() + (size_t)entry * cb.dimensions;
             if (offset + i + cb.dimensions > chan_len) throw InvalidData("residue vector overruns the block");
-            for (int j = 0; j < cb.dimensions; ++j) chan[offset + i + j] += lk[j];
+            for (int j = 0; j < cb.dimensions; ++j) chan[offset + i + j] = (T)(chan[offset + i + j] + lk[j]);
             i += cb.dimensions;
         }
         return false;
@@ -668,7 +694,8 @@ struct Residue {
 
     // Residue0.Decode :117-206.  buffer: `count` channels at stride `stride`.
     // (part_word_cache: the caller's scratch -- a Residue belongs to a setup that many streams share, so it is not written here)
-    void decode(BitReader &p, const std::vector<uint8_t> &do_not_decode, int block_size, float *buffer, int stride,
+    template <class T>
+    void decode(BitReader &p, const std::vector<uint8_t> &do_not_decode, int block_size, T *buffer, int stride,
                 const std::vector<Codebook> &cbs, std::vector<int> &part_word_cache) const
     {
         int half = block_size / 2;
@@ -1160,12 +1187,16 @@ struct vpzh_stream {
     // second audio packet (the first one only primes the overlap; PacketProvider.cs:283-287)
     std::vector<int64_t> cum_samples;
 
-    std::vector<float> scratch_decode;  // per-handle scratch of decode_packet (one thread per handle)
-    std::vector<float> scratch_i16;     // a packet's residue on its way to the int16 form (vpzh_decode_range_i16)
+    std::vector<float> scratch_decode;      // per-handle scratch of decode_packet (one thread per handle)
+    std::vector<int16_t> scratch_decode16;  // ... of its int16 form (vpzh_decode_range_i16)
+    std::vector<float> &scratch_of(float *) { return scratch_decode; }
+    std::vector<int16_t> &scratch_of(int16_t *) { return scratch_decode16; }
     std::vector<uint8_t> one_flag;
 
     // StreamDecoder.DecodeNextPacket :696-762 -> Mode.Decode -> Mapping.DecodePacket :98-163
-    void decode_packet(const OggPacket &pk, int32_t stream_id, int64_t residue_off, vpz_packet *out, float *residue,
+    // (T: the residue's element type -- float, or int16_t for a stream whose residue is integral, ABI v5)
+    template <class T>
+    void decode_packet(const OggPacket &pk, int32_t stream_id, int64_t residue_off, vpz_packet *out, T *residue,
                        int16_t *posts, uint8_t *post_counts, float *f0_amp = nullptr, float *f0_coeff = nullptr,
                        int f0_stride = 0)
     {
@@ -1228,8 +1259,8 @@ struct vpzh_stream {
         }
         // residues, Mapping.cs:132-163.  decodeBuffer is allocated once per packet and reused by every
         // submap without clearing (reference behaviour, matters only for multi-submap residue 0/1).
-        float *dst = residue;  // planar [ch][half] unless the interleaved shortcut below is taken
-        memset(dst, 0, sizeof(float) * (size_t)channels * half);
+        T *dst = residue;  // planar [ch][half] unless the interleaved shortcut below is taken
+        memset(dst, 0, sizeof(T) * (size_t)channels * half);
         const int submaps = (int)map.submap_residue.size();
         if (submaps == 1 && channels > 1 && su->residues[map.submap_residue[0]].type == 2) {
             // The common stereo / multichannel case, one Residue2 submap over every channel: decode the
@@ -1251,8 +1282,8 @@ struct vpzh_stream {
                 return;
             }
         }
-        std::vector<float> &decode_buffer = scratch_decode;
-        decode_buffer.assign((size_t)channels * block_size, 0.f);
+        std::vector<T> &decode_buffer = scratch_of(residue);
+        decode_buffer.assign((size_t)channels * block_size, (T)0);
         for (int i = 0; i < submaps; ++i) {
             std::vector<uint8_t> dnd;
             std::vector<int> members;
@@ -1264,19 +1295,19 @@ struct vpzh_stream {
                 bool any = false;
                 for (uint8_t f : dnd) if (!f) any = true;
                 if (!any) {
-                    for (int k = 0; k < count; ++k) memset(&decode_buffer[(size_t)k * block_size], 0, sizeof(float) * half);
+                    for (int k = 0; k < count; ++k) memset(&decode_buffer[(size_t)k * block_size], 0, sizeof(T) * half);
                 } else {
-                    std::vector<float> tmp((size_t)half * count, 0.f);
+                    std::vector<T> tmp((size_t)half * count, (T)0);
                     std::vector<uint8_t> one(1, 0);
                     res.decode(p, one, block_size * count, tmp.data(), half * count, su->books, residue_scratch);
                     if (submaps == 1 && count == channels && channels > 1) {
                         // hand the Residue2 vector over as it is: the GPU de-interleaves (Residue2.cs:42-51)
-                        memcpy(dst, tmp.data(), sizeof(float) * (size_t)half * channels);
+                        memcpy(dst, tmp.data(), sizeof(T) * (size_t)half * channels);
                         out->flags |= VPZ_PKT_INTERLEAVED;
                         return;
                     }
                     if (count == 1) {
-                        memcpy(&decode_buffer[0], tmp.data(), sizeof(float) * half);
+                        memcpy(&decode_buffer[0], tmp.data(), sizeof(T) * half);
                     } else {
                         for (int k = 0; k < count; ++k)
                             for (int b = 0; b < half; ++b) decode_buffer[(size_t)k * block_size + b] = tmp[(size_t)b * count + k];
@@ -1286,7 +1317,7 @@ struct vpzh_stream {
                 res.decode(p, dnd, block_size, decode_buffer.data(), block_size, su->books, residue_scratch);
             }
             for (int k = 0; k < count; ++k)
-                memcpy(dst + (size_t)members[k] * half, &decode_buffer[(size_t)k * block_size], sizeof(float) * half);
+                memcpy(dst + (size_t)members[k] * half, &decode_buffer[(size_t)k * block_size], sizeof(T) * half);
         }
     }
 };
@@ -1446,22 +1477,20 @@ static bool residue_integral(const SetupBlob &su)
                 const size_t b = r.books[cl][st];
                 if (b >= su.books.size()) return false;
                 const Codebook &cb = su.books[b];
-                double mx = 0.0;
-                for (float v : cb.lookup) {
-                    if (!(v == (float)(int32_t)v) || !(fabsf(v) < 32768.0f)) return false;
-                    mx = std::max(mx, (double)fabsf(v));
-                }
-                worst = std::max(worst, mx);
+                if (cb.lookup_i16.empty()) return false;  // (a fraction, a -0.0 or a value beyond 16 bits in the table)
+                worst = std::max(worst, cb.entry_l1);
             }
-        if (worst * std::max(1, r.max_stages) >= 32768.0) return false;
+        // per stage a bin takes one vector's value -- two where a partition's last vector overhangs into the next partition
+        // (Residue1.cs:12-34), the sum of an entry's dimensions for residue type 0 (Residue0.cs:208-231): entry_l1 covers all three
+        if (worst * 2.0 * std::max(1, r.max_stages) >= 32768.0) return false;
     }
     return true;
 }
 
 int vpzh_residue_is_integral(vpzh_stream *s) { return s && s->su && residue_integral(*s->su) ? 1 : 0; }
 
-// (residue16 != nullptr: the int16 form -- every packet is decoded into the stream's float scratch and converted; a value that is not
-// an integer of 16 bits after all fails the packet, which vpzh_residue_is_integral() == 1 rules out)
+// (residue16 != nullptr: the int16 form -- the same decode with the codebooks' integer tables, summed as integers straight into the
+// caller's vector; vpzh_residue_is_integral() == 1 is what makes those sums the float ones)
 static int decode_range_impl(vpzh_stream *s, int64_t first, int64_t count, int32_t stream_id, int64_t residue_base,
                              vpz_packet *packets, float *residue, int16_t *residue16, int16_t *posts, uint8_t *post_counts,
                              int64_t *residue_floats_used, float *f0_amp, float *f0_coeff, int32_t f0_stride)
@@ -1474,27 +1503,18 @@ static int decode_range_impl(vpzh_stream *s, int64_t first, int64_t count, int32
     s->first_failed_packet = -1;
     int64_t off = 0;
     const size_t C = (size_t)s->channels;
-    if (residue16) s->scratch_i16.resize((size_t)s->channels * (size_t)(s->size1 / 2));
     for (int64_t k = 0; k < count; ++k) {
         const OggPacket &pk = s->audio[(size_t)(first + k)];
         const int64_t n = s->packet_floats(pk);
         try {
-            s->decode_packet(pk, stream_id, residue_base + off, &packets[k], residue16 ? s->scratch_i16.data() : residue + off,
-                             posts + (size_t)k * 64 * C, post_counts + (size_t)k * C,
-                             f0_amp ? f0_amp + (size_t)k * C : nullptr,
-                             f0_coeff ? f0_coeff + (size_t)k * C * (size_t)f0_stride : nullptr, f0_stride);
-            if (residue16) {
-                const float *src = s->scratch_i16.data();
-                int16_t *dst = residue16 + off;
-                bool exact = true;
-                for (int64_t i = 0; i < n; ++i) {
-                    const float v = src[i];
-                    const int32_t q = (int32_t)v;
-                    exact &= (float)q == v && q >= -32768 && q <= 32767;
-                    dst[i] = (int16_t)q;
-                }
-                if (!exact) throw InvalidData("residue value outside the 16-bit integers");
-            }
+            float *amp_k = f0_amp ? f0_amp + (size_t)k * C : nullptr;
+            float *coeff_k = f0_coeff ? f0_coeff + (size_t)k * C * (size_t)f0_stride : nullptr;
+            if (residue16)
+                s->decode_packet(pk, stream_id, residue_base + off, &packets[k], residue16 + off, posts + (size_t)k * 64 * C,
+                                 post_counts + (size_t)k * C, amp_k, coeff_k, f0_stride);
+            else
+                s->decode_packet(pk, stream_id, residue_base + off, &packets[k], residue + off, posts + (size_t)k * 64 * C,
+                                 post_counts + (size_t)k * C, amp_k, coeff_k, f0_stride);
         } catch (const std::exception &e) {
             // An exception out of DecodeNextPacket (StreamDecoder.cs:696-762: "Unused mode index.", a residue vector
             // overrun, ...) costs the reference exactly that packet: it is consumed, no decoder state has changed
