@@ -533,6 +533,36 @@ def end_to_end_real_streams(ctx, torch, copies, threads, sub=16, synth_lanes=2, 
     return total, best
 
 
+def end_to_end_rank_dispatcher(torch, device_index, per_kind, threads, s16=False, repeats=3):
+    """A rank's shard of configs[4]'s job -- per_kind[k] streams of fixture k, container bytes in host memory -> interleaved PCM in
+    page-locked host memory -- through the product's own host path: ONE vpzm_decode_library call on the rank's device (open, entropy
+    decode -- as 16-bit integers where the setup header guarantees them, ABI v5 --, host-memory synth calls on four contexts).
+    Returns (samples, (wall, wall until the last stream was entropy-decoded, summed synth-call time))."""
+    from vorbispizza_amd import multi
+    raws = [np.frombuffer(open(os.path.join(ROOT, "tests", "golden", name), "rb").read(), dtype=np.uint8) for name, _ in REAL_FIXTURES]
+    kinds = [k for k, n in enumerate(per_kind) for _ in range(n)]
+    if not kinds:
+        return 0, (0.0, 0.0, 0.0)
+    datas = [raws[k] for k in kinds]
+    caps = np.array([REAL_FIXTURES[k][1] + 2048 for k in kinds], dtype=np.int64)
+    sizes = caps * 2
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    pcm = torch.empty(int(sizes.sum()), dtype=torch.int16 if s16 else torch.float32, pin_memory=True).numpy()
+    d = multi.Dispatcher([device_index], host_threads=threads)
+    best = None
+    try:
+        for _ in range(repeats):
+            results, stats = d.decode_library(datas, pcm, offs, caps, s16=s16)
+            assert (results["status"] == 0).all(), "dispatcher: a stream failed: %s" % d.last_error()
+            assert all(int(results["samples"][i]) == REAL_FIXTURES[k][1] for i, k in enumerate(kinds)), "sample counts"
+            if best is None or stats.wall_s < best[0]:
+                best = (stats.wall_s, stats.device_decode_s[0], stats.device_synth_s[0])
+    finally:
+        d.close()
+    del pcm
+    return int(results["samples"].sum()) * 2, best
+
+
 def dispatcher_whole_job(torch, device_ids, threads, s16=False, repeats=3, streams=None, checksum=True):
     """configs[4]'s whole job -- 1024 stereo streams, container bytes in host memory -> interleaved PCM in (page-locked) host
     memory -- through the in-process multi-device dispatcher of libvorbispizza_host.so (include/vorbispizza_multi.h): ONE
@@ -950,10 +980,25 @@ def main():
         thr = host_threads()
         if distributed:
             sharding.barrier()
-        tot_e_local, (t_all, t_dec, t_syn) = end_to_end_real_streams(ctx, torch, 0, thr, plan=plan)
+        # end to end: the rank's shard through the product's host path (the dispatcher on the rank's own device) ...
+        per_kind = [len(ids) for ids in plan]
+        # (decode threads: the library's own rule -- the rank's CPUs plus one per context, the issuing threads mostly wait -- unless
+        # --host-threads says otherwise)
+        thr_disp = thr if HOST_THREADS_CAP else thr + 4
+        tot_e_local, (t_all, t_dec, t_syn) = end_to_end_rank_dispatcher(torch, ctx.device, per_kind, thr_disp)
         if distributed:
             sharding.barrier()
-        _, (t_all16, t_dec16, t_syn16) = end_to_end_real_streams(ctx, torch, 0, thr, plan=plan, s16=True)
+        _, (t_all16, t_dec16, t_syn16) = end_to_end_rank_dispatcher(torch, ctx.device, per_kind, thr_disp, s16=True)
+        # ... and, for comparison with earlier rounds, through the bench's own Python pipeline (float32 residue over the link)
+        if distributed:
+            sharding.barrier()
+        _, (tp_all, tp_dec, tp_syn) = end_to_end_real_streams(ctx, torch, 0, thr, plan=plan)
+        if distributed:
+            sharding.barrier()
+        _, (tp_all16, tp_dec16, tp_syn16) = end_to_end_real_streams(ctx, torch, 0, thr, plan=plan, s16=True)
+        if distributed:
+            tp_all = sharding.max_over_ranks(tp_all, red_device)
+            tp_all16 = sharding.max_over_ranks(tp_all16, red_device)
         # every rank's own figures, so that a flat 1 -> 8 curve can be put down to the host (entropy decode) or to the
         # link (synth calls in host memory) at a glance
         rank_ms = sharding.gather_floats([t_all * 1e3, t_dec * 1e3, t_syn * 1e3, t_all16 * 1e3, t_dec16 * 1e3, t_syn16 * 1e3],
@@ -971,6 +1016,13 @@ def main():
             "end_to_end_Msamples_per_s": round(tot / t_all / 1e6, 1), "end_to_end_wall_ms_max_over_ranks": round(t_all * 1e3, 2),
             "end_to_end_s16_Msamples_per_s": round(tot / t_all16 / 1e6, 1),
             "end_to_end_s16_wall_ms_max_over_ranks": round(t_all16 * 1e3, 2),
+            "end_to_end_path": "every rank: ONE vpzm_decode_library call on its device (libvorbispizza_host.so: open, entropy decode -- "
+                               "the residue as 16-bit integers where the setup header guarantees them, ABI v5 --, host-memory synth "
+                               "calls on four contexts)",
+            "python_pipeline_end_to_end_Msamples_per_s": round(tot / tp_all / 1e6, 1),
+            "python_pipeline_end_to_end_s16_Msamples_per_s": round(tot / tp_all16 / 1e6, 1),
+            "python_pipeline_note": "the bench's own loop of rounds 2-4 (vpzh_decode_many_progress + host-memory synth calls from "
+                                    "Python on two contexts, float32 residue over the link), kept for comparison",
             "per_rank_ms": {"end_to_end_wall": [round(r[0], 2) for r in rank_ms],
                             "cpu_open_and_entropy_decode_wall": [round(r[1], 2) for r in rank_ms],
                             "synth_host_memory_calls_incl_h2d_d2h": [round(r[2], 2) for r in rank_ms],
