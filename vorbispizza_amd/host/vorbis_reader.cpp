@@ -45,6 +45,7 @@ struct Sub {
     // scratch for the front end
     std::vector<vpz_packet> packets;
     std::vector<float> residue;
+    std::vector<int16_t> residue16;  // ABI v5: the batch's residue as 16-bit integers, for a stream whose setup header guarantees them
     std::vector<int16_t> posts;
     std::vector<uint8_t> counts;
     std::vector<float> f0_amp, f0_coeff;
@@ -103,7 +104,9 @@ struct Sub {
         const int C = info.channels;
         const int half1 = info.block_size1 / 2;
         packets.resize((size_t)n);
-        residue.assign((size_t)n * C * half1, 0.f);
+        const bool i16 = vpzh_residue_is_integral(front) != 0;  // (half the bytes over the link, the same values)
+        if (i16) residue16.assign((size_t)n * C * half1, 0);
+        else residue.assign((size_t)n * C * half1, 0.f);
         posts.assign((size_t)n * C * 64, 0);
         counts.assign((size_t)n * C, 0);
         int64_t used = 0;
@@ -112,10 +115,13 @@ struct Sub {
             f0_amp.assign((size_t)n * C, 0.f);
             f0_coeff.assign((size_t)n * C * f0_stride, 0.f);
         }
-        if (vpzh_decode_range_ex(front, next_packet, n, 0, 0, packets.data(), residue.data(), posts.data(), counts.data(),
-                                 &used, f0_stride ? f0_amp.data() : nullptr, f0_stride ? f0_coeff.data() : nullptr,
-                                 f0_stride) != VPZH_OK)
-            return fail(VPZ_E_INVALID_ARG, vpzh_last_error(front));
+        const int drc = i16 ? vpzh_decode_range_i16(front, next_packet, n, 0, 0, packets.data(), residue16.data(), posts.data(), counts.data(),
+                                                    &used, f0_stride ? f0_amp.data() : nullptr, f0_stride ? f0_coeff.data() : nullptr, f0_stride)
+                            : vpzh_decode_range_ex(front, next_packet, n, 0, 0, packets.data(), residue.data(), posts.data(), counts.data(),
+                                                   &used, f0_stride ? f0_amp.data() : nullptr, f0_stride ? f0_coeff.data() : nullptr, f0_stride);
+        if (drc != VPZH_OK) return fail(VPZ_E_INVALID_ARG, vpzh_last_error(front));
+        if ((rc = vpz_decoder_set_residue_format(dec, i16 ? VPZ_RESIDUE_I16 : VPZ_RESIDUE_F32)) != VPZ_OK)
+            return fail(rc, vpz_context_last_error(ctx));
         {   // a packet that threw is consumed and changes nothing (StreamDecoder.cs:696-762: the exception leaves
             // DecodeNextPacket before any state is touched); the front end handed it over as "not decoded"
             int64_t first_failed = -1;
@@ -130,7 +136,8 @@ struct Sub {
         if (s16) pcm16.assign((size_t)cap * C, 0);
         else pcm.assign((size_t)cap * C, 0.f);
         int64_t written = 0;
-        rc = vpz_decoder_synth(dec, n, packets.data(), residue.data(), (int64_t)residue.size(), posts.data(), counts.data(),
+        rc = vpz_decoder_synth(dec, n, packets.data(), i16 ? reinterpret_cast<const float *>(residue16.data()) : residue.data(),
+                               (int64_t)(i16 ? residue16.size() : residue.size()), posts.data(), counts.data(),
                                (int64_t)counts.size(), VPZ_MEM_HOST,
                                s16 ? static_cast<void *>(pcm16.data()) : static_cast<void *>(pcm.data()), nullptr, cap,
                                s16 ? VPZ_OUT_INTERLEAVED_S16 : VPZ_OUT_INTERLEAVED, 0, &written);
