@@ -948,17 +948,18 @@ def main():
                 "note": "one decoder over both fixtures' setups (sharding.merge_setups); GPU stage = Floor1 unwrap + the stereo "
                         "fast path (synth_dual_kernel: one wavefront per stream-run, both channels), one launch each per step"}
             thr = host_threads()
-            tot_e, (t_all, t_dec, t_syn) = end_to_end_real_streams(ctx, torch, 64, thr)
+            thr_disp = thr if HOST_THREADS_CAP else thr + 4  # (the dispatcher's own rule: the CPUs plus one per context)
+            tot_e, (t_all, t_dec, t_syn) = end_to_end_rank_dispatcher(torch, ctx.device, [64, 64], thr_disp)
             extras["configs[4] end to end, one GPU's share: 128 real stereo streams, container bytes in host memory "
                    "-> interleaved PCM in host memory"] = {
-                "Msamples_per_s": round(tot_e / t_all / 1e6, 1), "host_threads": thr, "host": host_report(thr),
+                "Msamples_per_s": round(tot_e / t_all / 1e6, 1), "host_threads": thr_disp, "host": host_report(thr),
                 "cpu_open_and_entropy_decode_wall_ms": round(t_dec * 1e3, 2),
                 "synth_host_memory_calls_ms_incl_h2d_d2h": round(t_syn * 1e3, 2),
-                "note": "sub-batches of 16 streams on 2 contexts: synth calls overlap the entropy decode of later sub-batches "
-                        "and each other's PCIe copies; best of 3"}
-            tot_s, (t_all_s, t_dec_s, t_syn_s) = end_to_end_real_streams(ctx, torch, 64, thr, s16=True)
+                "note": "ONE vpzm_decode_library call (libvorbispizza_host.so): sub-batches of 16 streams on 4 contexts, the residue as "
+                        "16-bit integers over the link (ABI v5); best of 3"}
+            tot_s, (t_all_s, t_dec_s, t_syn_s) = end_to_end_rank_dispatcher(torch, ctx.device, [64, 64], thr_disp, s16=True)
             extras["configs[4] end to end, one GPU's share, 16-bit PCM out (VPZ_OUT_INTERLEAVED_S16: half the D2H bytes)"] = {
-                "Msamples_per_s": round(tot_s / t_all_s / 1e6, 1), "host_threads": thr,
+                "Msamples_per_s": round(tot_s / t_all_s / 1e6, 1), "host_threads": thr_disp,
                 "cpu_open_and_entropy_decode_wall_ms": round(t_dec_s * 1e3, 2),
                 "synth_host_memory_calls_ms_incl_h2d_d2h": round(t_syn_s * 1e3, 2)}
             extras["configs[0] plumbing"] = cpu_plumbing_2test()
