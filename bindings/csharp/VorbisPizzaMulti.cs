@@ -64,7 +64,8 @@ namespace NVorbis.Native
                                                      long* pcmOffset, long* pcmCapacity, StreamResult* results, Stats* stats);
 
         /// <summary>Decodes a library of in-memory .ogg files on every device of `deviceIds`: the C# a host adds around the call
-        /// (pin the arrays, hand them over, read the per-stream results).</summary>
+        /// (pin the arrays, hand them over, read the per-stream results).  Calls from several threads on one dispatcher are
+        /// safe: the library takes them in turn.</summary>
         public static StreamResult[] DecodeLibrary(DispatcherHandle dispatcher, byte[][] files, float[] pcm, long[] offsets, long[] capacities)
         {
             int n = files.Length;

@@ -84,7 +84,9 @@ typedef struct vpzm_stats {
  * be page-locked (vpz_host_alloc) for the link's full rate; any host memory works.
  * Streams may differ in setup headers, channel counts and block sizes: streams of one setup ride in the same calls.
  * results[n] (required) receives every stream's outcome; a stream that fails costs only itself.  Returns VPZM_OK when the
- * job ran (look at the per-stream statuses), VPZM_E_ARG for bad arguments.  One call at a time per dispatcher. */
+ * job ran (look at the per-stream statuses), VPZM_E_ARG for bad arguments.  A dispatcher runs one call at a time: calls from
+ * several host threads are safe and take it in turn (wall_s then counts from the moment the call got the dispatcher);
+ * vpzm_destroy must not race a call. */
 int vpzm_decode_library(vpzm_dispatcher *m, int32_t n, const uint8_t *const *data, const uint64_t *size, int32_t out_layout,
                         void *pcm_out, const int64_t *pcm_offset, const int64_t *pcm_capacity, vpzm_stream_result *results,
                         vpzm_stats *stats);

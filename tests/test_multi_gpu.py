@@ -159,6 +159,47 @@ def test_a_dispatcher_is_reusable_and_says_what_it_is(ctx):
         multi.Dispatcher([99])  # no such device
 
 
+def test_callers_on_several_threads_take_a_dispatcher_in_turn(ctx):
+    # ctypes drops the GIL for the call: without the dispatcher's own lock two callers would share slots and contexts
+    import threading
+    from vorbispizza_amd import multi
+    from vorbispizza_amd.front import OggVorbisFile
+    kinds = (("3test.ogg",), ("2test.ogg", "1test.ogg"), ("3test.ogg", "2test.ogg"), ("1test.ogg",))
+    d = multi.Dispatcher([0, 0], host_threads=4, streams_per_call=3)
+    jobs = []
+    for kind in kinds:
+        raws = library(kind, 9)
+        info = [(OggVorbisFile(r).channels, int(OggVorbisFile(r).total_samples)) for r in raws]
+        caps = np.array([n + 16 for _, n in info], dtype=np.int64)
+        sizes = np.array([c * (n + 16) for c, n in info], dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        jobs.append(dict(raws=raws, caps=caps, offs=offs, info=info, pcm=np.full(int(sizes.sum()), np.float32(7.0), dtype=np.float32)))
+
+    def call(j):
+        try:
+            j["res"], _ = d.decode_library([np.frombuffer(r, dtype=np.uint8) for r in j["raws"]], j["pcm"], j["offs"], j["caps"])
+        except Exception as e:  # noqa: BLE001 (handed to the asserting thread)
+            j["err"] = e
+
+    threads = [threading.Thread(target=call, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    d.close()
+    singles = {}
+    for j in jobs:
+        assert "err" not in j, j.get("err")
+        assert (j["res"]["status"] == 0).all()
+        for k, r in enumerate(j["raws"]):
+            if r not in singles:
+                singles[r] = single_stream_pcm(ctx, r)
+            ref, C_ = singles[r], j["info"][k][0]
+            assert j["res"]["samples"][k] == ref.shape[0]
+            got = j["pcm"][j["offs"][k]:j["offs"][k] + ref.shape[0] * C_].reshape(-1, C_)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), k
+
+
 def test_more_setups_than_a_context_keeps_decoders_for(ctx):
     """A context keeps the decoders of its last 8 setups (vorbis_multi.cpp: kDecodersPerContext): a library of 12 stereo streams with
     12 different setup headers, decoded twice on ONE context -- decoders are created, evicted and created again, the PCM stays that of

@@ -125,6 +125,7 @@ struct vpzm_dispatcher {
     vpzm_options opt{};
     std::string error;
     std::mutex err_mu;
+    std::mutex call_mu;  // vpzm_decode_library holds it: calls from several host threads take the dispatcher in turn
     void fail(const std::string &what)
     {
         std::lock_guard<std::mutex> g(err_mu);
@@ -661,6 +662,8 @@ int vpzm_decode_library(vpzm_dispatcher *m, int32_t n, const uint8_t *const *dat
     for (int32_t k = 0; k < n; ++k)
         if (!data[k] || pcm_offset[k] < 0 || pcm_capacity[k] < 0) return VPZM_E_ARG;
     if (stats) *stats = vpzm_stats{};
+    // (slots, contexts and decoder caches belong to one call at a time: a second caller waits here, it is not refused)
+    std::lock_guard<std::mutex> one_call(m->call_mu);
     m->error.clear();
     const auto t0 = Clock::now();
     const int D = (int)m->groups.size();
