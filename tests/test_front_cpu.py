@@ -85,6 +85,20 @@ def test_truncated_and_corrupt_input(front):
         front.OggVorbisFile(b"not an ogg file at all" * 10)
 
 
+def test_block_sizes_outside_the_format_are_refused_at_open(front):
+    # StreamDecoder.cs:226 accepts any two exponents; Vorbis I allows 64 ... 8192, short <= long, and the synthesis library
+    # refuses the rest at vpz_decoder_create -- so does the front end, before a block of one sample reaches its residue decode
+    import synthetic_streams as ss
+    import vorbis_writer as vw
+    for logs in ((0, 8), (5, 11), (9, 8), (8, 14)):
+        stream, _ = ss.mono_floor1_res1()
+        stream.bs_logs = logs
+        with pytest.raises(front.FrontError):
+            front.OggVorbisFile(bytes(vw.ogg_mux(stream.headers(), [0, 0, 0])))
+    stream, _ = ss.mono_floor1_res1()
+    front.OggVorbisFile(bytes(vw.ogg_mux(stream.headers(), [0, 0, 0])))  # (the unchanged headers open)
+
+
 def test_decode_into_shared_batch_buffers_from_threads(front):
     """Several handles decoded from several threads straight into slices of one batch buffer give what
     decode_packets gives for each stream alone (stream ids and residue offsets rebased)."""

@@ -1074,6 +1074,10 @@ struct vpzh_stream {
             size0 = 1 << b0;
             size1 = 1 << b1;
             if (channels < 1) throw InvalidData("no channels");
+            // (StreamDecoder.cs:226 takes any two exponents and fails later, inside its transforms; Vorbis I allows 64 ... 8192 with
+            // the short size not above the long one, the synthesis library refuses anything else at vpz_decoder_create, and a size
+            // of 1 would make every residue vector empty here)
+            if (b0 < 6 || b1 > 13 || b0 > b1) throw InvalidData("block sizes outside Vorbis I's range");
         }
         {   // comments: only the signature is checked (StreamDecoder.cs:242-260)
             BitReader p;
