@@ -142,6 +142,8 @@ namespace NVorbis.Native
         // ABI v5: `residue` of the following synth calls is short* (the same values as 16-bit integers: exact for integral residues --
         // every libvorbis stream --, half the bytes over the host link); ResidueF32 switches back
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_decoder_set_residue_format(DecoderHandle decoder, int format);
+        // output areas of different sizes in one batch: capacity[s] tightens stream_out_capacity for stream s; (null, 0) removes the bounds
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_decoder_set_stream_capacities(DecoderHandle decoder, long* capacity, int n);
 
         /// <summary>Status code to the exception the reference throws for the same condition.</summary>
         public static void ThrowOnError(int status, ContextHandle? ctx, string what)

@@ -220,7 +220,7 @@ int  vpz_decoder_reset(vpz_decoder *dec, int32_t stream);
  *   Both may be NULL (n_records 0) when every packet has VPZ_PKT_NO_FLOOR.
  * pcm_out: stream s writes at pcm_out + stream_out_offset[s] (float index; NULL offsets = all 0),
  *   interleaved [sample][channel] or planar with `channel_stride` floats between channels.
- *   At most stream_out_capacity samples per channel are written per stream.
+ *   At most stream_out_capacity samples per channel are written per stream (vpz_decoder_set_stream_capacities: per stream).
  * samples_written[n_streams]: samples per channel produced by this call (host memory, always).
  *   The count is final when the call returns even in VPZ_MEM_DEVICE mode (it is computed by the
  *   host-side state machine); the PCM itself is ready after vpz_context_synchronize.
@@ -275,6 +275,12 @@ int vpz_decoder_set_position(vpz_decoder *dec, int32_t stream, int64_t sample_po
 #define VPZ_RESIDUE_F32 0
 #define VPZ_RESIDUE_I16 1
 int vpz_decoder_set_residue_format(vpz_decoder *dec, int32_t format);
+
+/* Output areas of different sizes in one batch (files of one encoder setting differ in length): capacity[s] tightens
+ * stream_out_capacity for stream s in the synth calls that follow -- stream s may produce min(stream_out_capacity, capacity[s])
+ * samples per channel, a call that would produce more fails with VPZ_E_CAPACITY before anything is written or any state
+ * changes.  n must be the decoder's stream count; (NULL, 0) removes the per-stream bounds again. */
+int vpz_decoder_set_stream_capacities(vpz_decoder *dec, const int64_t *capacity, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,12 @@ def test_synth_rejects_bad_calls_and_keeps_its_state(ctx):
     assert _status(lambda: call(capacity=100)) == capi.E_CAPACITY
     assert "capacity" in ctx.last_error().lower()
     assert _status(lambda: call(stride=10)) == capi.E_INVALID_ARG                       # planar stride < capacity
+    # per-stream bounds (vpz_decoder_set_stream_capacities) tighten the call's: one value per stream of the decoder
+    assert _status(lambda: dec.set_stream_capacities([cap, cap])) == capi.E_INVALID_ARG
+    assert _status(lambda: dec.set_stream_capacities([-1])) == capi.E_INVALID_ARG
+    dec.set_stream_capacities([5 * 1024 - 1])
+    assert _status(call) == capi.E_CAPACITY
+    dec.set_stream_capacities([5 * 1024])                                               # (what the batch produces: enough)
     bad = pk.copy()
     bad["stream"][2] = 3
     assert _status(lambda: call(packets=bad)) == capi.E_INVALID_ARG                     # stream index
@@ -106,6 +112,7 @@ def test_synth_rejects_bad_calls_and_keeps_its_state(ctx):
     # nothing above touched the stream state: the good call still decodes from the start
     w = call()
     assert int(w[0]) == 5 * 1024 and dec.position(0) == 5 * 1024
+    dec.set_stream_capacities(None)
     ref = Decoder(ctx, 2, 256, 2048)
     want = ref.synth(pk, res)[0]
     assert np.array_equal(out.reshape(2, cap)[:, :5 * 1024], want)

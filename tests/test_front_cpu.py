@@ -99,6 +99,29 @@ def test_block_sizes_outside_the_format_are_refused_at_open(front):
     front.OggVorbisFile(bytes(vw.ogg_mux(stream.headers(), [0, 0, 0])))  # (the unchanged headers open)
 
 
+def test_an_ordered_codebook_that_runs_out_of_bits_is_refused_not_counted_to_the_end_of_int(front):
+    # Codebook.cs:60-66 with a packet that ends inside the length list: every count reads as zero, `len` goes up for ever
+    # (found by the sanitizer campaign as a signed overflow after 2^31 rounds)
+    import time
+    import synthetic_streams as ss
+    import vorbis_writer as vw
+    stream, _ = ss.mono_floor1_res1()
+    ident, comment, _ = stream.headers()
+    w = vw.BitWriter()
+    for c in b"\x05vorbis":
+        w.write(c, 8)
+    w.write(0, 8)            # one codebook
+    w.write(0x564342, 24)
+    w.write(1, 16)           # dimensions
+    w.write(100, 24)         # entries
+    w.write(1, 1)            # ordered
+    w.write(0, 5)            # first length 1 -- and the packet ends here
+    t0 = time.time()
+    with pytest.raises(front.FrontError):
+        front.OggVorbisFile(bytes(vw.ogg_mux([ident, comment, w.bytes()], [0, 0, 0])))
+    assert time.time() - t0 < 1.0
+
+
 def test_decode_into_shared_batch_buffers_from_threads(front):
     """Several handles decoded from several threads straight into slices of one batch buffer give what
     decode_packets gives for each stream alone (stream ids and residue offsets rebased)."""

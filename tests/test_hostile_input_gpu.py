@@ -1,0 +1,112 @@
+"""Containers whose AUDIO pages were damaged after encoding (checksums made valid again, so that the damage reaches the
+bit-level decode): they open, their packets decode to whatever the bits say -- floor posts and residue values no encoder
+writes -- and the device path must take that like any other input: no fault, every stream's outcome its own, and the same
+PCM bit for bit whichever way the job is partitioned and through the plain ABI one file at a time.  (What the reference
+does with such packets is its own table-index exceptions, Floor1.cs:407-473: there is nothing to compare values with --
+the properties are determinism and isolation.)"""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _pages(raw):
+    """(start, header length, body length, packets completed) of every page"""
+    out, pos = [], 0
+    while pos + 27 <= len(raw) and raw[pos:pos + 4] == b"OggS":
+        nseg = raw[pos + 26]
+        lac = raw[pos + 27: pos + 27 + nseg]
+        out.append((pos, 27 + nseg, sum(lac), sum(1 for v in lac if v < 255)))
+        pos += 27 + nseg + sum(lac)
+    return out
+
+
+def damage_audio(raw, seed, hits):
+    import vorbis_writer as vw
+    rng = np.random.default_rng(seed)
+    pages, done, first_audio = _pages(raw), 0, None
+    for i, (_, _, _, completed) in enumerate(pages):
+        if done >= 3:
+            first_audio = i
+            break
+        done += completed
+    assert first_audio is not None
+    data = bytearray(raw)
+    touched = set()
+    for _ in range(hits):
+        i = int(rng.integers(first_audio, len(pages)))
+        start, hdr, body, _ = pages[i]
+        if body == 0:
+            continue
+        at = start + hdr + int(rng.integers(0, body))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            data[at] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            data[at] = int(rng.integers(0, 256))
+        else:
+            n = min(int(rng.integers(1, 24)), start + hdr + body - at)
+            data[at:at + n] = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        touched.add(i)
+    for i in touched:
+        start, hdr, body, _ = pages[i]
+        page = bytes(data[start:start + 22]) + b"\0\0\0\0" + bytes(data[start + 26:start + hdr + body])
+        data[start + 22:start + 26] = struct.pack("<I", vw._crc(page))
+    return bytes(data)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vorbispizza_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def hostile_library():
+    import synthetic_streams as ss
+    raws = []
+    for name in ("1test.ogg", "2test.ogg", "3test.ogg"):
+        clean = open(os.path.join(GOLDEN, name), "rb").read()
+        raws.append(clean)
+        for seed, hits in ((1, 1), (2, 4), (3, 16), (4, 64)):
+            raws.append(damage_audio(clean, seed, hits))
+    for name in ("stereo_floor0", "six_channels_51", "three_channels_two_submaps", "mono_floor1_res1", "ten_channels"):
+        stream, rng = ss.ALL[name]()
+        ogg, _ = stream.build(rng, 40)
+        raws.append(bytes(ogg))
+        for seed, hits in ((5, 2), (6, 12)):
+            raws.append(damage_audio(bytes(ogg), seed, hits))
+    return raws
+
+
+def test_damaged_audio_pages_decode_the_same_way_however_the_job_is_cut(ctx):
+    from test_multi_gpu import run_dispatcher, single_stream_pcm
+    raws = hostile_library()
+    runs = [run_dispatcher([0], raws, host_threads=3, streams_per_call=5),
+            run_dispatcher([0, 0, 0], raws, host_threads=6, streams_per_call=2),
+            run_dispatcher([0, 0], raws, host_threads=4, streams_per_call=16, float_residue=1)]
+    pcm0, offs, res0, _, infos = runs[0]
+    assert (res0["status"] == 0).all()  # (they all opened: the damage is in the audio pages; bad packets are skipped ones)
+    assert int(res0["samples"].sum()) > 0
+    for pcm, _, res, _, _ in runs[1:]:
+        for field in ("status", "samples", "packets", "skipped_packets", "channels"):
+            assert np.array_equal(res[field], res0[field]), field
+        assert np.array_equal(pcm.view(np.uint32), pcm0.view(np.uint32))
+    # ... and the plain ABI, one file at a time, gives those very samples
+    for k, r in enumerate(raws):
+        ref = single_stream_pcm(ctx, r)
+        C_ = infos[r][0]
+        assert res0["samples"][k] == ref.shape[0], k
+        got = pcm0[offs[k]: offs[k] + ref.shape[0] * C_].reshape(-1, C_)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), k
+    # the context is as good as before: an undamaged file decodes to what it always did
+    clean = open(os.path.join(GOLDEN, "3test.ogg"), "rb").read()
+    again = run_dispatcher([0], [clean], host_threads=1)
+    ref = single_stream_pcm(ctx, clean)
+    assert np.array_equal(again[0][: ref.size].view(np.uint32), ref.reshape(-1).view(np.uint32))

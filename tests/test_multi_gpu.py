@@ -159,6 +159,54 @@ def test_a_dispatcher_is_reusable_and_says_what_it_is(ctx):
         multi.Dispatcher([99])  # no such device
 
 
+def _same_setup_streams(lengths, name="stereo_coupled_res2"):
+    import synthetic_streams as ss
+    raws = []
+    for n in lengths:
+        stream, rng = ss.ALL[name]()
+        ogg, _ = stream.build(rng, n)
+        raws.append(bytes(ogg))
+    return raws
+
+
+def test_files_of_one_setup_and_different_lengths_share_a_call(ctx):
+    """one encoder setting = one setup header, whatever the song's length: every stream of the call has its own area
+    (vpz_decoder_set_stream_capacities), none is held to the smallest one"""
+    raws = _same_setup_streams((20, 50, 35, 50, 8, 41))
+    for s16 in (False, True):
+        pcm, offs, results, stats, infos = run_dispatcher([0], raws, s16=s16, capacity_slack=0, host_threads=2, streams_per_call=8)
+        assert (results["status"] == 0).all(), results["status"]
+        assert len({infos[r][1] for r in raws}) == 5
+        for k, r in enumerate(raws):
+            ref = single_stream_pcm(ctx, r, s16=s16)
+            assert results["samples"][k] == ref.shape[0] == infos[r][1]
+            got = pcm[offs[k]: offs[k] + ref.shape[0] * 2].reshape(-1, 2)
+            assert np.array_equal(got.view(np.uint16 if s16 else np.uint32), ref.view(np.uint16 if s16 else np.uint32)), k
+        # (no area was written past its end: the next stream's first sample is where it belongs, the last area ends the array)
+        assert offs[-1] + results["samples"][-1] * 2 == pcm.size
+
+
+def test_after_a_failed_call_every_member_gets_a_call_of_its_own(ctx, monkeypatch):
+    """"a stream that fails costs only itself" also when it is the synth call of its sub-batch that fails: the members are
+    then synthesised one by one.  Nothing a front end hands over makes a call fail today (areas are checked when the
+    container is opened), so the test has the dispatcher count every sub-batch's call as failed (VPZM_FAIL_BATCH_CALLS):
+    the member-by-member path must give the very PCM, sample counts and skipped-packet counts of the batched one."""
+    import synthetic_streams as ss
+    raws = _same_setup_streams((20, 50, 35)) + library(("issue6test.ogg", "3test.ogg", "issue6test.ogg"), 3)
+    for name in ("stereo_floor0", "six_channels_51", "stereo_floor0"):
+        stream, rng = ss.ALL[name]()
+        ogg, _ = stream.build(rng, 25)
+        raws.append(bytes(ogg))
+    want = run_dispatcher([0, 0], raws, capacity_slack=0, host_threads=3, streams_per_call=4)
+    monkeypatch.setenv("VPZM_FAIL_BATCH_CALLS", "1")
+    got = run_dispatcher([0, 0], raws, capacity_slack=0, host_threads=3, streams_per_call=4)
+    monkeypatch.delenv("VPZM_FAIL_BATCH_CALLS")
+    assert (want[2]["status"] == 0).all() and int(want[2]["skipped_packets"].sum()) == 2
+    for field in ("status", "samples", "packets", "skipped_packets", "channels"):
+        assert np.array_equal(got[2][field], want[2][field]), field
+    assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+
+
 def test_callers_on_several_threads_take_a_dispatcher_in_turn(ctx):
     # ctypes drops the GIL for the call: without the dispatcher's own lock two callers would share slots and contexts
     import threading

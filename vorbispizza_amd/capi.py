@@ -89,6 +89,7 @@ _SIGNATURES = [
     ("vpz_decoder_position", C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64)]),
     ("vpz_decoder_set_position", C.c_int, [_vp, C.c_int32, C.c_int64]),
     ("vpz_decoder_set_residue_format", C.c_int, [_vp, C.c_int32]),
+    ("vpz_decoder_set_stream_capacities", C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int32]),
 ]
 # include/vorbispizza_synth_debug.h (test-only entry points, not part of the surface a C# host binds)
 _DEBUG_SIGNATURES = [
@@ -412,6 +413,14 @@ class Decoder:
         """RESIDUE_F32 (default) or RESIDUE_I16: the element type of `residue` in the synth calls that follow (ABI v5)"""
         self.ctx._check(lib().vpz_decoder_set_residue_format(self._h, int(fmt)))
         self.residue_format = int(fmt)
+
+    def set_stream_capacities(self, capacities):
+        """per-stream output bounds for the synth calls that follow (each tightens the call's stream_out_capacity); None removes them"""
+        if capacities is None:
+            self.ctx._check(lib().vpz_decoder_set_stream_capacities(self._h, None, 0))
+            return
+        caps = np.ascontiguousarray(capacities, dtype=np.int64)
+        self.ctx._check(lib().vpz_decoder_set_stream_capacities(self._h, caps.ctypes.data_as(C.POINTER(C.c_int64)), int(caps.size)))
 
     def set_position(self, position, stream=0):
         self.ctx._check(lib().vpz_decoder_set_position(self._h, stream, int(position)))

@@ -138,6 +138,7 @@ struct Decoder {
     std::vector<int64_t> s_base, s_cnt, out_count, anchor_pkt;  // per-stream scratch of a synth call
     int channels = 0, size0 = 0, size1 = 0, clip = 0;
     int n_streams = 0;
+    std::vector<int64_t> stream_caps;  // vpz_decoder_set_stream_capacities: empty, or one bound per stream
     std::vector<vpz_floor1_config> floors;
     std::vector<vpz_mapping_config> mappings;
     std::vector<StreamState> states;
@@ -640,6 +641,10 @@ struct SynthCall {
     void *pcm_out;
     const int64_t *stream_out_offset;
     const int64_t stream_out_capacity;
+    int64_t capacity_of(int s) const  // (vpz_decoder_set_stream_capacities tightens the call's bound per stream)
+    {
+        return D.stream_caps.empty() ? stream_out_capacity : std::min(stream_out_capacity, D.stream_caps[(size_t)s]);
+    }
     const int out_layout;
     const int64_t channel_stride;
     // ---- derived
@@ -1103,7 +1108,7 @@ struct SynthCall {
             S.current_position = pos_base + out_count[s];
         }
         for (int s = 0; s < D.n_streams; ++s)
-            if (out_count[s] > stream_out_capacity)
+            if (out_count[s] > capacity_of(s))
                 return set_error(ctx, VPZ_E_CAPACITY, "vpz_decoder_synth: stream_out_capacity too small");
         n_frames = (size_t)n_packets;
         for (int s = 0; s < D.n_streams; ++s) samples_written[s] = out_count[s];
@@ -1246,7 +1251,7 @@ struct SynthCall {
             frames[s_base[pk.stream] + s_cnt[pk.stream]++] = fd;
         }
         for (int s = 0; s < D.n_streams; ++s)
-            if (out_count[s] > stream_out_capacity)
+            if (out_count[s] > capacity_of(s))
                 return set_error(ctx, VPZ_E_CAPACITY, "vpz_decoder_synth: stream_out_capacity too small");
         // close the gaps skipped packets left between the streams' frame ranges
         for (int s = 0; s < D.n_streams; ++s) {
@@ -2250,6 +2255,26 @@ int vpz_decoder_set_residue_format(vpz_decoder *d, int32_t format)
     if (format != VPZ_RESIDUE_F32 && format != VPZ_RESIDUE_I16)
         return set_error(D.ctx, VPZ_E_INVALID_ARG, "vpz_decoder_set_residue_format: neither VPZ_RESIDUE_F32 nor VPZ_RESIDUE_I16");
     D.residue_format = format;
+    return VPZ_OK;
+}
+
+int vpz_decoder_set_stream_capacities(vpz_decoder *d, const int64_t *capacity, int32_t n)
+{
+    if (!d) return VPZ_E_INVALID_ARG;
+    Decoder &D = d->impl;
+    if (!capacity && n == 0) {
+        D.stream_caps.clear();
+        return VPZ_OK;
+    }
+    if (!capacity || n != D.n_streams)
+        return set_error(D.ctx, VPZ_E_INVALID_ARG, "vpz_decoder_set_stream_capacities: one capacity per stream of the decoder, or (NULL, 0)");
+    for (int32_t s = 0; s < n; ++s)
+        if (capacity[s] < 0) return set_error(D.ctx, VPZ_E_INVALID_ARG, "vpz_decoder_set_stream_capacities: negative capacity");
+    try {
+        D.stream_caps.assign(capacity, capacity + n);
+    } catch (const std::bad_alloc &) {
+        return set_error(D.ctx, VPZ_E_NOMEM, "vpz_decoder_set_stream_capacities: out of host memory");
+    }
     return VPZ_OK;
 }
 

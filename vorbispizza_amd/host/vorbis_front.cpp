@@ -149,8 +149,10 @@ struct Codebook {
             int len = (int)p.read_bits(5) + 1;
             for (int i = 0; i < entries;) {
                 int cnt = (int)p.read_bits(ilog(entries - i));
-                // codeword lengths above 32 index past the reference's `available` table (an exception there)
-                if (cnt > 0 && len > 32) throw InvalidData("codeword length above 32");
+                // codeword lengths above 32 index past the reference's `available` table (an exception there); with entries left
+                // and nothing but empty lengths to come -- a header that ran out of bits reads zeros -- Codebook.cs:60-66 counts `len`
+                // up until it wraps: no stream gets out of that loop with a usable book
+                if (len > 32) throw InvalidData("codeword length above 32");
                 while (--cnt >= 0) {
                     if (i >= entries) throw InvalidData("ordered codebook overruns its entry count");
                     lengths[i++] = len;

@@ -444,13 +444,13 @@ struct GroupRun {
     void synth_sub(Lane &L, size_t b, Sub &sb)
     {
         const int S = m->opt.streams_per_call;
-        std::vector<int64_t> offs((size_t)S), written((size_t)S);
+        std::vector<int64_t> offs((size_t)S), written((size_t)S), caps((size_t)S, 0);
         std::vector<int32_t> status;
         Slot &sl = G.slots[b % G.slots.size()];
         const Setup &st = *sb.st;
         const int C = st.info.channels;
         bool any = false, all_ok = true;
-        int64_t cap = INT64_MAX, base = INT64_MAX;
+        int64_t cap = 0, base = INT64_MAX;
         // (the call sees the sub-batch's part of the caller's PCM array: a host-memory call mirrors its output extent on the
         // device, so the offsets handed over start at the sub-batch's lowest one)
         for (size_t j = 0; j < sb.members.size(); ++j) base = std::min(base, pcm_offset[jobs[(size_t)sb.members[j]].k]);
@@ -459,7 +459,9 @@ struct GroupRun {
             offs[j] = pcm_offset[J.k] - base;
             if (J.status == VPZM_OK) {
                 any = true;
-                cap = std::min(cap, pcm_capacity[J.k]);
+                // (every stream has its own area: files of one encoder setting share a setup header and differ in length)
+                caps[j] = pcm_capacity[J.k];
+                cap = std::max(cap, caps[j]);
             } else {
                 all_ok = false;
             }
@@ -490,31 +492,60 @@ struct GroupRun {
             n_pk = w;
         }
         int rc = VPZ_OK;
+        std::vector<int> member_rc(sb.members.size(), VPZ_OK);  // (a sub-batch is one synth call; after a failed one, a call per member)
         const auto t0 = Clock::now();
         static const bool no_synth = getenv("VPZM_NO_SYNTH") != nullptr;  // (diagnosis: the decode side of the pipeline alone)
         if (any && n_pk > 0 && !no_synth) {
             vpz_decoder *dec = decoder_for(L, sb.st);
-            if (!dec) rc = VPZ_E_NOMEM;
-            // the decoder is re-used for new streams: back to what a StreamDecoder is after ProcessHeaderPackets
-            // (`_currentPosition = 0; _hasPosition = true`, StreamDecoder.cs:165-168) -- a bare reset would leave the position to be
-            // picked up from the first granule the way a seek does (:459-463), which moves the EOS trim (:658-666)
-            if (rc == VPZ_OK) rc = vpz_decoder_reset(dec, -1);
-            for (int sidx = 0; sidx < S && rc == VPZ_OK; ++sidx) rc = vpz_decoder_set_position(dec, sidx, 0);
-            if (rc == VPZ_OK && st.f0_stride > 0) rc = vpz_decoder_set_floor0_data(dec, sl.f0_amp, sl.f0_coeff, st.f0_stride);
-            if (rc == VPZ_OK) rc = vpz_decoder_set_residue_format(dec, use_i16(st) ? VPZ_RESIDUE_I16 : VPZ_RESIDUE_F32);
-            if (rc == VPZ_OK)
-                rc = vpz_decoder_synth(dec, n_pk, sl.packets, sl.residue, sb.res_floats, sl.posts, sl.counts, n_pk * C, VPZ_MEM_HOST, out_at,
-                                       offs.data(), cap, out_layout, 0, written.data());
-            if (rc != VPZ_OK) m->fail(std::string("vpz_decoder_synth: ") + vpz_context_last_error(L.ctx));
-            int64_t not_ok = 0;
-            if (rc == VPZ_OK && vpz_decoder_last_packet_status(dec, nullptr, 0, &not_ok) == VPZ_OK && not_ok > 0) {
-                status.assign((size_t)n_pk, 0);
-                vpz_decoder_last_packet_status(dec, status.data(), n_pk, nullptr);
-                for (int64_t p = 0; p < n_pk; ++p)
-                    if (status[(size_t)p] != VPZ_OK) {
-                        const int32_t sid = sl.packets[p].stream;
-                        if (sid >= 0 && (size_t)sid < sb.members.size()) results[jobs[(size_t)sb.members[(size_t)sid]].k].skipped_packets += 1;
+            std::vector<int64_t> wr((size_t)S);
+            // one synth call over the slot's packets [p0, p0 + n): the records, the Floor0 data and the statuses move with p0, the
+            // residue offsets are the slot's
+            auto call = [&](int64_t p0, int64_t n) -> int {
+                int r = dec ? VPZ_OK : VPZ_E_NOMEM;
+                // the decoder is re-used for new streams: back to what a StreamDecoder is after ProcessHeaderPackets
+                // (`_currentPosition = 0; _hasPosition = true`, StreamDecoder.cs:165-168) -- a bare reset would leave the position to be
+                // picked up from the first granule the way a seek does (:459-463), which moves the EOS trim (:658-666)
+                if (r == VPZ_OK) r = vpz_decoder_reset(dec, -1);
+                for (int sidx = 0; sidx < S && r == VPZ_OK; ++sidx) r = vpz_decoder_set_position(dec, sidx, 0);
+                if (r == VPZ_OK && st.f0_stride > 0)
+                    r = vpz_decoder_set_floor0_data(dec, sl.f0_amp + (size_t)p0 * C, sl.f0_coeff + (size_t)p0 * C * st.f0_stride, st.f0_stride);
+                if (r == VPZ_OK) r = vpz_decoder_set_residue_format(dec, use_i16(st) ? VPZ_RESIDUE_I16 : VPZ_RESIDUE_F32);
+                if (r == VPZ_OK) r = vpz_decoder_set_stream_capacities(dec, caps.data(), S);
+                if (r == VPZ_OK)
+                    r = vpz_decoder_synth(dec, n, sl.packets + p0, sl.residue, sb.res_floats, sl.posts + (size_t)p0 * 64 * C,
+                                          sl.counts + (size_t)p0 * C, n * C, VPZ_MEM_HOST, out_at, offs.data(), cap, out_layout, 0, wr.data());
+                if (r != VPZ_OK) m->fail(std::string("vpz_decoder_synth: ") + (dec ? vpz_context_last_error(L.ctx) : "no decoder"));
+                int64_t not_ok = 0;
+                if (r == VPZ_OK && vpz_decoder_last_packet_status(dec, nullptr, 0, &not_ok) == VPZ_OK && not_ok > 0) {
+                    status.assign((size_t)n, 0);
+                    vpz_decoder_last_packet_status(dec, status.data(), n, nullptr);
+                    for (int64_t p = 0; p < n; ++p)
+                        if (status[(size_t)p] != VPZ_OK) {
+                            const int32_t sid = sl.packets[p0 + p].stream;
+                            if (sid >= 0 && (size_t)sid < sb.members.size()) results[jobs[(size_t)sb.members[(size_t)sid]].k].skipped_packets += 1;
+                        }
+                }
+                return r;
+            };
+            // (VPZM_FAIL_BATCH_CALLS=1, tests: every sub-batch's call counts as failed, so that the member-by-member path runs)
+            const char *fb = getenv("VPZM_FAIL_BATCH_CALLS");
+            const bool fail_batch = fb && atoi(fb) != 0;
+            rc = fail_batch ? VPZ_E_CAPACITY : call(0, n_pk);
+            if (rc == VPZ_OK) {
+                written = wr;
+            } else {
+                // "a stream that fails costs only itself": whatever one member's packets did to the call, the others get a call
+                // of their own (the packets lie member by member)
+                for (int64_t p = 0; p < n_pk;) {
+                    const int32_t sid = sl.packets[p].stream;
+                    int64_t q = p;
+                    while (q < n_pk && sl.packets[q].stream == sid) ++q;
+                    if (sid >= 0 && (size_t)sid < sb.members.size()) {
+                        member_rc[(size_t)sid] = q - p == n_pk && !fail_batch ? rc : call(p, q - p);
+                        if (member_rc[(size_t)sid] == VPZ_OK) written[(size_t)sid] = wr[(size_t)sid];
                     }
+                    p = q;
+                }
             }
         }
         const double dt = seconds_since(t0);
@@ -526,7 +557,7 @@ struct GroupRun {
         for (size_t j = 0; j < sb.members.size(); ++j) {
             Job &J = jobs[(size_t)sb.members[j]];
             if (J.status != VPZM_OK) continue;
-            if (rc != VPZ_OK) { J.status = VPZM_E_SYNTH; continue; }
+            if (member_rc[j] != VPZ_OK) { J.status = member_rc[j] == VPZ_E_CAPACITY ? VPZM_E_CAPACITY : VPZM_E_SYNTH; continue; }
             results[J.k].samples = written[j];
             samples_total += written[j] * C;
         }
