@@ -70,18 +70,21 @@ def ctx():
 
 def hostile_library():
     import synthetic_streams as ss
+    rounds = int(os.environ.get("VPZ_HOSTILE_ROUNDS", "1"))  # (a longer campaign by hand: more seeds of the same recipe)
     raws = []
     for name in ("1test.ogg", "2test.ogg", "3test.ogg"):
         clean = open(os.path.join(GOLDEN, name), "rb").read()
         raws.append(clean)
-        for seed, hits in ((1, 1), (2, 4), (3, 16), (4, 64)):
-            raws.append(damage_audio(clean, seed, hits))
+        for r in range(rounds):
+            for seed, hits in ((1, 1), (2, 4), (3, 16), (4, 64)):
+                raws.append(damage_audio(clean, seed + 100 * r, hits * (1 + r % 4)))
     for name in ("stereo_floor0", "six_channels_51", "three_channels_two_submaps", "mono_floor1_res1", "ten_channels"):
         stream, rng = ss.ALL[name]()
         ogg, _ = stream.build(rng, 40)
         raws.append(bytes(ogg))
-        for seed, hits in ((5, 2), (6, 12)):
-            raws.append(damage_audio(bytes(ogg), seed, hits))
+        for r in range(rounds):
+            for seed, hits in ((5, 2), (6, 12)):
+                raws.append(damage_audio(bytes(ogg), seed + 100 * r, hits * (1 + r % 4)))
     return raws
 
 
@@ -94,6 +97,7 @@ def test_damaged_audio_pages_decode_the_same_way_however_the_job_is_cut(ctx):
     pcm0, offs, res0, _, infos = runs[0]
     assert (res0["status"] == 0).all()  # (they all opened: the damage is in the audio pages; bad packets are skipped ones)
     assert int(res0["samples"].sum()) > 0
+    print("%d containers, %d samples, %d skipped packets" % (len(raws), int(res0["samples"].sum()), int(res0["skipped_packets"].sum())))
     for pcm, _, res, _, _ in runs[1:]:
         for field in ("status", "samples", "packets", "skipped_packets", "channels"):
             assert np.array_equal(res[field], res0[field]), field
