@@ -62,6 +62,8 @@ int main(int argc,char**argv){
         d[pos] = (kind==2)? (uint8_t)rng() : (uint8_t)(d[pos]^(1u<<(rng()%8)));
       }
       if(rng()%4) fix_crcs(d);
+      if(getenv("FUZZ_VERBOSE")){ fprintf(stderr,"%s #%d\n",argv[f],it); fflush(stderr); }  // (which case a run hangs in)
+      if(const char*dump=getenv("FUZZ_DUMP_CASE")){ int wf=0,wi=0; if(sscanf(dump,"%d:%d",&wf,&wi)==2 && wf==f && wi==it){ FILE*o=fopen("fuzz_case.ogg","wb"); if(o){ fwrite(d.data(),1,d.size(),o); fclose(o);} } }
       int r=run(d); if(r==0)++ok; else if(r==1)++err_open; else ++err_dec;
     }
   }
