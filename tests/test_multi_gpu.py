@@ -186,6 +186,25 @@ def test_files_of_one_setup_and_different_lengths_share_a_call(ctx):
         assert offs[-1] + results["samples"][-1] * 2 == pcm.size
 
 
+def test_streams_of_every_length_from_one_packet_up(ctx):
+    """one packet (no sample yet: the first block only primes the overlap), two, three ... in sub-batches that mix them"""
+    lengths = list(range(1, 26)) + [40, 1, 2, 33, 1]
+    raws = _same_setup_streams(lengths) + _same_setup_streams(lengths[::3], name="mono_floor1_res1")
+    order = np.random.default_rng(11).permutation(len(raws))
+    raws = [raws[i] for i in order]
+    pcm, offs, results, stats, infos = run_dispatcher([0, 0, 0], raws, capacity_slack=0, host_threads=5, streams_per_call=7)
+    assert (results["status"] == 0).all(), results["status"]
+    refs = {}
+    for k, r in enumerate(raws):
+        if r not in refs:
+            refs[r] = single_stream_pcm(ctx, r)
+        ref, C_ = refs[r], infos[r][0]
+        assert results["samples"][k] == ref.shape[0] == infos[r][1], (k, results["samples"][k], ref.shape[0], infos[r][1])
+        got = pcm[offs[k]: offs[k] + ref.shape[0] * C_].reshape(-1, C_)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), k
+    assert min(infos[r][1] for r in raws) == 0
+
+
 def test_after_a_failed_call_every_member_gets_a_call_of_its_own(ctx, monkeypatch):
     """"a stream that fails costs only itself" also when it is the synth call of its sub-batch that fails: the members are
     then synthesised one by one.  Nothing a front end hands over makes a call fail today (areas are checked when the
