@@ -114,3 +114,41 @@ def test_damaged_audio_pages_decode_the_same_way_however_the_job_is_cut(ctx):
     again = run_dispatcher([0], [clean], host_threads=1)
     ref = single_stream_pcm(ctx, clean)
     assert np.array_equal(again[0][: ref.size].view(np.uint32), ref.reshape(-1).view(np.uint32))
+
+
+def _read_all(reader_cls, ctx, raw, batch, buf_samples, synth_error):
+    """the ReadSamples loop of a host that goes on after a throwing Read (tests/test_reader_gpu.py)"""
+    rd = reader_cls(ctx, raw, clip_samples=False, batch_packets=batch)
+    C_ = rd.Channels
+    buf = np.zeros(buf_samples * C_, dtype=np.float32)
+    chunks, thrown = [], 0
+    while True:
+        try:
+            n = rd.ReadSamples(buf)
+        except synth_error:
+            thrown += 1
+            assert thrown < 100000
+            continue
+        if n == 0:
+            break
+        chunks.append(buf[:n * C_].copy())
+    rd.Dispose()
+    got = np.concatenate(chunks).reshape(-1, C_) if chunks else np.zeros((0, C_), dtype=np.float32)
+    return got, thrown
+
+
+def test_the_reader_gives_damaged_streams_the_samples_of_the_batch_decode(ctx):
+    """VorbisReader.ReadSamples over the same damaged containers, in packet batches and buffers of odd sizes: a Read whose
+    packet fails the window check throws (StreamDecoder.cs:777-778) and the stream goes on -- the samples delivered are those
+    of the one-call decode, whatever the batching"""
+    from test_multi_gpu import single_stream_pcm
+    from vorbispizza_amd import capi
+    from vorbispizza_amd.front import VorbisReader
+    raws = [r for i, r in enumerate(hostile_library()) if i % 3 != 0][:14 * int(os.environ.get("VPZ_HOSTILE_ROUNDS", "1"))]
+    for k, raw in enumerate(raws):
+        ref = single_stream_pcm(ctx, raw)
+        outs = [_read_all(VorbisReader, ctx, raw, batch, buf, capi.SynthError) for batch, buf in ((7, 1000), (64, 4096), (1, 333))]
+        for got, thrown in outs:
+            assert got.shape == ref.shape, (k, got.shape, ref.shape)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), k
+        assert len({t for _, t in outs}) == 1, (k, [t for _, t in outs])
