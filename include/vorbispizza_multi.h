@@ -41,7 +41,7 @@ typedef struct vpzm_dispatcher vpzm_dispatcher;
 
 typedef struct vpzm_options {
     int32_t host_threads;         /* entropy-decode threads over ALL devices (0: vpzh_default_threads() plus one per context -- the issuing threads mostly wait); each device gets its share */
-    int32_t streams_per_call;     /* streams per vpz_decoder_synth call (0: 16) */
+    int32_t streams_per_call;     /* streams per vpz_decoder_synth call (0: 16); a call also closes at 64 Mi residue values, so whole songs ride in fewer per call */
     int32_t contexts_per_device;  /* contexts -- HIP streams, issuing threads -- that take a device's calls in turn (0: 4 when the device has 8 or more host threads, else 2) */
     int32_t clip_samples;         /* StreamDecoder.ClipSamples (VorbisReader sets it to true, VorbisReader.cs:71) */
     int32_t slots_per_device;     /* sub-batches in flight per device: decoded or being decoded ahead of their synth call (0: 4 * contexts + 4; about 70 MB of page-locked memory each for stereo streams of a few seconds -- with fewer the entropy decode waits for synth calls) */

@@ -186,6 +186,20 @@ def test_files_of_one_setup_and_different_lengths_share_a_call(ctx):
         assert offs[-1] + results["samples"][-1] * 2 == pcm.size
 
 
+def test_a_call_is_also_cut_by_the_residue_it_holds(ctx, monkeypatch):
+    """sub-batches close at streams_per_call streams OR at a residue budget (64 Mi values; here a few thousand, so that
+    long streams ride alone and short ones in twos and threes): the PCM does not know"""
+    raws = _same_setup_streams((20, 50, 3, 35, 50, 8, 41, 2, 2, 2)) + library(("3test.ogg", "1test.ogg"), 5)
+    want = run_dispatcher([0, 0], raws, capacity_slack=0, host_threads=3, streams_per_call=6)
+    monkeypatch.setenv("VPZM_MAX_CALL_VALUES", "30000")
+    got = run_dispatcher([0, 0], raws, capacity_slack=0, host_threads=3, streams_per_call=6)
+    monkeypatch.delenv("VPZM_MAX_CALL_VALUES")
+    assert (want[2]["status"] == 0).all()
+    for field in ("status", "samples", "packets", "skipped_packets", "channels"):
+        assert np.array_equal(got[2][field], want[2][field]), field
+    assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+
+
 def test_streams_of_every_length_from_one_packet_up(ctx):
     """one packet (no sample yet: the first block only primes the overlap), two, three ... in sub-batches that mix them"""
     lengths = list(range(1, 26)) + [40, 1, 2, 33, 1]

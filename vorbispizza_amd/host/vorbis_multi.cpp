@@ -135,6 +135,8 @@ struct vpzm_dispatcher {
 
 namespace {
 
+constexpr int64_t kCallValues = (int64_t)64 << 20;  // residue values of one synth call (256 MiB as float32), see plan_wave
+
 struct Job {  // one stream of the library inside its group
     int32_t k = 0;  // index in the caller's arrays
     vpzh_stream *h = nullptr;
@@ -261,22 +263,32 @@ struct GroupRun {
             by_setup[(size_t)at].push_back((int)i);
         }
         std::vector<Sub> fresh;
+        // a synth call holds up to streams_per_call streams of one setup and up to kCallValues residue values (a library of whole
+        // songs would otherwise ask for page-locked slots of gigabytes each): a long stream rides with fewer others, or alone
+        int64_t budget = kCallValues;
+        if (const char *e = getenv("VPZM_MAX_CALL_VALUES"))  // (tests: small calls)
+            if (atoll(e) > 0) budget = atoll(e);
         for (size_t q = 0; q < by_setup.size(); ++q) {
             const std::vector<int> &v = by_setup[q];
-            for (size_t s0 = 0; s0 < v.size(); s0 += (size_t)S) {
-                Sub sb;
-                sb.setup = (int)q;
-                sb.st = setups[q];
-                for (size_t j = s0; j < std::min(v.size(), s0 + (size_t)S); ++j) {
-                    const Job &J = jobs[(size_t)v[j]];
-                    sb.members.push_back(v[j]);
-                    sb.pbase.push_back(sb.n_packets);
-                    sb.rbase.push_back(sb.res_floats);
-                    sb.n_packets += J.packets;
-                    sb.res_floats += J.residue_floats;
+            Sub sb;
+            auto flush = [&] {
+                if (!sb.members.empty()) fresh.push_back(std::move(sb));
+                sb = Sub();
+            };
+            for (size_t j = 0; j < v.size(); ++j) {
+                const Job &J = jobs[(size_t)v[j]];
+                if (!sb.members.empty() && ((int)sb.members.size() >= S || sb.res_floats + J.residue_floats > budget)) flush();
+                if (sb.members.empty()) {
+                    sb.setup = (int)q;
+                    sb.st = setups[q];
                 }
-                fresh.push_back(std::move(sb));
+                sb.members.push_back(v[j]);
+                sb.pbase.push_back(sb.n_packets);
+                sb.rbase.push_back(sb.res_floats);
+                sb.n_packets += J.packets;
+                sb.res_floats += J.residue_floats;
             }
+            flush();
         }
         std::sort(fresh.begin(), fresh.end(), [](const Sub &x, const Sub &y) { return x.members[0] < y.members[0]; });
         for (Sub &sb : fresh) {
