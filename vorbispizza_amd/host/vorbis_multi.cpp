@@ -310,7 +310,9 @@ struct GroupRun {
         const Setup &st = *sb.st;
         const size_t C = (size_t)st.info.channels, rec = (size_t)sb.n_packets * C;
         vpz_context *ctx = G.lanes[0].ctx;
-        bool ok = grow(ctx, sl.packets, sl.cap_packets, (size_t)sb.n_packets) && grow(ctx, sl.residue, sl.cap_residue, (size_t)sb.res_floats) &&
+        // (the slot's residue array is float-typed: int16 values take half the elements)
+        const size_t res_elems = use_i16(st) ? ((size_t)sb.res_floats + 1) / 2 : (size_t)sb.res_floats;
+        bool ok = grow(ctx, sl.packets, sl.cap_packets, (size_t)sb.n_packets) && grow(ctx, sl.residue, sl.cap_residue, res_elems) &&
                   grow(ctx, sl.posts, sl.cap_posts, rec * 64) && grow(ctx, sl.counts, sl.cap_counts, rec);
         if (ok && st.f0_stride > 0)
             ok = grow(ctx, sl.f0_amp, sl.cap_f0, rec) && grow(ctx, sl.f0_coeff, sl.cap_f0c, rec * (size_t)st.f0_stride);
