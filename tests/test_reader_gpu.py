@@ -418,3 +418,38 @@ def test_chained_file_is_read_stream_by_stream(ctx, oracle):
     with pytest.raises(SynthError):
         rdr.SwitchStreams(7)
     rdr.Dispose()
+
+
+@pytest.mark.parametrize("name", ["stereo_floor0", "six_channels_51", "three_channels_two_submaps", "ten_channels",
+                                  "mono_floor1_res1", "five_channels", "four_channels_quad"])
+def test_seek_in_streams_of_other_shapes(ctx, name):
+    """the same property on the spec-based writer's streams: type-0 floors, 5.1, two submaps, ten channels (the
+    separate coupling pass), odd channel counts -- every route the reader can end up on seeks like the stereo fast path"""
+    import synthetic_streams as ss
+    from vorbispizza_amd.front import VorbisReader
+    stream, rng = ss.ALL[name]()
+    ogg, _ = stream.build(rng, 60)
+    r = VorbisReader(ctx, bytes(ogg), batch_packets=9)
+    C_ = r.Channels
+    buf = np.zeros(C_ * 4096, dtype=np.float32)
+    chunks = []
+    while True:
+        n = r.ReadSamples(buf)
+        if n == 0:
+            break
+        chunks.append(buf[: n * C_].reshape(n, C_).copy())
+    full = np.concatenate(chunks)
+    total = r.TotalSamples
+    assert total == full.shape[0] and total > 2000
+    rs = np.random.default_rng(9)
+    for g in [0, 1, total // 2, total - 700] + [int(v) for v in rs.integers(0, total - 700, 10)]:
+        r.SeekTo(g)
+        assert r.SamplePosition == g
+        got = []
+        while sum(len(c) for c in got) < 600:
+            n = r.ReadSamples(buf)
+            assert n > 0
+            got.append(buf[: n * C_].reshape(n, C_).copy())
+        got = np.concatenate(got)
+        assert np.array_equal(got.view(np.uint32), full[g: g + len(got)].view(np.uint32)), g
+    r.Dispose()
