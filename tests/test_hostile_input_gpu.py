@@ -109,6 +109,15 @@ def test_damaged_audio_pages_decode_the_same_way_however_the_job_is_cut(ctx):
         assert res0["samples"][k] == ref.shape[0], k
         got = pcm0[offs[k]: offs[k] + ref.shape[0] * C_].reshape(-1, C_)
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), k
+    # 16-bit PCM (`(int)(x * 32768f)` clamped, AssetTest.cs:131-132) of values no encoder produces: the same in both again
+    pcm16, offs16, res16, _, _ = run_dispatcher([0, 0], raws, s16=True, host_threads=4, streams_per_call=6)
+    assert np.array_equal(res16["samples"], res0["samples"])
+    for k, r in enumerate(raws[:: max(1, len(raws) // 40)]):
+        k = k * max(1, len(raws) // 40)
+        ref = single_stream_pcm(ctx, r, s16=True)
+        C_ = infos[r][0]
+        got = pcm16[offs16[k]: offs16[k] + ref.shape[0] * C_].reshape(-1, C_)
+        assert np.array_equal(got, ref), k
     # the context is as good as before: an undamaged file decodes to what it always did
     clean = open(os.path.join(GOLDEN, "3test.ogg"), "rb").read()
     again = run_dispatcher([0], [clean], host_threads=1)
