@@ -122,6 +122,24 @@ def test_an_ordered_codebook_that_runs_out_of_bits_is_refused_not_counted_to_the
     assert time.time() - t0 < 1.0
 
 
+def test_a_comment_header_over_many_pages_changes_nothing(front):
+    # album art: a 300 KB comment packet laced over five pages in front of the setup header (PacketProvider.cs:427-560)
+    import struct
+    import synthetic_streams as ss
+    stream, rng = ss.ALL["stereo_coupled_res2"]()
+    plain, _ = stream.build(rng, 20)
+    stream, rng = ss.ALL["stereo_coupled_res2"]()
+    headers = stream.headers
+    big = b"\x03vorbis" + struct.pack("<I", 4) + b"test" + struct.pack("<II", 1, 300000) + b"A" * 300000 + b"\x01"
+    stream.headers = lambda: [headers()[0], big, headers()[2]]
+    padded, _ = stream.build(rng, 20)
+    assert len(padded) > len(plain) + 300000
+    a, b = front.OggVorbisFile(bytes(plain)), front.OggVorbisFile(bytes(padded))
+    pa, pb = a.decode_packets(), b.decode_packets()
+    assert (a.audio_packets, int(a.total_samples)) == (b.audio_packets, int(b.total_samples)) == (20, 13184)
+    assert np.array_equal(pa[0]["flags"], pb[0]["flags"]) and np.array_equal(pa[1], pb[1]) and np.array_equal(pa[2], pb[2])
+
+
 def test_decode_into_shared_batch_buffers_from_threads(front):
     """Several handles decoded from several threads straight into slices of one batch buffer give what
     decode_packets gives for each stream alone (stream ids and residue offsets rebased)."""
