@@ -135,6 +135,7 @@ struct vpzm_dispatcher {
 
 namespace {
 
+constexpr int kNoDecoder = 1;  // (synth_sub: no decoder for the sub-batch's setup; not a VPZ_* status, those are <= 0)
 constexpr int64_t kCallValues = (int64_t)64 << 20;  // residue values of one synth call (256 MiB as float32), see plan_wave
 
 struct Job {  // one stream of the library inside its group
@@ -544,9 +545,12 @@ struct GroupRun {
             // (VPZM_FAIL_BATCH_CALLS=1, tests: every sub-batch's call counts as failed, so that the member-by-member path runs)
             const char *fb = getenv("VPZM_FAIL_BATCH_CALLS");
             const bool fail_batch = fb && atoi(fb) != 0;
-            rc = fail_batch ? VPZ_E_CAPACITY : call(0, n_pk);
+            rc = !dec ? kNoDecoder : fail_batch ? VPZ_E_CAPACITY : call(0, n_pk);
             if (rc == VPZ_OK) {
                 written = wr;
+            } else if (rc == kNoDecoder) {
+                // vpz_decoder_create refused the setup (its text is in vpzm_last_error): no member of it can be synthesised
+                std::fill(member_rc.begin(), member_rc.end(), kNoDecoder);
             } else {
                 // "a stream that fails costs only itself": whatever one member's packets did to the call, the others get a call
                 // of their own (the packets lie member by member)
@@ -571,7 +575,10 @@ struct GroupRun {
         for (size_t j = 0; j < sb.members.size(); ++j) {
             Job &J = jobs[(size_t)sb.members[j]];
             if (J.status != VPZM_OK) continue;
-            if (member_rc[j] != VPZ_OK) { J.status = member_rc[j] == VPZ_E_CAPACITY ? VPZM_E_CAPACITY : VPZM_E_SYNTH; continue; }
+            if (member_rc[j] != VPZ_OK) {
+                J.status = member_rc[j] == kNoDecoder ? VPZM_E_SETUP : member_rc[j] == VPZ_E_CAPACITY ? VPZM_E_CAPACITY : VPZM_E_SYNTH;
+                continue;
+            }
             results[J.k].samples = written[j];
             samples_total += written[j] * C;
         }
