@@ -262,7 +262,10 @@ def make_floor_packets(rng, frames, channels, flags, interleaved, silent_prob=0.
     (1, [], False), (2, [(0, 1)], True), (2, [(0, 1)], False), (6, [(0, 1), (2, 3)], True),
     (3, [(0, 1), (0, 2)], True), (5, [(4, 0), (1, 2), (0, 3)], False), (7, [(0, 6), (5, 1)], True),
     (34, [(0, 33), (32, 1), (2, 0)], True), (33, [(1, 32)], False),
-    (255, [(0, 254), (253, 1), (7, 200)], True), (255, [(254, 0)], False)])  # (VPZ_MAX_CHANNELS)
+    (255, [(0, 254), (253, 1), (7, 200)], True), (255, [(254, 0)], False),  # (VPZ_MAX_CHANNELS)
+    # VPZ_MAX_COUPLING steps (Mapping.cs reads 8 bits + 1), and a long chain that still fits group mode's step table
+    (7, [(i % 7, (i * 3 + 1 + i // 7) % 7) for i in range(300) if i % 7 != (i * 3 + 1 + i // 7) % 7][:256], True),
+    (6, [(i % 6, (i * 5 + 1 + i // 6) % 6) for i in range(60) if i % 6 != (i * 5 + 1 + i // 6) % 6], True)])
 def test_floor1_and_coupling_match_oracle(ctx, oracle, channels, coupling, interleaved):
     """BASELINE config 4 shape at small size: Residue2-interleaved residue, inverse coupling,
     Floor1 render on the GPU, silent channels (ExecuteChannel false)."""
