@@ -294,6 +294,43 @@ def test_floor1_and_coupling_match_oracle(ctx, oracle, channels, coupling, inter
     dec.close()
 
 
+@pytest.mark.parametrize("channels,n_pairs", [(6, 15), (6, 128), (2, 128), (3, 40)])
+def test_many_mappings_with_their_own_coupling(ctx, oracle, channels, n_pairs):
+    """a packet's mode picks its mapping, a mapping has its own coupling steps: 30 mappings whose steps still fit group
+    mode's table, and 256 -- what a setup header can hold (Mapping count: 6 bits + 1 in the reference, 8 in this ABI) --
+    which do not (the separate coupling pass, or the stereo path's own table)"""
+    from vorbispizza_amd import Decoder, make_packets
+    frames = 40
+    rng = np.random.default_rng(channels * 1000 + n_pairs)
+    flags = helpers.markov_block_flags(frames, seed=channels + n_pairs)
+    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)]
+    mappings = []
+    for k in range(n_pairs):
+        steps = []
+        for _ in range(int(rng.integers(0, 3)) if channels > 1 else 0):
+            m_ = int(rng.integers(0, channels))
+            a_ = int((m_ + 1 + rng.integers(0, channels - 1)) % channels)
+            steps.append((m_, a_))
+        for bf in (0, 1):
+            mappings.append({"coupling": steps, "channel_floor": [bf] * channels})
+    opk = make_floor_packets(rng, frames, channels, flags, True)
+    pk = make_packets(frames)
+    off = 0
+    for f, p in enumerate(opk):
+        p["mapping"] = 2 * int(rng.integers(0, n_pairs)) + (int(flags[f]) & 1)
+        pk[f]["flags"], pk[f]["mapping"], pk[f]["granule"], pk[f]["residue_offset"] = p["flags"], p["mapping"], -1, off
+        off += p["residue"].size
+    res = np.concatenate([p["residue"] for p in opk])
+    posts = np.concatenate([p["posts"] for p in opk]).astype(np.int16)
+    counts = np.concatenate([p["post_count"] for p in opk]).astype(np.uint8)
+    dec = Decoder(ctx, channels, 256, 2048, floors=floors, mappings=mappings)
+    got = dec.synth(pk, res, posts, counts)[0]
+    ref, _, _ = helpers.oracle_decode(oracle, channels, 256, 2048, opk, floors=floors, mappings=mappings)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= TOL * max(1.0, float(np.abs(ref).max()))
+    dec.close()
+
+
 def test_floor_curve_is_bit_exact(ctx, oracle):
     """The integer part of Floor1 (UnwrapPosts + DDA) must be bit-exact: with a one-hot residue of
     1.0 every IMDCT output is floor[k] * cos(...), so compare via a flat spectrum trick -- feed
