@@ -453,3 +453,36 @@ def test_seek_in_streams_of_other_shapes(ctx, name):
         got = np.concatenate(got)
         assert np.array_equal(got.view(np.uint32), full[g: g + len(got)].view(np.uint32)), g
     r.Dispose()
+
+
+@pytest.mark.parametrize("n_packets", [1, 2, 3, 5])
+def test_streams_of_one_two_three_packets(ctx, n_packets):
+    """the first packet only primes the overlap (StreamDecoder.cs:679): a one-packet stream is zero samples long, and the
+    reader says so instead of waiting for more"""
+    import synthetic_streams as ss
+    from vorbispizza_amd import Decoder, capi
+    from vorbispizza_amd.front import OggVorbisFile, VorbisReader
+    stream, rng = ss.ALL["stereo_coupled_res2"]()
+    ogg, _ = stream.build(rng, n_packets)
+    raw = bytes(ogg)
+    f = OggVorbisFile(raw)
+    pk, res, posts, counts = f.decode_packets()
+    dec = Decoder(ctx, f.channels, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings)
+    ref = dec.synth(pk, res, posts, counts, out_layout=capi.OUT_INTERLEAVED)[0]
+    dec.close()
+    r = VorbisReader(ctx, raw, clip_samples=False, batch_packets=2)
+    assert r.TotalSamples == ref.shape[0] == int(f.total_samples)
+    buf = np.zeros(2 * 4096, dtype=np.float32)
+    chunks = []
+    while True:
+        n = r.ReadSamples(buf)
+        if n == 0:
+            break
+        chunks.append(buf[: n * 2].reshape(n, 2).copy())
+    got = np.concatenate(chunks) if chunks else np.zeros((0, 2), dtype=np.float32)
+    assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert r.IsEndOfStream and r.SamplePosition == ref.shape[0] and r.ReadSamples(buf) == 0
+    if ref.shape[0] > 0:
+        r.SeekTo(0)
+        assert r.ReadSamples(buf) > 0
+    r.Dispose()
