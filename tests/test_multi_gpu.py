@@ -281,6 +281,25 @@ def test_callers_on_several_threads_take_a_dispatcher_in_turn(ctx):
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), k
 
 
+def test_an_empty_library_and_one_of_nothing_but_garbage(ctx):
+    from vorbispizza_amd import multi
+    d = multi.Dispatcher([0, 0], host_threads=3)
+    res, st = d.decode_library([], np.zeros(4, dtype=np.float32), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+    assert len(res) == 0 and st.device_streams[0] == 0 and st.device_samples[0] == 0
+    junk = [np.frombuffer(bytes([i]) * 300 + b"OggS" + bytes(60), dtype=np.uint8) for i in range(7)]
+    pcm = np.full(70, np.float32(7.0), dtype=np.float32)
+    res, st = d.decode_library(junk, pcm, np.arange(7, dtype=np.int64) * 10, np.full(7, 5, dtype=np.int64))
+    assert (res["status"] == multi.E_OPEN).all() and (res["samples"] == 0).all() and (pcm == np.float32(7.0)).all()
+    # ... and the dispatcher is as good as new
+    raw = library(("1test.ogg",), 1)[0]
+    ref = single_stream_pcm(ctx, raw)
+    pcm = np.zeros(ref.size + 64, dtype=np.float32)
+    res, st = d.decode_library([np.frombuffer(raw, dtype=np.uint8)], pcm, np.zeros(1, dtype=np.int64), np.full(1, ref.shape[0] + 64, dtype=np.int64))
+    assert res["status"][0] == 0 and res["samples"][0] == ref.shape[0]
+    assert np.array_equal(pcm[: ref.size].view(np.uint32), ref.reshape(-1).view(np.uint32))
+    d.close()
+
+
 def test_more_setups_than_a_context_keeps_decoders_for(ctx):
     """A context keeps the decoders of its last 8 setups (vorbis_multi.cpp: kDecodersPerContext): a library of 12 stereo streams with
     12 different setup headers, decoded twice on ONE context -- decoders are created, evicted and created again, the PCM stays that of
