@@ -33,7 +33,7 @@ extern "C" {
 #define VPZM_E_NOMEM      (-3)
 /* per-stream status (vpzm_stream_result.status): VPZM_OK, or */
 #define VPZM_E_OPEN       (-10)  /* the container could not be opened (vpzh_open_memory failed) */
-#define VPZM_E_CAPACITY   (-11)  /* pcm_capacity[k] is smaller than the stream's sample count */
+#define VPZM_E_CAPACITY   (-11)  /* pcm_capacity[k] is smaller than the stream's sample count -- the announced one (vpzh_total_samples), or what a damaged stream that lost its end-of-stream trim really produces */
 #define VPZM_E_SYNTH      (-12)  /* the stream's synthesis failed (after the call that held it failed, every member is synthesised alone: its own outcome) */
 #define VPZM_E_SETUP      (-13)  /* a setup the back end cannot represent (e.g. a Floor1 with more than 64 posts) */
 

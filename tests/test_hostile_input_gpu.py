@@ -91,7 +91,7 @@ def hostile_library():
 def test_damaged_audio_pages_decode_the_same_way_however_the_job_is_cut(ctx):
     from test_multi_gpu import run_dispatcher, single_stream_pcm
     raws = hostile_library()
-    runs = [run_dispatcher([0], raws, host_threads=3, streams_per_call=5),
+    runs = [run_dispatcher([0], raws, host_threads=3, streams_per_call=5, capacity_slack=int(os.environ.get("VPZ_HOSTILE_SLACK", "2048"))),
             run_dispatcher([0, 0, 0], raws, host_threads=6, streams_per_call=2),
             run_dispatcher([0, 0], raws, host_threads=4, streams_per_call=16, float_residue=1)]
     pcm0, offs, res0, _, infos = runs[0]
@@ -161,3 +161,27 @@ def test_the_reader_gives_damaged_streams_the_samples_of_the_batch_decode(ctx):
             assert got.shape == ref.shape, (k, got.shape, ref.shape)
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), k
         assert len({t for _, t in outs}) == 1, (k, [t for _, t in outs])
+
+
+def test_a_stream_that_outgrows_its_announced_length_costs_only_itself(ctx):
+    """damage that takes the end-of-stream trim away (StreamDecoder.cs:658-666 trims when the marked packet is read): the
+    stream produces more samples than PacketProvider.GetGranuleCount announced (:35-49).  With areas of exactly the announced
+    sizes the synth call that holds it fails -- and every other member gets a call of its own: four neighbours of the same
+    setup decode to their usual bits, the one that does not fit is VPZM_E_CAPACITY, nothing of it is written"""
+    from test_multi_gpu import run_dispatcher, single_stream_pcm
+    from vorbispizza_amd import multi
+    clean = open(os.path.join(GOLDEN, "1test.ogg"), "rb").read()
+    grown = damage_audio(clean, 501, 2)
+    raws = [clean, clean, grown, clean, clean]
+    pcm, offs, res, _, infos = run_dispatcher([0], raws, capacity_slack=0, host_threads=2, streams_per_call=8)
+    produced = single_stream_pcm(ctx, grown).shape[0]
+    assert produced > infos[grown][1] == infos[clean][1]
+    assert list(res["status"]) == [0, 0, multi.E_CAPACITY, 0, 0]
+    ref = single_stream_pcm(ctx, clean)
+    for k in (0, 1, 3, 4):
+        assert res["samples"][k] == ref.shape[0]
+        assert np.array_equal(pcm[offs[k]: offs[k] + ref.size].view(np.uint32), ref.reshape(-1).view(np.uint32)), k
+    assert (pcm[offs[2]: offs[3]] == np.float32(7.0)).all()
+    # with room for what it produces it is a stream like any other
+    pcm, offs, res, _, _ = run_dispatcher([0], raws, capacity_slack=produced - infos[grown][1], host_threads=2, streams_per_call=8)
+    assert (res["status"] == 0).all() and res["samples"][2] == produced

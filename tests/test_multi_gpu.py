@@ -221,9 +221,9 @@ def test_streams_of_every_length_from_one_packet_up(ctx):
 
 def test_after_a_failed_call_every_member_gets_a_call_of_its_own(ctx, monkeypatch):
     """"a stream that fails costs only itself" also when it is the synth call of its sub-batch that fails: the members are
-    then synthesised one by one.  Nothing a front end hands over makes a call fail today (areas are checked when the
-    container is opened), so the test has the dispatcher count every sub-batch's call as failed (VPZM_FAIL_BATCH_CALLS):
-    the member-by-member path must give the very PCM, sample counts and skipped-packet counts of the batched one."""
+    then synthesised one by one.  (A damaged stream that loses its end-of-stream trim does that for real:
+    tests/test_hostile_input_gpu.py.)  Here the dispatcher counts EVERY sub-batch's call as failed (VPZM_FAIL_BATCH_CALLS), over
+    streams of all kinds: the member-by-member path must give the very PCM, sample counts and skipped-packet counts of the batched one."""
     import synthetic_streams as ss
     raws = _same_setup_streams((20, 50, 35)) + library(("issue6test.ogg", "3test.ogg", "issue6test.ogg"), 3)
     for name in ("stereo_floor0", "six_channels_51", "stereo_floor0"):
