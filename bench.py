@@ -4,20 +4,23 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over one batch of synthetic, HBM-resident input:
-BASELINE.json configs[1] -- batched long-block IMDCT (`Mdct.Reverse` semantics), N = 2048, 2 channels,
-65 536 frames = 131 072 channel-blocks per GPU (weak scaling: every rank owns its own batch; streams
-are independent, so there is no collective on the data path).  One sample = one float32 PCM value of
-one channel (N/2 per channel-block).
+A "step" is one pass of the hot path over one batch of synthetic, HBM-resident input: north_star's workload -- batched
+stereo N = 2048 inverse MDCT + window + overlap-add to PCM (`Mdct.Reverse` + `OverlapBuffers` + `StoreContiguous`:
+Mdct.cs:15-19, StreamDecoder.cs:764-791, 594-638) through the fused kernel, 65 536 all-long frames x 2 channels per GPU
+(BASELINE configs[1]'s batch, taken all the way to PCM), one vpz_decoder_synth call = one kernel launch per step; weak scaling:
+every rank owns its own batch; streams are independent, so there is no collective on the data path.  One sample = one
+float32 PCM value of one channel; 8 algorithmic bytes per sample (4 read + 4 written).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  "roofline":     algorithmic bytes of the dominant kernel / its HIP-event duration vs 8 TB/s,
-  "cpu_baseline": the CPU oracle (restated reference, kind "port") timed on the host cores,
-  "extra_workloads": N = 1: north_star's all-long fused line, configs[2] (mixed 256/2048 window switching +
-                  overlap-add), configs[3] (6 channels, Residue2-interleaved, coupled, Floor1 on the GPU), configs[4]
-                  one GPU's share, configs[0]; every N: configs[4]'s whole job -- 1024 real stereo streams
-                  PARTITIONED over the ranks (vorbispizza_amd/sharding.py), GPU stage and end to end, with the
-                  per-rank sample counts and a PCM checksum that does not depend on the partition.
+  "roofline":     algorithmic bytes of the fused kernel / its HIP-event duration (events on the library's stream) vs 8 TB/s,
+  "cpu_baseline": the CPU oracle (restated reference, kind "port") on the same workload, timed on the host cores,
+  "extra_workloads": N = 1: configs[1] (Mdct.Reverse alone, the contract line of rounds 1-4, with its own roofline), configs[2]
+                  (mixed 256/2048 window switching), configs[3] (6 channels, Residue2-interleaved, coupled, Floor1 on the GPU;
+                  fractions from the bytes that have to move), configs[4] one GPU's share, configs[0]; every N: configs[4]'s whole
+                  job -- 1024 real stereo streams PARTITIONED over the ranks (vorbispizza_amd/sharding.py), GPU stage and end to
+                  end, with a PCM checksum that does not depend on the partition.
+The stdout line carries the figures only (it has to fit the driver's 8 KB stdout tail); the same record with every note goes to
+gpurun_out/bench_detail.json and to stderr.
 """
 import argparse
 import json
@@ -236,7 +239,7 @@ def cpu_baseline_fused(which, seconds=1.0, reps=3):
                           "configs4": "3test.ogg + issue6test.ogg, decoded spectra"}[which])}
 
 
-def build_synth_ola(torch, device, frames=FRAMES, all_long=False):
+def build_synth_ola(torch, device, frames=FRAMES, all_long=False, seed=3):
     """BASELINE configs[2]: one stereo stream, 65 536 frames, Markov block flags (seed 3); all_long: every block long
     with long windows on both sides (north_star's "batched stereo N=2048 IMDCT+window+OLA")."""
     import helpers
@@ -250,7 +253,7 @@ def build_synth_ola(torch, device, frames=FRAMES, all_long=False):
     pk["flags"] = flags | capi.PKT_NO_FLOOR
     pk["granule"] = -1
     pk["residue_offset"] = offs[:-1]
-    g = torch.Generator(device=device).manual_seed(3)
+    g = torch.Generator(device=device).manual_seed(seed)
     residue = torch.randn(int(offs[-1]), generator=g, device=device, dtype=torch.float32) * 2.0 ** -8
     # samples per channel: every packet but the first emits RightStart - LeftStart
     samples = 0
@@ -610,29 +613,137 @@ def dispatcher_whole_job(torch, device_ids, threads, s16=False, repeats=3, strea
     return out
 
 
+METRIC = "decoded PCM Msamples/s (batched stereo N=2048)"
+NS_KERNEL = "synth_dual_kernel<false, false, 0, false>"
+NS_WORKLOAD = ("north_star: batched stereo 44.1 kHz N=2048 IMDCT + window + overlap-add to PCM through the fused kernel "
+               "(Mdct.Reverse + OverlapBuffers + StoreContiguous, Mdct.cs:15-19 + StreamDecoder.cs:764-791, 594-638): 65536 all-long "
+               "frames x 2 ch per GPU (BASELINE configs[1]'s batch taken all the way to PCM), spectra N(0, 2^-8) device-resident, "
+               "planar float32 PCM out, 8 B per sample")
+
+
+class NorthStarLine:
+    """The contract workload: one stereo stream of `frames` all-long N = 2048 packets (VPZ_PKT_NO_FLOOR: the spectra are what
+    Mdct.Reverse gets), device-resident, through ONE vpz_decoder_synth call per step -- inverse MDCT, window, overlap-add, planar
+    store; the stream's state is reset in front of every step (a host-side epoch, no device work)."""
+
+    def __init__(self, torch, ctx, device, seed, frames=FRAMES):
+        from vorbispizza_amd import Decoder, capi
+        self.capi = capi
+        self.pk, self.residue, self.samples, self.res_floats = build_synth_ola(torch, device, frames, all_long=True, seed=seed)
+        self.dec = Decoder(ctx, CHANNELS, 256, 2048)
+        self.cap = self.samples + 1024
+        self.out = torch.empty(CHANNELS * self.cap, device=device, dtype=torch.float32)
+        self.alg_bytes = 4 * self.res_floats + 4 * self.samples * CHANNELS  # spectra read once + PCM written once
+        self.pcm_values = self.samples * CHANNELS
+
+    def step(self):
+        self.dec.reset(-1)
+        w = self.dec.synth_raw(self.pk, self.residue, None, None, self.out, None, self.cap, self.capi.OUT_PLANAR, self.cap,
+                               self.capi.MEM_DEVICE)
+        assert int(w[0]) == self.samples, (int(w[0]), self.samples)
+
+    def close(self):
+        self.dec.close()
+        del self.residue, self.out
+
+
+def cpu_baseline_contract():
+    """`cpu_baseline` of the contract line: the oracle (restated reference, scalar C) on the SAME workload -- all-long stereo
+    N = 2048 frames through orc_synth_stream_floored (IMDCT + window + overlap-add + store) -- 1 thread and every core the rank
+    may use; a bounded sample (1024 frames per thread, repeated until the deadline)."""
+    r = cpu_baseline_fused("north_star_line", seconds=2.0, reps=3)
+    return {"value": r["Msamples_per_s_all_threads"], "unit": "Msamples/s", "cores": r["threads_used"], "kind": "port",
+            "value_1thread": r["Msamples_per_s_1thread"], "cores_available": r["cores_available"], "cpu_quota": cpu_quota(),
+            "machine_cores": os.cpu_count(),
+            "sample": "oracle (orc_synth_stream_floored, gcc -O2 -ffp-contract=off, scalar): 1024 all-long stereo N=2048 frames per "
+                      "thread, repeated for 2 s, median of 3; 1 thread, then %d threads" % r["threads_used"]}
+
+
+def imdct_only_extra(torch, ctx, device, seed, steps, cpu=True):
+    """BASELINE configs[1] as it was the contract line in rounds 1-4: Mdct.Reverse alone (no window, no overlap-add: its output
+    is not PCM yet), 131 072 channel-blocks, 12 288 B each."""
+    from vorbispizza_amd import capi
+    count = FRAMES * CHANNELS
+    g = torch.Generator(device=device).manual_seed(seed)
+    spectra = torch.randn((count, N // 2), generator=g, device=device, dtype=torch.float32) * 2.0 ** -8
+    out = torch.empty((count, N), device=device, dtype=torch.float32)
+    for _ in range(3):
+        ctx.imdct_batch(spectra, N, capi.IMDCT_FAST, out=out)
+    ctx.synchronize()
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.imdct_batch(spectra, N, capi.IMDCT_FAST, out=out)
+    kernel_ms = ctx.timer_stop() / steps
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    alg = count * (4 * (N // 2) + 4 * N)
+    ach = alg / (kernel_ms * 1e-3) / 1e9
+    e = {"Msamples_per_s": round(count * (N // 2) / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 4),
+         "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                      "traffic": pmc_traffic_bytes("headline"), "kernel": "imdct2048_kernel", "kernel_ms": round(kernel_ms, 4),
+                      "algorithmic_bytes_per_launch": alg},
+         "note": "vpz_imdct_batch, Mdct.Reverse semantics only; the contract line of rounds 1-4"}
+    if cpu:
+        c = cpu_baseline_imdct(2.0, 4.0)
+        e["cpu_oracle"] = {"Msamples_per_s_1thread": c["value_1thread"], "Msamples_per_s_all_threads": c["value"], "threads_used": c["cores"]}
+    del spectra, out
+    torch.cuda.empty_cache()
+    return e
+
+
+DROP_FROM_STDOUT = ("note", "sample", "how", "host", "end_to_end_path", "python_pipeline_note", "per_rank_ms", "kind", "repetitions",
+                    "cores_in_affinity_mask", "machine_cores", "local_world_size")
+
+
+def slim(x, top=True):
+    """The stdout line keeps the figures; notes and per-rank detail go to the detail file (the driver's record keeps 8 KB of stdout)."""
+    if isinstance(x, dict):
+        return {k: slim(v, False) for k, v in x.items() if k not in DROP_FROM_STDOUT or top}
+    return x
+
+
+def emit(result, extras):
+    """ONE JSON line on stdout (contract fields + roofline + cpu_baseline + the extras' figures, short enough for the driver's
+    stdout tail); the same record with every note under gpurun_out/bench_detail.json and on stderr."""
+    full = dict(result)
+    if extras:
+        full["extra_workloads"] = extras
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError:
+        pass
+    sys.stderr.write("bench detail: " + json.dumps(full) + "\n")
+    sys.stderr.flush()
+    line = dict(result)
+    if extras:
+        line["extra_workloads"] = {k: slim(v, False) for k, v in extras.items()}
+    print(json.dumps(line, separators=(",", ":")))
+    sys.stdout.flush()
+
+
 def main_single_process(args):
     """bench.py --gpus N --single-process: the alternative launcher -- ONE process, N devices, no torchrun, no
-    torch.distributed.  The contract workload (configs[1]) runs as N host threads, one vpz_context and one batch per device,
+    torch.distributed.  The contract workload runs as N host threads, one vpz_context, one decoder and one batch per device,
     started together and timed from the first launch to the last completion (the in-process form of "barrier, K steps,
     max over ranks"); the 1024-stream job runs through the in-process dispatcher.  Prints one JSON line of the same shape."""
     import torch
     import __graft_entry__ as ge
     ge.build()
-    from vorbispizza_amd import Context, capi
+    from vorbispizza_amd import Context
     n_dev = args.gpus
     have = torch.cuda.device_count()
     rehearsal = os.environ.get("VPZ_BENCH_REHEARSAL") == "1"  # every context on device 0 (a one-GPU box)
     if n_dev > have and not rehearsal:
         raise SystemExit("--gpus %d: only %d device(s) visible (VPZ_BENCH_REHEARSAL=1 puts every context on device 0)" % (n_dev, have))
     ids = [0] * n_dev if rehearsal else list(range(n_dev))
-    count = FRAMES * CHANNELS
-    ctxs, ins, outs = [], [], []
+    ctxs, lines = [], []
+    frames = args.frames
     for r, dev in enumerate(ids):
-        device = torch.device("cuda", dev)
-        g = torch.Generator(device=device).manual_seed(2048 + r)
-        ins.append(torch.randn((count, N // 2), generator=g, device=device, dtype=torch.float32) * 2.0 ** -8)
-        outs.append(torch.empty((count, N), device=device, dtype=torch.float32))
         ctxs.append(Context(dev))
+        lines.append(NorthStarLine(torch, ctxs[r], torch.device("cuda", dev), 3 + r, frames))
     for dev in set(ids):
         torch.cuda.synchronize(dev)
     start = threading.Barrier(n_dev + 1)
@@ -641,12 +752,12 @@ def main_single_process(args):
 
     def lane(r):
         for _ in range(args.warmup):
-            ctxs[r].imdct_batch(ins[r], N, capi.IMDCT_FAST, out=outs[r])
+            lines[r].step()
         ctxs[r].synchronize()
         start.wait()
         ctxs[r].timer_start()
         for _ in range(args.steps):
-            ctxs[r].imdct_batch(ins[r], N, capi.IMDCT_FAST, out=outs[r])
+            lines[r].step()
         kernel_ms[r] = ctxs[r].timer_stop() / args.steps
         ctxs[r].synchronize()
         done.wait()
@@ -660,34 +771,33 @@ def main_single_process(args):
     elapsed = time.perf_counter() - t0
     for t in ths:
         t.join()
-    value = n_dev * count * (N // 2) * args.steps / elapsed / 1e6
-    alg_bytes = count * (4 * (N // 2) + 4 * N)
+    value = n_dev * lines[0].pcm_values * args.steps / elapsed / 1e6
+    alg_bytes = lines[0].alg_bytes
     achieved = alg_bytes / (max(kernel_ms) * 1e-3) / 1e9
     result = {
-        "metric": "decoded PCM Msamples/s (batched stereo N=2048)", "value": round(value, 1), "unit": "Msamples/s",
+        "metric": METRIC, "value": round(value, 1), "unit": "Msamples/s",
         "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "launcher": "single process: one host thread + one vpz_context per device (bench.py --single-process)",
-        "config": {"workload": "BASELINE configs[1]: batched long-block IMDCT (Mdct.Reverse semantics), N=2048, 2 ch, "
-                               "65536 frames = 131072 channel-blocks per GPU, spectra N(0, 2^-8) device-resident",
-                   "channel_blocks_per_gpu": count, "block_size": N, "sharding": "independent batch per GPU, no collective",
-                   "devices": ids},
+        "config": {"workload": NS_WORKLOAD, "frames_per_gpu": frames, "channels": CHANNELS, "block_size": N,
+                   "sharding": "independent batch per GPU, no collective", "devices": ids},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_bytes(), "kernel": "imdct2048_kernel",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": pmc_traffic_bytes("north_star_line") if frames == FRAMES else None, "kernel": NS_KERNEL,
                      "kernel_ms": round(max(kernel_ms), 4), "kernel_ms_per_device": [round(k, 4) for k in kernel_ms],
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
-    del ins, outs
+    for ln in lines:
+        ln.close()
     for c in ctxs:
         c.close()
     torch.cuda.empty_cache()
+    extras = {}
     if not args.no_extras:
         thr = host_threads(whole_node=True) if HOST_THREADS_CAP else None  # (None: the dispatcher's own count)
-        result["extra_workloads"] = {
-            "configs[4] whole job in ONE process: 1024 real stereo streams through the in-process dispatcher "
-            "(vpzm_decode_library), %d device(s), float32 PCM" % n_dev: dispatcher_whole_job(torch, ids, thr),
-            "... with 16-bit PCM": dispatcher_whole_job(torch, ids, thr, s16=True)}
-    print(json.dumps(result))
+        extras = {"configs[4] job, ONE process (vpzm_decode_library), %d device(s), f32 PCM" % n_dev: dispatcher_whole_job(torch, ids, thr),
+                  "configs[4] job, ONE process, s16 PCM": dispatcher_whole_job(torch, ids, thr, s16=True)}
+    emit(result, extras)
 
 
 def cpu_plumbing_2test():
@@ -753,13 +863,32 @@ def time_decoder(ctx, dec, torch, pk, residue, posts, counts, samples, channels,
     return best, out
 
 
+def fused_entry(samples_total, dt, byt, traffic=None, cpu=None, note=None, **more):
+    e = {"Msamples_per_s": round(samples_total / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
+         "GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4), "bytes": byt}
+    if traffic is not None:
+        e["traffic"] = traffic
+    e.update(more)
+    if getattr(time_decoder, "last_spread", None):
+        s = time_decoder.last_spread
+        e["device_us_per_call"] = [s["device_us_per_call_min"], s["device_us_per_call_mean"], s["device_us_per_call_max"]]
+        time_decoder.last_spread = None
+    if cpu:
+        e["cpu_oracle"] = {"Msamples_per_s_1thread": cpu["Msamples_per_s_1thread"], "Msamples_per_s_all_threads": cpu["Msamples_per_s_all_threads"],
+                           "threads_used": cpu["threads_used"], "sample": cpu["sample"]}
+    if note:
+        e["note"] = note
+    return e
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-extras", action="store_true", help="skip the configs[2]/[3] side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[1]/[2]/[3]/[4] side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames", type=int, default=FRAMES, help="frames of the contract workload (default: BASELINE's 65536)")
     ap.add_argument("--extras-frames", type=int, default=FRAMES, help="frames of the configs[2] side measurement")
     ap.add_argument("--extras-frames6", type=int, default=16384, help="frames of the configs[3] side measurement")
     ap.add_argument("--host-threads", type=int, default=0, help="explicit cap on the host threads of a rank (default: every "
@@ -799,15 +928,12 @@ def main():
     ctx = Context(local_rank)
     red_device = "cpu" if rehearsal else device  # where the tiny reduction tensors live
 
-    # ---------------- configs[1]: batched long-block IMDCT, device-resident
-    count = FRAMES * CHANNELS
-    g = torch.Generator(device=device).manual_seed(2048 + rank)
-    spectra = torch.randn((count, N // 2), generator=g, device=device, dtype=torch.float32) * 2.0 ** -8
-    out = torch.empty((count, N), device=device, dtype=torch.float32)
+    # ---------------- the contract line: north_star's workload -- batched stereo N = 2048 IMDCT + window + overlap-add to PCM,
+    # device-resident, one fused kernel launch per step (weak scaling: every rank owns its own batch, no collective)
+    line = NorthStarLine(torch, ctx, device, 3 + rank, args.frames)
     torch.cuda.synchronize()
-
     for _ in range(args.warmup):
-        ctx.imdct_batch(spectra, N, capi.IMDCT_FAST, out=out)
+        line.step()
     ctx.synchronize()
     if distributed:
         sharding.barrier()
@@ -815,8 +941,8 @@ def main():
     ctx.timer_start()  # HIP events on the stream the kernel is launched on
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.imdct_batch(spectra, N, capi.IMDCT_FAST, out=out)
-    kernel_ms = ctx.timer_stop() / args.steps  # also synchronises the stream
+        line.step()
+    kernel_ms = ctx.timer_stop() / args.steps  # also synchronises the stream; the K launches back to back incl. their gaps
     ctx.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -825,13 +951,11 @@ def main():
         kernel_ms = sharding.max_over_ranks(kernel_ms, red_device)
         sharding.barrier()
 
-    samples_per_step = world * count * (N // 2)
-    value = samples_per_step * args.steps / elapsed / 1e6
-    alg_bytes = count * (4 * (N // 2) + 4 * N)  # 12 288 B per channel-block
+    value = world * line.pcm_values * args.steps / elapsed / 1e6
+    alg_bytes = line.alg_bytes  # 4 B x spectra values read + 4 B x PCM values written = 8 B per sample
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-
     result = {
-        "metric": "decoded PCM Msamples/s (batched stereo N=2048)",
+        "metric": METRIC,
         "value": round(value, 1),
         "unit": "Msamples/s",
         "n_gpus": world,
@@ -843,126 +967,83 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {
-            "workload": "BASELINE configs[1]: batched long-block IMDCT (Mdct.Reverse semantics), N=2048, 2 ch, "
-                        "65536 frames = 131072 channel-blocks per GPU, spectra N(0, 2^-8) device-resident",
-            "channel_blocks_per_gpu": count, "block_size": N, "sharding": "independent batch per GPU, no collective",
-        },
+        "config": {"workload": NS_WORKLOAD, "frames_per_gpu": args.frames, "channels": CHANNELS, "block_size": N,
+                   "pcm_values_per_step_per_gpu": line.pcm_values, "sharding": "independent batch per GPU, no collective"},
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_bytes(),
-            "kernel": "imdct2048_kernel", "kernel_ms": round(kernel_ms, 4),
-            "algorithmic_bytes_per_launch": alg_bytes,
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic_bytes("north_star_line") if args.frames == FRAMES else None,
+            "kernel": NS_KERNEL, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+            "bytes_per_sample": round(alg_bytes / line.pcm_values, 3),
         },
     }
+    line.close()
+    del line
+    torch.cuda.empty_cache()
 
     extras = {}
-    if not args.no_extras:
-        del out, spectra
-        torch.cuda.empty_cache()
+    cpu = not args.no_cpu_baseline
     if rank == 0 and world == 1:
-        if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_imdct()
+        if cpu:
+            result["cpu_baseline"] = cpu_baseline_contract()
         if not args.no_extras:
-            # north_star's literal line: batched stereo N=2048 IMDCT + window + OLA through the fused kernel
-            pk, residue, samples, res_floats = build_synth_ola(torch, device, args.extras_frames, all_long=True)
-            dec = Decoder(ctx, CHANNELS, 256, 2048)
-            dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 40, 3)
-            byt = 4 * res_floats + 4 * samples * CHANNELS
-            extras["north_star line: all-long N=2048 stereo IMDCT + window + OLA (fused synth kernel), %d frames, planar out"
-                   % args.extras_frames] = {
-                "Msamples_per_s": round(samples * CHANNELS / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
-                "roofline": {"bound": "hbm", "achieved": round(byt / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": byt,
-                             "traffic": pmc_traffic_bytes("north_star_line") if args.extras_frames == FRAMES else None,
-                             "kernel": "synth_dual_kernel<false, false, 0, false> (stereo fast path, no floor, planar in / out)",
-                             "bytes_per_sample": round(byt / (samples * CHANNELS), 3)},
-                "gpu_time_per_call": time_decoder.last_spread,
-                "note": "whole vpz_decoder_synth call incl. the host state machine; 8 B per sample; best of 3 loops of 40 calls",
-                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_fused("north_star_line")}
-            dec.close()
-            del residue
-            torch.cuda.empty_cache()
+            # configs[1]: Mdct.Reverse alone (the contract line of rounds 1-4), with its own roofline
+            extras["configs[1] IMDCT only, N=2048, 131072 ch-blocks"] = imdct_only_extra(torch, ctx, device, 2048 + rank, 20, cpu)
             # configs[2]
             pk, residue, samples, res_floats = build_synth_ola(torch, device, args.extras_frames)
             dec = Decoder(ctx, CHANNELS, 256, 2048)
             dt, _ = time_decoder(ctx, dec, torch, pk, residue, None, None, samples, CHANNELS, 40, 3)
             byt = 4 * res_floats + 4 * samples * CHANNELS
-            extras["configs[2] mixed 256/2048 + window + OLA, stereo, %d frames, planar out" % args.extras_frames] = {
-                "Msamples_per_s": round(samples * CHANNELS / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
-                "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes": byt, "traffic": pmc_traffic_bytes("configs2") if args.extras_frames == FRAMES else None,
-                "gpu_time_per_call": time_decoder.last_spread,
-                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_fused("configs2"),
-                "note": "whole vpz_decoder_synth call incl. the host state machine; best of 3 loops of 40 calls"}
+            extras["configs[2] mixed 256/2048 + window + OLA, stereo, %d frames" % args.extras_frames] = fused_entry(
+                samples * CHANNELS, dt, byt, traffic=pmc_traffic_bytes("configs2") if args.extras_frames == FRAMES else None,
+                cpu=cpu_baseline_fused("configs2") if cpu else None,
+                note="whole vpz_decoder_synth call incl. the host state machine; best of 3 loops of 40 calls; planar out")
             dec.close()
             del residue
             torch.cuda.empty_cache()
-            # configs[3]
+            # configs[3]: `bytes` = what has to move -- with the support declared (ABI v4) the upper half of every vector is
+            # neither loaded nor staged; the full-vector figure of rounds 1-3 is the secondary one
             pk, res6, posts, counts, floors, mappings, samples6 = build_floor6(torch, device, args.extras_frames6)
             dec = Decoder(ctx, 6, 256, 2048, floors=floors, mappings=mappings)
             dt, _ = time_decoder(ctx, dec, torch, pk, res6, posts, counts, samples6, 6, 40, 3)
-            byt = 4 * res6.numel() + 4 * samples6 * 6 + posts.numel() * 2
-            # ... and with the bytes the declared support leaves to read: the lower half of every vector (the kernels work in
-            # halves of a block; the support ends at bin FLOOR6_RESIDUE_END of 1024)
-            byt_needed = byt - 4 * res6.numel() // 2
-            extras["configs[3] 6ch Residue2-interleaved + coupling + Floor1 on GPU, N=2048, %d frames" % args.extras_frames6] = {
-                "Msamples_per_s": round(samples6 * 6 / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
-                "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4),
-                "bytes_required_with_declared_support": byt_needed,
-                "required_GBps": round(byt_needed / dt / 1e9, 1),
-                "frac_of_8TBps_required_bytes": round(byt_needed / dt / 1e9 / HBM_PEAK_GBS, 4),
-                "gpu_time_per_call": time_decoder.last_spread,
-                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_fused("configs3"),
-                "note": "2 kernels (Floor1 unwrap; fused de-interleave + coupling + floor + IMDCT + OLA); whole call; "
-                        "best of 3 loops of 40 calls.  The mapping declares the residue's support (ABI v4 residue_end = %d of "
-                        "1024 bins): the upper half of every vector is neither loaded nor staged nor de-coupled; algorithmic_* "
-                        "counts the full vectors as rounds 1-3 did, *_required the bytes that have to move" % FLOOR6_RESIDUE_END}
-            # the same workload with the support NOT declared (what ABI v3 could say): every zero loaded and multiplied
+            byt_full = 4 * res6.numel() + 4 * samples6 * 6 + posts.numel() * 2
+            byt = byt_full - 4 * res6.numel() // 2
+            extras["configs[3] 6ch Residue2 + coupling + Floor1, N=2048, %d frames, planar out" % args.extras_frames6] = fused_entry(
+                samples6 * 6, dt, byt, cpu=cpu_baseline_fused("configs3") if cpu else None,
+                frac_full_vector_accounting=round(byt_full / dt / 1e9 / HBM_PEAK_GBS, 4),
+                note="2 kernels (Floor1 unwrap; fused de-interleave + coupling + floor + IMDCT + OLA); whole call; best of 3 loops of "
+                     "40.  The mapping declares the residue's support (residue_end = %d of 1024 bins): `bytes` counts the lower "
+                     "half of every vector (what is loaded), frac_full_vector_accounting the whole vector as rounds 1-3 did"
+                     % FLOOR6_RESIDUE_END)
+            # ... as `ReadSamples(Span<float>)` hands a 5.1 stream over: interleaved (IStreamDecoder.cs:126)
+            dt, _ = time_decoder(ctx, dec, torch, pk, res6, posts, counts, samples6, 6, 40, 3, layout=capi.OUT_INTERLEAVED)
+            extras["configs[3] interleaved out"] = fused_entry(samples6 * 6, dt, byt)
+            dec.close()
+            # ... with the support NOT declared (what ABI v3 could say): every zero loaded and multiplied
             pk_n, res_n, posts_n, counts_n, floors_n, mappings_n, _ = build_floor6(torch, device, args.extras_frames6, declare_support=False)
             dec_n = Decoder(ctx, 6, 256, 2048, floors=floors_n, mappings=mappings_n)
             dt_n, _ = time_decoder(ctx, dec_n, torch, pk_n, res_n, posts_n, counts_n, samples6, 6, 40, 3)
-            extras["configs[3] with the residue's support not declared (ABI v3 accounting)"] = {
-                "Msamples_per_s": round(samples6 * 6 / dt_n / 1e6, 1), "ms_per_step": round(dt_n * 1e3, 3),
-                "algorithmic_GBps": round(byt / dt_n / 1e9, 1), "frac_of_8TBps": round(byt / dt_n / 1e9 / HBM_PEAK_GBS, 4)}
+            extras["configs[3] support not declared"] = fused_entry(samples6 * 6, dt_n, byt_full)
             dec_n.close()
-            del res_n, posts_n, counts_n
-            # ... and as `ReadSamples(Span<float>)` hands a 5.1 stream over: interleaved (IStreamDecoder.cs:126)
-            dt, _ = time_decoder(ctx, dec, torch, pk, res6, posts, counts, samples6, 6, 40, 3, layout=capi.OUT_INTERLEAVED)
-            extras["configs[3] with interleaved output (the six waves of a packet write it together)"] = {
-                "Msamples_per_s": round(samples6 * 6 / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
-                "algorithmic_GBps": round(byt / dt / 1e9, 1), "frac_of_8TBps": round(byt / dt / 1e9 / HBM_PEAK_GBS, 4)}
-            dec.close()
-            del res6, posts, counts
+            del res_n, posts_n, counts_n, res6, posts, counts
             torch.cuda.empty_cache()
             # configs[4], one GPU's share: 128 stereo streams (64 x 3test.ogg + 64 x issue6test.ogg)
             dt, tot, t_front, _ = time_real_streams(ctx, torch, device, 64, steps=40, warmup=3)
-            extras["configs[4] share of one GPU: 128 real stereo streams (64x 3test.ogg + 64x issue6test.ogg), "
-                   "interleaved out, decoded spectra device-resident"] = {
-                "Msamples_per_s": round(tot / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 3),
-                "algorithmic_GBps": round(8 * tot / dt / 1e9, 1), "frac_of_8TBps": round(8 * tot / dt / 1e9 / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes": 8 * tot, "traffic": pmc_traffic_bytes("configs4_share"),
-                "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_fused("configs4"),
-                "cpu_entropy_decode_s_for_128_streams_1thread": round(t_front, 3),
-                "end_to_end_Msamples_per_s_incl_cpu_entropy_decode_1thread": round(tot / (dt + t_front) / 1e6, 2),
-                "note": "one decoder over both fixtures' setups (sharding.merge_setups); GPU stage = Floor1 unwrap + the stereo "
-                        "fast path (synth_dual_kernel: one wavefront per stream-run, both channels), one launch each per step"}
+            extras["configs[4] one GPU's share: 128 real stereo streams, interleaved out, GPU stage"] = fused_entry(
+                tot, dt, 8 * tot, traffic=pmc_traffic_bytes("configs4_share"), cpu=cpu_baseline_fused("configs4") if cpu else None,
+                cpu_entropy_decode_s_1thread=round(t_front, 3),
+                note="64x 3test.ogg + 64x issue6test.ogg, decoded spectra device-resident; one decoder over both fixtures' setups "
+                     "(sharding.merge_setups); Floor1 unwrap + the stereo fast path, one launch each per step")
             thr = host_threads()
             thr_disp = thr if HOST_THREADS_CAP else thr + 4  # (the dispatcher's own rule: the CPUs plus one per context)
             tot_e, (t_all, t_dec, t_syn) = end_to_end_rank_dispatcher(torch, ctx.device, [64, 64], thr_disp)
-            extras["configs[4] end to end, one GPU's share: 128 real stereo streams, container bytes in host memory "
-                   "-> interleaved PCM in host memory"] = {
-                "Msamples_per_s": round(tot_e / t_all / 1e6, 1), "host_threads": thr_disp, "host": host_report(thr),
-                "cpu_open_and_entropy_decode_wall_ms": round(t_dec * 1e3, 2),
-                "synth_host_memory_calls_ms_incl_h2d_d2h": round(t_syn * 1e3, 2),
-                "note": "ONE vpzm_decode_library call (libvorbispizza_host.so): sub-batches of 16 streams on 4 contexts, the residue as "
-                        "16-bit integers over the link (ABI v5); best of 3"}
             tot_s, (t_all_s, t_dec_s, t_syn_s) = end_to_end_rank_dispatcher(torch, ctx.device, [64, 64], thr_disp, s16=True)
-            extras["configs[4] end to end, one GPU's share, 16-bit PCM out (VPZ_OUT_INTERLEAVED_S16: half the D2H bytes)"] = {
-                "Msamples_per_s": round(tot_s / t_all_s / 1e6, 1), "host_threads": thr_disp,
-                "cpu_open_and_entropy_decode_wall_ms": round(t_dec_s * 1e3, 2),
-                "synth_host_memory_calls_ms_incl_h2d_d2h": round(t_syn_s * 1e3, 2)}
-            extras["configs[0] plumbing"] = cpu_plumbing_2test()
+            extras["configs[4] share end to end (container bytes -> PCM in host memory)"] = {
+                "f32_Msamples_per_s": round(tot_e / t_all / 1e6, 1), "s16_Msamples_per_s": round(tot_s / t_all_s / 1e6, 1),
+                "host_threads": thr_disp, "f32_decode_done_ms": round(t_dec * 1e3, 2), "s16_decode_done_ms": round(t_dec_s * 1e3, 2),
+                "host": host_report(thr),
+                "note": "ONE vpzm_decode_library call: sub-batches of 16 streams on 4 contexts, int16 residue over the link (ABI v5); best of 3"}
+            extras["configs[0] 2test.ogg, CPU only"] = cpu_plumbing_2test()
     if not args.no_extras:
         # ---------------- configs[4], the whole job: 1024 stereo streams partitioned over the ranks (strong scaling).
         # Every rank decodes ONLY its contiguous shard of global stream ids (no data-path collective); what crosses
@@ -981,27 +1062,13 @@ def main():
         thr = host_threads()
         if distributed:
             sharding.barrier()
-        # end to end: the rank's shard through the product's host path (the dispatcher on the rank's own device) ...
+        # end to end: the rank's shard through the product's host path (the dispatcher on the rank's own device)
         per_kind = [len(ids) for ids in plan]
-        # (decode threads: the library's own rule -- the rank's CPUs plus one per context, the issuing threads mostly wait -- unless
-        # --host-threads says otherwise)
         thr_disp = thr if HOST_THREADS_CAP else thr + 4
         tot_e_local, (t_all, t_dec, t_syn) = end_to_end_rank_dispatcher(torch, ctx.device, per_kind, thr_disp)
         if distributed:
             sharding.barrier()
         _, (t_all16, t_dec16, t_syn16) = end_to_end_rank_dispatcher(torch, ctx.device, per_kind, thr_disp, s16=True)
-        # ... and, for comparison with earlier rounds, through the bench's own Python pipeline (float32 residue over the link)
-        if distributed:
-            sharding.barrier()
-        _, (tp_all, tp_dec, tp_syn) = end_to_end_real_streams(ctx, torch, 0, thr, plan=plan)
-        if distributed:
-            sharding.barrier()
-        _, (tp_all16, tp_dec16, tp_syn16) = end_to_end_real_streams(ctx, torch, 0, thr, plan=plan, s16=True)
-        if distributed:
-            tp_all = sharding.max_over_ranks(tp_all, red_device)
-            tp_all16 = sharding.max_over_ranks(tp_all16, red_device)
-        # every rank's own figures, so that a flat 1 -> 8 curve can be put down to the host (entropy decode) or to the
-        # link (synth calls in host memory) at a glance
         rank_ms = sharding.gather_floats([t_all * 1e3, t_dec * 1e3, t_syn * 1e3, t_all16 * 1e3, t_dec16 * 1e3, t_syn16 * 1e3],
                                          red_device)
         if distributed:
@@ -1010,34 +1077,28 @@ def main():
             t_all16 = sharding.max_over_ranks(t_all16, red_device)
         per_rank = [sum(samples[s] for s in range(*sharding.shard_range(TOTAL_REAL_STREAMS, world, r))) * 2
                     for r in range(world)]
-        extras["configs[4] whole job: 1024 real stereo streams (512x 3test.ogg + 512x issue6test.ogg) partitioned over "
-               "%d GPU(s), interleaved out" % world] = {
-            "gpu_stage_Msamples_per_s": round(tot / dt / 1e6, 1), "gpu_stage_ms_per_step_max_over_ranks": round(dt * 1e3, 3),
+        extras["configs[4] whole job: 1024 real stereo streams over %d GPU(s), interleaved out" % world] = {
+            "gpu_stage_Msamples_per_s": round(tot / dt / 1e6, 1), "gpu_stage_ms_per_step": round(dt * 1e3, 3),
             "gpu_stage_frac_of_8TBps_per_gpu": round(8 * tot / world / dt / 1e9 / HBM_PEAK_GBS, 4),
-            "end_to_end_Msamples_per_s": round(tot / t_all / 1e6, 1), "end_to_end_wall_ms_max_over_ranks": round(t_all * 1e3, 2),
-            "end_to_end_s16_Msamples_per_s": round(tot / t_all16 / 1e6, 1),
-            "end_to_end_s16_wall_ms_max_over_ranks": round(t_all16 * 1e3, 2),
+            "end_to_end_Msamples_per_s": round(tot / t_all / 1e6, 1), "end_to_end_ms": round(t_all * 1e3, 2),
+            "end_to_end_s16_Msamples_per_s": round(tot / t_all16 / 1e6, 1), "end_to_end_s16_ms": round(t_all16 * 1e3, 2),
+            "host_threads_per_rank": thr, "samples_per_rank": per_rank,
+            "pcm_checksum": "%016x" % job_sum, "checksum_equals_single_stream_decode": job_sum == expect,
+            "collectives_on_the_data_path": 0,
             "end_to_end_path": "every rank: ONE vpzm_decode_library call on its device (libvorbispizza_host.so: open, entropy decode -- "
-                               "the residue as 16-bit integers where the setup header guarantees them, ABI v5 --, host-memory synth "
-                               "calls on four contexts)",
-            "python_pipeline_end_to_end_Msamples_per_s": round(tot / tp_all / 1e6, 1),
-            "python_pipeline_end_to_end_s16_Msamples_per_s": round(tot / tp_all16 / 1e6, 1),
-            "python_pipeline_note": "the bench's own loop of rounds 2-4 (vpzh_decode_many_progress + host-memory synth calls from "
-                                    "Python on two contexts, float32 residue over the link), kept for comparison",
+                               "int16 residue where the setup header guarantees integers, ABI v5 --, host-memory synth calls on 4 contexts)",
             "per_rank_ms": {"end_to_end_wall": [round(r[0], 2) for r in rank_ms],
                             "cpu_open_and_entropy_decode_wall": [round(r[1], 2) for r in rank_ms],
                             "synth_host_memory_calls_incl_h2d_d2h": [round(r[2], 2) for r in rank_ms],
                             "s16_end_to_end_wall": [round(r[3], 2) for r in rank_ms],
                             "s16_cpu_open_and_entropy_decode_wall": [round(r[4], 2) for r in rank_ms],
                             "s16_synth_host_memory_calls": [round(r[5], 2) for r in rank_ms]},
-            "host_threads_per_rank": thr, "host": host_report(thr), "samples_total": tot, "samples_per_rank": per_rank,
+            "host": host_report(thr), "samples_total": tot,
             "streams_per_rank": [sharding.shard_range(TOTAL_REAL_STREAMS, world, r)[1] -
                                  sharding.shard_range(TOTAL_REAL_STREAMS, world, r)[0] for r in range(world)],
-            "pcm_checksum": "%016x" % job_sum, "checksum_equals_single_stream_decode": job_sum == expect,
-            "scaling": "strong (1024 streams in total)", "collectives_on_the_data_path": 0,
-            "note": "GPU stage: decoded spectra device-resident, best of 3 loops of 5 steps (barrier before, max over ranks after each); end to end: container "
+            "note": "512x 3test.ogg + 512x issue6test.ogg; strong scaling (1024 streams in total).  GPU stage: decoded spectra "
+                    "device-resident, best of 3 loops of 5 steps (barrier before, max over ranks after each); end to end: container "
                     "bytes in host memory -> PCM in host memory incl. CPU entropy decode, best of 3 per rank, max over ranks"}
-    if not args.no_extras:
         # ---------------- the same job in ONE process: rank 0 drives all `world` devices through the in-process dispatcher
         # (include/vorbispizza_multi.h) while the other ranks wait -- both launchers' curves from one driver run
         if distributed:
@@ -1046,26 +1107,23 @@ def main():
             ids = [0] * world if rehearsal else list(range(world))
             thr_all = host_threads(whole_node=True)
             try:
-                # (no --host-threads: the dispatcher counts its decode threads itself -- the CPUs this process may use plus one per context)
-                # (under torchrun the library's own count is this RANK's share of the CPUs: the whole node's is passed instead)
+                # (no --host-threads: the dispatcher counts its decode threads itself -- the CPUs this process may use plus one per
+                # context; under torchrun the library's own count is this RANK's share of the CPUs: the whole node's is passed instead)
                 thr_disp = thr_all if (HOST_THREADS_CAP or world > 1) else None
                 one = dispatcher_whole_job(torch, ids, thr_disp)
                 one16 = dispatcher_whole_job(torch, ids, thr_disp, s16=True, checksum=False)
                 one["checksum_equals_the_per_process_job"] = one.get("pcm_checksum") == "%016x" % job_sum
-                extras["configs[4] whole job in ONE process: the in-process multi-device dispatcher (vpzm_decode_library), "
-                       "%d device(s), container bytes -> float32 PCM in host memory" % world] = one
-                extras["... with 16-bit PCM"] = one16
+                extras["configs[4] job in ONE process (vpzm_decode_library), %d device(s), f32 PCM" % world] = one
+                extras["configs[4] job in ONE process, s16 PCM"] = one16
             except Exception as e:  # (the leg is an extra: its failure must not cost the contract line)
-                extras["configs[4] whole job in ONE process: FAILED"] = repr(e)
+                extras["configs[4] job in ONE process: FAILED"] = repr(e)
         if distributed:
             sharding.barrier()
-    if rank == 0 and extras:
-        result["extra_workloads"] = extras
     ctx.close()
     if distributed:
         sharding.finalize()
     if rank == 0:
-        print(json.dumps(result))
+        emit(result, extras)
 
 
 if __name__ == "__main__":

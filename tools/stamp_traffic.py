@@ -28,7 +28,7 @@ FUSED_SOURCES = ["vorbispizza_amd/csrc/synth_dual.hip", "vorbispizza_amd/csrc/sy
                  "vorbispizza_amd/csrc/vpz_decoder.hip"]
 WORKLOADS = {
     # key: (command after the interpreter, kernel-name substrings, sources, algorithmic bytes or None = parse the log)
-    "headline": (["bench.py", "--steps", "5", "--no-extras", "--no-cpu-baseline"], ["imdct2048_kernel"],
+    "headline": (["tools/kbench.py", "--reps", "5"], ["imdct2048_kernel"],
                  ["vorbispizza_amd/csrc/imdct_fast.hip", "vorbispizza_amd/csrc/imdct_core.hpp"], 65536 * 2 * (4 * 1024 + 4 * 2048)),
     "north_star_line": (["tools/kbench_synth.py", "--which", "olalong", "--steps", "3"], ["synth_dual_kernel<false, false, 0, false"],
                         FUSED_SOURCES, None),
