@@ -83,6 +83,13 @@ struct GenericFrame {
 constexpr int32_t kPreNone = 0;     // the stream has no previous block (first packet / after reset)
 constexpr int32_t kPreState = 1;    // previous block's h is in the decoder's device state
 constexpr int32_t kPreRecompute = 2;// previous block is frame first-1 of this batch: recompute it
+// The stereo fast path only: the previous block is the LAST block of the run that the wavefront before this one in the same
+// workgroup walks (runs r - 1 and r of one stream, back to back, r not the first of its workgroup), and the run's first frame is
+// the steady state (a 2048 block after a 2048 block, long windows on both sides).  Nothing is recomputed: the wave transforms its
+// first frame, parks the lower half of its h in registers, walks the rest of its run, and emits the first frame's PCM LAST -- over
+// the tail the neighbour's last tail save left in ITS LDS rows (a flag per wave in LDS says when that has happened; the
+// neighbour never waits for anybody, so the chain of waits ends at the workgroup's first wave).
+constexpr int32_t kPreNeighbour = 3;
 constexpr uint32_t kRunSaveState = 1u;  // run ends the stream's batch: save h of its last block
 // COMPACT runs: the host uploads two bytes per frame (the packet's window flags and its mapping index) instead of a
 // 32-byte FrameDesc; the wave that owns the run derives its descriptors -- window geometry from the flag pairs,

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     __shared__ float s_work[kDualWaves][2][kWaveBufFloats];   // h of the two blocks being built
     __shared__ float s_tail[kDualWaves][2][kWaveTailFloats];  // upper halves of the previous blocks' h
     __shared__ uint4 s_desc[kDualWaves][(kMaxRunLengthDual + 1) * 2];
+    __shared__ int s_done[kDualWaves];  // kPreNeighbour: wave w has left the last tail of its run in s_tail[w]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     for (int i = threadIdx.x; i < a.size0 / 2 && i < 128; i += kDualThreads) s_slope0[i] = a.slope0[i];
     if (kHasFloor && threadIdx.x < 256) s_db[threadIdx.x] = a.inv_db[threadIdx.x];
     if (threadIdx.x < 8) s_geom[threadIdx.x] = a.geom[threadIdx.x];
+    if (threadIdx.x < kDualWaves) s_done[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 2 * a.n_step_pairs && i < 2 * kGroupMaxStepPairs; i += kDualThreads) s_steps[i] = a.steps[i];
     __syncthreads();
     if (!active) return;  // the only workgroup barrier is behind us: waves run free from here
@@ -231,6 +233,16 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     float *hL = s_work[wave][0], *hR = s_work[wave][1];
     float *tailL = s_tail[wave][0], *tailR = s_tail[wave][1];
     int prev_n4 = 0;  // n/4 of the previous block (0: none yet)
+    // kPreNeighbour: the run's first frame is emitted in one pass more at the end of the loop (see synth_desc.hpp)
+    const bool defer = run.pre_kind == kPreNeighbour && run.count > 0 && wave > 0;
+    float4 stashL0, stashL1, stashR0, stashR1;  // h[0:512) of the deferred frame, both channels
+    stashL0 = stashL1 = stashR0 = stashR1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    bool published = false;
+    auto publish = [&]() {  // this wave's s_tail rows hold the upper half of its run's last block from here on
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&s_done[wave], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        published = true;
+    };
 
     auto size_of = [&](uint32_t flags) -> int { return (flags & kFrameLong) ? a.size1 : a.size0; };
 
@@ -326,6 +338,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     }
     int iters = run.count - fi0 - (int)__popcll(__ballot(batch_member));
     if (VPZ_ABLATE(a) & 64) iters = 0;  // (tuning only: the kernel's prologue and nothing else)
+    const int iters_real = iters;       // passes that transform a block
+    if (defer && iters > 0) ++iters;    // + the pass that emits the deferred first frame
     __builtin_amdgcn_wave_barrier();
     auto frame_from = [&](const uint4 lo, const uint4 hi) -> FrameDesc {  // a descriptor's two LDS words into SGPRs
         FrameDesc fd;
@@ -457,9 +471,11 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         int cpna = 0, cpnb = 0;
         uint2 stwnext;
         bool valid_next;
+        const bool first_deferred = defer && it == 0;            // transform and park: no PCM yet
+        const bool deferred_pass = defer && it == iters_real;     // no transform: the parked frame's PCM
         {
             const bool has_next = fin < run.count;
-            fd_next = frame_at(has_next ? fin : fi);
+            fd_next = frame_at(has_next ? fin : (defer ? 0 : fi));  // (behind the run's last frame: the deferred one again)
             valid_next = has_next && !(fd_next.flags & kFrameDrain) && !(VPZ_ABLATE(a) & 4);  // (4: tuning only, no input loads)
             prefetch(fd_next, valid_next, na, nb, cpna, cpnb);
             stwnext = steps_word(fd_next, valid_next);
@@ -481,8 +497,27 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         // ABI v4: point groups m >= 8 - skip lie beyond the residue's support -- zeros by the setup header's word (their loads
         // stay: the vector is in memory with its zeros; what is saved is the arithmetic).  Halves are all this path looks at.
         const bool upper = ((fd.flags >> kFrameSkipShift) & kFrameSkipMask) < 4;
+        const float *ptL = tailL, *ptR = tailR;  // the previous block's tail: this wave's own rows, or -- deferred pass -- the neighbour's
 
-        if (!drain) {
+        if (deferred_pass) {
+            // the neighbour's last tail save is behind it once its flag is up (it raised it right after; it waits for nobody)
+            // (the bound is a safety net against a hung device should the flag never come up: about a second, then wrong PCM)
+            int spins = 0;
+            while (__hip_atomic_load(&s_done[wave - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 && ++spins < (1 << 23))
+                __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            ptL = s_tail[wave - 1][0];
+            ptR = s_tail[wave - 1][1];
+            prev_n4 = 512;
+            int ls = lane;
+            asm volatile("" : "+v"(ls));
+            float4 *dl = reinterpret_cast<float4 *>(hL), *dr = reinterpret_cast<float4 *>(hR);
+            dl[ls] = stashL0;
+            dl[ls + 64] = stashL1;
+            dr[ls] = stashR0;
+            dr[ls + 64] = stashR1;
+            __builtin_amdgcn_wave_barrier();
+        } else if (!drain) {
             int ln = lane;
             asm volatile("" : "+v"(ln));
             // ---- the two spectra of this lane's points
@@ -693,7 +728,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             }
         };
         const float4 *hL4 = reinterpret_cast<const float4 *>(hL), *hR4 = reinterpret_cast<const float4 *>(hR);
-        const float4 *tL4 = reinterpret_cast<const float4 *>(tailL), *tR4 = reinterpret_cast<const float4 *>(tailR);
+        const float4 *tL4 = reinterpret_cast<const float4 *>(ptL), *tR4 = reinterpret_cast<const float4 *>(ptR);
         int lf = lane;
         asm volatile("" : "+v"(lf));  // (no address of the epilogue may be computed ahead of the frame loop)
         if (VPZ_ABLATE(a) & 1) {
@@ -736,7 +771,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                     }
                 }
             }
-        } else if (fi >= 0 && fd.out_count > 0) {
+        } else if (fi >= 0 && fd.out_count > 0 && !first_deferred) {
             // equal block sizes share one slope table (s_slope0 only holds a 128-entry short slope)
             const float *slope = ((fd.flags & kFrameSlope1) || a.size0 == a.size1) ? s_slope1 : s_slope0;
             const int plen = fd.packet_len;
@@ -804,15 +839,15 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 for (int i = lf; i < fd.out_count; i += 64) {  // [census: cold]
                     float l, r;
                     if (drain) {
-                        l = tail_at(tailL, fd.prev_end + i, prev_n4);
-                        r = tail_at(tailR, fd.prev_end + i, prev_n4);
+                        l = tail_at(ptL, fd.prev_end + i, prev_n4);
+                        r = tail_at(ptR, fd.prev_end + i, prev_n4);
                     } else {
                         l = y_from_h(hL, fd.left_start + i, n4);
                         r = y_from_h(hR, fd.left_start + i, n4);
                         if (i < plen) {
                             const float wl = slope[i], wr = slope[plen - 1 - i];
-                            l = ola(l, wl, tail_at(tailL, fd.prev_end + i, prev_n4), wr);
-                            r = ola(r, wl, tail_at(tailR, fd.prev_end + i, prev_n4), wr);
+                            l = ola(l, wl, tail_at(ptL, fd.prev_end + i, prev_n4), wr);
+                            r = ola(r, wl, tail_at(ptR, fd.prev_end + i, prev_n4), wr);
                         }
                     }
                     emit1(i, l, r);
@@ -821,8 +856,14 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         }
         VPZ_STAMP(5);  // window + overlap-add + stores
         // ---- keep what a later block can overlap with: y[N/2 .. N) lives in the upper half of h
-        if (!drain && !(VPZ_ABLATE(a) & 1024)) {
+        if (!drain && !deferred_pass && !(VPZ_ABLATE(a) & 1024)) {
             __builtin_amdgcn_wave_barrier();
+            if (first_deferred) {  // (a steady frame: a 2048 block) what its PCM needs of h, parked until the run's end
+                stashL0 = hL4[lf];
+                stashL1 = hL4[lf + 64];
+                stashR0 = hR4[lf];
+                stashR1 = hR4[lf + 64];
+            }
             if (is_long) {
                 const float4 *sl = reinterpret_cast<const float4 *>(hL + 512), *sr = reinterpret_cast<const float4 *>(hR + 512);
                 float4 *dl = reinterpret_cast<float4 *>(tailL), *dr = reinterpret_cast<float4 *>(tailR);
@@ -840,6 +881,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             prev_n4 = n4;
             __builtin_amdgcn_wave_barrier();
         }
+        if (it + 1 == iters_real) publish();  // the run's last tail is in place: the next wave of the workgroup may overlap with it
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             va[m] = na[m];
@@ -872,6 +914,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     }
 #endif
 
+    if (!published) publish();  // (a run without passes: nobody may wait for it for ever)
     // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
     if ((run.flags & kRunSaveState) && prev_n4 > 0) {
         float *st = a.state_h + (size_t)(run.state_slot ^ 1) * a.state_slot_floats + (size_t)run.stream * 2 * half1;
@@ -934,6 +977,8 @@ hipError_t launch_synth_dual(const SynthArgs &args, bool has_floor, bool interle
 #undef VPZ_LAUNCH_DUAL
     return hipGetLastError();
 }
+
+int synth_dual_waves() { return kDualWaves; }
 
 // channel-blocks the chip keeps resident and busy under synth_dual_kernel (a wavefront holds two)
 int synth_dual_resident_slots(bool has_floor, int num_cu)

@@ -36,6 +36,7 @@ bool synth_group_supported(int channels);
 bool synth_dual_supported(int channels, int size0, int size1);
 hipError_t launch_synth_dual(const SynthArgs &args, bool has_floor, bool interleaved_in, hipStream_t stream);
 int synth_dual_resident_slots(bool has_floor, int num_cu);
+int synth_dual_waves();
 hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, int half1, float *spec,
                                 const uint8_t *post_counts, const uint8_t *curve_y, const float *inv_db,
                                 hipStream_t stream);
@@ -198,6 +199,8 @@ struct Decoder {
     int32_t f0_stride = 0;
     PacketInfo packet_info[8];  // Mode.GetPacketInfo by (block | prev << 1 | next << 2) == vpz_packet.flags & 7
     int run_length_override = 0;
+    int dual_run = 8;  // preferred run length of the stereo fast path's chained runs (VPZ_DUAL_RUN)
+    bool no_chain = false;  // VPZ_NO_CHAIN=1 (A/B tests): no run of the stereo fast path takes its predecessor's tail over in LDS
     int ablate = 0;  // VPZ_SYNTH_ABLATE, tuning experiments only
     bool no_early_upload = false;  // VPZ_NO_EARLY_UPLOAD=1 (A/B tests): a host-memory call's H2D copies stay behind its host pass
     std::vector<int32_t> packet_samples;  // per packet of the last synth call
@@ -355,6 +358,8 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     static_assert(VPZ_PKT_BLOCK_FLAG == 1 && VPZ_PKT_PREV_FLAG == 2 && VPZ_PKT_NEXT_FLAG == 4, "packet_info index");
     for (int f = 0; f < 8; ++f) D.packet_info[f] = get_packet_info(D.size0, D.size1, f & 1, f & 2, f & 4);
     if (const char *e = getenv("VPZ_RUN_LENGTH")) D.run_length_override = atoi(e);
+    if (const char *e = getenv("VPZ_NO_CHAIN")) D.no_chain = atoi(e) != 0;  // A/B tests: every run recomputes its predecessor block
+    if (const char *e = getenv("VPZ_DUAL_RUN")) D.dual_run = std::max(4, atoi(e));
     if (const char *e = getenv("VPZ_SYNTH_ABLATE")) D.ablate = atoi(e);
     if (const char *e = getenv("VPZ_NO_BATCH")) {  // A/B tests: one short block per pass, runs of equal length
         if (atoi(e)) D.ablate |= 128;
@@ -1381,11 +1386,21 @@ struct SynthCall {
             const int64_t work = (total_units + 7) / 8 * C;
             R = 4;
             int64_t best = -1;
+            // The stereo fast path chains the runs of a workgroup (chain_runs: three of four recompute nothing), and the memory
+            // system delivers more the shorter the runs are -- the launch's waves then sweep the batch round by round instead of
+            // streaming through all of it at once (tools/io_shapes.hip, profiles/r5_io_shapes.txt: 5.05 / 5.5 / 5.7 TB/s for runs of
+            // 32 / 16 / 8 frames with the arithmetic removed): the rounds whose runs come closest to kDualChainRun frames.
+            const int chain_run = D.dual_run;
+            // (batches cut by COST -- streams with short blocks -- keep their long runs: measured, shorter ones lose there, configs[2]
+            // 0.205 -> 0.226 ms and configs[4]'s share 0.258 -> 0.302 at 8 frames, profiles/r5_ab_chain_batches.txt; their runs are
+            // chained all the same)
+            const bool chained = use_dual && compact && D.size1 == 2048 && !D.no_chain && !batches;
             for (int k = 1; k <= 64; ++k) {
                 int64_t r = (work + k * slots - 1) / (k * slots);
                 if (r > r_max) continue;
                 if (r < 4) break;
-                const int64_t cost = (int64_t)k * (r + 1);
+                // (chained: four runs share one recomputed block, and a run length below the preferred one only adds prologues)
+                const int64_t cost = chained ? (r >= chain_run ? 4 * r + 1 : 1000 + (chain_run - r)) : (int64_t)k * (r + 1);
                 if (best < 0 || cost < best) { best = cost; R = (int)r; run_slots = k * slots / C; single_round = k == 1; }
             }
         }
@@ -1591,11 +1606,46 @@ struct SynthCall {
             return;
         }
         if (batches && !reuse) D.cut_hint_runs = (int64_t)n_runs;
+        chain_runs();
         if (getenv("VPZ_HOST_PROFILE"))
             fprintf(stderr, "[vpz host] cut: %s, by %s, R %d, target %lld eighths, %zu runs for %lld slots, %d segments on %d threads, heavy below %lld, "
-                            "hint (frames %lld, runs %lld)\n", reuse ? "hint reused" : "fitted", batches ? "cost" : "length", R,
+                            "hint (frames %lld, runs %lld), chained %lld\n", reuse ? "hint reused" : "fitted", batches ? "cost" : "length", R,
                     (long long)target_units, n_runs, (long long)run_slots, n_segs, parties, (long long)heavy_work,
-                    (long long)D.cut_hint_frames, (long long)D.cut_hint_runs);
+                    (long long)D.cut_hint_frames, (long long)D.cut_hint_runs, (long long)n_chained);
+    }
+
+    // The stereo fast path: runs r - 1 and r of one stream that land in ONE workgroup (the kernel takes run i in wave i mod
+    // kDualWaves of workgroup i / kDualWaves) and meet in the steady state -- a 2048 block after a 2048 block, long windows on
+    // both sides -- are CHAINED: the later one recomputes nothing, it overlaps its first frame with the tail the earlier one
+    // leaves in LDS (kPreNeighbour, synth_desc.hpp).  With three runs of four chained, short runs cost a quarter of what their
+    // recomputed blocks did, and short runs are what the memory system likes (tools/io_shapes.hip: the waves of a launch then
+    // sweep a quarter or an eighth of the batch at a time instead of all of it).
+    int64_t n_chained = 0;
+    void chain_runs()
+    {
+        n_chained = 0;
+        if (!use_dual || !compact || D.size1 != 2048 || D.no_chain) return;
+        for (size_t i = 1; i < n_runs; ++i) {
+            RunDesc &r = runs[i];
+            const RunDesc &pr = runs[i - 1];
+            if (i % (size_t)synth_dual_waves() == 0 || r.pre_kind != kPreRecompute || r.stream != pr.stream || pr.count <= 0 ||
+                r.first != pr.first + pr.count || !(r.flags & kRunCompact) || r.count <= 0)
+                continue;
+            const int64_t q = r.first;
+            if (q <= 0 || packets[q - 1].stream != r.stream) continue;
+            const uint8_t cf = cflags[q], pcf = cflags[q - 1];
+            // frame q: long, long windows on both sides, taken; frame q - 1: long with a long window towards q, taken
+            if ((cf & (7u | kCfSkip)) != 7u || (pcf & (1u | 4u | kCfSkip)) != 5u) continue;
+            if (r.count == 1 && (r.flags & kRunLastTrimmed)) continue;  // (its only frame is the stream's EOS-trimmed last one)
+            r.pre_kind = kPreNeighbour;
+            r.rec_base = (int32_t)(q * C);
+            r.spec_base = packets[q].residue_offset;
+            const PacketInfo &ppi = D.packet_info[packets[q - 1].flags & 7];
+            r.has_prev0 = 1;
+            r.prev_end0 = (uint16_t)ppi.right_start;
+            r.prev_stop0 = (uint16_t)ppi.right_end;
+            ++n_chained;
+        }
     }
 
     // coupling packets: de-interleave + inverse coupling into a planar temp laid out in frame order
