@@ -160,6 +160,9 @@ struct SynthArgs {
     const FrameDesc *frames;    // explicit descriptors (nullptr when every run is compact)
     const uint8_t *cflags;      // compact runs: [frame] flag byte, [frame] mapping index,
     const uint8_t *cmap;
+    const uint8_t *run_inline;  // stereo fast path, compact runs: [run][32] -- flag byte and mapping index of the run's first 16 STAGED
+                                // frames (16 + 16 bytes, zero beyond the run), at an address the wave knows before its run record
+                                // has arrived; nullptr: the bytes are read from cflags / cmap at the run's `first`
     const uint32_t *map_bits;   // [mapping] group-mode flag bits of a floored frame of that mapping (stage / steps)
     PacketGeom geom[8];
     const RunDesc *runs;

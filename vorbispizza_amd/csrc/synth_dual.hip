@@ -186,25 +186,81 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
 #ifdef VPZ_WAVE_TIMES
     const unsigned long long t_wave_begin = __builtin_amdgcn_s_memtime();
 #endif
+    // A compact run's flag bytes, INLINE: 32 bytes per run (flag byte and mapping index of its first 16 staged frames) at an
+    // address that depends on the run's index only -- asked for together with the run record, so that a short run's descriptors
+    // cost ONE trip to the pinned host memory they sit in instead of two in a row (record, then the bytes at its `first`)
+    uint32_t icf = 0, imp = 0;
+    if (a.run_inline != nullptr && lane < 16) {
+        const uint8_t *inl = a.run_inline + (size_t)(active ? run_idx : 0) * 32;
+        icf = inl[lane];
+        imp = inl[16 + lane];
+    }
     RunDesc run = a.runs[active ? run_idx : 0];
     if (!active) {
         run.count = 0;
         run.pre_kind = kPreNone;
         run.flags = 0;
     }
-    // (the run record and a compact run's bytes sit in pinned host memory: asked for ahead of the table staging)
-    const int fi0 = (run.pre_kind == kPreRecompute && run.count > 0) ? -1 : 0;
-    uint32_t cf_early = 0, mp_early = 0;
-    int cc_early = 0;
-    if (run.flags & kRunCompact) {
-        const int n = run.count - fi0, f0 = run.first + fi0;
-        if (lane < n) {
-            cf_early = a.cflags[f0 + lane];
-            mp_early = a.cmap[f0 + lane];
-            if (kHasFloor && a.ccount != nullptr)  // both channels' post counts: records 2p, 2p + 1
-                cc_early = *reinterpret_cast<const uint16_t *>(a.ccount + run.rec_base + lane * 2);
-        }
+    auto size_of = [&](uint32_t flags) -> int { return (flags & kFrameLong) ? a.size1 : a.size0; };
+    // The input of a frame: 32 registers, va[m] | vb[m] = the 16 bytes lane-point m of an interleaved packet comes in
+    // ((L[2k], R[2k]) | (L[2k+1], R[2k+1])), or the point's two 8-byte pairs of a planar one ((L[2k], L[2k+1]) |
+    // (R[2k], R[2k+1])).  Every load is UNCONDITIONAL (a frame that needs no input reads the head of the inverse dB
+    // table): a load under a condition would make the wave wait for it right behind the load (see synth_kernel).
+    // Points of a lane: k = lane + 64 m for a 2048 block; for 256 blocks lane group g = lane >> 3 takes block g of the
+    // pass (block 0 again where the pass has fewer), k = (lane & 7) + 8 m.
+    // The pointers a pass needs once -- the spectra, the inverse dB table (what a frame without input reads), the active posts -- would
+    // be re-loaded from the argument segment once per pass (scalar registers are short; an s_load's wait drains the LDS queue with
+    // it): parked in the lanes of a vector register, fetched with v_readlane_b32 (see synth_kernel).
+    int kv = 0;
+    {
+        const uint64_t sp = reinterpret_cast<uint64_t>(a.spec), db = reinterpret_cast<uint64_t>(a.inv_db);
+        const uint64_t cpp = a.cposts != nullptr ? reinterpret_cast<uint64_t>(a.cposts) : db;
+        const int vals[8] = {(int)(uint32_t)sp, (int)(uint32_t)(sp >> 32), (int)(uint32_t)db, (int)(uint32_t)(db >> 32),
+                             (int)(uint32_t)cpp, (int)(uint32_t)(cpp >> 32), a.cposts != nullptr ? 1 : 0, a.f0_stride};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kv = lane == i ? vals[i] : kv;
+        asm volatile("" : "+v"(kv));
     }
+    auto parked64 = [&](int i) -> uint64_t {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(kv, i + 1) << 32) | (uint32_t)__builtin_amdgcn_readlane(kv, i);
+    };
+    auto prefetch = [&](const FrameDesc &fd, bool valid, float2 (&va)[8], float2 (&vb)[8], int &cpa, int &cpb) {
+        const bool is_long = size_of(fd.flags) == 2048;
+        const int bsz = (int)((fd.flags >> kFrameBatchShift) & 7u) + 1;
+        int l = lane;
+        asm volatile("" : "+v"(l));  // (frame-invariant lane arithmetic stays inside the iteration that uses it)
+        const int g = l >> 3, gg = g < bsz ? g : 0;
+        const VPZ_GLOBAL float *src = valid ? (const VPZ_GLOBAL float *)parked64(0) + fd.spec_off : (const VPZ_GLOBAL float *)parked64(2);
+        if (kIlvIn) {
+            const VPZ_GLOBAL float4 *s4 = (const VPZ_GLOBAL float4 *)src;
+            const int base = !valid ? 0 : (is_long ? l : 64 * gg + (l & 7));
+            const int step = !valid ? 0 : (is_long ? 64 : 8);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float4 v = s4[base + step * m];
+                va[m] = make_float2(v.x, v.y);
+                vb[m] = make_float2(v.z, v.w);
+            }
+        } else {
+            const VPZ_GLOBAL float2 *s2 = (const VPZ_GLOBAL float2 *)src;
+            // block gg of the pass: its L row at + gg * 2 * 128 floats, its R row half a packet further on
+            const int base = !valid ? 0 : (is_long ? l : 128 * gg + (l & 7));
+            const int step = !valid ? 0 : (is_long ? 64 : 8);
+            const int rofs = !valid ? 0 : (is_long ? 512 : 64);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                va[m] = s2[base + step * m];
+                vb[m] = s2[base + step * m + rofs];
+            }
+        }
+        if (kHasFloor) {
+            const bool floored = valid && !(fd.flags & kFrameNoFloor) && __builtin_amdgcn_readlane(kv, 6) != 0;  // (a.cposts != nullptr)
+            const VPZ_GLOBAL int32_t *cp = (const VPZ_GLOBAL int32_t *)parked64(4);  // (the posts, or the table's head)
+            const size_t rec = floored ? (size_t)fd.rec : 0;
+            cpa = cp[rec * 64 + l];
+            cpb = cp[(floored ? rec + 1 : 0) * 64 + l];
+        }
+    };
     {
         const bool has_long = a.size1 == 2048 || a.size0 == 2048;
         const bool has_short = a.size0 == 256 || a.size1 == 256;
@@ -226,6 +282,37 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     if (threadIdx.x < 8) s_geom[threadIdx.x] = a.geom[threadIdx.x];
     if (threadIdx.x < kDualWaves) s_done[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 2 * a.n_step_pairs && i < 2 * kGroupMaxStepPairs; i += kDualThreads) s_steps[i] = a.steps[i];
+    // ---- what depends on the run record (pinned host memory: one trip, under way since the kernel's first instructions)
+    const int fi0 = (run.pre_kind == kPreRecompute && run.count > 0) ? -1 : 0;
+    uint32_t cf_early = 0, mp_early = 0;
+    int cc_early = 0;
+    float2 va[8], vb[8];
+    int cpa = 0, cpb = 0;
+    bool early_input = false;  // the first staged frame's input is under way already
+    if (run.flags & kRunCompact) {
+        const int n = run.count - fi0, f0 = run.first + fi0;
+        if (a.run_inline != nullptr && n <= 16) {
+            cf_early = icf;  // (zero beyond the run's frames, like the lanes the other branch leaves alone)
+            mp_early = imp;
+        } else if (lane < n) {
+            cf_early = a.cflags[f0 + lane];
+            mp_early = a.cmap[f0 + lane];
+        }
+        if (lane < n && kHasFloor && a.ccount != nullptr)  // both channels' post counts: records 2p, 2p + 1
+            cc_early = *reinterpret_cast<const uint16_t *>(a.ccount + run.rec_base + lane * 2);
+        // The first staged frame of a run that starts with a 2048 block: its input is asked for HERE, ahead of the barrier and of
+        // the descriptors' derivation (its place is the run's spec_base, its records the run's rec_base whatever the other
+        // frames are; a short first frame may head a batch of blocks, which only the derivation knows)
+        const uint32_t cf0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cf_early);
+        if (n > 0 && (cf0 & 1u) && !(cf0 & kCfSkip) && a.size1 == 2048) {
+            FrameDesc fd0{};
+            fd0.spec_off = run.spec_base;
+            fd0.rec = run.rec_base;
+            fd0.flags = kFrameLong | ((cf0 & kCfNoFloor) ? kFrameNoFloor : 0u);
+            prefetch(fd0, true, va, vb, cpa, cpb);
+            early_input = true;
+        }
+    }
     __syncthreads();
     if (!active) return;  // the only workgroup barrier is behind us: waves run free from here
 
@@ -243,8 +330,6 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         if (lane == 0) __hip_atomic_store(&s_done[wave], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         published = true;
     };
-
-    auto size_of = [&](uint32_t flags) -> int { return (flags & kFrameLong) ? a.size1 : a.size0; };
 
     // ---- the run's frame descriptors into LDS (explicit ones copied, a compact run's derived here)
     bool batch_member = false;
@@ -378,76 +463,15 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     }
     float clip_peak = 0.0f;
 
-    // The input of a frame: 32 registers, va[m] | vb[m] = the 16 bytes lane-point m of an interleaved packet comes in
-    // ((L[2k], R[2k]) | (L[2k+1], R[2k+1])), or the point's two 8-byte pairs of a planar one ((L[2k], L[2k+1]) |
-    // (R[2k], R[2k+1])).  Every load is UNCONDITIONAL (a frame that needs no input reads the head of the inverse dB
-    // table): a load under a condition would make the wave wait for it right behind the load (see synth_kernel).
-    // Points of a lane: k = lane + 64 m for a 2048 block; for 256 blocks lane group g = lane >> 3 takes block g of the
-    // pass (block 0 again where the pass has fewer), k = (lane & 7) + 8 m.
-    // The pointers a pass needs once -- the spectra, the inverse dB table (what a frame without input reads), the active posts -- would
-    // be re-loaded from the argument segment once per pass (scalar registers are short; an s_load's wait drains the LDS queue with
-    // it): parked in the lanes of a vector register, fetched with v_readlane_b32 (see synth_kernel).
-    int kv = 0;
-    {
-        const uint64_t sp = reinterpret_cast<uint64_t>(a.spec), db = reinterpret_cast<uint64_t>(a.inv_db);
-        const uint64_t cpp = a.cposts != nullptr ? reinterpret_cast<uint64_t>(a.cposts) : db;
-        const int vals[8] = {(int)(uint32_t)sp, (int)(uint32_t)(sp >> 32), (int)(uint32_t)db, (int)(uint32_t)(db >> 32),
-                             (int)(uint32_t)cpp, (int)(uint32_t)(cpp >> 32), a.cposts != nullptr ? 1 : 0, a.f0_stride};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) kv = lane == i ? vals[i] : kv;
-        asm volatile("" : "+v"(kv));
-    }
-    auto parked64 = [&](int i) -> uint64_t {
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(kv, i + 1) << 32) | (uint32_t)__builtin_amdgcn_readlane(kv, i);
-    };
-    auto prefetch = [&](const FrameDesc &fd, bool valid, float2 (&va)[8], float2 (&vb)[8], int &cpa, int &cpb) {
-        const bool is_long = size_of(fd.flags) == 2048;
-        const int bsz = (int)((fd.flags >> kFrameBatchShift) & 7u) + 1;
-        int l = lane;
-        asm volatile("" : "+v"(l));  // (frame-invariant lane arithmetic stays inside the iteration that uses it)
-        const int g = l >> 3, gg = g < bsz ? g : 0;
-        const VPZ_GLOBAL float *src = valid ? (const VPZ_GLOBAL float *)parked64(0) + fd.spec_off : (const VPZ_GLOBAL float *)parked64(2);
-        if (kIlvIn) {
-            const VPZ_GLOBAL float4 *s4 = (const VPZ_GLOBAL float4 *)src;
-            const int base = !valid ? 0 : (is_long ? l : 64 * gg + (l & 7));
-            const int step = !valid ? 0 : (is_long ? 64 : 8);
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const float4 v = s4[base + step * m];
-                va[m] = make_float2(v.x, v.y);
-                vb[m] = make_float2(v.z, v.w);
-            }
-        } else {
-            const VPZ_GLOBAL float2 *s2 = (const VPZ_GLOBAL float2 *)src;
-            // block gg of the pass: its L row at + gg * 2 * 128 floats, its R row half a packet further on
-            const int base = !valid ? 0 : (is_long ? l : 128 * gg + (l & 7));
-            const int step = !valid ? 0 : (is_long ? 64 : 8);
-            const int rofs = !valid ? 0 : (is_long ? 512 : 64);
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                va[m] = s2[base + step * m];
-                vb[m] = s2[base + step * m + rofs];
-            }
-        }
-        if (kHasFloor) {
-            const bool floored = valid && !(fd.flags & kFrameNoFloor) && __builtin_amdgcn_readlane(kv, 6) != 0;  // (a.cposts != nullptr)
-            const VPZ_GLOBAL int32_t *cp = (const VPZ_GLOBAL int32_t *)parked64(4);  // (the posts, or the table's head)
-            const size_t rec = floored ? (size_t)fd.rec : 0;
-            cpa = cp[rec * 64 + l];
-            cpb = cp[(floored ? rec + 1 : 0) * 64 + l];
-        }
-    };
     // the first four coupling steps of a frame's mapping, read a frame ahead like the input
     auto steps_word = [&](const FrameDesc &fd, bool valid) -> uint2 {
         const uint32_t off = valid ? 2u * ((fd.flags >> kFrameStepsOffShift) & kFrameStepsOffMask) : 0u;
         return *reinterpret_cast<const uint2 *>(s_steps + (off < 2u * kGroupMaxStepPairs ? off : 0u));
     };
 
-    float2 va[8], vb[8];
-    int cpa = 0, cpb = 0;
     FrameDesc fd_next = frame_at(fi0);
     bool valid_cur = run.count > 0 && !(fd_next.flags & kFrameDrain);
-    prefetch(fd_next, valid_cur, va, vb, cpa, cpb);
+    if (!early_input) prefetch(fd_next, valid_cur, va, vb, cpa, cpb);
     uint2 stwcur = steps_word(fd_next, valid_cur);
     // the first frame's input has to be there before the loop is entered (see synth_kernel: wait-count bookkeeping)
 #pragma unroll

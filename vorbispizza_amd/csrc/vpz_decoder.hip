@@ -200,6 +200,7 @@ struct Decoder {
     PacketInfo packet_info[8];  // Mode.GetPacketInfo by (block | prev << 1 | next << 2) == vpz_packet.flags & 7
     int run_length_override = 0;
     int dual_run = 8;  // preferred run length of the stereo fast path's chained runs (VPZ_DUAL_RUN)
+    bool no_run_inline = false;
     bool no_chain = false;  // VPZ_NO_CHAIN=1 (A/B tests): no run of the stereo fast path takes its predecessor's tail over in LDS
     int ablate = 0;  // VPZ_SYNTH_ABLATE, tuning experiments only
     bool no_early_upload = false;  // VPZ_NO_EARLY_UPLOAD=1 (A/B tests): a host-memory call's H2D copies stay behind its host pass
@@ -358,6 +359,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     static_assert(VPZ_PKT_BLOCK_FLAG == 1 && VPZ_PKT_PREV_FLAG == 2 && VPZ_PKT_NEXT_FLAG == 4, "packet_info index");
     for (int f = 0; f < 8; ++f) D.packet_info[f] = get_packet_info(D.size0, D.size1, f & 1, f & 2, f & 4);
     if (const char *e = getenv("VPZ_RUN_LENGTH")) D.run_length_override = atoi(e);
+    if (const char *e = getenv("VPZ_NO_RUN_INLINE")) D.no_run_inline = atoi(e) != 0;  // A/B tests: flag bytes from cflags / cmap only
     if (const char *e = getenv("VPZ_NO_CHAIN")) D.no_chain = atoi(e) != 0;  // A/B tests: every run recomputes its predecessor block
     if (const char *e = getenv("VPZ_DUAL_RUN")) D.dual_run = std::max(4, atoi(e));
     if (const char *e = getenv("VPZ_SYNTH_ABLATE")) D.ablate = atoi(e);
@@ -677,6 +679,7 @@ struct SynthCall {
     bool align2_ok = true;        // every packet starts on an 8-byte boundary (planar packets are read 8 bytes at a time)
     bool compact = false;         // every run compact: two bytes per frame instead of a FrameDesc (parallel pass only)
     uint8_t *cflags = nullptr, *cmap = nullptr;
+    uint8_t *run_inline = nullptr;  // [run][32]: the flag bytes of a run's first 16 staged frames (SynthArgs.run_inline)
     int64_t mismatches = 0, res_extent = 0;
     // ---- descriptor tables (pinned arena; dev() gives the device mirror's address)
     RunDesc *runs = nullptr;
@@ -742,7 +745,7 @@ struct SynthCall {
         for (uint8_t t : D.floor_types) has_floor0_type |= (t == 0);
         const size_t np = (size_t)n_packets;
         // (runs hold >= 3 frames unless VPZ_RUN_LENGTH says otherwise: see cut_runs)
-        size_t need = (sizeof(FrameDesc) + (D.run_length_override > 0 ? sizeof(RunDesc) : sizeof(RunDesc) / 2) + 2 +
+        size_t need = (sizeof(FrameDesc) + (D.run_length_override > 0 ? sizeof(RunDesc) + 32 : sizeof(RunDesc) / 2 + 16) + 2 +
                        coupling_packet_size()) * np +
                       sizeof(RunDesc) * ((size_t)D.n_streams + 1 + 4 * 64) + (have_posts ? (size_t)n_rec : 0) +  // (+ the pieces of long streams)
                       sizeof(int64_t) * (size_t)D.n_streams + 4096;
@@ -1512,7 +1515,74 @@ struct SynthCall {
             D.cut_hint_frames = total_frames;
             D.cut_hint_streams = D.n_streams;
         }
-        std::vector<std::vector<RunDesc>> cut(parties);
+        // the run of segment g (stream s, its packets from `base` on) that starts f0 frames into the segment and holds len frames
+        auto make_run = [&](int g, int f0, int len) -> RunDesc {
+            const int s = segs[g].stream, seg_off = segs[g].off;
+            const int base = (int)D.s_base[s] + seg_off;
+            const int stream_cnt = (int)D.s_cnt[s];
+            RunDesc r{};
+            r.first = base + f0;
+            r.count = len;
+            r.stream = s;
+            if (seg_off + f0 == 0) {
+                r.pre_kind = started_with_prev[s] ? kPreState : kPreNone;
+                r.prev_long = started_prev_long[s];
+            } else {
+                r.pre_kind = kPreRecompute;
+            }
+            const bool last = seg_off + f0 + len >= stream_cnt;
+            if (last) r.flags |= kRunSaveState;
+            r.clip_epoch = D.states[s].clip_epoch;
+            r.state_slot = D.states[s].state_slot;
+            if (compact) {
+                r.flags |= kRunCompact;
+                const int64_t q = (int64_t)r.first + (r.pre_kind == kPreRecompute ? -1 : 0);  // first staged frame
+                r.rec_base = (int32_t)(q * C);
+                r.spec_base = packets[q].residue_offset;
+                r.out_base = D.out_off_scratch[(size_t)r.first];
+                if (q > 0 && packets[q - 1].stream == s) {
+                    const PacketInfo &ppi = D.packet_info[packets[q - 1].flags & 7];
+                    r.has_prev0 = 1;
+                    r.prev_end0 = (uint16_t)ppi.right_start;
+                    r.prev_stop0 = (uint16_t)ppi.right_end;
+                } else {
+                    const StreamState &S0 = D.states[s];
+                    r.has_prev0 = S0.has_prev ? 1 : 0;
+                    r.prev_end0 = (uint16_t)S0.prev_end;
+                    r.prev_stop0 = (uint16_t)S0.prev_stop;
+                }
+                if (last && D.trim_out_count[s] >= 0) {  // the stream's last frame was cut by the EOS trim
+                    r.flags |= kRunLastTrimmed;
+                    r.last_out_count = (uint16_t)D.trim_out_count[s];
+                    r.last_left_start = (uint16_t)D.trim_left_start[s];
+                }
+            }
+            return r;
+        };
+        // Runs of equal LENGTH: the k-th run of a segment is its frames [k R, (k + 1) R) -- every run's place is known in advance,
+        // so a large batch is filled in by the host pool, every thread its share of the run indices (thousands of runs of 8 frames
+        // were 85 us on one thread: as long as the kernel takes for a third of them)
+        const bool by_length_wide = !batches && !skew_frames && pool && pool->parties() > 1 && total_frames / std::max(1, R) >= 1024;
+        if (by_length_wide) {
+            std::vector<int64_t> &seg_first = D.cut_prefix;
+            seg_first.assign((size_t)n_segs + 1, 0);
+            for (int g = 0; g < n_segs; ++g) seg_first[(size_t)g + 1] = seg_first[(size_t)g] + (segs[g].cnt + R - 1) / R;
+            const int64_t total_runs = seg_first[(size_t)n_segs];
+            if ((size_t)total_runs > runs_cap) { host_failed = true; n_runs = 0; return; }
+            const int P = pool->parties();
+            host_failed |= !pool->run([&](int c) {
+                const int64_t lo = total_runs * c / P, hi = total_runs * (c + 1) / P;
+                int g = (int)(std::upper_bound(seg_first.begin(), seg_first.end(), lo) - seg_first.begin()) - 1;
+                for (int64_t i = lo; i < hi; ++i) {
+                    while (i >= seg_first[(size_t)g + 1]) ++g;
+                    const int f0 = (int)(i - seg_first[(size_t)g]) * R;
+                    runs[i] = make_run(g, f0, std::min(R, segs[g].cnt - f0));
+                }
+            });
+            if (host_failed) { n_runs = 0; return; }
+            n_runs = (size_t)total_runs;
+        }
+        std::vector<std::vector<RunDesc>> cut(by_length_wide ? 0 : parties);
         auto cut_streams = [&](int c) {
           int s_lo, s_hi;
           seg_range(c, s_lo, s_hi);
@@ -1527,7 +1597,6 @@ struct SynthCall {
           for (int g = s_lo; g < s_hi; ++g) {
             const int s = segs[g].stream, seg_off = segs[g].off;
             const int cnt = segs[g].cnt, base = (int)D.s_base[s] + seg_off;  // (f0 below counts from the segment's start)
-            const int stream_cnt = (int)D.s_cnt[s];
             if (reuse) {  // (the codes of this segment's packets, skipped with the counting pass)
                 bool prev_ok = false;
                 for (int64_t p = base, e = (int64_t)base + cnt; p < e; ++p) {
@@ -1542,43 +1611,7 @@ struct SynthCall {
                 // (runs of equal LENGTH: the skew is a frame more in the first half of the frames, a frame less in the second)
                 const int len = batches ? run_length(base, f0, cnt, target_at(g, before, target_units), run_units)
                                         : std::min(R + (skew_frames ? ((int64_t)base + f0 < heavy_frames ? 1 : -1) : 0), cnt - f0);
-                RunDesc r{};
-                r.first = base + f0;
-                r.count = len;
-                r.stream = s;
-                if (seg_off + f0 == 0) {
-                    r.pre_kind = started_with_prev[s] ? kPreState : kPreNone;
-                    r.prev_long = started_prev_long[s];
-                } else {
-                    r.pre_kind = kPreRecompute;
-                }
-                const bool last = seg_off + f0 + len >= stream_cnt;
-                if (last) r.flags |= kRunSaveState;
-                r.clip_epoch = D.states[s].clip_epoch;
-                r.state_slot = D.states[s].state_slot;
-                if (compact) {
-                    r.flags |= kRunCompact;
-                    const int64_t q = (int64_t)r.first + (r.pre_kind == kPreRecompute ? -1 : 0);  // first staged frame
-                    r.rec_base = (int32_t)(q * C);
-                    r.spec_base = packets[q].residue_offset;
-                    r.out_base = D.out_off_scratch[(size_t)r.first];
-                    if (q > 0 && packets[q - 1].stream == s) {
-                        const PacketInfo &ppi = D.packet_info[packets[q - 1].flags & 7];
-                        r.has_prev0 = 1;
-                        r.prev_end0 = (uint16_t)ppi.right_start;
-                        r.prev_stop0 = (uint16_t)ppi.right_end;
-                    } else {
-                        const StreamState &S0 = D.states[s];
-                        r.has_prev0 = S0.has_prev ? 1 : 0;
-                        r.prev_end0 = (uint16_t)S0.prev_end;
-                        r.prev_stop0 = (uint16_t)S0.prev_stop;
-                    }
-                    if (last && D.trim_out_count[s] >= 0) {  // the stream's last frame was cut by the EOS trim
-                        r.flags |= kRunLastTrimmed;
-                        r.last_out_count = (uint16_t)D.trim_out_count[s];
-                        r.last_left_start = (uint16_t)D.trim_left_start[s];
-                    }
-                }
+                const RunDesc r = make_run(g, f0, len);
                 if (parties > 1) mine.push_back(r);
                 else if (n_runs < runs_cap) runs[n_runs++] = r;
                 else { host_failed = true; return; }
@@ -1586,7 +1619,9 @@ struct SynthCall {
             }
           }
         };
-        if (parties > 1) {
+        if (by_length_wide) {
+            // (filled in above)
+        } else if (parties > 1) {
             host_failed |= !pool->run(cut_streams);
             if (host_failed) { n_runs = 0; return; }
             for (const std::vector<RunDesc> &v : cut) {
@@ -1606,6 +1641,7 @@ struct SynthCall {
             return;
         }
         if (batches && !reuse) D.cut_hint_runs = (int64_t)n_runs;
+        cut_R = R;
         chain_runs();
         if (getenv("VPZ_HOST_PROFILE"))
             fprintf(stderr, "[vpz host] cut: %s, by %s, R %d, target %lld eighths, %zu runs for %lld slots, %d segments on %d threads, heavy below %lld, "
@@ -1621,30 +1657,70 @@ struct SynthCall {
     // recomputed blocks did, and short runs are what the memory system likes (tools/io_shapes.hip: the waves of a launch then
     // sweep a quarter or an eighth of the batch at a time instead of all of it).
     int64_t n_chained = 0;
+    int cut_R = 0;  // the run length (or cost target, in passes) cut_runs settled on
     void chain_runs()
     {
         n_chained = 0;
         if (!use_dual || !compact || D.size1 != 2048 || D.no_chain) return;
-        for (size_t i = 1; i < n_runs; ++i) {
-            RunDesc &r = runs[i];
-            const RunDesc &pr = runs[i - 1];
-            if (i % (size_t)synth_dual_waves() == 0 || r.pre_kind != kPreRecompute || r.stream != pr.stream || pr.count <= 0 ||
-                r.first != pr.first + pr.count || !(r.flags & kRunCompact) || r.count <= 0)
-                continue;
-            const int64_t q = r.first;
-            if (q <= 0 || packets[q - 1].stream != r.stream) continue;
-            const uint8_t cf = cflags[q], pcf = cflags[q - 1];
-            // frame q: long, long windows on both sides, taken; frame q - 1: long with a long window towards q, taken
-            if ((cf & (7u | kCfSkip)) != 7u || (pcf & (1u | 4u | kCfSkip)) != 5u) continue;
-            if (r.count == 1 && (r.flags & kRunLastTrimmed)) continue;  // (its only frame is the stream's EOS-trimmed last one)
-            r.pre_kind = kPreNeighbour;
-            r.rec_base = (int32_t)(q * C);
-            r.spec_base = packets[q].residue_offset;
-            const PacketInfo &ppi = D.packet_info[packets[q - 1].flags & 7];
-            r.has_prev0 = 1;
-            r.prev_end0 = (uint16_t)ppi.right_start;
-            r.prev_stop0 = (uint16_t)ppi.right_end;
-            ++n_chained;
+        const size_t waves = (size_t)synth_dual_waves();
+        // (a run looks at its predecessor's place and length only -- what the chaining never changes: any split of the runs works)
+        auto chain_range = [&](size_t lo, size_t hi) -> int64_t {
+            int64_t n = 0;
+            for (size_t i = std::max<size_t>(lo, 1); i < hi; ++i) {
+                RunDesc &r = runs[i];
+                const RunDesc &pr = runs[i - 1];
+                if (i % waves == 0 || r.pre_kind != kPreRecompute || r.stream != pr.stream || pr.count <= 0 ||
+                    r.first != pr.first + pr.count || !(r.flags & kRunCompact) || r.count <= 0)
+                    continue;
+                const int64_t q = r.first;
+                if (q <= 0 || packets[q - 1].stream != r.stream) continue;
+                const uint8_t cf = cflags[q], pcf = cflags[q - 1];
+                // frame q: long, long windows on both sides, taken; frame q - 1: long with a long window towards q, taken
+                if ((cf & (7u | kCfSkip)) != 7u || (pcf & (1u | 4u | kCfSkip)) != 5u) continue;
+                if (r.count == 1 && (r.flags & kRunLastTrimmed)) continue;  // (its only frame is the stream's EOS-trimmed last one)
+                r.pre_kind = kPreNeighbour;
+                r.rec_base = (int32_t)(q * C);
+                r.spec_base = packets[q].residue_offset;
+                const PacketInfo &ppi = D.packet_info[packets[q - 1].flags & 7];
+                r.has_prev0 = 1;
+                r.prev_end0 = (uint16_t)ppi.right_start;
+                r.prev_stop0 = (uint16_t)ppi.right_end;
+                ++n;
+            }
+            return n;
+        };
+        // the runs' flag bytes inline (SynthArgs.run_inline): one trip to the pinned arena per run instead of two
+        // (only where runs are short enough to use them: the kernel takes the bytes of a run of up to 16 staged frames inline)
+        const bool want_inline = cut_R > 0 && cut_R + 1 <= 16;
+        run_inline = want_inline ? arena_alloc<uint8_t>(*A, 32 * n_runs + 32) : nullptr;
+        auto inline_range = [&](size_t lo, size_t hi) {
+            for (size_t i = lo; want_inline && i < hi; ++i) {
+                const RunDesc &r = runs[i];
+                uint8_t *dst = run_inline + 32 * i;
+                memset(dst, 0, 32);
+                if (!(r.flags & kRunCompact)) continue;
+                const int64_t q = (int64_t)r.first + (r.pre_kind == kPreRecompute ? -1 : 0);
+                const int n = std::min(16, r.count + (r.pre_kind == kPreRecompute ? 1 : 0));
+                for (int j = 0; j < n; ++j) {
+                    dst[j] = cflags[q + j];
+                    dst[16 + j] = cmap[q + j];
+                }
+            }
+        };
+        // (one sweep does both: a run's bytes depend on its own record only, its chaining on its predecessor's place and length)
+        HostPool *pool = static_cast<HostPool *>(ctx->host_pool);
+        if (pool && pool->parties() > 1 && n_runs >= 4096) {
+            const int P = pool->parties();
+            std::vector<int64_t> part((size_t)P, 0);
+            host_failed |= !pool->run([&](int c) {
+                const size_t lo = n_runs * (size_t)c / P, hi = n_runs * (size_t)(c + 1) / P;
+                part[(size_t)c] = chain_range(lo, hi);
+                inline_range(lo, hi);
+            });
+            for (int64_t v : part) n_chained += v;
+        } else {
+            n_chained = chain_range(0, n_runs);
+            inline_range(0, n_runs);
         }
     }
 
@@ -1967,6 +2043,7 @@ struct SynthCall {
         a.frames = static_cast<const FrameDesc *>(dev(frames));
         a.cflags = static_cast<const uint8_t *>(dev(cflags));
         a.cmap = static_cast<const uint8_t *>(dev(cmap));
+        a.run_inline = (use_dual && !D.no_run_inline) ? static_cast<const uint8_t *>(dev(run_inline)) : nullptr;
         a.map_bits = D.d_map_bits;
         for (int f = 0; f < 8; ++f) {
             const PacketInfo &pi = D.packet_info[f];
