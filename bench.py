@@ -594,13 +594,13 @@ def dispatcher_whole_job(torch, device_ids, threads, s16=False, repeats=3, strea
                 best = (stats.wall_s, [round(stats.device_wall_s[g] * 1e3, 2) for g in range(min(n, 16))],
                         [round(stats.device_decode_s[g] * 1e3, 2) for g in range(min(n, 16))],
                         [round(stats.device_synth_s[g] * 1e3, 2) for g in range(min(n, 16))],
-                        [int(stats.device_streams[g]) for g in range(min(n, 16))], stats.threads_per_device)
+                        [int(stats.device_streams[g]) for g in range(min(n, 16))], stats.threads_per_device, int(stats.pinned_mib))
     finally:
         d.close()
     tot = int(results["samples"].sum()) * 2
     out = {"Msamples_per_s": round(tot / best[0] / 1e6, 1), "wall_ms": round(best[0] * 1e3, 2), "devices": list(device_ids),
            "per_device_ms": {"wall": best[1], "until_last_stream_entropy_decoded": best[2], "summed_synth_calls": best[3]},
-           "streams_per_device": best[4],
+           "streams_per_device": best[4], "decode_threads_per_device": best[5], "page_locked_slot_memory_MiB": best[6],
            "host": dict(host_report(threads if threads else host_threads(whole_node=True)), decode_threads_per_device=best[5]),
            "pcm": "int16" if s16 else "float32", "collectives_on_the_data_path": 0, "samples_total": tot}
     if checksum and not s16:

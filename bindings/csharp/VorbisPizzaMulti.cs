@@ -44,7 +44,7 @@ namespace NVorbis.Native
             public fixed double DeviceSynthS[16];
             public fixed long DeviceStreams[16];
             public fixed long DeviceSamples[16];
-            public int ThreadsPerDevice, Reserved;
+            public int ThreadsPerDevice, PinnedMib;
         }
 
         public sealed class DispatcherHandle : SafeHandle

@@ -15,7 +15,7 @@ namespace NVorbis.Native
     internal static unsafe class VorbisPizzaSynth
     {
         private const string Lib = "vorbispizza_synth";              // libvorbispizza_synth.so
-        public const int AbiVersion = 5;
+        public const int AbiVersion = 6;
 
         // status codes (vorbispizza_synth.h), mapped to exceptions by ThrowOnError below the way
         // NativeDecoder.cs:145-161 maps OV_*
@@ -144,6 +144,7 @@ namespace NVorbis.Native
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_decoder_set_residue_format(DecoderHandle decoder, int format);
         // output areas of different sizes in one batch: capacity[s] tightens stream_out_capacity for stream s; (null, 0) removes the bounds
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_decoder_set_stream_capacities(DecoderHandle decoder, long* capacity, int n);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int vpz_decoder_set_host_threads(DecoderHandle decoder, int n);
 
         /// <summary>Status code to the exception the reference throws for the same condition.</summary>
         public static void ThrowOnError(int status, ContextHandle? ctx, string what)

@@ -74,7 +74,8 @@ typedef struct vpzm_stats {
     int64_t device_streams[16];
     int64_t device_samples[16];   /* samples x channels produced */
     int32_t threads_per_device;
-    int32_t reserved;
+    int32_t pinned_mib;           /* page-locked host memory the dispatcher's slots hold after this call, all groups, in MiB: it grows to
+                                     slots_per_device sub-batches of the largest size seen per group and is kept until vpzm_destroy */
 } vpzm_stats;
 
 /* Decodes containers 0..n-1 (first logical stream of each) to interleaved PCM in host memory: stream k's sample s of

@@ -27,14 +27,16 @@
 extern "C" {
 #endif
 
-#define VPZ_ABI_VERSION 5   /* 2: s16 output layouts, VPZ_PKT_RESYNC, vpz_decoder_set_position; structs unchanged
+#define VPZ_ABI_VERSION 6   /* 2: s16 output layouts, VPZ_PKT_RESYNC, vpz_decoder_set_position; structs unchanged
                                3: vpz_decoder_synth takes the extents of its input buffers (residue_floats, n_records) and
                                   reports a window mismatch per packet (vpz_decoder_last_packet_status) instead of failing
                                   the batch; structs unchanged
                                4: vpz_mapping_config carries the residue's support (residue_begin / residue_end, what
                                   Residue0.cs:122-125 clamps every decode to): the kernels neither load nor de-couple nor
                                   floor-multiply the bins the setup header says are zero.  The struct grew by 16 bytes
-                               5: vpz_decoder_set_residue_format: the residue may be handed over as 16-bit integers */
+                               5: vpz_decoder_set_residue_format: the residue may be handed over as 16-bit integers
+                               6: vpz_decoder_set_host_threads: the host that runs several decoders at once gives each its share of
+                                  the host's threads.  Nothing else changed: a v5 caller works unchanged */
 
 /* ---- status codes (negative like the OV_* codes, Vorbisfile.cs:10-24) ---- */
 #define VPZ_OK                 0
@@ -86,7 +88,9 @@ int vpz_context_timer_stop(vpz_context *ctx, float *elapsed_ms);
 int vpz_device_alloc(vpz_context *ctx, uint64_t bytes, void **dev_ptr);
 int vpz_device_free(vpz_context *ctx, void *dev_ptr);
 /* Page-locked host memory (ABI v4): VPZ_MEM_HOST calls copy from / to it at the link's full rate and asynchronously; any
- * other host memory works too, through the runtime's staging.  Usable from every context of the process. */
+ * other host memory works too, through the runtime's staging.  Usable from every context of the process.  These two calls
+ * are the exception to "one thread at a time per context": they write nothing of the context (no error text either -- the
+ * status is all there is) and may run while another thread is inside a call on it. */
 int vpz_host_alloc(vpz_context *ctx, uint64_t bytes, void **host_ptr);
 int vpz_host_free(vpz_context *ctx, void *host_ptr);
 int vpz_memcpy_h2d(vpz_context *ctx, void *dev_dst, const void *host_src, uint64_t bytes);
@@ -281,6 +285,15 @@ int vpz_decoder_set_residue_format(vpz_decoder *dec, int32_t format);
  * samples per channel, a call that would produce more fails with VPZ_E_CAPACITY before anything is written or any state
  * changes.  n must be the decoder's stream count; (NULL, 0) removes the per-stream bounds again. */
 int vpz_decoder_set_stream_capacities(vpz_decoder *dec, const int64_t *capacity, int32_t n);
+
+/* Host threads the integer half of this decoder's synth calls may use (ABI v6): the state machine of a large batch -- the
+ * restatement of StreamDecoder.ReadNextPacket / Read, packet by packet -- is split over a small pool of host threads owned by the
+ * decoder's context.  n = 0 (the default): the CPUs the process may run on (affinity mask, divided by LOCAL_WORLD_SIZE), at most
+ * 16; n = 1: no pool, everything on the calling thread; n > 1: that many (at most 16).  A host that drives several contexts at
+ * once (one thread per context, like the reference's one StreamDecoder per thread, VorbisReader.cs:56-85) gives each decoder
+ * its share here -- otherwise every context would start a pool of its own for the whole machine.  The result of a synth call
+ * does not depend on the value. */
+int vpz_decoder_set_host_threads(vpz_decoder *dec, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -71,7 +71,7 @@ def test_host_library_headers_are_exported_and_plain_c(capi, tmp_path):
 
 def test_abi_version_and_error_strings(capi):
     L = capi.lib()
-    assert L.vpz_abi_version() == 5
+    assert L.vpz_abi_version() == 6
     assert L.vpz_error_string(0) == b"ok"
     for code in range(-7, 0):
         assert L.vpz_error_string(code) not in (b"ok", b"unknown status")

@@ -62,7 +62,7 @@ def run_dispatcher(device_ids, raws, s16=False, capacity_slack=2048, **opt):
     return pcm, offs, results, stats, infos
 
 
-@pytest.mark.parametrize("groups", [1, 2, 4])
+@pytest.mark.parametrize("groups", [1, 2, 4, 8])
 @pytest.mark.parametrize("s16", [False, True])
 def test_partitioned_library_equals_the_stream_by_stream_decode(ctx, groups, s16):
     raws = library(("3test.ogg", "issue6test.ogg", "2test.ogg", "1test.ogg"), 22)
@@ -84,6 +84,26 @@ def test_partitioned_library_equals_the_stream_by_stream_decode(ctx, groups, s16
     # issue6test.ogg's trailing packet fails the window check (StreamDecoder.cs:777-778): a per-stream count, not a failure
     name = open(os.path.join(GOLDEN, "issue6test.ogg"), "rb").read()
     assert all(results["skipped_packets"][k] == (1 if r == name else 0) for k, r in enumerate(raws))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("threads_per_group", [2, 3])
+def test_eight_groups_with_the_few_thread_defaults(ctx, threads_per_group):
+    """The shape of the 8-GPU job on a 16-CPU box, rehearsed on one GPU: EIGHT context groups (all on device 0), two or three host
+    threads each and every other option left to its default -- below 8 threads per device that is 2 contexts and 12 slots per
+    group.  No deadlock (the timeout), the PCM of the one-group decode bit for bit, every group its contiguous share, and the
+    page-locked memory the slots hold is reported and stays bounded (what vpzm_stats.pinned_mib is for)."""
+    raws = library(("3test.ogg", "issue6test.ogg"), 72)
+    base = run_dispatcher([0], raws, host_threads=4)
+    pcm, offs, results, stats, infos = run_dispatcher([0] * 8, raws, host_threads=8 * threads_per_group)
+    assert (results["status"] == 0).all()
+    assert np.array_equal(base[0].view(np.uint32), pcm.view(np.uint32))
+    assert np.array_equal(base[2]["samples"], results["samples"])
+    assert stats.threads_per_device == threads_per_group
+    assert [int(stats.device_streams[g]) for g in range(8)] == [9] * 8
+    assert all(results["device_slot"][k] == k // 9 for k in range(72))
+    # 9 streams per group in calls of up to 16: at most 12 slots per group hold arrays, each a sub-batch of these short files
+    assert 0 < stats.pinned_mib < 8 * 12 * 64, stats.pinned_mib
 
 
 def test_partition_does_not_change_a_single_bit(ctx):

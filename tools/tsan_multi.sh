@@ -8,11 +8,13 @@ mkdir -p $T && cp vorbispizza_amd/lib/libvorbispizza_synth.so $T/ &&
 g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=thread -ffp-contract=off -fno-fast-math -Wall -pthread -o $T/libvorbispizza_host.so \
     vorbispizza_amd/host/vorbis_front.cpp vorbispizza_amd/host/vorbis_reader.cpp vorbispizza_amd/host/vorbis_multi.cpp \
     -Iinclude -L$T -lvorbispizza_synth '-Wl,-rpath,$ORIGIN' || exit 1
-OUT=${1:-gpurun_out/r4/tsan_multi.txt}
+OUT=${1:-gpurun_out/r5/tsan_multi.txt}
 mkdir -p $(dirname $OUT)
 export VPZ_LIB_DIR=$PWD/vorbispizza_amd/lib_ab/tsan
-export TSAN_OPTIONS="ignore_noninstrumented_modules=1 halt_on_error=0 report_signal_unsafe=0 exitcode=0 log_path=$PWD/gpurun_out/r4/tsan_log"
-rm -f gpurun_out/r4/tsan_log.*
-timeout -k 10 600 setarch $(uname -m) -R env LD_PRELOAD=$(gcc -print-file-name=libtsan.so) python -m pytest tests/test_multi_gpu.py tests/test_residue_i16_gpu.py -x -q -k "not device_memory" > $OUT   # (torch's own GPU start-up does not survive the preloaded libtsan: the one test that needs it stays out) 2>&1   # (-R: no address randomisation, this libtsan needs its mappings where it expects them)
+export TSAN_OPTIONS="ignore_noninstrumented_modules=1 halt_on_error=0 report_signal_unsafe=0 exitcode=0 log_path=$PWD/gpurun_out/r5/tsan_log"
+rm -f gpurun_out/r5/tsan_log.*
+# (torch's own GPU start-up does not survive the preloaded libtsan: the one test that needs it stays out)
+# (-R: no address randomisation, this libtsan needs its mappings where it expects them)
+timeout -k 10 600 setarch $(uname -m) -R env LD_PRELOAD=$(gcc -print-file-name=libtsan.so) python -m pytest tests/test_multi_gpu.py tests/test_residue_i16_gpu.py -x -q -k "not device_memory" > $OUT 2>&1
 tail -3 $OUT
-ls gpurun_out/r4/tsan_log.* 2>/dev/null | head; cat gpurun_out/r4/tsan_log.* 2>/dev/null | grep -E "WARNING|#0|#1|#2|Location|Previous|vorbis_" | head -60
+ls gpurun_out/r5/tsan_log.* 2>/dev/null | head; cat gpurun_out/r5/tsan_log.* 2>/dev/null | grep -E "WARNING|#0|#1|#2|Location|Previous|vorbis_" | head -60

@@ -90,6 +90,7 @@ _SIGNATURES = [
     ("vpz_decoder_set_position", C.c_int, [_vp, C.c_int32, C.c_int64]),
     ("vpz_decoder_set_residue_format", C.c_int, [_vp, C.c_int32]),
     ("vpz_decoder_set_stream_capacities", C.c_int, [_vp, C.POINTER(C.c_int64), C.c_int32]),
+    ("vpz_decoder_set_host_threads", C.c_int, [_vp, C.c_int32]),
 ]
 # include/vorbispizza_synth_debug.h (test-only entry points, not part of the surface a C# host binds)
 _DEBUG_SIGNATURES = [
@@ -413,6 +414,10 @@ class Decoder:
         """RESIDUE_F32 (default) or RESIDUE_I16: the element type of `residue` in the synth calls that follow (ABI v5)"""
         self.ctx._check(lib().vpz_decoder_set_residue_format(self._h, int(fmt)))
         self.residue_format = int(fmt)
+
+    def set_host_threads(self, n):
+        """Host threads this decoder's synth calls may use for their integer half (0: the process's CPUs, 1: none but the caller's)."""
+        self.ctx._check(lib().vpz_decoder_set_host_threads(self._h, int(n)))
 
     def set_stream_capacities(self, capacities):
         """per-stream output bounds for the synth calls that follow (each tightens the call's stream_out_capacity); None removes them"""

@@ -336,9 +336,11 @@ int vpz_host_alloc(vpz_context *c, uint64_t bytes, void **host_ptr)
 {
     if (!c || !host_ptr) return VPZ_E_INVALID_ARG;
     *host_ptr = nullptr;
-    VPZ_HIP_TRY(&c->impl, hipSetDevice(c->impl.device));
+    // (may be called while another thread is inside a synth call of the same context -- the dispatcher's workers get their
+    // page-locked arrays this way --: nothing of the context is written, not even its error text; the status says it all)
+    if (hipSetDevice(c->impl.device) != hipSuccess) { (void)hipGetLastError(); return VPZ_E_HIP; }
     hipError_t e = hipHostMalloc(host_ptr, bytes ? bytes : 1, hipHostMallocPortable);
-    if (e != hipSuccess) return vpz::set_error(&c->impl, VPZ_E_NOMEM, "hipHostMalloc", e);
+    if (e != hipSuccess) { (void)hipGetLastError(); *host_ptr = nullptr; return VPZ_E_NOMEM; }
     return VPZ_OK;
 }
 
@@ -346,8 +348,7 @@ int vpz_host_free(vpz_context *c, void *host_ptr)
 {
     if (!c) return VPZ_E_INVALID_ARG;
     if (!host_ptr) return VPZ_OK;
-    VPZ_HIP_TRY(&c->impl, hipSetDevice(c->impl.device));
-    VPZ_HIP_TRY(&c->impl, hipHostFree(host_ptr));
+    if (hipSetDevice(c->impl.device) != hipSuccess || hipHostFree(host_ptr) != hipSuccess) { (void)hipGetLastError(); return VPZ_E_HIP; }
     return VPZ_OK;
 }
 

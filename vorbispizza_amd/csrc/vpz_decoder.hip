@@ -238,9 +238,8 @@ static int arena_begin(Context *ctx, PinnedArena &A, size_t need)
 }
 
 // Carves `count` objects out of the call's arena.  open_arena sizes the arena for everything a call can ask for; should a
-// request not fit after all, the arena is marked overflown -- the pointer returned then addresses a small spare block of
-// ordinary memory that absorbs nothing but keeps the caller's next store harmless when count == 0 -- and the call fails with
-// VPZ_E_NOMEM at its next check (SynthCall::arena_ok) instead of writing beyond the allocation.
+// request not fit after all, ArenaOverflow is thrown -- vpz_decoder_synth turns it into VPZ_E_NOMEM -- instead of a write
+// beyond the allocation.
 struct ArenaOverflow {};
 template <typename T>
 static T *arena_alloc(PinnedArena &A, size_t count)
@@ -1783,9 +1782,36 @@ struct SynthCall {
         if (!out_interleaved && channel_stride < stream_out_capacity && C > 1)
             return set_error(ctx, VPZ_E_INVALID_ARG, "vpz_decoder_synth: channel_stride smaller than stream_out_capacity");
         offs = arena_alloc<int64_t>(*A, (size_t)D.n_streams);
-        for (int s = 0; s < D.n_streams; ++s) offs[s] = stream_out_offset ? stream_out_offset[s] : 0;
+        dev_channel_stride = channel_stride;
+        if (mem_space == VPZ_MEM_HOST) {
+            // A host-memory call mirrors its PCM on the device: the streams' areas BACK TO BACK there, whatever lies between them in
+            // the caller's array (two short songs at either end of a library's PCM array are two short areas, not the span between
+            // them), each on a 256-byte boundary so that every store of the kernels takes its widest form; copy_back knows both places
+            const int64_t align = 64;
+            auto up = [&](int64_t v) { return (v + align - 1) / align * align; };
+            int64_t at = 0;
+            if (out_interleaved) {
+                for (int s = 0; s < D.n_streams; ++s) {
+                    offs[s] = at;
+                    at += up(D.out_count[s] * C);
+                }
+            } else {
+                int64_t most = 0;
+                for (int s = 0; s < D.n_streams; ++s) most = std::max(most, D.out_count[s]);
+                dev_channel_stride = up(most);
+                for (int s = 0; s < D.n_streams; ++s) {
+                    offs[s] = at;
+                    if (D.out_count[s] > 0) at += dev_channel_stride * C;
+                }
+            }
+            mirror_elems = at;
+        } else {
+            for (int s = 0; s < D.n_streams; ++s) offs[s] = stream_out_offset ? stream_out_offset[s] : 0;
+        }
         return VPZ_OK;
     }
+    int64_t dev_channel_stride = 0;  // the channel stride the kernels use: the caller's, or the device mirror's (host-memory calls)
+    int64_t mirror_elems = 0;        // PCM elements of a host-memory call's device mirror
 
     // any-block-size path: per-frame records + gather lists of the two exact-IMDCT launches
     void build_generic_lists()
@@ -1926,13 +1952,7 @@ struct SynthCall {
                 d_amp = static_cast<const float *>(D.b_in_amp.p);
                 d_coeff = static_cast<const float *>(D.b_in_coeff.p);
             }
-            int64_t out_floats = 0;
-            for (int s = 0; s < D.n_streams; ++s) {
-                const int64_t ext = out_interleaved ? offs[s] + D.out_count[s] * C
-                                                    : offs[s] + (int64_t)(C - 1) * channel_stride + D.out_count[s];
-                if (D.out_count[s] > 0) out_floats = std::max(out_floats, ext);
-            }
-            if ((rc = grow(ctx, D.b_out, out_elem * (size_t)out_floats + 16)) != VPZ_OK) return rc;
+            if ((rc = grow(ctx, D.b_out, out_elem * (size_t)mirror_elems + 16)) != VPZ_OK) return rc;
             d_out = D.b_out.p;
         }
         if (need_coupling && !use_group && !use_dual && (rc = grow(ctx, D.b_temp, sizeof(float) * (size_t)temp_floats)) != VPZ_OK)
@@ -1964,7 +1984,7 @@ struct SynthCall {
     int launch()
     {
         const float *d_spec = d_res;
-        const int64_t *d_outoff = stream_out_offset ? static_cast<const int64_t *>(dev(offs)) : nullptr;
+        const int64_t *d_outoff = (stream_out_offset || mem_space == VPZ_MEM_HOST) ? static_cast<const int64_t *>(dev(offs)) : nullptr;
         if (need_coupling && !use_group && !use_dual) {
             hipError_t e = launch_coupling(dev(cpk), n_cpk, D.d_steps, C, d_res, static_cast<float *>(D.b_temp.p), half1,
                                            ctx->stream);
@@ -2031,7 +2051,7 @@ struct SynthCall {
                                    static_cast<const int64_t *>(dev(dst1)));
             if (e == hipSuccess)
                 e = launch_generic_ola(d_gf, (int)n_frames, C, D.size0, D.size1, d_y, D.d_state_h, D.t0->d_slope,
-                                       D.t1->d_slope, static_cast<float *>(d_out), d_outoff, channel_stride, out_interleaved,
+                                       D.t1->d_slope, static_cast<float *>(d_out), d_outoff, dev_channel_stride, out_interleaved,
                                        D.clip, D.d_clipped, out_s16 ? 1 : 0, ctx->stream);
             if (e == hipSuccess)
                 e = launch_generic_save_state(d_gf, static_cast<const int32_t *>(dev(save_list)), (int)n_save, C, D.size1,
@@ -2075,7 +2095,7 @@ struct SynthCall {
         a.slope1 = D.t1->d_slope;
         a.out = static_cast<float *>(d_out);
         a.stream_out_off = d_outoff;
-        a.channel_stride = channel_stride;
+        a.channel_stride = dev_channel_stride;
         a.interleaved = out_interleaved;
         a.s16 = out_s16 ? 1 : 0;
         a.clip = D.clip;
@@ -2139,14 +2159,16 @@ struct SynthCall {
             if (D.out_count[s] <= 0) continue;
             char *h = static_cast<char *>(pcm_out);
             const char *dv = static_cast<const char *>(d_out);
+            const int64_t host_off = stream_out_offset ? stream_out_offset[s] : 0;  // (the device mirror packs the areas: offs[s])
             if (out_interleaved) {
-                VPZ_HIP_TRY(ctx, hipMemcpyAsync(h + out_elem * (size_t)offs[s], dv + out_elem * (size_t)offs[s],
+                VPZ_HIP_TRY(ctx, hipMemcpyAsync(h + out_elem * (size_t)host_off, dv + out_elem * (size_t)offs[s],
                                                 out_elem * (size_t)(D.out_count[s] * C), hipMemcpyDeviceToHost,
                                                 ctx->stream));
             } else {
                 for (int ch = 0; ch < C; ++ch) {
-                    const size_t at = out_elem * (size_t)(offs[s] + (int64_t)ch * channel_stride);
-                    VPZ_HIP_TRY(ctx, hipMemcpyAsync(h + at, dv + at, out_elem * (size_t)D.out_count[s],
+                    const size_t at_h = out_elem * (size_t)(host_off + (int64_t)ch * channel_stride);
+                    const size_t at_d = out_elem * (size_t)(offs[s] + (int64_t)ch * dev_channel_stride);
+                    VPZ_HIP_TRY(ctx, hipMemcpyAsync(h + at_h, dv + at_d, out_elem * (size_t)D.out_count[s],
                                                     hipMemcpyDeviceToHost, ctx->stream));
                 }
             }
@@ -2382,6 +2404,15 @@ int vpz_decoder_set_residue_format(vpz_decoder *d, int32_t format)
     if (format != VPZ_RESIDUE_F32 && format != VPZ_RESIDUE_I16)
         return set_error(D.ctx, VPZ_E_INVALID_ARG, "vpz_decoder_set_residue_format: neither VPZ_RESIDUE_F32 nor VPZ_RESIDUE_I16");
     D.residue_format = format;
+    return VPZ_OK;
+}
+
+int vpz_decoder_set_host_threads(vpz_decoder *d, int32_t n)
+{
+    if (!d) return VPZ_E_INVALID_ARG;
+    Decoder &D = d->impl;
+    if (n < 0) return set_error(D.ctx, VPZ_E_INVALID_ARG, "vpz_decoder_set_host_threads: negative thread count");
+    D.host_threads = std::min<int32_t>(n, 16);
     return VPZ_OK;
 }
 

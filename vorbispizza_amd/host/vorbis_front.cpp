@@ -1423,6 +1423,8 @@ int vpzh_get_floor1(vpzh_stream *s, int index, vpz_floor1_config *out)
     return VPZH_OK;
 }
 
+static bool residue_tiles_its_partitions(const SetupBlob &su, const Residue &r);
+
 int vpzh_get_mapping(vpzh_stream *s, int index, vpz_mapping_config *out)
 {
     if (!s || !out || index < 0 || index >= (int)s->su->mappings.size()) return VPZH_E_ARG;
@@ -1448,6 +1450,7 @@ int vpzh_get_mapping(vpzh_stream *s, int index, vpz_mapping_config *out)
             for (int c = 0; c < s->channels; ++c) count += m.mux[c] == (int)i;
             if (count == 0 || m.submap_residue[i] >= s->su->residues.size()) continue;
             const Residue &r = s->su->residues[m.submap_residue[i]];
+            if (!residue_tiles_its_partitions(*s->su, r)) { lo = 0; hi = half; break; }  // (a vector may overhang `end`: the whole block)
             const int64_t n = r.type == 2 ? (int64_t)half * count : half;
             const int64_t rb = std::min<int64_t>(r.begin, n), re = std::min<int64_t>(r.end, n);
             if (re <= rb) continue;
@@ -1473,9 +1476,28 @@ int vpzh_get_residue_type(vpzh_stream *s, int index)
 // the vector can travel as int16 -- exactly: sums of integers below 2^24 are the same in float32 -- at half the bytes.  Decided
 // from the setup header alone, conservatively: every value book any residue names must hold integers only, and the worst case --
 // the largest magnitude of any of a residue's books, times its stages -- must stay below 2^15.
+// A residue whose value books do not tile its partitions -- a book of more dimensions than a partition has bins, or of a
+// dimension that does not divide the partition size: the reference decodes such setups (Residue0.cs:171-203 steps by the book's
+// dimensions whatever the partition size) -- lets one vector cover several of the following partitions and overhang the
+// residue's `end`: neither the "two vectors per bin and stage" bound of residue_integral nor "nothing beyond [begin, end)" of
+// vpzh_get_mapping holds for it.  libvorbis never writes one.
+static bool residue_tiles_its_partitions(const SetupBlob &su, const Residue &r)
+{
+    for (size_t cl = 0; cl < r.books.size(); ++cl)
+        for (size_t st = 0; st < r.books[cl].size(); ++st) {
+            if (!(r.cascade[cl] & (1u << st))) continue;
+            const size_t b = r.books[cl][st];
+            if (b >= su.books.size()) return false;
+            const int dim = su.books[b].dimensions;
+            if (dim <= 0 || dim > r.partition_size || r.partition_size % dim != 0) return false;
+        }
+    return true;
+}
+
 static bool residue_integral(const SetupBlob &su)
 {
     for (const Residue &r : su.residues) {
+        if (!residue_tiles_its_partitions(su, r)) return false;
         double worst = 0.0;
         for (size_t cl = 0; cl < r.books.size(); ++cl)
             for (size_t st = 0; st < r.books[cl].size(); ++st) {

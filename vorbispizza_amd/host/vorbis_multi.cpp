@@ -145,6 +145,7 @@ struct Job {  // one stream of the library inside its group
     int setup = -1;
     int64_t packets = 0, residue_floats = 0, total_samples = 0;
     int32_t status = VPZM_OK;
+    bool finished = false;  // its PCM has been written (or it has its own failure status): what an aborted run leaves alone
 };
 
 struct Sub {  // streams of one setup that ride in one vpz_decoder_synth call
@@ -201,6 +202,7 @@ struct GroupRun {
         : m(m_), G(g), slot_index(si), lo(lo_), hi(hi_), data(d), size(sz), out_layout(layout), pcm_out(out), pcm_offset(off),
           pcm_capacity(cap), results(res), threads(thr)
     {
+        lane_host_threads = std::max(1, std::min(8, thr / std::max(1, (int)G.lanes.size())));
     }
 
     int wave_size() const { return 4 * m->opt.streams_per_call; }
@@ -356,6 +358,7 @@ struct GroupRun {
         const size_t open_ahead = (size_t)wave_size() * 3;
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
+            if (aborted) return;
             if (next_task < tasks.size()) {
                 const size_t b = (size_t)tasks[next_task].first;
                 Sub &sb = subs[b];
@@ -404,6 +407,35 @@ struct GroupRun {
     // streams whose decode task has been handed out (under `mu`): what the open-ahead limit is measured against
     size_t done_decoding() const { return std::min(next_task + skipped_streams, jobs.size()); }
     size_t skipped_streams = 0;  // (streams that never become a decode task: failed to open, no packets, area too small)
+    // An exception on one of the run's threads (std::bad_alloc out of a vector in plan_wave / synth_sub, ...) must neither leave
+    // the thread (std::terminate inside a C ABI that promises statuses) nor leave the others waiting for a counter that will never
+    // move: the run is ABORTED -- every loop looks at the flag --, and the streams without a result get VPZM_E_SYNTH
+    bool aborted = false;  // (under `mu`)
+    void abort_run(const char *what) noexcept
+    {
+        try {
+            std::lock_guard<std::mutex> lk(mu);
+            aborted = true;
+        } catch (...) {
+        }
+        try {
+            m->fail(what);
+        } catch (...) {
+        }
+        cv.notify_all();
+    }
+    template <class F>
+    void guarded(F &&body) noexcept
+    {
+        try {
+            body();
+        } catch (const std::bad_alloc &) {
+            abort_run("vpzm_decode_library: out of host memory on a pipeline thread");
+        } catch (...) {
+            abort_run("vpzm_decode_library: a pipeline thread failed");
+        }
+    }
+    int lane_host_threads = 1;   // vpz_decoder_set_host_threads of every lane's decoders: the device's threads / its contexts
 
     vpz_decoder *decoder_for(Lane &L, const std::shared_ptr<Setup> &st)
     {
@@ -425,6 +457,9 @@ struct GroupRun {
             m->fail(std::string("vpz_decoder_create: ") + vpz_context_last_error(L.ctx));
             return nullptr;
         }
+        // The integer half of a synth call may fork over a pool of the decoder's context (batches of whole songs do): every lane its
+        // share of the device's host threads, not a pool for the whole machine each -- the decode workers need the CPUs
+        (void)vpz_decoder_set_host_threads(dec, lane_host_threads);
         // (a library of files from many encoders: a context keeps the decoders of the last few setups, not of every one it has seen)
         constexpr size_t kDecodersPerContext = 8;
         if (L.decs.size() >= kDecodersPerContext) {
@@ -444,12 +479,14 @@ struct GroupRun {
             {
                 std::unique_lock<std::mutex> lk(mu);
                 for (;;) {
+                    if (aborted) return;
                     if (next_synth < subs.size()) break;
                     if (all_planned()) return;
                     cv.wait(lk);
                 }
                 b = next_synth++;
-                cv.wait(lk, [&] { return subs[b].decoded == (int)subs[b].members.size(); });
+                cv.wait(lk, [&] { return aborted || subs[b].decoded == (int)subs[b].members.size(); });
+                if (aborted) return;
                 sp = &subs[b];
             }
             synth_sub(L, b, *sp);
@@ -575,6 +612,7 @@ struct GroupRun {
         for (size_t j = 0; j < sb.members.size(); ++j) {
             Job &J = jobs[(size_t)sb.members[j]];
             if (J.status != VPZM_OK) continue;
+            J.finished = true;
             if (member_rc[j] != VPZ_OK) {
                 J.status = member_rc[j] == kNoDecoder ? VPZM_E_SETUP : member_rc[j] == VPZ_E_CAPACITY ? VPZM_E_CAPACITY : VPZM_E_SYNTH;
                 continue;
@@ -584,6 +622,25 @@ struct GroupRun {
         }
         sb.synth_done = true;
         cv.notify_all();
+    }
+
+    // run() for a thread of its own: whatever it throws before its pipeline stands (the job table's allocation) becomes the
+    // statuses of the group's streams, never an exception out of the thread
+    void run_guarded() noexcept
+    {
+        try {
+            run();
+        } catch (...) {
+            for (int32_t k = lo; k < hi; ++k) {
+                results[k] = vpzm_stream_result{};
+                results[k].device_slot = slot_index;
+                results[k].status = VPZM_E_SYNTH;
+            }
+            try {
+                m->fail("vpzm_decode_library: a device group could not set its pipeline up (out of host memory)");
+            } catch (...) {
+            }
+        }
     }
 
     void run()
@@ -597,36 +654,42 @@ struct GroupRun {
         int workers = 0;
         try {
             for (int t = 0; t < threads; ++t) {
-                pool.emplace_back([this] { worker(); });
+                pool.emplace_back([this] { guarded([this] { worker(); }); });
                 ++workers;
             }
         } catch (...) {
         }
         if (workers == 0) {
             // no thread could be started: everything in order on this one
-            for (size_t i = 0; i < jobs.size(); ++i) open_one(i);
-            for (int w = 0; w < (int)wave_left.size(); ++w) plan_wave(w);
-            for (size_t b = 0; b < subs.size(); ++b) {
-                if (!prep_slot(b, subs[b])) {
-                    for (int mi : subs[b].members) jobs[(size_t)mi].status = VPZM_E_SYNTH;
-                    m->fail("vpzm_decode_library: page-locked batch arrays could not be allocated");
+            guarded([this] {
+                for (size_t i = 0; i < jobs.size(); ++i) open_one(i);
+                for (int w = 0; w < (int)wave_left.size(); ++w) plan_wave(w);
+                for (size_t b = 0; b < subs.size(); ++b) {
+                    if (!prep_slot(b, subs[b])) {
+                        for (int mi : subs[b].members) jobs[(size_t)mi].status = VPZM_E_SYNTH;
+                        m->fail("vpzm_decode_library: page-locked batch arrays could not be allocated");
+                    }
+                    for (size_t j = 0; j < subs[b].members.size(); ++j) decode_member(b, subs[b], (int)j);
+                    subs[b].decoded = (int)subs[b].members.size();
+                    synth_sub(G.lanes[0], b, subs[b]);
                 }
-                for (size_t j = 0; j < subs[b].members.size(); ++j) decode_member(b, subs[b], (int)j);
-                subs[b].decoded = (int)subs[b].members.size();
-                synth_sub(G.lanes[0], b, subs[b]);
-            }
+            });
             t_decode = seconds_since(t_begin);
         } else {
             try {
-                for (size_t l = 1; l < G.lanes.size(); ++l) pool.emplace_back([this, l] { issuer(G.lanes[l]); });
+                for (size_t l = 1; l < G.lanes.size(); ++l) pool.emplace_back([this, l] { guarded([this, l] { issuer(G.lanes[l]); }); });
             } catch (...) {  // (fewer issuing threads: this thread's one drains every sub-batch)
             }
-            issuer(G.lanes[0]);
+            guarded([this] { issuer(G.lanes[0]); });
         }
         for (std::thread &t : pool) t.join();
         for (Job &J : jobs) {
             if (J.h) vpzh_close(J.h);
             J.h = nullptr;
+            if (aborted && J.status == VPZM_OK && !J.finished) {  // (an aborted run: no PCM, no count -- the stream has no result)
+                J.status = VPZM_E_SYNTH;
+                results[J.k].samples = 0;
+            }
             results[J.k].status = J.status;
         }
         t_wall = seconds_since(t_begin);
@@ -729,8 +792,8 @@ int vpzm_decode_library(vpzm_dispatcher *m, int32_t n, const uint8_t *const *dat
             runs.emplace_back(new GroupRun(m, m->groups[(size_t)d], d, lo, hi, data, size, out_layout, pcm_out, pcm_offset,
                                            pcm_capacity, results, per_device));
         }
-        for (int d = 1; d < D; ++d) threads.emplace_back([&runs, d] { runs[(size_t)d]->run(); });
-        runs[0]->run();
+        for (int d = 1; d < D; ++d) threads.emplace_back([&runs, d] { runs[(size_t)d]->run_guarded(); });
+        runs[0]->run_guarded();
     } catch (const std::bad_alloc &) {
         for (std::thread &t : threads) t.join();
         return VPZM_E_NOMEM;
@@ -743,6 +806,12 @@ int vpzm_decode_library(vpzm_dispatcher *m, int32_t n, const uint8_t *const *dat
     if (stats) {
         stats->wall_s = seconds_since(t0);
         stats->threads_per_device = per_device;
+        size_t pinned = 0;
+        for (const Group &G : m->groups)
+            for (const Slot &sl : G.slots)
+                pinned += sl.cap_packets * sizeof(vpz_packet) + sl.cap_residue * sizeof(float) + sl.cap_posts * sizeof(int16_t) + sl.cap_counts +
+                          (sl.cap_f0 + sl.cap_f0c) * sizeof(float);
+        stats->pinned_mib = (int32_t)std::min<size_t>(pinned >> 20, 0x7fffffff);
         for (int d = 0; d < D && d < 16; ++d) {
             stats->device_wall_s[d] = runs[(size_t)d]->t_wall;
             stats->device_decode_s[d] = runs[(size_t)d]->t_decode;

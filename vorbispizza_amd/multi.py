@@ -25,7 +25,7 @@ class StreamResult(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("wall_s", C.c_double), ("device_wall_s", C.c_double * 16), ("device_decode_s", C.c_double * 16),
                 ("device_synth_s", C.c_double * 16), ("device_streams", C.c_int64 * 16), ("device_samples", C.c_int64 * 16),
-                ("threads_per_device", C.c_int32), ("reserved", C.c_int32)]
+                ("threads_per_device", C.c_int32), ("pinned_mib", C.c_int32)]
 
 
 RESULT_DTYPE = np.dtype([("status", "<i4"), ("device_slot", "<i4"), ("channels", "<i4"), ("sample_rate", "<i4"),
