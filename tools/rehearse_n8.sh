@@ -1,21 +1,22 @@
 #!/bin/bash
 # The 8-way job rehearsed on a ONE-GPU box, both launchers (never what the driver runs):
 #  (a) one process per rank under torchrun, gloo for the barrier / reductions, every rank on device 0.  The GPU boxes of this pool
-#      allow at most SIX processes on the card at once (the process guard kills a seventh), so the per-process launcher is
-#      rehearsed with 6 ranks -- 16 CPUs / 6 = 2 host threads per rank, the figure 8 ranks get --; the partition logic for 8 ranks
-#      is covered on the CPU (tests/test_sharding_cpu.py) and (b) runs the full 8;
+#      allow at most SIX processes on the card at once (the process guard kills the run at a seventh, and torchrun's own agent
+#      counts as one), so the per-process launcher is rehearsed with 5 ranks and --host-threads 2 -- the two host threads a
+#      rank gets when 8 ranks share 16 CPUs --; the partition logic for 8 ranks is covered on the CPU
+#      (tests/test_sharding_cpu.py) and (b) runs the full 8;
 #  (b) ONE process, 8 context groups on device 0 through the in-process dispatcher (bench.py --gpus 8 --single-process).
 # usage (through gpurun): bash tools/rehearse_n8.sh [outdir]
 cd "$GRAFT_REPO_ROOT"
 O=${1:-gpurun_out/r5_rehearsal}
 mkdir -p $O
-VPZ_BENCH_REHEARSAL=1 timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 6 --master-addr 127.0.0.1 --master-port 29519 \
-    bench.py --gpus 6 --steps 5 --warmup 2 > $O/bench_n6_rehearsal_one_gpu.json 2> $O/bench_n6_rehearsal_one_gpu.err || { tail -20 $O/bench_n6_rehearsal_one_gpu.err; exit 1; }
+VPZ_BENCH_REHEARSAL=1 timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 5 --master-addr 127.0.0.1 --master-port 29519 \
+    bench.py --gpus 5 --steps 5 --warmup 2 --host-threads 2 > $O/bench_n5_rehearsal_one_gpu.json 2> $O/bench_n5_rehearsal_one_gpu.err || { tail -20 $O/bench_n5_rehearsal_one_gpu.err; exit 1; }
 VPZ_BENCH_REHEARSAL=1 timeout -k 10 400 python bench.py --gpus 8 --single-process --steps 5 --warmup 2 > $O/bench_single_process_8groups_one_gpu.json 2> $O/bench_single_process_8groups_one_gpu.err || { tail -20 $O/bench_single_process_8groups_one_gpu.err; exit 1; }
 python - "$O" <<'PY'
 import json, sys
 o = sys.argv[1]
-d = json.loads([l for l in open(o + "/bench_n6_rehearsal_one_gpu.json") if l.startswith("{")][-1])
+d = json.loads([l for l in open(o + "/bench_n5_rehearsal_one_gpu.json") if l.startswith("{")][-1])
 job = [v for k, v in d["extra_workloads"].items() if "whole job" in k][0]
 print("torchrun: n_gpus", d["n_gpus"], "value", d["value"], "checksum", job["pcm_checksum"], job["checksum_equals_single_stream_decode"],
       "streams per rank", job["streams_per_rank"], "host threads per rank", job["host_threads_per_rank"], "e2e", job["end_to_end_Msamples_per_s"],
