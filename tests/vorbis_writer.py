@@ -558,7 +558,7 @@ class Stream:
             else:
                 pc, raw = fl.write_packet(bw, self.books, rng, silent=rng.random() < silent_prob)
                 counts[ch] = pc
-                posts[ch, :pc] = raw
+                posts[ch, :min(pc, posts.shape[1])] = raw[:posts.shape[1]]  # (a 65-post floor: what the expectation array holds)
                 no_energy[ch] = pc == 0
         for m, a in mp.coupling:
             if not (no_energy[m] and no_energy[a]):
