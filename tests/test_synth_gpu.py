@@ -588,3 +588,80 @@ def test_floor0_inside_the_stereo_fast_path_equals_the_separate_floor0_pass(ctx,
         ref, _, _ = helpers.oracle_decode(oracle, 2, 256, 2048, opk, floors=floors, mappings=mappings)
         assert ref.shape == outs["fused"].shape
         assert np.abs(outs["fused"] - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("size0,size1", [(512, 4096), (1024, 8192), (256, 4096), (2048, 8192), (4096, 4096), (4096, 8192), (8192, 8192),
+                                         (2048, 4096), (256, 8192)])
+@pytest.mark.parametrize("layout", ["planar", "interleaved", "planar_s16"])
+def test_the_fused_kernel_for_4096_and_8192_blocks_equals_the_three_pass_path(ctx, monkeypatch, size0, size1, layout):
+    """synth_big_kernel (one pass over HBM: Floor1 render + multiply, the 4096 / 8192-point wave transforms, window + overlap-add,
+    store) against the three-pass path it replaces (VPZ_NO_BIG=1: generic_floor_kernel -> gathered IMDCT -> generic_ola_kernel),
+    which the oracle tests of this file pin: the same values bit for bit (zeros of a silent channel: +0.0 here), floored and coupled packets, silent channels, planar and
+    Residue2-interleaved input, window switching, three batches with the state carried between the calls, three channels."""
+    from vorbispizza_amd import Decoder, capi, make_packets
+    rng = np.random.default_rng(size0 * 11 + size1)
+    channels, frames = 3, 26
+    bf = (rng.random(frames) < 0.6).astype(np.uint8) if size0 != size1 else np.zeros(frames, dtype=np.uint8)
+    prev = np.concatenate([[1], bf[:-1]])
+    nxt = np.concatenate([bf[1:], [1]])
+    flags = (bf * PKT_BLOCK_FLAG | prev * PKT_PREV_FLAG * bf | nxt * PKT_NEXT_FLAG * bf).astype(np.uint8)
+    h0, h1 = size0 // 2, size1 // 2
+    floors = [(random_xlist(rng, h0, min(19, h0 // 2)), 2), (random_xlist(rng, h1, min(61, h1 // 2)), 1)]
+    mappings = [{"coupling": [(0, 1)], "channel_floor": [0, 0, 0]}, {"coupling": [(1, 0), (2, 1)], "channel_floor": [1, 1, 1]}]
+    pk = make_packets(frames)
+    res_parts, posts_parts, count_parts, off = [], [], [], 0
+    for f in range(frames):
+        half = h1 if bf[f] else h0
+        xl, mult = floors[int(bf[f])]
+        res = (rng.standard_normal((channels, half)) * 3).round().astype(np.float32)
+        res[:, int(half * 0.85):] = 0
+        posts, counts = helpers.random_posts(rng, xl, mult, channels, silent_prob=0.15)
+        no_floor = f % 5 == 4
+        interleaved = bool(f % 2) and not no_floor
+        pk[f]["flags"] = int(flags[f]) | (PKT_INTERLEAVED if interleaved else 0) | (capi.PKT_NO_FLOOR if no_floor else 0)
+        pk[f]["mapping"], pk[f]["granule"], pk[f]["residue_offset"] = int(bf[f]), -1, off
+        if no_floor:
+            res = (res * 2.0 ** -6).astype(np.float32)
+        res_parts.append(res.T.reshape(-1).copy() if interleaved else res.reshape(-1))
+        posts_parts.append(posts)
+        count_parts.append(counts)
+        off += res.size
+    res = np.concatenate(res_parts)
+    posts = np.concatenate(posts_parts).astype(np.int16)
+    counts = np.concatenate(count_parts).astype(np.uint8)
+    out_layout = {"planar": capi.OUT_PLANAR, "interleaved": capi.OUT_INTERLEAVED, "planar_s16": capi.OUT_PLANAR_S16}[layout]
+
+    def decode(no_big, splits):
+        if no_big:
+            monkeypatch.setenv("VPZ_NO_BIG", "1")
+        else:
+            monkeypatch.delenv("VPZ_NO_BIG", raising=False)
+        dec = Decoder(ctx, channels, size0, size1, floors=floors, mappings=mappings, clip_samples=True)
+        outs, a = [], 0
+        for n in splits:
+            sub = pk[a:a + n].copy()
+            base = int(sub["residue_offset"][0])
+            end = int(pk[a + n]["residue_offset"]) if a + n < frames else res.size
+            sub["residue_offset"] -= base
+            out = dec.synth(sub, res[base:end], posts[a * channels:(a + n) * channels], counts[a * channels:(a + n) * channels],
+                            out_layout=out_layout)[0]
+            outs.append(out)
+            a += n
+        clipped = dec.has_clipped()
+        dec.close()
+        axis = 0 if layout == "interleaved" else 1
+        return np.concatenate(outs, axis=axis), clipped
+
+    want, want_clip = decode(True, [frames])
+    assert want.size > 0
+    for splits in ([frames], [5, 1, frames - 6]):
+        got, got_clip = decode(False, splits)
+        assert got.shape == want.shape, (got.shape, want.shape)
+        # value for value; the only bit patterns that may differ are zeros: a silent channel's block is all +0.0 here, as in the
+        # reference (Mapping.cs:190-194 clears it) and in the other fused kernels, where the three-pass path transforms zeros and
+        # leaves zeros of both signs
+        assert np.array_equal(got, want), (size0, size1, layout, splits)
+        if layout != "planar_s16":
+            differing = got.view(np.uint32) != want.view(np.uint32)
+            assert (got[differing] == 0).all() and not np.signbit(got[differing]).any(), (size0, size1, layout, splits)
+        assert got_clip == want_clip

@@ -2,7 +2,7 @@
 """The paths no BASELINE config exercises, timed once so that BASELINE.md can say what they cost:
   (a) more than 8 channels (no group mode: separate coupling pass through a planar temp), 10 channels, Floor1 + coupling;
   (b) a type-0 floor stream (Floor0.Apply on the planar temp, then the fused kernel), stereo;
-  (c) block sizes outside {256 ... 2048}: 512/4096 and 1024/8192 (the three-pass path);
+  (c) long blocks of 4096 / 8192 samples: 512/4096 and 1024/8192 (synth_big_kernel since round 5; VPZ_NO_BIG=1: the three-pass path);
 whole vpz_decoder_synth calls, device-resident inputs, algorithmic bytes = residue in + PCM out."""
 import os
 import sys
@@ -121,7 +121,7 @@ def main():
         dt, w = timed(ctx, step_c)
         smp = int(w[0]) * 2
         byt = 4 * int(offs[-1]) + 4 * smp
-        print("(c) block sizes %d/%d, stereo, %d frames (three passes over HBM): %.3f ms/call  %.1f Msamples/s  %.0f GB/s algorithmic = "
+        print("(c) block sizes %d/%d, stereo, %d frames (synth_big_kernel; VPZ_NO_BIG=1: three passes over HBM): %.3f ms/call  %.1f Msamples/s  %.0f GB/s algorithmic = "
               "%.3f of 8 TB/s" % (size0, size1, frames, dt * 1e3, smp / dt / 1e6, byt / dt / 1e9, byt / dt / 8e12), flush=True)
         dec.close()
         del res, out

@@ -20,6 +20,7 @@ SOURCES = {
     "imdct_exact.hip": ["-ffp-contract=off"],
     "synth_kernels.hip": [],
     "synth_dual.hip": [],
+    "synth_big.hip": [],
     "floor0.hip": ["-ffp-contract=off"],
     "vpz_context.hip": ["-ffp-contract=off"],
     "vpz_decoder.hip": ["-ffp-contract=off"],

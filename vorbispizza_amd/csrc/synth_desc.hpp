@@ -58,6 +58,7 @@ struct FrameDesc {        // 32 bytes: staged per run into LDS by the wavefront 
 static_assert(sizeof(FrameDesc) == 32, "FrameDesc is staged as two 16-byte words");
 constexpr int kMaxRunLength = 32;
 constexpr int kMaxRunLengthGeneral = 16;  // the general-size kernel variant trades descriptor space for tables
+constexpr int kMaxRunLengthBig = 32;      // synth_big_kernel (4096 / 8192 blocks): a recomputed block is a whole big transform
 #ifndef VPZ_DUAL_WAVES
 #define VPZ_DUAL_WAVES 4   // wavefronts per workgroup of the stereo fast path (tuning builds: -DVPZ_DUAL_WAVES=10, one workgroup per CU)
 #endif

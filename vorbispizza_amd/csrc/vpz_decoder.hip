@@ -37,6 +37,9 @@ bool synth_dual_supported(int channels, int size0, int size1);
 hipError_t launch_synth_dual(const SynthArgs &args, bool has_floor, bool interleaved_in, hipStream_t stream);
 int synth_dual_resident_slots(bool has_floor, int num_cu);
 int synth_dual_waves();
+bool synth_big_supported(int size0, int size1);
+hipError_t launch_synth_big(const SynthArgs &args, bool has_floor, hipStream_t stream);
+int synth_big_resident_waves(bool has_floor, int num_cu, int size0, int size1);
 hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, int half1, float *spec,
                                 const uint8_t *post_counts, const uint8_t *curve_y, const float *inv_db,
                                 hipStream_t stream);
@@ -180,7 +183,8 @@ struct Decoder {
     DevBuf b_in_res16;              // VPZ_RESIDUE_I16: the int16 values as they came over the link, widened into b_in_res
     int residue_format = VPZ_RESIDUE_F32;
     DevBuf b_ybuf;                                    // any-block-size path
-    bool generic = false;  // a block size outside {256, 512, 1024, 2048}: three-pass path (synth_kernels.hip)
+    bool generic = false;  // a block size the fused kernels do not take (64, 128): three-pass path (synth_kernels.hip)
+    bool big = false;      // the long block is 4096 or 8192 samples: synth_big_kernel (synth_big.hip; VPZ_NO_BIG=1: the three-pass path)
     // type-0 floors (Floor0.cs)
     std::vector<uint8_t> floor_types;
     std::vector<vpz_floor0_config> floors0;
@@ -344,7 +348,11 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     D.size1 = cfg->block_size1;
     D.clip = cfg->clip_samples ? 1 : 0;
     D.n_streams = n_streams;
-    D.generic = !synth_supports_sizes(cfg->block_size0, cfg->block_size1);
+    {
+        const char *no_big = getenv("VPZ_NO_BIG");  // A/B and bit-equality tests: the three-pass path for 4096 / 8192 blocks
+        D.big = synth_big_supported(cfg->block_size0, cfg->block_size1) && !(no_big && atoi(no_big));
+    }
+    D.generic = !synth_supports_sizes(cfg->block_size0, cfg->block_size1) && !D.big;
     D.states.assign(n_streams, StreamState());
     D.floors.assign((size_t)cfg->floor_count, vpz_floor1_config{});
     D.floor_types.assign((size_t)cfg->floor_count, 1);
@@ -439,7 +447,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         for (uint8_t t : D.floor_types) has_floor0 |= (t == 0);
         for (uint8_t t : D.floor_types) D.has_floor1 |= (t != 0);
         const char *no_group = getenv("VPZ_NO_GROUP");  // tuning / A-B tests: force the separate coupling pass
-        D.group_ok = synth_group_supported(D.channels) && !D.generic && !has_floor0 && D.max_steps <= 255 &&
+        D.group_ok = synth_group_supported(D.channels) && !D.generic && !D.big && !has_floor0 && D.max_steps <= 255 &&
                      D.n_step_pairs <= kGroupMaxStepPairs && !(no_group && atoi(no_group));
         const char *no_dual = getenv("VPZ_NO_DUAL");
         // (type-0 floors ride in the stereo fast path when their bark maps fit a wave's LDS row; VPZ_NO_F0_FUSED=1: the old route)
@@ -941,7 +949,7 @@ struct SynthCall {
         // back residues and a batch the fused kernel takes as it is (no planar temp, no type-0 floor pass)
         const bool group_usable = D.group_ok && group_align_ok &&
                                   (mem_space == VPZ_MEM_HOST || D.residue_format == VPZ_RESIDUE_I16 || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
-        compact = all_dense && !D.generic && (!any_floor0 || (D.f0_fused && dual_usable())) && !D.no_compact &&
+        compact = all_dense && !D.generic && !D.big && (!any_floor0 || (D.f0_fused && dual_usable())) && !D.no_compact &&
                   (!need_coupling || group_usable || dual_usable());
         if (compact) {
             cflags = arena_alloc<uint8_t>(*A, (size_t)n_packets);
@@ -1278,7 +1286,7 @@ struct SynthCall {
     void cut_runs()
     {
         const int64_t total_frames = (int64_t)n_frames;
-        const int r_max = use_dual ? kMaxRunLengthDual : (synth_needs_general(D.size0, D.size1) ? kMaxRunLengthGeneral : kMaxRunLength);
+        const int r_max = use_dual ? kMaxRunLengthDual : D.big ? kMaxRunLengthBig : (synth_needs_general(D.size0, D.size1) ? kMaxRunLengthGeneral : kMaxRunLength);
         // Group mode synthesises up to eight consecutive SHORT blocks of a run in one pass (synth_kernel's run builder):
         // a block that rides along costs a fraction of a pass.  Runs are cut to equal COST, in eighths of a pass -- a
         // run rich in short blocks holds more frames --, so that every wavefront of the launch has the same amount to do.
@@ -1384,7 +1392,8 @@ struct SynthCall {
         bool single_round = false;  // every run has a resident wave slot of its own from the start of the launch
         if (R <= 0) {
             const int64_t slots = std::max(1, use_dual ? synth_dual_resident_slots(any_floor, ctx->num_cu)
-                                                       : synth_resident_waves(any_floor, ctx->num_cu, C, use_group));
+                                              : D.big ? synth_big_resident_waves(any_floor, ctx->num_cu, D.size0, D.size1)
+                                                      : synth_resident_waves(any_floor, ctx->num_cu, C, use_group));
             const int64_t work = (total_units + 7) / 8 * C;
             R = 4;
             int64_t best = -1;
@@ -2110,7 +2119,8 @@ struct SynthCall {
         (void)hipMemsetAsync(d_stamps, 0, (16 + 16 * std::min<size_t>(kStampWaves, n_runs)) * sizeof(unsigned long long), ctx->stream);
         a.stamps = d_stamps;
 #endif
-        hipError_t e = use_dual ? launch_synth_dual(a, any_floor, ilv_seen, ctx->stream) : launch_synth(a, any_floor, ctx->stream);
+        hipError_t e = use_dual ? launch_synth_dual(a, any_floor, ilv_seen, ctx->stream)
+                                : D.big ? launch_synth_big(a, any_floor, ctx->stream) : launch_synth(a, any_floor, ctx->stream);
         if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "synth kernel launch", e);
 #if defined(VPZ_STAMPS) || defined(VPZ_WAVE_TIMES)
         {
