@@ -299,13 +299,13 @@ def build_floor6(torch, device, frames=16384, declare_support=True):
         floors, mappings, (frames - 1) * 1024
 
 
-def build_real_streams(torch, device, name, copies):
+def build_real_streams(torch, device, name, copies, int16=False):
     """`copies` independent streams of one fixture: CPU entropy decode once (C++ front end), batch
     arrays replicated with their own stream ids (BASELINE configs[4]: per-GPU share of 1024 streams)."""
     from vorbispizza_amd.front import OggVorbisFile
     t0 = time.perf_counter()
     f = OggVorbisFile(os.path.join(ROOT, "tests", "golden", name))
-    pk, res, posts, counts = f.decode_packets()
+    pk, res, posts, counts = f.decode_packets(int16=int16)  # (int16: the residue as 16-bit integers, ABI v5 -- exact for these files)
     t_front = time.perf_counter() - t0
     n = len(pk)
     pk_all = np.tile(pk, copies)
@@ -322,7 +322,7 @@ TOTAL_REAL_STREAMS = 1024  # BASELINE configs[4]; global stream s plays fixture 
 
 
 def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, before_timing=None, reduce_time=None,
-                      repeats=3):
+                      repeats=3, int16=False):
     """GPU-stage rate over real stereo streams, interleaved output, decoded spectra device-resident.
     `copies` streams of each fixture, or `plan` = [global ids playing fixture 0, global ids playing fixture 1]
     (one decoder group per fixture: streams of a group share a setup header).  Returns (seconds per step, samples,
@@ -345,7 +345,7 @@ def time_real_streams(ctx, torch, device, copies, steps=5, warmup=2, plan=None, 
         n = len(ids)
         if n == 0:
             continue
-        f, pk, res, posts, counts, t_front = build_real_streams(torch, device, name, n)
+        f, pk, res, posts, counts, t_front = build_real_streams(torch, device, name, n, int16=int16)
         parts.append((f, pk, res, posts, counts, samples, ids))
         total_samples += n * samples * f.channels
         t_front_total += t_front * n  # a real host decodes every stream; we decoded one copy
@@ -1034,6 +1034,10 @@ def main():
                 cpu_entropy_decode_s_1thread=round(t_front, 3),
                 note="64x 3test.ogg + 64x issue6test.ogg, decoded spectra device-resident; one decoder over both fixtures' setups "
                      "(sharding.merge_setups); Floor1 unwrap + the stereo fast path, one launch each per step")
+            # ... the same share with the residue as 16-bit integers in device memory (ABI v5; exact for these files): the floored
+            # stereo kernel reads them in place -- 2 B in + 4 B out per sample
+            dt16, tot16, _, _ = time_real_streams(ctx, torch, device, 64, steps=40, warmup=3, int16=True)
+            extras["configs[4] share, int16 residue (6 B per sample)"] = fused_entry(tot16, dt16, 6 * tot16)
             thr = host_threads()
             thr_disp = thr if HOST_THREADS_CAP else thr + 4  # (the dispatcher's own rule: the CPUs plus one per context)
             tot_e, (t_all, t_dec, t_syn) = end_to_end_rank_dispatcher(torch, ctx.device, [64, 64], thr_disp)

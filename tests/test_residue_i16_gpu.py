@@ -1,6 +1,7 @@
 """ABI v5: vpz_decoder_set_residue_format(VPZ_RESIDUE_I16).  The same values as 16-bit integers must give the bits of the float32
-call on every route -- the device widens them into the decoder's staging buffer before anything else looks at them -- from host
-memory and from device memory, and through the dispatcher (which ships integral residues as int16 by default)."""
+call on every route -- the floored stereo fast path reads them in place and widens them in registers (round 5), every other kernel
+gets them widened into the decoder's staging buffer first -- from host memory and from device memory (aligned for the in-place read
+or not), and through the dispatcher (which ships integral residues as int16 by default)."""
 import os
 
 import numpy as np
@@ -78,10 +79,10 @@ def test_int16_residue_in_device_memory_and_bad_formats(ctx):
     dec = Decoder(ctx, f.channels, f.block_size0, f.block_size1, floors=f.floors, mappings=f.mappings)
     cap = int(f.total_samples) + 2048
     outs = []
-    for int16 in (False, True):
+    for int16 in (False, True, "misaligned"):
         r = torch.from_numpy(res.astype(np.int16) if int16 else res).to(dev)
-        if int16:
-            r = torch.cat([torch.zeros(1, dtype=torch.int16, device=dev), r])[1:]  # (a pointer that is only 2-byte aligned)
+        if int16 == "misaligned":  # (a pointer that is only 2-byte aligned: no 8-byte loads, the values are widened first)
+            r = torch.cat([torch.zeros(1, dtype=torch.int16, device=dev), r])[1:]
         out = torch.zeros(cap * f.channels, device=dev)
         dec.reset(-1)
         w = dec.synth_raw(pk, r, torch.from_numpy(posts).to(dev), torch.from_numpy(counts).to(dev), out, None, cap, capi.OUT_INTERLEAVED, 0,
@@ -89,6 +90,7 @@ def test_int16_residue_in_device_memory_and_bad_formats(ctx):
         ctx.synchronize()
         outs.append(out.cpu().numpy()[: int(w[0]) * f.channels])
     assert outs[0].size > 0 and np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))
     with pytest.raises(capi.SynthError) as e:
         dec.set_residue_format(7)
     assert e.value.status == capi.E_INVALID_ARG

@@ -188,7 +188,8 @@ struct SynthArgs {
     const float *f0_curve;
     const uint16_t *f0_bark;
     int32_t f0_stride;
-    int32_t f0_reserved;
+    int32_t spec_i16;           // stereo fast path, floored batches: `spec` points to 16-bit integers (VPZ_RESIDUE_I16, ABI v5) -- the kernel
+                                // widens them in registers (exact: every int16 is a float32), no float32 copy of the residue exists
     const float *inv_db;        // 256 floats
     float *state_h;             // [2][stream][channel][size1/2]: two copies -- a run that starts from the saved state reads
                                 // copy RunDesc.state_slot, the run that ends its stream's batch writes the OTHER one (the

@@ -159,8 +159,10 @@ __device__ __forceinline__ void floor0_multiply(float2 (&x)[8], float *row, cons
 
 // kIlvIn : every packet of the batch is the Residue2-interleaved vector [bin][2] (else: every packet planar [2][bin])
 // kOut   : 0 planar output, 1 interleaved
+// kI16   : the residue is 16-bit integers (VPZ_RESIDUE_I16, ABI v5): half the bytes per value from HBM, widened in registers
+//          (v_cvt_f32_i32 of the sign-extended halves: exact) -- floored batches only, others get the widened float32 copy
 // kExp: tuning experiments, A/B on one box through VPZ_DUAL_EXP (none at the moment; DESIGN.md 4.7 lists what was tried)
-template <bool kHasFloor, bool kIlvIn, int kOut, bool kS16, int kExp = 0>
+template <bool kHasFloor, bool kIlvIn, int kOut, bool kS16, bool kI16 = false, int kExp = 0>
 __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_kernel(SynthArgs a)
 {
     using out_t = typename std::conditional<kS16, int16_t, float>::type;
@@ -231,7 +233,32 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         asm volatile("" : "+v"(l));  // (frame-invariant lane arithmetic stays inside the iteration that uses it)
         const int g = l >> 3, gg = g < bsz ? g : 0;
         const VPZ_GLOBAL float *src = valid ? (const VPZ_GLOBAL float *)parked64(0) + fd.spec_off : (const VPZ_GLOBAL float *)parked64(2);
-        if (kIlvIn) {
+        if (kI16) {
+            // 16-bit values: a point's four values are 8 bytes (interleaved: L[2k] R[2k] L[2k+1] R[2k+1]) or two words (planar: the L
+            // pair and, half a packet on, the R pair); kept as they came -- va[m] holds the two words -- and widened where the frame
+            // is taken up, so that nothing here waits for the loads
+            const VPZ_GLOBAL int16_t *s16 = valid ? (const VPZ_GLOBAL int16_t *)parked64(0) + fd.spec_off : (const VPZ_GLOBAL int16_t *)parked64(2);
+            const int step = !valid ? 0 : (is_long ? 64 : 8);
+            if (kIlvIn) {
+                const VPZ_GLOBAL uint2 *s8 = (const VPZ_GLOBAL uint2 *)s16;
+                const int base = !valid ? 0 : (is_long ? l : 64 * gg + (l & 7));
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const uint2 v = s8[base + step * m];
+                    va[m] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+                    vb[m] = make_float2(0.0f, 0.0f);
+                }
+            } else {
+                const VPZ_GLOBAL uint32_t *s4 = (const VPZ_GLOBAL uint32_t *)s16;
+                const int base = !valid ? 0 : (is_long ? l : 128 * gg + (l & 7));
+                const int rofs = !valid ? 0 : (is_long ? 512 : 64);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    va[m] = make_float2(__uint_as_float(s4[base + step * m]), __uint_as_float(s4[base + step * m + rofs]));
+                    vb[m] = make_float2(0.0f, 0.0f);
+                }
+            }
+        } else if (kIlvIn) {
             const VPZ_GLOBAL float4 *s4 = (const VPZ_GLOBAL float4 *)src;
             const int base = !valid ? 0 : (is_long ? l : 64 * gg + (l & 7));
             const int step = !valid ? 0 : (is_long ? 64 : 8);
@@ -548,7 +575,18 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             float2 xL[8], xR[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                if (kIlvIn) {
+                if (kI16) {
+                    const int w0 = (int)__float_as_uint(va[m].x), w1 = (int)__float_as_uint(va[m].y);
+                    const float lo0 = (float)(int)(int16_t)(w0 & 0xFFFF), hi0 = (float)(w0 >> 16);
+                    const float lo1 = (float)(int)(int16_t)(w1 & 0xFFFF), hi1 = (float)(w1 >> 16);
+                    if (kIlvIn) {  // w0 = L[2k] | R[2k] << 16, w1 = L[2k+1] | R[2k+1] << 16
+                        xL[m] = make_float2(lo0, lo1);
+                        xR[m] = make_float2(hi0, hi1);
+                    } else {       // w0 = L[2k] | L[2k+1] << 16, w1 = R[2k] | R[2k+1] << 16
+                        xL[m] = make_float2(lo0, hi0);
+                        xR[m] = make_float2(lo1, hi1);
+                    }
+                } else if (kIlvIn) {
                     xL[m] = make_float2(va[m].x, vb[m].x);
                     xR[m] = make_float2(va[m].y, vb[m].y);
                 } else {
@@ -976,11 +1014,17 @@ bool synth_dual_supported(int channels, int size0, int size1)
 hipError_t launch_synth_dual(const SynthArgs &args, bool has_floor, bool interleaved_in, hipStream_t stream)
 {
     if (args.n_runs <= 0) return hipSuccess;
+    if (args.spec_i16 && !has_floor) return hipErrorInvalidValue;  // (16-bit values are read in place by the floored variants only)
     const int grid = (args.n_runs + kDualWaves - 1) / kDualWaves;
     static const int extra_lds = getenv("VPZ_SYNTH_EXTRA_LDS") ? atoi(getenv("VPZ_SYNTH_EXTRA_LDS")) : 0;  // occupancy experiments
 #define VPZ_LAUNCH_DUAL(F, I, O)                                                                                          \
     do {                                                                                                                  \
-        if (args.s16)                                                                                                     \
+        if (F && args.spec_i16) {                                                                                         \
+            if (args.s16)                                                                                                 \
+                hipLaunchKernelGGL((synth_dual_kernel<F, I, O, true, F>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
+            else                                                                                                          \
+                hipLaunchKernelGGL((synth_dual_kernel<F, I, O, false, F>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
+        } else if (args.s16)                                                                                              \
             hipLaunchKernelGGL((synth_dual_kernel<F, I, O, true>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
         else                                                                                                              \
             hipLaunchKernelGGL((synth_dual_kernel<F, I, O, false>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \

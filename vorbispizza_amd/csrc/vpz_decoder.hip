@@ -204,6 +204,7 @@ struct Decoder {
     PacketInfo packet_info[8];  // Mode.GetPacketInfo by (block | prev << 1 | next << 2) == vpz_packet.flags & 7
     int run_length_override = 0;
     int dual_run = 8;  // preferred run length of the stereo fast path's chained runs (VPZ_DUAL_RUN)
+    bool no_direct_i16 = false;
     bool no_run_inline = false;
     bool no_chain = false;  // VPZ_NO_CHAIN=1 (A/B tests): no run of the stereo fast path takes its predecessor's tail over in LDS
     int ablate = 0;  // VPZ_SYNTH_ABLATE, tuning experiments only
@@ -366,6 +367,7 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     static_assert(VPZ_PKT_BLOCK_FLAG == 1 && VPZ_PKT_PREV_FLAG == 2 && VPZ_PKT_NEXT_FLAG == 4, "packet_info index");
     for (int f = 0; f < 8; ++f) D.packet_info[f] = get_packet_info(D.size0, D.size1, f & 1, f & 2, f & 4);
     if (const char *e = getenv("VPZ_RUN_LENGTH")) D.run_length_override = atoi(e);
+    if (const char *e = getenv("VPZ_NO_DIRECT_I16")) D.no_direct_i16 = atoi(e) != 0;  // A/B and bit-equality tests: always widen int16 residue first
     if (const char *e = getenv("VPZ_NO_RUN_INLINE")) D.no_run_inline = atoi(e) != 0;  // A/B tests: flag bytes from cflags / cmap only
     if (const char *e = getenv("VPZ_NO_CHAIN")) D.no_chain = atoi(e) != 0;  // A/B tests: every run recomputes its predecessor block
     if (const char *e = getenv("VPZ_DUAL_RUN")) D.dual_run = std::max(4, atoi(e));
@@ -708,6 +710,7 @@ struct SynthCall {
     const uint8_t *d_counts = nullptr;
     void *d_out = nullptr;
     bool early_residue = false, early_posts = false;  // stage_inputs_early has the copies under way
+    bool spec_i16 = false;        // the synth kernel reads the 16-bit residue in place (SynthArgs.spec_i16)
     int64_t early_res_extent = 0;
 
     SynthCall(Decoder &dec, int64_t n, const vpz_packet *pk, const float *res, const int16_t *po, const uint8_t *pc,
@@ -1885,12 +1888,13 @@ struct SynthCall {
     int upload_residue(int64_t ext)
     {
         int rc;
-        if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)ext)) != VPZ_OK) return rc;
         if (D.residue_format == VPZ_RESIDUE_I16) {
+            // (the 16-bit values go over as they are; whether a kernel reads them in place or they are widened first is settled in
+            // stage_inputs, once the state machine has said which kernels run)
             if ((rc = grow(ctx, D.b_in_res16, sizeof(int16_t) * (size_t)ext)) != VPZ_OK) return rc;
             VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res16.p, residue, sizeof(int16_t) * (size_t)ext, hipMemcpyHostToDevice, ctx->stream));
-            VPZ_HIP_TRY(ctx, launch_widen_i16(D.b_in_res16.p, static_cast<float *>(D.b_in_res.p), ext, ctx->num_cu, ctx->stream));
         } else {
+            if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)ext)) != VPZ_OK) return rc;
             VPZ_HIP_TRY(ctx, hipMemcpyAsync(D.b_in_res.p, residue, sizeof(float) * (size_t)ext, hipMemcpyHostToDevice, ctx->stream));
         }
         return VPZ_OK;
@@ -1931,14 +1935,23 @@ struct SynthCall {
         d_amp = D.f0_amp;
         d_coeff = D.f0_coeff;
         d_out = pcm_out;
-        if (mem_space != VPZ_MEM_HOST && D.residue_format == VPZ_RESIDUE_I16) {  // device-resident int16 values: widened into the staging buffer
+        // VPZ_RESIDUE_I16 (ABI v5): the floored stereo fast path reads the 16-bit values in place and widens them in registers; every
+        // other kernel reads float32 -- the values are widened into the decoder's staging buffer first (exact either way)
+        const bool i16 = D.residue_format == VPZ_RESIDUE_I16;
+        spec_i16 = i16 && use_dual && any_floor && !D.no_direct_i16 &&
+                   (mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & 7) == 0);
+        if (mem_space != VPZ_MEM_HOST && i16 && !spec_i16) {  // device-resident int16 values: widened into the staging buffer
             if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)res_extent)) != VPZ_OK) return rc;
             VPZ_HIP_TRY(ctx, launch_widen_i16(residue, static_cast<float *>(D.b_in_res.p), res_extent, ctx->num_cu, ctx->stream));
             d_res = static_cast<const float *>(D.b_in_res.p);
         }
         if (mem_space == VPZ_MEM_HOST) {
             if (!(early_residue && early_res_extent >= res_extent) && (rc = upload_residue(res_extent)) != VPZ_OK) return rc;
-            d_res = static_cast<const float *>(D.b_in_res.p);
+            if (i16 && !spec_i16) {
+                if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)res_extent)) != VPZ_OK) return rc;
+                VPZ_HIP_TRY(ctx, launch_widen_i16(D.b_in_res16.p, static_cast<float *>(D.b_in_res.p), res_extent, ctx->num_cu, ctx->stream));
+            }
+            d_res = spec_i16 ? static_cast<const float *>(D.b_in_res16.p) : static_cast<const float *>(D.b_in_res.p);
             if (any_floor) {
                 if (!early_posts) {
                     if ((rc = grow(ctx, D.b_in_posts, sizeof(int16_t) * 64 * (size_t)n_rec)) != VPZ_OK) return rc;
@@ -2096,6 +2109,7 @@ struct SynthCall {
         a.f0_curve = static_cast<const float *>(D.b_f0curve.p);
         a.f0_bark = D.d_f0_bark;
         a.f0_stride = D.f0_k;
+        a.spec_i16 = spec_i16 ? 1 : 0;
         a.state_h = D.d_state_h;
         a.state_slot_floats = (int64_t)D.n_streams * C * half1;
         a.tw_long = D.t1->d_fast;
