@@ -751,7 +751,7 @@ def main_single_process(args):
     kernel_ms = [0.0] * n_dev
 
     def lane(r):
-        for _ in range(args.warmup):
+        for _ in range(max(0, args.ramp_steps) + args.warmup):  # (the clocks' ramp of a fresh process, then the W warm-up steps: see main())
             lines[r].step()
         ctxs[r].synchronize()
         start.wait()
@@ -780,7 +780,8 @@ def main_single_process(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "launcher": "single process: one host thread + one vpz_context per device (bench.py --single-process)",
         "config": {"workload": NS_WORKLOAD, "frames_per_gpu": frames, "channels": CHANNELS, "block_size": N,
-                   "sharding": "independent batch per GPU, no collective", "devices": ids},
+                   "sharding": "independent batch per GPU, no collective", "devices": ids,
+                   "device_state": "steady: %d untimed steps of the workload in front of the W warm-up steps" % max(0, args.ramp_steps)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": pmc_traffic_bytes("north_star_line") if frames == FRAMES else None, "kernel": NS_KERNEL,
@@ -889,6 +890,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[1]/[2]/[3]/[4] side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames", type=int, default=FRAMES, help="frames of the contract workload (default: BASELINE's 65536)")
+    ap.add_argument("--ramp-steps", type=int, default=200, help="untimed steps of the contract workload between its cold measurement and "
+                    "the one reported (the device's clocks ramp up over the first few milliseconds of load; 0: none)")
     ap.add_argument("--extras-frames", type=int, default=FRAMES, help="frames of the configs[2] side measurement")
     ap.add_argument("--extras-frames6", type=int, default=16384, help="frames of the configs[3] side measurement")
     ap.add_argument("--host-threads", type=int, default=0, help="explicit cap on the host threads of a rank (default: every "
@@ -932,24 +935,39 @@ def main():
     # device-resident, one fused kernel launch per step (weak scaling: every rank owns its own batch, no collective)
     line = NorthStarLine(torch, ctx, device, 3 + rank, args.frames)
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
+
+    def measure():
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; (wall seconds, kernel ms per step)"""
+        for _ in range(args.warmup):
+            line.step()
+        ctx.synchronize()
+        if distributed:
+            sharding.barrier()
+        torch.cuda.synchronize()
+        ctx.timer_start()  # HIP events on the stream the kernel is launched on
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            line.step()
+        k_ms = ctx.timer_stop() / args.steps  # also synchronises the stream; the K launches back to back incl. their gaps
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if distributed:
+            el = sharding.max_over_ranks(el, red_device)
+            k_ms = sharding.max_over_ranks(k_ms, red_device)
+            sharding.barrier()
+        return el, k_ms
+
+    # A process that has just started finds the device at idle clocks: the first ~25 calls (6 ms) of ANY cut of this workload run
+    # 8-12 % slower than the calls after them (profiles/r5_bench_cold_and_steady.txt: 0.254-0.268 ms per step over steps 6-25,
+    # 0.229-0.232 over 200).  The contract line is the device's steady state -- what a decode service runs in --: the same W + K
+    # measurement is taken twice, once cold (reported as `cold_start`) and once behind `ramp_steps` untimed steps of the workload.
+    cold_elapsed, cold_kernel_ms = measure()
+    ramp_steps = max(0, args.ramp_steps)
+    for _ in range(ramp_steps):
         line.step()
     ctx.synchronize()
-    if distributed:
-        sharding.barrier()
-    torch.cuda.synchronize()
-    ctx.timer_start()  # HIP events on the stream the kernel is launched on
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        line.step()
-    kernel_ms = ctx.timer_stop() / args.steps  # also synchronises the stream; the K launches back to back incl. their gaps
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        elapsed = sharding.max_over_ranks(elapsed, red_device)
-        kernel_ms = sharding.max_over_ranks(kernel_ms, red_device)
-        sharding.barrier()
+    elapsed, kernel_ms = measure()
 
     value = world * line.pcm_values * args.steps / elapsed / 1e6
     alg_bytes = line.alg_bytes  # 4 B x spectra values read + 4 B x PCM values written = 8 B per sample
@@ -968,7 +986,12 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": NS_WORKLOAD, "frames_per_gpu": args.frames, "channels": CHANNELS, "block_size": N,
-                   "pcm_values_per_step_per_gpu": line.pcm_values, "sharding": "independent batch per GPU, no collective"},
+                   "pcm_values_per_step_per_gpu": line.pcm_values, "sharding": "independent batch per GPU, no collective",
+                   "device_state": "steady: %d untimed steps of the workload between the cold measurement and this one" % ramp_steps},
+        "cold_start": {"ms_per_step": round(cold_elapsed / args.steps * 1e3, 4), "kernel_ms": round(cold_kernel_ms, 4),
+                       "value": round(world * line.pcm_values * args.steps / cold_elapsed / 1e6, 1),
+                       "frac": round(line.alg_bytes / (cold_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "note": "the same W warm-up + K timed steps taken first, on the device as the fresh process found it (idle clocks)"},
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),

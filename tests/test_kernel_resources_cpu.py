@@ -47,12 +47,21 @@ def test_every_synth_kernel_instantiation_is_built_and_keeps_two_workgroups_per_
 
 def test_stereo_fast_path_instantiations_and_their_budget(kernels):
     dual = [k for k in kernels.values() if "synth_dual_kernel" in k["name"]]
-    # <floor?, Residue2-interleaved / planar input, planar / interleaved output, float32 / int16 samples>
-    assert len(dual) == 2 * 2 * 2 * 2
+    # <floor?, Residue2-interleaved / planar input, planar / interleaved output, float32 / int16 samples> + the floored ones once
+    # more for 16-bit residue read in place (kI16)
+    assert len(dual) == 2 * 2 * 2 * 2 + 2 * 2 * 2
     for k in dual:
         assert k["vgprs"] <= 256, k["name"]                   # 2 waves per SIMD: 512 / 2
         assert k["lds"] <= 80 * 1024, (k["name"], k["lds"])   # two 4-wave workgroups per CU (160 KiB)
         assert k.get("occupancy", 2) >= 2, k["name"]
+
+
+def test_the_kernel_for_4096_and_8192_blocks_keeps_its_budget(kernels):
+    big = [k for k in kernels.values() if "synth_big_kernel" in k["name"]]
+    assert len(big) == 2 * 2  # <floor?, float32 / int16 samples>
+    for k in big:
+        assert k["vgprs"] <= 256, k["name"]  # two waves per SIMD where the LDS allows them (4096: two 4-wave workgroups per CU)
+        assert k["lds"] <= 28 * 1024, (k["name"], k["lds"])  # the STATIC part: the two sizes' tables; the waves' areas are dynamic
 
 
 @pytest.mark.parametrize("flags", [["-DVPZ_STAMPS"], ["-DVPZ_WAVE_TIMES"], ["-DVPZ_TUNING"], ["-DVPZ_STAMPS", "-DVPZ_WAVE_TIMES", "-DVPZ_TUNING"],
@@ -67,7 +76,7 @@ def test_the_diagnostic_builds_still_parse(flags):
     if not (shutil.which(hipcc) or os.path.exists(hipcc)):
         pytest.skip("no hipcc")
     csrc = os.path.join(ROOT, "vorbispizza_amd", "csrc")
-    for unit in ("synth_dual.hip", "synth_kernels.hip", "floor0.hip"):
+    for unit in ("synth_dual.hip", "synth_kernels.hip", "floor0.hip", "synth_big.hip"):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "--cuda-device-only", "-Wno-unused-function",
                             "-I", csrc, "-I", os.path.join(ROOT, "include")] + flags + [os.path.join(csrc, unit)],
                            capture_output=True, text=True)

@@ -7,6 +7,6 @@ for i in $(seq $R); do
     echo "== VPZ_NO_DUAL=$nd (round $i)"
     VPZ_NO_DUAL=$nd python tools/kbench_synth.py --which real --steps 40 || exit 1
     VPZ_NO_DUAL=$nd python tools/kbench_synth.py --which ola --steps 40 || exit 1
-    VPZ_NO_DUAL=$nd python tools/kbench_short_long.py || exit 1
+    VPZ_NO_DUAL=$nd python tools/experiments/kbench_short_long.py || exit 1
   done
 done

@@ -13,7 +13,7 @@ for i in 1 2 3; do
 done
 for nd in 1 0; do
   echo "== VPZ_GROUP_DMA=$nd"
-  VPZ_GROUP_DMA=$nd python tools/kbench_layouts.py 2>&1 | tail -6 || exit 1
+  VPZ_GROUP_DMA=$nd python tools/experiments/kbench_layouts.py 2>&1 | tail -6 || exit 1
   VPZ_NO_DUAL=1 VPZ_GROUP_DMA=$nd python tools/kbench_synth.py --which real --steps 40 2>&1 | tail -1 || exit 1
 done
 } 2>&1 | tee $OUT

@@ -2,7 +2,7 @@
 """debugging aid: where synth_big_kernel and the three-pass path (VPZ_NO_BIG=1) differ for one block-size pair"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa
 import helpers

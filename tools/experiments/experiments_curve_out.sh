@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r5_curve_out
 mkdir -p $O
 for w in floor6 real; do
-  rocprofv3 --kernel-trace --stats -d $O/render_$w -o k --output-format csv -- python tools/experiments_curve_out.py $w > $O/render_$w.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/render_$w -o k --output-format csv -- python tools/experiments/experiments_curve_out.py $w > $O/render_$w.log 2>&1
   echo "== separate pass, $w: $(tail -1 $O/render_$w.log)" | tee -a $O/summary.txt
   python tools/prof_summary.py $O/render_$w/k_kernel_stats.csv 2>&1 | grep -E "floor1" | tee -a $O/summary.txt
 done

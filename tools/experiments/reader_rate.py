@@ -1,6 +1,6 @@
 """Tuning helper: one file through the VorbisReader mirror (ReadSamples loop) for several batch sizes."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

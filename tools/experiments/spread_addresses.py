@@ -3,7 +3,7 @@
 back-to-back calls per trial (wall time, one synchronisation at the end); between trials only the addresses of the residue and PCM
 buffers change (a pad in front of each).  And: the same trial repeated without changing anything."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench

@@ -2,7 +2,7 @@
 """configs[2], call by call: the GPU time of 40 consecutive vpz_decoder_synth calls on ONE fixed batch (HIP events around each
 call) -- what the run cutting's determinism is judged by.  VPZ_HOST_PROFILE=1 adds the cut's parameters per call (stderr)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench

@@ -10,6 +10,6 @@ python -c "import __graft_entry__ as g; g.build()"
 for e in ${2:-0}; do
 VPZ_DUAL_EXP=$e VPZ_STAMPS_DUMP=$GRAFT_REPO_ROOT/gpurun_out/r3/wave_times_${W}_exp$e.csv python tools/kbench_synth.py --steps 3 --which $W 2>&1 | grep "configs" | tail -2
 done
-python tools/wave_times_fit.py gpurun_out/r3/wave_times_${W}_exp0.csv
+python tools/experiments/wave_times_fit.py gpurun_out/r3/wave_times_${W}_exp0.csv
 unset VPZ_EXTRA_HIPCC_FLAGS
 python -c "import __graft_entry__ as g; g.build()"

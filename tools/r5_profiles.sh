@@ -18,7 +18,7 @@ counters)
   KERNEL=synth_dual WHICH=real bash tools/pmc_sq_counters.sh gpurun_out/r5/pmc_SQ_config4.txt > /dev/null 2>&1
   KERNEL=synth_kernel WHICH=floor bash tools/pmc_sq_counters.sh gpurun_out/r5/pmc_SQ_config3.txt > /dev/null 2>&1
   python tools/kbench_slow_paths.py > gpurun_out/r5/slow_paths.txt 2>&1; cat gpurun_out/r5/slow_paths.txt
-  bash tools/prof_slow_paths2.sh > gpurun_out/r5/slow_paths_kernels.txt 2>&1
+  bash tools/prof_slow_paths.sh > gpurun_out/r5/slow_paths_kernels.txt 2>&1
   python bench.py --steps 20 --warmup 5 > gpurun_out/r5/bench_final.json 2> gpurun_out/r5/bench_final.err; tail -c 600 gpurun_out/r5/bench_final.json
   ;;
 esac
