@@ -199,3 +199,36 @@ def test_streams_come_and_go_between_calls(ctx, seed):
             dec.close()
     same_bits(results["dual"], results["separate"], "streams coming and going, seed %d" % seed)
     assert len(calls) >= 8 and results["dual"][1].min() > 0
+
+
+@pytest.mark.parametrize("floor,interleaved_in", [(False, False), (True, True), (True, False)])
+def test_chained_runs_give_the_bits_of_recomputed_ones(ctx, floor, interleaved_in):
+    """The stereo fast path chains the runs of a workgroup (round 5: the later run overlaps its first frame with the tail its
+    neighbour leaves in LDS and emits that frame last, nothing is recomputed -- kPreNeighbour) wherever two runs of one stream meet in
+    the steady state, and cuts all-long batches into short runs.  Whatever the run length (VPZ_DUAL_RUN 4 ... 33, the default), all-long
+    streams and window-switching ones, streams shorter than a run, three calls with the state carried and an end-of-stream trim on
+    the last packet of some streams: the PCM, the counts and the positions are those of the cut that recomputes every predecessor
+    (VPZ_NO_CHAIN=1) -- float32 and 16-bit, planar and interleaved."""
+    from vorbispizza_amd import capi
+    channels = 2
+    floors = [(helpers.SHORT_XLIST, 2), (helpers.LONG_XLIST, 2)] if floor else ()
+    maps = [{"coupling": [(0, 1)], "channel_floor": [0, 0]}, {"coupling": [(1, 0)], "channel_floor": [1, 1]}] if floor else ()
+    for n_streams, frames, p_ls in ((3, 260, 0.0), (7, 90, 0.04), (40, 23, 0.0), (2, 515, 0.3)):
+        pk, res, posts, counts = stream_major_batch(n_streams, frames, channels, seed=9000 + n_streams + frames, floor=floor,
+                                                    interleaved=interleaved_in, p_ls=p_ls, p_sl=0.4, silent_prob=0.1)
+        if floor:
+            pk["mapping"] = pk["flags"] & 1
+        # an end-of-stream trim on every other stream's last packet (StreamDecoder.cs:658-666): a granule 100 samples short
+        per = frames
+        for s in range(0, n_streams, 2):
+            last = s * per + per - 1
+            pk[last]["flags"] |= PKT_EOS
+            pk[last]["granule"] = max(1, (per - 2) * 1024 - 100)
+        for layout in (capi.OUT_PLANAR, capi.OUT_INTERLEAVED, capi.OUT_INTERLEAVED_S16):
+            with env(VPZ_NO_CHAIN=1, VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=3):
+                ref = run(ctx, pk, res, posts, counts, n_streams, channels, floors, maps, layout=layout, splits=3)
+            assert np.abs(ref[0].astype(np.float64)).max() > 0
+            for run_len in (None, 4, 5, 8, 13, 33):
+                with env(VPZ_NO_CHAIN=None, VPZ_DUAL_RUN=run_len, VPZ_PAR_MIN_PACKETS=1, VPZ_HOST_THREADS=3):
+                    got = run(ctx, pk, res, posts, counts, n_streams, channels, floors, maps, layout=layout, splits=3)
+                same_bits(got, ref, "chained runs of %r, %d streams x %d frames, layout %d" % (run_len, n_streams, frames, layout))

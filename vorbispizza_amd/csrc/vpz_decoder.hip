@@ -1720,7 +1720,7 @@ struct SynthCall {
         };
         // (one sweep does both: a run's bytes depend on its own record only, its chaining on its predecessor's place and length)
         HostPool *pool = static_cast<HostPool *>(ctx->host_pool);
-        if (pool && pool->parties() > 1 && n_runs >= 4096) {
+        if (pool && pool->parties() > 1 && n_runs >= 1024) {  // (the pool's workers are still spinning from the cut's fork-join)
             const int P = pool->parties();
             std::vector<int64_t> part((size_t)P, 0);
             host_failed |= !pool->run([&](int c) {
