@@ -414,10 +414,13 @@ bool synth_big_supported(int size0, int size1)
     return (size1 == 4096 || size1 == 8192) && fused(size0) && (size0 <= 2048 || size0 == size1);
 }
 
+// The kernel's dynamic LDS goes beyond the 64 KB a launch may ask for by default: the limit is raised to what the largest pair needs --
+// ONE value whatever the decoder, so that contexts launching from several host threads (the dispatcher's lanes) never lower it under each other
 template <typename K>
 static hipError_t big_prepare(K kernel, int lds)
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int most = big_layout(8192, 8192).total;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds > most ? lds : most);
 }
 
 hipError_t launch_synth_big(const SynthArgs &args, bool has_floor, hipStream_t stream)
