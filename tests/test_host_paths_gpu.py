@@ -229,12 +229,16 @@ def test_group_mode_equals_the_separate_coupling_pass(ctx, oracle, channels, ste
     mappings = [{"coupling": steps, "channel_floor": [0] * channels}, {"coupling": steps, "channel_floor": [1] * channels}]
     outs = {}
     for layout in (capi.OUT_PLANAR, capi.OUT_INTERLEAVED):
-        with env(VPZ_NO_GROUP=None):
+        # (VPZ_NO_PAIRS: channel counts and steps the pair route would take -- tests/test_pairs_gpu.py -- stay with group mode here)
+        with env(VPZ_NO_GROUP=None, VPZ_NO_PAIRS=1):
             g = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
-        with env(VPZ_NO_GROUP=1):
+        with env(VPZ_NO_GROUP=1, VPZ_NO_PAIRS=1):
             l = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
         assert np.array_equal(g[1], l[1]) and np.array_equal(g[2], l[2])
         assert np.array_equal(g[0].view(np.uint32), l[0].view(np.uint32)), (channels, layout)
+        with env(VPZ_NO_GROUP=None, VPZ_NO_PAIRS=None):  # ... and whatever route the decoder picks by itself
+            dflt = run(ctx, pk, res, posts, counts, n_streams, channels, floors, mappings, layout=layout, splits=2)
+        assert np.array_equal(dflt[1], g[1]) and np.array_equal(dflt[0].view(np.uint32), g[0].view(np.uint32)), (channels, layout)
         # ... and the opt-in variant that leaves the interleaved packet as it is in LDS (LDS-DMA landing, the wave's own
         # coupling step applied at pick-up; even channel counts, no channel in two steps -- otherwise the switch does nothing)
         with env(VPZ_NO_GROUP=None, VPZ_NO_DUAL=1, VPZ_GROUP_DMA=1):

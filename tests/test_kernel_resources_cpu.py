@@ -56,6 +56,17 @@ def test_stereo_fast_path_instantiations_and_their_budget(kernels):
         assert k.get("occupancy", 2) >= 2, k["name"]
 
 
+def test_the_pair_route_is_the_stereo_kernel_once_more_with_its_budget(kernels):
+    pairs = [k for k in kernels.values() if "synth_pairs_kernel" in k["name"]]
+    # <floor?, Residue2-interleaved / planar input, planar / interleaved output, float32 / int16 samples> (float32 residue only)
+    assert len(pairs) == 2 * 2 * 2 * 2
+    for k in pairs:
+        assert k["unit"] == "synth_pairs.hip"
+        assert k["vgprs"] <= 256, k["name"]
+        assert k["lds"] <= 80 * 1024, (k["name"], k["lds"])
+        assert k.get("occupancy", 2) >= 2, k["name"]
+
+
 def test_the_kernel_for_4096_and_8192_blocks_keeps_its_budget(kernels):
     big = [k for k in kernels.values() if "synth_big_kernel" in k["name"]]
     assert len(big) == 2 * 2  # <floor?, float32 / int16 samples>
@@ -76,7 +87,7 @@ def test_the_diagnostic_builds_still_parse(flags):
     if not (shutil.which(hipcc) or os.path.exists(hipcc)):
         pytest.skip("no hipcc")
     csrc = os.path.join(ROOT, "vorbispizza_amd", "csrc")
-    for unit in ("synth_dual.hip", "synth_kernels.hip", "floor0.hip", "synth_big.hip"):
+    for unit in ("synth_dual.hip", "synth_pairs.hip", "synth_kernels.hip", "floor0.hip", "synth_big.hip"):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "--cuda-device-only", "-Wno-unused-function",
                             "-I", csrc, "-I", os.path.join(ROOT, "include")] + flags + [os.path.join(csrc, unit)],
                            capture_output=True, text=True)

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--frames", type=int, default=65536)
     ap.add_argument("--layout", default="planar")
+    ap.add_argument("--planar-in", action="store_true", help="floor6: the residue as planar [6][1024] packets instead of the Residue2 vector")
+    ap.add_argument("--no-support", action="store_true", help="floor6: the mapping does not declare the residue's support")
     args = ap.parse_args()
     import torch
     import bench
@@ -60,8 +62,11 @@ def main():
         byt = 8 * sum(expect) * 2
         args.layout = "interleaved"
     elif args.which == "floor6":
-        pk, residue, posts, counts, floors, mappings, samples = bench.build_floor6(torch, dev, 16384)
+        pk, residue, posts, counts, floors, mappings, samples = bench.build_floor6(torch, dev, 16384, declare_support=not args.no_support)
         ch = 6
+        if args.planar_in:
+            residue = residue.reshape(16384, 1024, 6).transpose(1, 2).contiguous().reshape(-1)
+            pk["flags"] &= np.uint8(~capi.PKT_INTERLEAVED & 0xFF)
         byt = 4 * residue.numel() // 2 + 4 * samples * 6 + posts.numel() * 2
     else:
         pk, residue, samples, res_floats = bench.build_synth_ola(torch, dev, args.frames, all_long=args.which == "olalong")

@@ -32,7 +32,11 @@ PRESETS = {
     "group_ilv": ("synth_kernels.hip", "synth_kernel<true, 1, false, true, false>"),
     "dual": ("synth_dual.hip", "synth_dual_kernel<true, true, 1, false, 0>"),
     "dual_nofloor": ("synth_dual.hip", "synth_dual_kernel<false, false, 0, false, 0>"),
+    "pairs": ("synth_pairs.hip", "synth_pairs_kernel<true, true, 0, false, false, 0>"),
+    "pairs_ilv": ("synth_pairs.hip", "synth_pairs_kernel<true, true, 1, false, false, 0>"),
 }
+# a unit that is another one compiled once more under a macro: (the file its kernel's text is in, the kernel's name there)
+SOURCE_OF = {"synth_pairs.hip": ("synth_dual.hip", "synth_dual_kernel")}
 
 # Source regions that an all-long floored frame does not execute.  Functions by name (innermost or anywhere in the
 # inlining chain); kernel-body regions by a `// [census: cold]` mark on the line that opens their brace block.
@@ -211,9 +215,10 @@ def main():
         m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"\s+"([^"]*)"', l)
         if m:
             files[int(m.group(1))] = os.path.normpath(os.path.join(m.group(2), m.group(3)))
-    unit_path = os.path.join(CSRC, unit)
+    src_unit = SOURCE_OF.get(unit, (unit, None))[0]
+    unit_path = os.path.join(CSRC, src_unit)
     src_lines = open(unit_path).read().split("\n")
-    kname = kernel.split("<")[0]
+    kname = SOURCE_OF.get(unit, (None, kernel.split("<")[0]))[1]
     kfirst = next(i for i, l in enumerate(src_lines) if re.search(r"\bvoid " + kname + r"\(SynthArgs a\)", l)) + 1
     klast = next(i for i in range(kfirst, len(src_lines)) if src_lines[i].startswith("}")) + 1
     loop_line = next(i for i in range(kfirst, klast) if re.search(r"for \(int it = 0; it < iters; \+\+it\)", src_lines[i])) + 1
@@ -292,7 +297,7 @@ def main():
         chain = ins["chain"]
         body_line = None
         for path, line in reversed(chain):  # outermost first
-            if os.path.basename(path) == unit and kfirst <= line <= klast:
+            if os.path.basename(path) == src_unit and kfirst <= line <= klast:
                 body_line = line
                 break
         inner_path, inner_line = chain[0] if chain else ("?", 0)
@@ -301,7 +306,7 @@ def main():
             fn = "(kernel body)"
         cold = None
         for path, line in chain:
-            if os.path.basename(path) == unit:
+            if os.path.basename(path) == src_unit:
                 for a, b, anchor in cold_ranges:
                     if a <= line <= b:
                         cold = anchor

@@ -50,6 +50,10 @@ def main():
     posts[:, 2:29] = rng.integers(0, 8, size=(frames * C_, 27))
     counts = np.full(frames * C_, 29, dtype=np.uint8)
     d_posts, d_counts = torch.from_numpy(posts).to(dev), torch.from_numpy(counts).to(dev)
+    planar_a = os.environ.get("SLOW_A_PLANAR", "0") not in ("", "0")  # (a) with planar [10][1024] packets (residue types 0 / 1)
+    if planar_a:
+        res = res.transpose(1, 2).contiguous()
+        pk["flags"] &= np.uint8(~capi.PKT_INTERLEAVED & 0xFF)
     dec = Decoder(ctx, C_, 256, 2048, floors=[(helpers.LONG_XLIST, 2)],
                   mappings=[{"coupling": [(0, 1), (2, 3), (4, 5)], "channel_floor": [0] * C_}])
     samples = (frames - 1) * 1024
@@ -62,8 +66,9 @@ def main():
 
     dt, w = timed(ctx, step_a)
     byt = 4 * res.numel() + 4 * samples * C_
-    print("(a) 10 channels, coupled, Floor1, %d frames (separate coupling pass + one wave per channel): %.3f ms/call  %.1f Msamples/s  "
-          "%.0f GB/s algorithmic = %.3f of 8 TB/s" % (frames, dt * 1e3, samples * C_ / dt / 1e6, byt / dt / 1e9, byt / dt / 8e12), flush=True)
+    print("(a) 10 channels, %s, coupled, Floor1, %d frames (Residue2 vector: separate coupling pass + one wave per channel; planar packets: "
+          "the pair route, VPZ_NO_PAIRS=1 the separate pass): %.3f ms/call  %.1f Msamples/s  "
+          "%.0f GB/s algorithmic = %.3f of 8 TB/s" % ("planar packets" if planar_a else "Residue2 vector", frames, dt * 1e3, samples * C_ / dt / 1e6, byt / dt / 1e9, byt / dt / 8e12), flush=True)
     dec.close()
     del res, out
 

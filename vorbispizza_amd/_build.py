@@ -20,6 +20,7 @@ SOURCES = {
     "imdct_exact.hip": ["-ffp-contract=off"],
     "synth_kernels.hip": [],
     "synth_dual.hip": [],
+    "synth_pairs.hip": [],   # synth_dual.hip once more, for channel pairs of streams with 4, 6, 8, ... channels
     "synth_big.hip": [],
     "floor0.hip": ["-ffp-contract=off"],
     "vpz_context.hip": ["-ffp-contract=off"],
@@ -38,6 +39,8 @@ def _hipcc():
 
 def _deps(src):
     deps = [src]
+    if os.path.basename(src) == "synth_pairs.hip":
+        deps.append(os.path.join(CSRC, "synth_dual.hip"))
     for name in os.listdir(CSRC):
         if name.endswith(".hpp"):
             deps.append(os.path.join(CSRC, name))

@@ -391,6 +391,14 @@ __device__ __forceinline__ void store_pcm4_pair(float4 *p, float4 v0, float4 v1)
 }
 template <class T>
 __device__ __forceinline__ void store_pcm(T *p, T v) { *(VPZ_GLOBAL T *)p = v; }
+// two adjacent float32 samples (a column pair of an interleaved PCM row: the pair route), one 8-byte global store, plain -- the
+// rest of the row's lines comes from other workgroups, the L2 puts them together
+typedef float vpz_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_pcm2(float *p, float a, float b)
+{
+    vpz_f2v t = {a, b};
+    *((VPZ_GLOBAL vpz_f2v *)reinterpret_cast<vpz_f2v *>(p)) = t;
+}
 
 // Branch-free addressing of the IMDCT output through its mirror symmetries (Mdct.cs:378-381).
 // y[pos..pos+3] (pos, n4 multiples of 4) = h4[idx] possibly reversed / negated.

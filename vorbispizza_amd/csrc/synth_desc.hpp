@@ -165,6 +165,10 @@ struct SynthArgs {
                                 // frames (16 + 16 bytes, zero beyond the run), at an address the wave knows before its run record
                                 // has arrived; nullptr: the bytes are read from cflags / cmap at the run's `first`
     const uint32_t *map_bits;   // [mapping] group-mode flag bits of a floored frame of that mapping (stage / steps)
+                                // (pair route: [pair][mapping], the steps of that pair only, in the pair's own step table)
+    const uint8_t *pair_ch;     // pair route (synth_pairs_kernel): [pair][2] the pair's channels -- the first is "channel 0" of its steps
+    int32_t n_pairs;            // channels / 2
+    int32_t n_mappings;
     PacketGeom geom[8];
     const RunDesc *runs;
     int32_t n_runs;

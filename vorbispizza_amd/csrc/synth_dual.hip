@@ -27,8 +27,23 @@
 #include "synth_desc.hpp"
 #include "vpz_internal.hpp"
 
+// The same kernel for CHANNEL PAIRS of streams with more than two channels (synth_pairs.hip compiles this file with
+// VPZ_DUAL_PAIRS=1): a stream whose coupling steps, over all its mappings, join its channels two by two (5.1 as libvorbis
+// writes it: L-R, Ls-Rs; C and LFE on their own) is, to the arithmetic, a set of stereo streams -- no value of one pair ever
+// meets a value of another (Mapping.cs:166-195).  A workgroup then walks four runs of ONE pair (SynthArgs.pair_ch: its two
+// channels), the pairs of a chunk of runs are neighbours in the grid and on one XCD (an interleaved packet's lines are fetched
+// by all of them: from HBM once), and what changes against the stereo kernel is addressing only -- rows of a [C][bin] packet or
+// columns of a [bin][C] one, the records and the saved state of channels chA / chB, PCM rows or columns of those two.
+#ifndef VPZ_DUAL_PAIRS
+#define VPZ_DUAL_PAIRS 0
+#endif
+#if VPZ_DUAL_PAIRS
+#define synth_dual_kernel synth_pairs_kernel
+#endif
+
 namespace vpz {
 
+constexpr bool kPairs = VPZ_DUAL_PAIRS != 0;
 constexpr int kDualWaves = VPZ_DUAL_WAVES;
 constexpr int kDualWavesPerSimd = VPZ_DUAL_WAVES >= 10 ? 3 : 2;  // 4-wave workgroups: two per CU (LDS); 10-wave ones: one
 constexpr int kDualThreads = 64 * kDualWaves;
@@ -183,7 +198,17 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int run_idx = blockIdx.x * kDualWaves + wave;
+    // pairs: the grid is laid out in groups of 8 chunks x n_pairs workgroups -- workgroup id % 8 (its XCD) is its chunk's, the
+    // pairs of a chunk are 8 ids apart
+    const int n_pairs = kPairs ? a.n_pairs : 1;
+    const int pair = kPairs ? ((int)blockIdx.x % (8 * n_pairs)) / 8 : 0;
+    const int chunk = kPairs ? ((int)blockIdx.x / (8 * n_pairs)) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+    // (channels of a packet and this workgroup's two, "L" and "R" below: parked with the pointers further down -- nC(), cA(), cB())
+    const int C0 = kPairs ? a.channels : 2;
+    const int chA0 = kPairs ? (int)a.pair_ch[2 * pair] : 0;
+    const int chB0 = kPairs ? (int)a.pair_ch[2 * pair + 1] : 1;
+    const uint32_t *map_bits = kPairs ? a.map_bits + (size_t)pair * a.n_mappings : a.map_bits;
+    const int run_idx = chunk * kDualWaves + wave;
     const bool active = run_idx < a.n_runs;
 #ifdef VPZ_WAVE_TIMES
     const unsigned long long t_wave_begin = __builtin_amdgcn_s_memtime();
@@ -203,7 +228,6 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         run.pre_kind = kPreNone;
         run.flags = 0;
     }
-    auto size_of = [&](uint32_t flags) -> int { return (flags & kFrameLong) ? a.size1 : a.size0; };
     // The input of a frame: 32 registers, va[m] | vb[m] = the 16 bytes lane-point m of an interleaved packet comes in
     // ((L[2k], R[2k]) | (L[2k+1], R[2k+1])), or the point's two 8-byte pairs of a planar one ((L[2k], L[2k+1]) |
     // (R[2k], R[2k+1])).  Every load is UNCONDITIONAL (a frame that needs no input reads the head of the inverse dB
@@ -217,12 +241,22 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     {
         const uint64_t sp = reinterpret_cast<uint64_t>(a.spec), db = reinterpret_cast<uint64_t>(a.inv_db);
         const uint64_t cpp = a.cposts != nullptr ? reinterpret_cast<uint64_t>(a.cposts) : db;
-        const int vals[8] = {(int)(uint32_t)sp, (int)(uint32_t)(sp >> 32), (int)(uint32_t)db, (int)(uint32_t)(db >> 32),
-                             (int)(uint32_t)cpp, (int)(uint32_t)(cpp >> 32), a.cposts != nullptr ? 1 : 0, a.f0_stride};
+        const int vals[14] = {(int)(uint32_t)sp, (int)(uint32_t)(sp >> 32), (int)(uint32_t)db, (int)(uint32_t)(db >> 32),
+                              (int)(uint32_t)cpp, (int)(uint32_t)(cpp >> 32), a.cposts != nullptr ? 1 : 0, a.f0_stride,
+                              C0, chA0, chB0, a.size0, a.size1, a.ccount != nullptr ? 1 : 0};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) kv = lane == i ? vals[i] : kv;
+        for (int i = 0; i < (kPairs ? 14 : 8); ++i) kv = lane == i ? vals[i] : kv;
         asm volatile("" : "+v"(kv));
     }
+    // (pairs: the block sizes come from the parked values as well -- the frame loop has no scalar register to keep them in)
+    auto size_of = [&](uint32_t flags) -> int {
+        return kPairs ? __builtin_amdgcn_readlane(kv, (flags & kFrameLong) ? 12 : 11) : ((flags & kFrameLong) ? a.size1 : a.size0);
+    };
+    auto nC = [&]() -> int { return kPairs ? __builtin_amdgcn_readlane(kv, 8) : 2; };
+    auto cA = [&]() -> int { return kPairs ? __builtin_amdgcn_readlane(kv, 9) : 0; };
+    auto cB = [&]() -> int { return kPairs ? __builtin_amdgcn_readlane(kv, 10) : 1; };
+    // (pairs: adjacent channels are one 8-byte column of an interleaved packet / PCM row)
+    auto adjacent = [&]() -> bool { return !kPairs || (cB() == cA() + 1 && !(cA() & 1)); };
     auto parked64 = [&](int i) -> uint64_t {
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(kv, i + 1) << 32) | (uint32_t)__builtin_amdgcn_readlane(kv, i);
     };
@@ -258,6 +292,37 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                     vb[m] = make_float2(0.0f, 0.0f);
                 }
             }
+        } else if (kIlvIn && kPairs) {
+            // columns chA, chB of the [bin][C] vector: point k = bins 2k, 2k + 1 -- two 8-byte pieces (adjacent channels) or four
+            // values; block gg of a pass of short blocks is the gg-th packet, C * 128 floats further on
+            // Point groups beyond the residue's declared support (ABI v4; the frame's skip field) are +0.0 by the setup header's word:
+            // their loads go to a line of zeros behind the inverse dB table instead -- still unconditional, but every lane asks for
+            // the same 16 bytes, and a third of every line of the vector's upper part is not pulled through this CU's cache for nothing
+            const int live = !valid ? 8 : 8 - (int)((fd.flags >> kFrameSkipShift) & kFrameSkipMask);
+            const VPZ_GLOBAL float *zeros = (const VPZ_GLOBAL float *)parked64(2) + 256;
+            const int base = !valid ? 0 : (is_long ? 2 * l * nC() : gg * nC() * 128 + 2 * (l & 7) * nC()) + cA();
+            const int step = !valid ? 0 : (is_long ? 128 * nC() : 16 * nC());
+            const int row = !valid ? 0 : nC();
+            if (adjacent()) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const bool z = m >= live;
+                    const VPZ_GLOBAL float *pm = z ? zeros : src;
+                    const int o = z ? 0 : base + step * m;
+                    va[m] = *(const VPZ_GLOBAL float2 *)(pm + o);
+                    vb[m] = *(const VPZ_GLOBAL float2 *)(pm + o + (z ? 0 : row));
+                }
+            } else {  // [census: cold]
+                const int db = !valid ? 0 : cB() - cA();
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const bool z = m >= live;
+                    const VPZ_GLOBAL float *pm = z ? zeros : src;
+                    const int o = z ? 0 : base + step * m, r1 = z ? 0 : row, d1 = z ? 0 : db;
+                    va[m] = make_float2(pm[o], pm[o + d1]);
+                    vb[m] = make_float2(pm[o + r1], pm[o + r1 + d1]);
+                }
+            }
         } else if (kIlvIn) {
             const VPZ_GLOBAL float4 *s4 = (const VPZ_GLOBAL float4 *)src;
             const int base = !valid ? 0 : (is_long ? l : 64 * gg + (l & 7));
@@ -267,6 +332,23 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 const float4 v = s4[base + step * m];
                 va[m] = make_float2(v.x, v.y);
                 vb[m] = make_float2(v.z, v.w);
+            }
+        } else if (kPairs) {
+            // rows chA, chB of the [C][bin] packet (8-byte pieces: two bins of one channel)
+            const VPZ_GLOBAL float2 *s2 = (const VPZ_GLOBAL float2 *)src;
+            const int hb = is_long ? 512 : 64;  // a row in 8-byte pieces
+            const int live = !valid ? 8 : 8 - (int)((fd.flags >> kFrameSkipShift) & kFrameSkipMask);  // (see the interleaved case)
+            const VPZ_GLOBAL float2 *zeros = (const VPZ_GLOBAL float2 *)((const VPZ_GLOBAL float *)parked64(2) + 256);
+            const int base = !valid ? 0 : (is_long ? l : gg * nC() * 64 + (l & 7)) + cA() * hb;
+            const int step = !valid ? 0 : (is_long ? 64 : 8);
+            const int rofs = !valid ? 0 : (cB() - cA()) * hb;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const bool z = m >= live;
+                const VPZ_GLOBAL float2 *pm = z ? zeros : s2;
+                const int o = z ? 0 : base + step * m;
+                va[m] = pm[o];
+                vb[m] = pm[o + (z ? 0 : rofs)];
             }
         } else {
             const VPZ_GLOBAL float2 *s2 = (const VPZ_GLOBAL float2 *)src;
@@ -284,8 +366,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             const bool floored = valid && !(fd.flags & kFrameNoFloor) && __builtin_amdgcn_readlane(kv, 6) != 0;  // (a.cposts != nullptr)
             const VPZ_GLOBAL int32_t *cp = (const VPZ_GLOBAL int32_t *)parked64(4);  // (the posts, or the table's head)
             const size_t rec = floored ? (size_t)fd.rec : 0;
-            cpa = cp[rec * 64 + l];
-            cpb = cp[(floored ? rec + 1 : 0) * 64 + l];
+            cpa = cp[(floored ? rec + cA() : 0) * 64 + l];
+            cpb = cp[(floored ? rec + cB() : 0) * 64 + l];
         }
     };
     {
@@ -325,8 +407,12 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             cf_early = a.cflags[f0 + lane];
             mp_early = a.cmap[f0 + lane];
         }
-        if (lane < n && kHasFloor && a.ccount != nullptr)  // both channels' post counts: records 2p, 2p + 1
-            cc_early = *reinterpret_cast<const uint16_t *>(a.ccount + run.rec_base + lane * 2);
+        if (lane < n && kHasFloor && a.ccount != nullptr) {  // both channels' post counts: records 2p, 2p + 1
+            if (kPairs)
+                cc_early = (int)a.ccount[run.rec_base + lane * nC() + cA()] | ((int)a.ccount[run.rec_base + lane * nC() + cB()] << 8);
+            else
+                cc_early = *reinterpret_cast<const uint16_t *>(a.ccount + run.rec_base + lane * 2);
+        }
         // The first staged frame of a run that starts with a 2048 block: its input is asked for HERE, ahead of the barrier and of
         // the descriptors' derivation (its place is the run's spec_base, its records the run's rec_base whatever the other
         // frames are; a short first frame may head a batch of blocks, which only the derivation knows)
@@ -373,7 +459,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         uint32_t fl = ((cf & 1) ? kFrameLong : 0u) | (g.left_use_size1 ? kFrameSlope1 : 0u) |
                       ((cf & kCfNoFloor) ? kFrameNoFloor : 0u);
         if (!(cf & kCfNoFloor)) {  // the mapping's coupling steps and what its setup header says about the residue's support
-            const uint32_t mb = a.map_bits[mp];
+            const uint32_t mb = map_bits[mp];
             fl |= (mb & 0x00FFFF00u) | ((((cf & 1) ? mb >> kFrameSkipShift : mb >> kMapSkipShortShift) & kFrameSkipMask) << kFrameSkipShift);
         }
         if (cf & kCfSkip) { fl = kFrameDrain; out_count = 0; }
@@ -409,7 +495,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             }
         }
         const int half = (cf & 1) ? (a.size1 >> 1) : (a.size0 >> 1);
-        int spec_sz = lane < n ? 2 * half : 0;
+        int spec_sz = lane < n ? nC() * half : 0;
         int out_sz = (lane < n && lane >= -fi0) ? out_count : 0;
         int spec_incl = spec_sz, out_incl = out_sz;
 #pragma unroll
@@ -423,7 +509,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             uint4 lo, hi;
             lo.x = (uint32_t)spec_off; lo.y = (uint32_t)((uint64_t)spec_off >> 32);
             lo.z = (uint32_t)out_off; lo.w = (uint32_t)((uint64_t)out_off >> 32);
-            hi.x = (uint32_t)(run.rec_base + lane * 2);
+            hi.x = (uint32_t)(run.rec_base + lane * nC());
             const int plen_d = (has_prev && !(cf & kCfSkip)) ? prev_stop - prev_end : 0, pend_d = (has_prev && !(cf & kCfSkip)) ? prev_end : 0;
             hi.y = (uint32_t)left_start | ((uint32_t)plen_d << 16);
             hi.z = (uint32_t)pend_d | ((uint32_t)out_count << 16);
@@ -435,7 +521,12 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     } else {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.frames + (run.first + fi0));
         const int n16 = (run.count - fi0) * 2;
-        for (int i = lane; i < n16; i += 64) s_desc[wave][i] = src[i];
+        for (int i = lane; i < n16; i += 64) {
+            uint4 w = src[i];
+            if (kPairs && (i & 1) && !(w.w & (kFrameDrain | kFrameNoFloor)))  // (the frame names its mapping: this pair's steps of it)
+                w.w = (w.w & ~0x00FFFF00u) | (map_bits[(w.w >> kFrameStepsOffShift) & 0xFFu] & 0x00FFFF00u);
+            s_desc[wave][i] = w;
+        }
     }
     // post counts of the run's frames (ExecuteChannel), both channels in one register: lane i = the i-th staged frame
     int cc_run = 0;
@@ -444,8 +535,10 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             cc_run = cc_early;
         } else {
             __builtin_amdgcn_wave_barrier();
-            if (lane < run.count - fi0)
-                cc_run = *reinterpret_cast<const uint16_t *>(a.ccount + (int)s_desc[wave][2 * lane + 1].x);
+            if (lane < run.count - fi0) {
+                const uint8_t *cc = a.ccount + (int)s_desc[wave][2 * lane + 1].x;
+                cc_run = (int)cc[cA()] | ((int)cc[cB()] << 8);
+            }
         }
     }
     int iters = run.count - fi0 - (int)__popcll(__ballot(batch_member));
@@ -475,11 +568,11 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
 
     // ---- block preceding the run: from the saved state, or recomputed as "frame -1" of the loop
     if (run.pre_kind == kPreState) {
-        const float *st = a.state_h + (size_t)run.state_slot * a.state_slot_floats + (size_t)run.stream * 2 * half1;
+        const float *st = a.state_h + (size_t)run.state_slot * a.state_slot_floats + (size_t)run.stream * nC() * half1;
         prev_n4 = run.prev_long ? (a.size1 >> 2) : (a.size0 >> 2);
         for (int i = lane; i < prev_n4; i += 64) {
-            tailL[i] = st[i];
-            tailR[i] = st[half1 + i];
+            tailL[i] = st[cA() * half1 + i];
+            tailR[i] = st[cB() * half1 + i];
         }
     }
     out_t *out_base = reinterpret_cast<out_t *>(a.out) + (a.stream_out_off ? a.stream_out_off[run.stream] : 0);
@@ -543,7 +636,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         const int nblk = size_of(fd.flags);
         const bool is_long = nblk == 2048;
         const int n4 = is_long ? 512 : 64;
-        const bool no_floor = !kHasFloor || (fd.flags & kFrameNoFloor) || a.ccount == nullptr;
+        const bool no_floor = !kHasFloor || (fd.flags & kFrameNoFloor) || (kPairs ? __builtin_amdgcn_readlane(kv, 13) == 0 : a.ccount == nullptr);
         const int slot = fi - fi0;
         // ABI v4: point groups m >= 8 - skip lie beyond the residue's support -- zeros by the setup header's word (their loads
         // stay: the vector is in memory with its zeros; what is saved is the arithmetic).  Halves are all this path looks at.
@@ -635,8 +728,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                     silentR = cntR == 0;
                     const int lpb = is_long ? 64 : 8;
                     const int n = nblk >> 1;
-                    f0L = cntL == kFloor0Marker;  // (type-0 floors: no curve to render, see floor0_multiply below)
-                    f0R = cntR == kFloor0Marker;
+                    f0L = !kPairs && cntL == kFloor0Marker;  // (type-0 floors: no curve to render, see floor0_multiply below;
+                    f0R = !kPairs && cntR == kFloor0Marker;  // the pair route is not taken by setups that have them)
                     const int nrL = (silentL || f0L || (VPZ_ABLATE(a) & 512)) ? 0 : 2 * (spectrum_top(xL, lpb, ln) + 1);
                     const int nrR = (silentR || f0R || (VPZ_ABLATE(a) & 512)) ? 0 : 2 * (spectrum_top(xR, lpb, ln) + 1);
                     const int pa = ln < cntL ? cpa : 0, pb = ln < cntR ? cpb : 0;
@@ -659,8 +752,9 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
 #pragma unroll
                     for (int f = 0; f < 8; ++f) {
                         const int ff = f < bsz ? f : 0;
-                        cps[f][0] = a.cposts[(size_t)(fd.rec + 2 * ff) * 64 + ln];
-                        cps[f][1] = a.cposts[(size_t)(fd.rec + 2 * ff + 1) * 64 + ln];
+                        const int32_t *posts = kPairs ? (const int32_t *)parked64(4) : a.cposts;
+                        cps[f][0] = posts[(size_t)(fd.rec + nC() * ff + cA()) * 64 + ln];
+                        cps[f][1] = posts[(size_t)(fd.rec + nC() * ff + cB()) * 64 + ln];
                     }
 #pragma unroll
                     for (int f = 0; f < 8; ++f) {
@@ -697,10 +791,10 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                     const int f0s = __builtin_amdgcn_readlane(kv, 7);  // (a.f0_stride)
                     const int kc = min(f0s, kFloor0MaxBark);
                     if (f0L)
-                        floor0_multiply(xL, hL, a.f0_curve + (size_t)fd.rec * f0s, kc,
+                        floor0_multiply(xL, hL, a.f0_curve + (size_t)(fd.rec + cA()) * f0s, kc,
                                         a.f0_bark + ((size_t)__builtin_amdgcn_readlane(cpa, 0) * 2 + (is_long ? 1 : 0)) * 1024, lpb0, ln);
                     if (f0R)
-                        floor0_multiply(xR, hR, a.f0_curve + (size_t)(fd.rec + 1) * f0s, kc,
+                        floor0_multiply(xR, hR, a.f0_curve + (size_t)(fd.rec + cB()) * f0s, kc,
                                         a.f0_bark + ((size_t)__builtin_amdgcn_readlane(cpb, 0) * 2 + (is_long ? 1 : 0)) * 1024, lpb0, ln);
                 }
                 }
@@ -748,10 +842,12 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         VPZ_STAMP(4);  // wait for the next frame's input
         // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 515-638)
         // 4 consecutive samples of both channels, sample 4 g .. 4 g + 3 of the pass's output
-        out_t *row_i = out_base + fd.out_off * 2;                          // interleaved: sample s at [2 s, 2 s + 1]
-        out_t *row_l = out_base + fd.out_off;                              // planar
-        out_t *row_r = out_base + a.channel_stride + fd.out_off;
-        const bool aligned = kInterleavedOut ? (reinterpret_cast<uintptr_t>(row_i) & 15) == 0
+        out_t *row_i = out_base + fd.out_off * nC() + cA();                    // interleaved: sample s at [C s + chA], [C s + chB]
+        out_t *row_l = out_base + cA() * a.channel_stride + fd.out_off;     // planar
+        out_t *row_r = out_base + cB() * a.channel_stride + fd.out_off;
+        // (pairs, interleaved: a sample's two values are one 8-byte -- 4-byte for 16-bit PCM -- piece when the channels are adjacent)
+        const bool aligned = kInterleavedOut ? (kPairs ? adjacent() && (reinterpret_cast<uintptr_t>(row_i) & (kS16 ? 3 : 7)) == 0
+                                                       : (reinterpret_cast<uintptr_t>(row_i) & 15) == 0)
                                              : ((reinterpret_cast<uintptr_t>(row_l) | reinterpret_cast<uintptr_t>(row_r)) & (kS16 ? 7 : 15)) == 0;
         auto emit4 = [&](int g, float l0, float l1, float l2, float l3, float r0, float r1, float r2, float r3) {
             if (VPZ_ABLATE(a) & 32) {  // (tuning only: the arithmetic without the stores)
@@ -762,7 +858,23 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 clip_group(l0, l1, l2, l3, clip_peak);
                 clip_group(r0, r1, r2, r3, clip_peak);
             }
-            if (kInterleavedOut) {
+            if (kInterleavedOut && kPairs) {
+                // four samples' columns chA, chB of the [sample][C] rows: plain stores -- the other pairs' workgroups write the rest
+                // of these lines, and the L2 they share puts them together
+                out_t *q = row_i + (size_t)(4 * g) * nC();
+                if (kS16) {
+                    store_pcm(reinterpret_cast<uint32_t *>(q), pack_s16(l0, r0));
+                    store_pcm(reinterpret_cast<uint32_t *>(q + nC()), pack_s16(l1, r1));
+                    store_pcm(reinterpret_cast<uint32_t *>(q + 2 * nC()), pack_s16(l2, r2));
+                    store_pcm(reinterpret_cast<uint32_t *>(q + 3 * nC()), pack_s16(l3, r3));
+                } else {
+                    float *qf = reinterpret_cast<float *>(q);
+                    store_pcm2(qf, l0, r0);
+                    store_pcm2(qf + nC(), l1, r1);
+                    store_pcm2(qf + 2 * nC(), l2, r2);
+                    store_pcm2(qf + 3 * nC(), l3, r3);
+                }
+            } else if (kInterleavedOut) {
                 if (kS16) {
                     store_nt(reinterpret_cast<uint4 *>(row_i) + g, pack_s16(l0, r0), pack_s16(l1, r1), pack_s16(l2, r2), pack_s16(l3, r3));
                 } else {
@@ -782,8 +894,8 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 r = clip_track(r, clip_peak);
             }
             if (kInterleavedOut) {
-                store_pcm(row_i + 2 * i, kS16 ? (out_t)to_s16(l) : (out_t)l);
-                store_pcm(row_i + 2 * i + 1, kS16 ? (out_t)to_s16(r) : (out_t)r);
+                store_pcm(row_i + (size_t)i * nC(), kS16 ? (out_t)to_s16(l) : (out_t)l);
+                store_pcm(row_i + (size_t)i * nC() + (cB() - cA()), kS16 ? (out_t)to_s16(r) : (out_t)r);
             } else {
                 store_pcm(row_l + i, kS16 ? (out_t)to_s16(l) : (out_t)l);
                 store_pcm(row_r + i, kS16 ? (out_t)to_s16(r) : (out_t)r);
@@ -979,10 +1091,10 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     if (!published) publish();  // (a run without passes: nobody may wait for it for ever)
     // ---- keep the last block's tail for the next batch (the reference keeps _prevPacketBuf)
     if ((run.flags & kRunSaveState) && prev_n4 > 0) {
-        float *st = a.state_h + (size_t)(run.state_slot ^ 1) * a.state_slot_floats + (size_t)run.stream * 2 * half1;
+        float *st = a.state_h + (size_t)(run.state_slot ^ 1) * a.state_slot_floats + (size_t)run.stream * nC() * half1;
         for (int i = lane; i < prev_n4; i += 64) {
-            st[i] = tailL[i];
-            st[half1 + i] = tailR[i];
+            st[cA() * half1 + i] = tailL[i];
+            st[cB() * half1 + i] = tailR[i];
         }
     }
     // HasClipped is sticky until ResetDecoder: the flag holds the stream's reset epoch
@@ -1005,6 +1117,23 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
 // ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
+#if VPZ_DUAL_PAIRS
+// channel pairs of streams with 4, 6, 8, ... channels (the decoder has checked that the mappings' coupling steps join the channels
+// two by two and built SynthArgs.pair_ch and the per-pair step tables)
+bool synth_pairs_supported(int channels, int size0, int size1)
+{
+    auto plain = [](int n) { return n == 256 || n == 2048; };
+    return channels >= 4 && channels <= 254 && (channels & 1) == 0 && plain(size0) && plain(size1);
+}
+
+hipError_t launch_synth_pairs(const SynthArgs &args, bool has_floor, bool interleaved_in, hipStream_t stream)
+{
+    if (args.n_runs <= 0) return hipSuccess;
+    if (args.spec_i16 || args.n_pairs < 1 || 2 * args.n_pairs != args.channels || !args.pair_ch || args.n_mappings < 1)
+        return hipErrorInvalidValue;  // (float32 residue, every channel in one pair)
+    const int chunks = (args.n_runs + kDualWaves - 1) / kDualWaves;
+    const int grid = (chunks + 7) / 8 * 8 * args.n_pairs;  // (groups of 8 chunks x n_pairs, see the kernel's first lines)
+#else
 bool synth_dual_supported(int channels, int size0, int size1)
 {
     auto plain = [](int n) { return n == 256 || n == 2048; };
@@ -1016,14 +1145,15 @@ hipError_t launch_synth_dual(const SynthArgs &args, bool has_floor, bool interle
     if (args.n_runs <= 0) return hipSuccess;
     if (args.spec_i16 && !has_floor) return hipErrorInvalidValue;  // (16-bit values are read in place by the floored variants only)
     const int grid = (args.n_runs + kDualWaves - 1) / kDualWaves;
+#endif
     static const int extra_lds = getenv("VPZ_SYNTH_EXTRA_LDS") ? atoi(getenv("VPZ_SYNTH_EXTRA_LDS")) : 0;  // occupancy experiments
 #define VPZ_LAUNCH_DUAL(F, I, O)                                                                                          \
     do {                                                                                                                  \
-        if (F && args.spec_i16) {                                                                                         \
+        if (!kPairs && F && args.spec_i16) {                                                                              \
             if (args.s16)                                                                                                 \
-                hipLaunchKernelGGL((synth_dual_kernel<F, I, O, true, F>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
+                hipLaunchKernelGGL((synth_dual_kernel<F, I, O, true, F && !kPairs>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
             else                                                                                                          \
-                hipLaunchKernelGGL((synth_dual_kernel<F, I, O, false, F>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
+                hipLaunchKernelGGL((synth_dual_kernel<F, I, O, false, F && !kPairs>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
         } else if (args.s16)                                                                                              \
             hipLaunchKernelGGL((synth_dual_kernel<F, I, O, true>), dim3(grid), dim3(kDualThreads), extra_lds, stream, args); \
         else                                                                                                              \
@@ -1046,6 +1176,7 @@ hipError_t launch_synth_dual(const SynthArgs &args, bool has_floor, bool interle
     return hipGetLastError();
 }
 
+#if !VPZ_DUAL_PAIRS
 int synth_dual_waves() { return kDualWaves; }
 
 // channel-blocks the chip keeps resident and busy under synth_dual_kernel (a wavefront holds two)
@@ -1060,5 +1191,6 @@ int synth_dual_resident_slots(bool has_floor, int num_cu)
     }
     return num_cu * per_cu * kDualWaves * 2;
 }
+#endif
 
 }  // namespace vpz

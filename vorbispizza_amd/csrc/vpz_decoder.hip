@@ -37,6 +37,8 @@ bool synth_dual_supported(int channels, int size0, int size1);
 hipError_t launch_synth_dual(const SynthArgs &args, bool has_floor, bool interleaved_in, hipStream_t stream);
 int synth_dual_resident_slots(bool has_floor, int num_cu);
 int synth_dual_waves();
+bool synth_pairs_supported(int channels, int size0, int size1);
+hipError_t launch_synth_pairs(const SynthArgs &args, bool has_floor, bool interleaved_in, hipStream_t stream);
 bool synth_big_supported(int size0, int size1);
 hipError_t launch_synth_big(const SynthArgs &args, bool has_floor, hipStream_t stream);
 int synth_big_resident_waves(bool has_floor, int num_cu, int size0, int size1);
@@ -176,6 +178,14 @@ struct Decoder {
     bool group_dma = false;      // ... and interleaved packets may land in LDS as they are (SynthArgs.group_dma)
     // stereo fast path (synth_dual.hip: one wavefront per stream synthesises both channels, coupling in registers)
     bool dual_ok = false;        // two channels, 256 / 2048 blocks, type-1 floors only (VPZ_NO_DUAL=1: off, for A/B tests)
+    // ... and its kernel for channel PAIRS (synth_pairs.hip): 4, 6, 8, ... channels that the coupling steps of all mappings join two
+    // by two -- every pair is a stereo stream to the arithmetic (VPZ_NO_PAIRS=1: off, for A/B and bit-equality tests)
+    bool pairs = false;          // (implies dual_ok)
+    bool pairs_always = false;   // VPZ_PAIRS=1: the pair route wherever it can run, also where group mode is as fast or faster
+    uint8_t *d_pair_ch = nullptr;         // [pair][2]: the pair's channels, coupled ones first ("channel 0" of its steps), in channel order
+    uint32_t *d_pair_map_bits = nullptr;  // [pair][mapping]: SynthArgs.map_bits of the pair route
+    uint8_t *d_pair_steps = nullptr;      // the pairs' step lists: (0 | 1: which of the pair's channels is the magnitude, unused)
+    int n_pair_step_pairs = 0;
     int max_steps = 0, n_step_pairs = 0;
     int host_threads = 0;        // parties of the parallel state machine (VPZ_HOST_THREADS; 0: pick)
     int64_t par_min_packets = 16384;  // batches below this take the serial state machine (VPZ_PAR_MIN_PACKETS)
@@ -499,6 +509,71 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
         for (int ch = 0; ch < D.channels; ++ch)
             if (!D.floor_types.empty() && D.floor_types[D.mappings[m].channel_floor[ch]] == 0) D.mapping_uses_floor0[m] = 1;
     }
+    // The pair route: do the coupling steps of ALL mappings join the channels two by two (a channel has at most one partner, the
+    // same in every mapping)?  Then the coupled pairs and, two by two in channel order, the uncoupled channels are the pairs;
+    // every (pair, mapping) gets its own step list -- the mapping's steps between the pair's channels, in the mapping's order.
+    std::vector<uint8_t> pair_ch, pair_steps;
+    std::vector<uint32_t> pair_map_bits;
+    {
+        // (VPZ_NO_GROUP=1 asks for the separate coupling pass for everything with more than two channels: no pairs either)
+        const char *no_dual = getenv("VPZ_NO_DUAL"), *no_pairs = getenv("VPZ_NO_PAIRS"), *no_group = getenv("VPZ_NO_GROUP");
+        bool has_floor0 = false;
+        for (uint8_t t : D.floor_types) has_floor0 |= (t == 0);
+        const int C = D.channels;
+        bool ok = synth_pairs_supported(C, D.size0, D.size1) && !D.generic && !has_floor0 && !(no_dual && atoi(no_dual)) &&
+                  !(no_pairs && atoi(no_pairs)) && !(no_group && atoi(no_group)) && D.mappings.size() <= 255;
+        std::vector<int> partner((size_t)std::max(C, 1), -1);
+        for (size_t m = 0; m < D.mappings.size() && ok; ++m) {
+            const int n = D.mappings[m].coupling_steps, off = D.mapping_steps_off[m];
+            for (int i = 0; i < n && ok; ++i) {
+                const int mag = steps[off + 2 * i], ang = steps[off + 2 * i + 1];
+                if (mag >= C || ang >= C || mag == ang) ok = false;
+                else if (partner[mag] < 0 && partner[ang] < 0) { partner[mag] = ang; partner[ang] = mag; }
+                else if (partner[mag] != ang || partner[ang] != mag) ok = false;
+            }
+        }
+        if (ok) {
+            int lone = -1;
+            for (int c = 0; c < C; ++c) {
+                if (partner[c] > c) { pair_ch.push_back((uint8_t)c); pair_ch.push_back((uint8_t)partner[c]); }
+                else if (partner[c] < 0) {
+                    if (lone < 0) lone = c;
+                    else { pair_ch.push_back((uint8_t)lone); pair_ch.push_back((uint8_t)c); lone = -1; }
+                }
+            }
+            ok = lone < 0 && (int)pair_ch.size() == C;
+        }
+        if (ok) {
+            const size_t nm = std::max<size_t>(1, D.mappings.size());
+            const int n_pairs = C / 2;
+            pair_map_bits.assign((size_t)n_pairs * nm, 0u);
+            for (int p = 0; p < n_pairs && ok; ++p)
+                for (size_t m = 0; m < D.mappings.size() && ok; ++m) {
+                    const int n = D.mappings[m].coupling_steps, off = D.mapping_steps_off[m];
+                    const int a = pair_ch[2 * p], b = pair_ch[2 * p + 1];
+                    const size_t first = pair_steps.size() / 2;
+                    int cnt = 0;
+                    for (int i = 0; i < n; ++i) {
+                        const int mag = steps[off + 2 * i];
+                        if (mag != a && mag != b) continue;
+                        pair_steps.push_back(mag == a ? 0 : 1);
+                        pair_steps.push_back(mag == a ? 1 : 0);
+                        ++cnt;
+                    }
+                    if (cnt > 255 || first > 255) ok = false;
+                    uint32_t w = ((uint32_t)D.mapping_skip[1][m] << kFrameSkipShift) | ((uint32_t)D.mapping_skip[0][m] << kMapSkipShortShift);
+                    if (cnt > 0) w |= ((uint32_t)cnt << kFrameStepsShift) | ((uint32_t)first << kFrameStepsOffShift);
+                    pair_map_bits[(size_t)p * nm + m] = w;
+                }
+            ok = ok && pair_steps.size() / 2 <= (size_t)kGroupMaxStepPairs;
+        }
+        D.pairs = ok;
+        if (const char *e = getenv("VPZ_PAIRS")) D.pairs_always = atoi(e) != 0;
+        if (ok) {
+            D.dual_ok = true;
+            D.n_pair_step_pairs = (int)(pair_steps.size() / 2);
+        }
+    }
     if ((rc = get_tables(ctx, D.size0, &D.t0)) != VPZ_OK || (rc = get_tables(ctx, D.size1, &D.t1)) != VPZ_OK) {
         delete d;
         return rc;
@@ -506,7 +581,9 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     hipError_t e = hipSuccess;
     const size_t state_bytes = 2 * sizeof(float) * (size_t)n_streams * D.channels * (D.size1 / 2);  // two copies, see StreamState
     if (!ctx->d_inv_db) {
-        e = hipMalloc((void **)&ctx->d_inv_db, 256 * sizeof(float));
+        // (+ 64 floats of +0.0 behind the table: where the pair route sends the loads of bins beyond a residue's declared support)
+        e = hipMalloc((void **)&ctx->d_inv_db, (256 + 64) * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(ctx->d_inv_db, 0, (256 + 64) * sizeof(float));
         if (e == hipSuccess)
             e = hipMemcpy(ctx->d_inv_db, k_inverse_db_bits, 256 * sizeof(float), hipMemcpyHostToDevice);
     }
@@ -520,6 +597,16 @@ int vpz_decoder_create(vpz_context *c, const vpz_stream_config *cfg, int32_t n_s
     if (e == hipSuccess && !steps.empty()) e = hipMemcpy(D.d_steps, steps.data(), steps.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&D.d_map_bits, sizeof(uint32_t) * map_bits.size());
     if (e == hipSuccess) e = hipMemcpy(D.d_map_bits, map_bits.data(), sizeof(uint32_t) * map_bits.size(), hipMemcpyHostToDevice);
+    if (D.pairs) {
+        if (e == hipSuccess) e = hipMalloc((void **)&D.d_pair_ch, pair_ch.size());
+        if (e == hipSuccess) e = hipMemcpy(D.d_pair_ch, pair_ch.data(), pair_ch.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&D.d_pair_map_bits, sizeof(uint32_t) * pair_map_bits.size());
+        if (e == hipSuccess)
+            e = hipMemcpy(D.d_pair_map_bits, pair_map_bits.data(), sizeof(uint32_t) * pair_map_bits.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&D.d_pair_steps, pair_steps.size() + 8);
+        if (e == hipSuccess && !pair_steps.empty())
+            e = hipMemcpy(D.d_pair_steps, pair_steps.data(), pair_steps.size(), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&D.d_steps_lvl, steps_lvl.size() ? steps_lvl.size() : 1);
     if (e == hipSuccess && !steps_lvl.empty())
         e = hipMemcpy(D.d_steps_lvl, steps_lvl.data(), steps_lvl.size(), hipMemcpyHostToDevice);
@@ -609,6 +696,9 @@ void vpz_decoder_destroy(vpz_decoder *d)
     if (D.d_steps) (void)hipFree(D.d_steps);
     if (D.d_steps_lvl) (void)hipFree(D.d_steps_lvl);
     if (D.d_map_bits) (void)hipFree(D.d_map_bits);
+    if (D.d_pair_ch) (void)hipFree(D.d_pair_ch);
+    if (D.d_pair_map_bits) (void)hipFree(D.d_pair_map_bits);
+    if (D.d_pair_steps) (void)hipFree(D.d_pair_steps);
     if (D.d_floors0) (void)hipFree(D.d_floors0);
     if (D.d_bark_maps) (void)hipFree(D.d_bark_maps);
     for (PinnedArena &A : D.arenas) {
@@ -739,9 +829,24 @@ struct SynthCall {
     {
         if (!D.dual_ok || (any_floor0 && !D.f0_fused) || (ilv_seen && planar_seen)) return false;
         // (int16 values are widened into the decoder's own, aligned staging buffer whatever the memory space)
+        // (the pair route reads 8 bytes -- two adjacent channels of a bin, or two bins of a channel -- whatever the layout)
+        const bool wide = ilv_seen && !D.pairs;
         const bool dev_ok = mem_space == VPZ_MEM_HOST || D.residue_format == VPZ_RESIDUE_I16 ||
-                            (reinterpret_cast<uintptr_t>(residue) & (ilv_seen ? 15 : 7)) == 0;
-        return dev_ok && (ilv_seen ? group_align_ok : align2_ok);
+                            (reinterpret_cast<uintptr_t>(residue) & (wide ? 15 : 7)) == 0;
+        if (!(dev_ok && (wide ? group_align_ok : align2_ok))) return false;
+        // Pairs or group mode, where both can take the call (measured on BASELINE configs[3], 6 channels, profiles/r5_ab_pairs.txt):
+        // planar packets to planar PCM the pairs are 8 % faster; the Residue2 vector read by columns (a third of every line per
+        // workgroup) ties with group mode's staging; interleaved PCM written by columns loses 20 % against the packet's waves writing
+        // whole rows together.  VPZ_PAIRS=1 (tests, A/B): the pairs wherever they can.
+        // Beyond eight channels (no group mode) the columns of the Residue2 vector cost what the separate coupling pass costs
+        // (10 channels: 0.390 against 0.375 ms): the pairs take planar packets to planar PCM there too.
+        if (D.pairs && !D.pairs_always && (ilv_seen || out_interleaved)) return false;
+        return true;
+    }
+    bool group_usable() const
+    {
+        return D.group_ok && group_align_ok &&
+               (mem_space == VPZ_MEM_HOST || D.residue_format == VPZ_RESIDUE_I16 || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
     }
     bool zero_copy = false;
     bool host_failed = false;  // a share of a fork-join threw (allocation): the call returns VPZ_E_NOMEM
@@ -950,10 +1055,8 @@ struct SynthCall {
         }
         // Compact runs (two bytes per frame, descriptors built on the device) need consecutive packets with back to
         // back residues and a batch the fused kernel takes as it is (no planar temp, no type-0 floor pass)
-        const bool group_usable = D.group_ok && group_align_ok &&
-                                  (mem_space == VPZ_MEM_HOST || D.residue_format == VPZ_RESIDUE_I16 || (reinterpret_cast<uintptr_t>(residue) & 15) == 0);
         compact = all_dense && !D.generic && !D.big && (!any_floor0 || (D.f0_fused && dual_usable())) && !D.no_compact &&
-                  (!need_coupling || group_usable || dual_usable());
+                  (!need_coupling || group_usable() || dual_usable());
         if (compact) {
             cflags = arena_alloc<uint8_t>(*A, (size_t)n_packets);
             cmap = arena_alloc<uint8_t>(*A, (size_t)n_packets);
@@ -1409,8 +1512,19 @@ struct SynthCall {
             // 0.205 -> 0.226 ms and configs[4]'s share 0.258 -> 0.302 at 8 frames, profiles/r5_ab_chain_batches.txt; their runs are
             // chained all the same)
             const bool chained = use_dual && compact && D.size1 == 2048 && !D.no_chain && !batches;
+            // (chained runs are cut by length: the grid is known exactly -- four runs to a workgroup, one workgroup per channel pair
+            // of a chunk on the pair route -- and a run length whose grid is ONE workgroup over k rounds costs a round: 8 192 frames
+            // of 10 channels in runs of 10 are 1 025 workgroups on 1 024 places)
+            const int64_t resident_wgs = std::max<int64_t>(1, slots / (2 * synth_dual_waves()));
+            auto grid_of = [&](int64_t r) -> int64_t {
+                int64_t n = 0;
+                for (int st_i = 0; st_i < D.n_streams; ++st_i) n += (D.s_cnt[st_i] + r - 1) / r;
+                return (n + synth_dual_waves() - 1) / synth_dual_waves() * (D.pairs ? C / 2 : 1);
+            };
             for (int k = 1; k <= 64; ++k) {
                 int64_t r = (work + k * slots - 1) / (k * slots);
+                if (chained)
+                    while (r <= r_max && grid_of(r) > k * resident_wgs) ++r;
                 if (r > r_max) continue;
                 if (r < 4) break;
                 // (chained: four runs share one recomputed block, and a run length below the preferred one only adds prologues)
@@ -1738,6 +1852,15 @@ struct SynthCall {
     // coupling packets: de-interleave + inverse coupling into a planar temp laid out in frame order
     void build_coupling_packets()
     {
+        if (use_dual && D.pairs && !compact) {
+            // explicit descriptors for the pair route: which steps a frame has depends on the PAIR that looks at it -- the frame
+            // names its mapping (bits 16..23), and the kernel puts the pair's count and offset in (SynthArgs.map_bits)
+            for (size_t fi = 0; fi < n_frames; ++fi) {
+                FrameDesc &fd = frames[fi];
+                fd.flags &= ~0x00FFFF00u;
+                if (!(fd.flags & (kFrameDrain | kFrameNoFloor))) fd.flags |= (uint32_t)packets[fd.rec / C].mapping << kFrameStepsOffShift;
+            }
+        }
         if (!need_coupling || use_group || use_dual) return;
         // the separate pass hands planar, de-coupled spectra over: the frames lose their group-mode bits
         for (size_t fi = 0; fi < n_frames; ++fi) frames[fi].flags &= 0xFu | (kFrameSkipMask << kFrameSkipShift) | kFrameSteady;
@@ -1938,7 +2061,7 @@ struct SynthCall {
         // VPZ_RESIDUE_I16 (ABI v5): the floored stereo fast path reads the 16-bit values in place and widens them in registers; every
         // other kernel reads float32 -- the values are widened into the decoder's staging buffer first (exact either way)
         const bool i16 = D.residue_format == VPZ_RESIDUE_I16;
-        spec_i16 = i16 && use_dual && any_floor && !D.no_direct_i16 &&
+        spec_i16 = i16 && use_dual && !D.pairs && any_floor && !D.no_direct_i16 &&
                    (mem_space == VPZ_MEM_HOST || (reinterpret_cast<uintptr_t>(residue) & 7) == 0);
         if (mem_space != VPZ_MEM_HOST && i16 && !spec_i16) {  // device-resident int16 values: widened into the staging buffer
             if ((rc = grow(ctx, D.b_in_res, sizeof(float) * (size_t)res_extent)) != VPZ_OK) return rc;
@@ -2087,6 +2210,9 @@ struct SynthCall {
         a.cmap = static_cast<const uint8_t *>(dev(cmap));
         a.run_inline = (use_dual && !D.no_run_inline) ? static_cast<const uint8_t *>(dev(run_inline)) : nullptr;
         a.map_bits = D.d_map_bits;
+        a.pair_ch = D.d_pair_ch;
+        a.n_pairs = C / 2;
+        a.n_mappings = (int32_t)std::max<size_t>(1, D.mappings.size());
         for (int f = 0; f < 8; ++f) {
             const PacketInfo &pi = D.packet_info[f];
             a.geom[f] = PacketGeom{(uint16_t)pi.left_start, (uint16_t)pi.right_start, (uint16_t)pi.right_end,
@@ -2103,6 +2229,11 @@ struct SynthCall {
         a.steps = D.d_steps_lvl;
         a.n_step_pairs = D.n_step_pairs;
         a.max_steps = D.max_steps;
+        if (use_dual && D.pairs) {  // the pairs' own step lists and per-(pair, mapping) words
+            a.map_bits = D.d_pair_map_bits;
+            a.steps = D.d_pair_steps;
+            a.n_step_pairs = D.n_pair_step_pairs;
+        }
         a.group = use_group ? 1 : 0;
         a.group_dma = (use_group && D.group_dma) ? 1 : 0;
         a.inv_db = ctx->d_inv_db;
@@ -2133,7 +2264,7 @@ struct SynthCall {
         (void)hipMemsetAsync(d_stamps, 0, (16 + 16 * std::min<size_t>(kStampWaves, n_runs)) * sizeof(unsigned long long), ctx->stream);
         a.stamps = d_stamps;
 #endif
-        hipError_t e = use_dual ? launch_synth_dual(a, any_floor, ilv_seen, ctx->stream)
+        hipError_t e = use_dual ? (D.pairs ? launch_synth_pairs(a, any_floor, ilv_seen, ctx->stream) : launch_synth_dual(a, any_floor, ilv_seen, ctx->stream))
                                 : D.big ? launch_synth_big(a, any_floor, ctx->stream) : launch_synth(a, any_floor, ctx->stream);
         if (e != hipSuccess) return set_error(ctx, VPZ_E_HIP, "synth kernel launch", e);
 #if defined(VPZ_STAMPS) || defined(VPZ_WAVE_TIMES)
