@@ -3,7 +3,7 @@
 
   python tools/isa_census.py group    [-o profiles/r4_isa_synth_kernel_group.txt]
   python tools/isa_census.py dual     [-o profiles/r4_isa_synth_dual_kernel.txt]
-  python tools/isa_census.py --unit synth_dual.hip --kernel 'synth_dual_kernel<false, false, 0, false, 0>' ...
+  python tools/isa_census.py --unit synth_dual.hip --kernel 'synth_dual_kernel<false, false, 0, false, false, 0>' ...
 
 The translation unit is compiled for the device only with `-S -gline-tables-only` (line tables do not change the code:
 the instruction count is the same with and without), so every instruction carries its source position WITH its inlining
@@ -30,8 +30,8 @@ CSRC = os.path.join(ROOT, "vorbispizza_amd", "csrc")
 PRESETS = {
     "group": ("synth_kernels.hip", "synth_kernel<true, 0, false, true, false>"),
     "group_ilv": ("synth_kernels.hip", "synth_kernel<true, 1, false, true, false>"),
-    "dual": ("synth_dual.hip", "synth_dual_kernel<true, true, 1, false, 0>"),
-    "dual_nofloor": ("synth_dual.hip", "synth_dual_kernel<false, false, 0, false, 0>"),
+    "dual": ("synth_dual.hip", "synth_dual_kernel<true, true, 1, false, false, 0>"),
+    "dual_nofloor": ("synth_dual.hip", "synth_dual_kernel<false, false, 0, false, false, 0>"),
     "pairs": ("synth_pairs.hip", "synth_pairs_kernel<true, true, 0, false, false, 0>"),
     "pairs_ilv": ("synth_pairs.hip", "synth_pairs_kernel<true, true, 1, false, false, 0>"),
 }

@@ -241,11 +241,14 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     {
         const uint64_t sp = reinterpret_cast<uint64_t>(a.spec), db = reinterpret_cast<uint64_t>(a.inv_db);
         const uint64_t cpp = a.cposts != nullptr ? reinterpret_cast<uint64_t>(a.cposts) : db;
-        const int vals[14] = {(int)(uint32_t)sp, (int)(uint32_t)(sp >> 32), (int)(uint32_t)db, (int)(uint32_t)(db >> 32),
+        const uint64_t cs = (uint64_t)a.channel_stride;
+        const int vals[17] = {(int)(uint32_t)sp, (int)(uint32_t)(sp >> 32), (int)(uint32_t)db, (int)(uint32_t)(db >> 32),
                               (int)(uint32_t)cpp, (int)(uint32_t)(cpp >> 32), a.cposts != nullptr ? 1 : 0, a.f0_stride,
-                              C0, chA0, chB0, a.size0, a.size1, a.ccount != nullptr ? 1 : 0};
+                              C0, chA0, chB0, a.size0, a.size1, a.ccount != nullptr ? 1 : 0,
+                              (int)(uint32_t)cs, (int)(uint32_t)(cs >> 32), a.clip};
 #pragma unroll
-        for (int i = 0; i < (kPairs ? 14 : 8); ++i) kv = lane == i ? vals[i] : kv;
+        for (int i = 0; i < 17; ++i)
+            if (kPairs || i < 8 || i >= 14) kv = lane == i ? vals[i] : kv;
         asm volatile("" : "+v"(kv));
     }
     // (pairs: the block sizes come from the parked values as well -- the frame loop has no scalar register to keep them in)
@@ -843,8 +846,10 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 515-638)
         // 4 consecutive samples of both channels, sample 4 g .. 4 g + 3 of the pass's output
         out_t *row_i = out_base + fd.out_off * nC() + cA();                    // interleaved: sample s at [C s + chA], [C s + chB]
-        out_t *row_l = out_base + cA() * a.channel_stride + fd.out_off;     // planar
-        out_t *row_r = out_base + cB() * a.channel_stride + fd.out_off;
+        const int64_t ch_stride = (int64_t)parked64(14);                    // (a.channel_stride, a.clip: parked like the pointers)
+        const bool clip_on = __builtin_amdgcn_readlane(kv, 16) != 0;
+        out_t *row_l = out_base + cA() * ch_stride + fd.out_off;            // planar
+        out_t *row_r = out_base + cB() * ch_stride + fd.out_off;
         // (pairs, interleaved: a sample's two values are one 8-byte -- 4-byte for 16-bit PCM -- piece when the channels are adjacent)
         const bool aligned = kInterleavedOut ? (kPairs ? adjacent() && (reinterpret_cast<uintptr_t>(row_i) & (kS16 ? 3 : 7)) == 0
                                                        : (reinterpret_cast<uintptr_t>(row_i) & 15) == 0)
@@ -854,7 +859,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 clip_peak = fmaxf(clip_peak, fmaxf(fmaxf(l0 + r0, l1 + r1), fmaxf(l2 + r2, l3 + r3)));
                 return;
             }
-            if (a.clip) {
+            if (clip_on) {
                 clip_group(l0, l1, l2, l3, clip_peak);
                 clip_group(r0, r1, r2, r3, clip_peak);
             }
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             }
         };
         auto emit1 = [&](int i, float l, float r) {  // sample i of the pass, no alignment assumed
-            if (a.clip) {
+            if (clip_on) {
                 l = clip_track(l, clip_peak);
                 r = clip_track(r, clip_peak);
             }
@@ -1098,7 +1103,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         }
     }
     // HasClipped is sticky until ResetDecoder: the flag holds the stream's reset epoch
-    if (a.clip && __any(clip_peak > 0.99999994f) && lane == 0) atomicMax(&a.clipped[run.stream], run.clip_epoch);
+    if (__builtin_amdgcn_readlane(kv, 16) != 0 && __any(clip_peak > 0.99999994f) && lane == 0) atomicMax(&a.clipped[run.stream], run.clip_epoch);
 #ifdef VPZ_WAVE_TIMES
     // diagnostic builds (-DVPZ_WAVE_TIMES): when each wave ran and where (HW_ID), two clock reads per wave
     if (a.stamps && lane == 0 && run_idx < (1 << 16)) {
