@@ -69,10 +69,13 @@ def test_the_pair_route_is_the_stereo_kernel_once_more_with_its_budget(kernels):
 
 def test_the_kernel_for_4096_and_8192_blocks_keeps_its_budget(kernels):
     big = [k for k in kernels.values() if "synth_big_kernel" in k["name"]]
-    assert len(big) == 2 * 2  # <floor?, float32 / int16 samples>
+    assert len(big) == 2 * 2 * 2  # <floor?, float32 / int16 samples, 4096 (tails in LDS) / 8192 (tails in global memory, eight waves)>
     for k in big:
         assert k["vgprs"] <= 256, k["name"]  # two waves per SIMD where the LDS allows them (4096: two 4-wave workgroups per CU)
-        assert k["lds"] <= 28 * 1024, (k["name"], k["lds"])  # the STATIC part: the two sizes' tables; the waves' areas are dynamic
+        # the STATIC part (the two sizes' tables; the waves' areas are dynamic): 8192 keeps its twiddle tables here too, beside seven waves
+        tail_g = "Lb1EEE" in k["name"] or k["name"].rstrip(">").endswith("true")
+        assert k["lds"] <= (38 if tail_g else 28) * 1024, (k["name"], k["lds"])
+        assert k["lds"] + (7 * 17440 if tail_g else 2 * 53376) <= 160 * 1024 + (0 if tail_g else k["lds"]), (k["name"], k["lds"])
 
 
 @pytest.mark.parametrize("flags", [["-DVPZ_STAMPS"], ["-DVPZ_WAVE_TIMES"], ["-DVPZ_TUNING"], ["-DVPZ_STAMPS", "-DVPZ_WAVE_TIMES", "-DVPZ_TUNING"],

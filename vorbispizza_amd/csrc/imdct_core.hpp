@@ -448,7 +448,7 @@ __device__ __forceinline__ void imdct4096_wave(const float4 (&xa)[8], float2 *h,
 // lo[m] = X[8k' .. 8k'+3], hi[m] = X[8k'+4 .. 8k'+7] for k' = lane + 64*m.  On return `h` (>= 2048 float2,
 // wave-private; its first 576 float2 double as the transposes' scratch) holds h[0..4096) in natural order.
 //   g_tw  : 2048 float2 tw[k] = exp(2*pi*i*(k + 1/8)/8192)   (global memory: read once per block and lane)
-//   g_w2  : 1024 float2 exp(2*pi*i*J/2048)                    (global memory)
+//   g_w2  : 1024 float2 exp(2*pi*i*J/2048), of which the lower 512 are read (global memory, or LDS)
 //   s_w1  :  512 float2 exp(2*pi*i*j/1024), s_twAB / s_twBC: the 512-point tables (LDS)
 // -------------------------------------------------------------------------------------------
 __device__ __forceinline__ void imdct8192_wave(const float4 (&lo)[8], const float4 (&hi)[8], float2 *h,
@@ -481,7 +481,9 @@ __device__ __forceinline__ void imdct8192_wave(const float4 (&lo)[8], const floa
         const float2 te = cmul(a2[q], s_w1[j]), to = cmul(a3[q], s_w1[j]);
         const float2 el = cadd(a0[q], te), eu = csub(a0[q], te);
         const float2 ol = cadd(a1[q], to), ou = csub(a1[q], to);
-        const float2 tl = cmul(ol, g_w2[j]), tu = cmul(ou, g_w2[j + 512]);
+        // (w2[J + 512] = i w2[J]: the table's upper half IS the lower one turned -- vpz_context.hip builds it so --, one read serves both)
+        const float2 w2l = g_w2[j], w2u = make_float2(-w2l.y, w2l.x);
+        const float2 tl = cmul(ol, w2l), tu = cmul(ou, w2u);
         z0[q] = cmul(cadd(el, tl), g_tw[j]);
         z1[q] = cmul(cadd(eu, tu), g_tw[j + 512]);
         z2[q] = cmul(csub(el, tl), g_tw[j + 1024]);

@@ -14,7 +14,10 @@
 // two give the same bits (tests/test_synth_gpu.py, VPZ_NO_BIG=1 selects the old path).
 //
 // LDS is sized at run time (the tables of the two block sizes, then per wave: h of the long size, its tail, the run's
-// descriptors): 4 waves per workgroup and 78 KB for 4096 (two workgroups per CU), 5 waves and 150 KB for 8192 (one).
+// descriptors): 4 waves per workgroup and 78 KB for 4096 (two workgroups per CU).  An 8192 decoder keeps the TAIL in global
+// memory instead (SynthArgs.big_tail, 8 KB per wave, written at the end of a block and read back one block later: it never
+// leaves the L2): with h, tail and descriptors in LDS a CU held five waves, with h alone it holds eight -- two per SIMD, what
+// the registers allow -- and this kernel is bound by the latencies of its dependent LDS round trips, i.e. by its occupancy.
 #include <cstdlib>
 #include <type_traits>
 
@@ -25,11 +28,18 @@
 
 namespace vpz {
 
-constexpr int kBigMaxWaves = 5;
-constexpr int kBigMaxThreads = 64 * kBigMaxWaves;
 constexpr int kBigRunMax = kMaxRunLengthBig;
-// wavefronts per workgroup: what the LDS holds -- 4 x 12.8 KB beside the tables for 4096 (two workgroups per CU), 5 x 24.6 KB for 8192 (one)
-__host__ __device__ inline int big_waves(int size1) { return size1 == 8192 ? 5 : 4; }
+// 8192 decoders: seven waves of 17.4 KB beside 38 KB of tables -- the transform's 2048-entry twiddle table and the read half of its
+// level-2 table are in LDS too (read from global memory they cost the pass some twenty trips to the L2, one behind the other:
+// tools/kbench_slow_paths.py (c), 0.404 ms with eight waves and both in global memory, 0.376 with seven and the twiddles here)
+#ifndef VPZ_BIG_WAVES_8192
+#define VPZ_BIG_WAVES_8192 7
+#endif
+constexpr int kBigWaves8192 = VPZ_BIG_WAVES_8192;
+constexpr int kBigTw8192 = kBigWaves8192 <= 7 ? 2048 + 512 : 0;  // entries of the 8192 twiddle tables kept in LDS: tw, and the half of w2 that is read
+// wavefronts per workgroup: what the LDS holds -- 4 x 12.8 KB beside the tables for 4096 (two workgroups per CU), 8 x 17.4 KB for
+// 8192 (one; the tails are in global memory)
+__host__ __device__ inline int big_waves(int size1) { return size1 == 8192 ? kBigWaves8192 : 4; }
 
 struct BigLayout {
     int tab_long, tab_short;  // float2 offsets of the two table sets (equal when the sizes are)
@@ -55,7 +65,7 @@ __host__ __device__ inline BigLayout big_layout(int size0, int size1)
     L.db = 0;
     L.wave0 = 0;  // (the tables are static arrays in front of the dynamic part)
     L.h_floats = size1 / 2;
-    L.tail_floats = size1 / 4;
+    L.tail_floats = size1 == 8192 ? 0 : size1 / 4;  // (8192: SynthArgs.big_tail)
     L.per_wave = 4 * (L.h_floats + L.tail_floats) + 16 * 2 * (kBigRunMax + 1);
     L.total = L.wave0 + big_waves(size1) * L.per_wave;
     return L;
@@ -71,13 +81,14 @@ __device__ __forceinline__ void floor4(float4 &v, uint32_t w, const float *s_db)
     v.w *= t3;
 }
 
-template <bool kHasFloor, bool kS16>
-__global__ __launch_bounds__(kBigMaxThreads, 1) void synth_big_kernel(SynthArgs a)
+// kTailG: the long block is 8192 samples -- eight waves, the tails in global memory, 8.5 KB of long tables
+template <bool kHasFloor, bool kS16, bool kTailG>
+__global__ __launch_bounds__(kTailG ? 64 * kBigWaves8192 : 320, 1) void synth_big_kernel(SynthArgs a)
 {
     using out_t = typename std::conditional<kS16, int16_t, float>::type;
-    // the tables of the two block sizes: static (the largest set is 4096's: tw 1024 | twAB 512 | twBC 64 | w 512), the waves' areas
-    // behind them in the dynamic part
-    __shared__ __attribute__((aligned(16))) float2 s_tab_long[kFast4096TableCount];
+    // the tables of the two block sizes: static (4096's set: tw 1024 | twAB 512 | twBC 64 | w 512; 8192 keeps twAB 512 | twBC 64 | w1 512
+    // here and its two big tables in global memory), the waves' areas behind them in the dynamic part
+    __shared__ __attribute__((aligned(16))) float2 s_tab_long[kTailG ? 1088 + kBigTw8192 : kFast4096TableCount];
     __shared__ __attribute__((aligned(16))) float2 s_tab_short[kFastTableCount];  // (the short size is at most 2048, or the long one)
     __shared__ float s_db[256];
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -94,14 +105,22 @@ __global__ __launch_bounds__(kBigMaxThreads, 1) void synth_big_kernel(SynthArgs 
     RunDesc run = a.runs[run_idx];
 
     for (int i = threadIdx.x; i < L.n_long; i += n_threads) s_tab_long[i] = a.tw_long[big_table_source(a.size1) + i];
+    if (kTailG)
+        for (int i = threadIdx.x; i < kBigTw8192; i += n_threads)
+            s_tab_long[1088 + i] = a.tw_long[i < 2048 ? kFast8192TwOffset + i : kFast8192W2Offset + (i - 2048)];
     for (int i = threadIdx.x; i < L.n_short; i += n_threads) s_tab_short[i] = a.tw_short[big_table_source(a.size0) + i];
     if (threadIdx.x < 256) s_db[threadIdx.x] = kHasFloor ? a.inv_db[threadIdx.x] : 0.0f;
     __syncthreads();
     if (!active) return;
 
     float *hcur = reinterpret_cast<float *>(s_raw + L.wave0 + wave * L.per_wave);
-    float *tail = hcur + L.h_floats;
-    uint4 *s_desc = reinterpret_cast<uint4 *>(tail + L.tail_floats);
+    // (kTailG: this wave's own 8 KB of a.big_tail -- written and read back by this wave only, a block apart)
+    float *tail = kTailG ? a.big_tail + (size_t)item * (a.size1 >> 2) : hcur + L.h_floats;
+    uint4 *s_desc = reinterpret_cast<uint4 *>(hcur + L.h_floats + L.tail_floats);
+    // the tail's stores of one block and its loads of the next are different lanes' (mirrored indices): ordered by a release / acquire
+    // pair at workgroup scope -- a wait for the stores; the CU's cache is the same for both
+    auto tail_written = [&]() { if (kTailG) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); };
+    auto tail_wanted = [&]() { if (kTailG) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
     const int half1 = a.size1 >> 1;
     int prev_n4 = 0;
 
@@ -141,6 +160,7 @@ __global__ __launch_bounds__(kBigMaxThreads, 1) void synth_big_kernel(SynthArgs 
         const float *st = a.state_h + (size_t)run.state_slot * a.state_slot_floats + ((size_t)run.stream * C + ch) * half1;
         prev_n4 = run.prev_long ? (a.size1 >> 2) : (a.size0 >> 2);
         for (int i = lane; i < prev_n4; i += 64) tail[i] = st[i];
+        tail_written();
     }
     out_t *out_base = reinterpret_cast<out_t *>(a.out) + (a.stream_out_off ? a.stream_out_off[run.stream] : 0);
     {
@@ -273,7 +293,14 @@ __global__ __launch_bounds__(kBigMaxThreads, 1) void synth_big_kernel(SynthArgs 
 #pragma unroll
                 for (int m = 0; m < 8; ++m) { lo[m] = Xc[2 * m]; hi[m] = Xc[2 * m + 1]; }
                 const float2 *gt = (nblk == a.size1 ? a.tw_long : a.tw_short);
-                imdct8192_wave(lo, hi, h2, gt + kFast8192TwOffset, gt + kFast8192W2Offset, tl + 576, tl, tl + 512, ln);
+                // (8192 is the long size, or both: the long set -- with the twiddle table behind it where that is staged)
+                const float2 *tw = (kTailG && kBigTw8192 > 0) ? tl + 1088 : gt + kFast8192TwOffset;
+#ifdef VPZ_BIG_W2_GLOBAL  // (A/B builds: the level-2 table read from global memory although its half is staged)
+                const float2 *w2 = gt + kFast8192W2Offset;
+#else
+                const float2 *w2 = (kTailG && kBigTw8192 > 0) ? tl + 1088 + 2048 : gt + kFast8192W2Offset;
+#endif
+                imdct8192_wave(lo, hi, h2, tw, w2, tl + 576, tl, tl + 512, ln);
             } else if (nblk == 4096) {
                 const float2 *tl = tables_of(4096);
                 float4 xa[8];
@@ -302,6 +329,7 @@ __global__ __launch_bounds__(kBigMaxThreads, 1) void synth_big_kernel(SynthArgs 
 
         // ---- window + overlap-add + clip + store (StreamDecoder.cs:782-789, 515-638)
         if (fi >= 0 && fd.out_count > 0) {
+            tail_wanted();
             const bool ilv = a.interleaved != 0;
             out_t *dst = ilv ? out_base + fd.out_off * C + ch : out_base + (int64_t)ch * a.channel_stride + fd.out_off;
             const int64_t ostep = ilv ? C : 1;
@@ -314,48 +342,75 @@ __global__ __launch_bounds__(kBigMaxThreads, 1) void synth_big_kernel(SynthArgs 
             if (vec) {
                 const float4 *h4 = reinterpret_cast<const float4 *>(hcur);
                 const float4 *t4 = reinterpret_cast<const float4 *>(tail);
+                const VPZ_GLOBAL float4 *t4g = (const VPZ_GLOBAL float4 *)t4;  // (kTailG)
                 const VPZ_GLOBAL float4 *s4 = (const VPZ_GLOBAL float4 *)slope;
                 const int cnt4 = fd.out_count >> 2;
                 const int nr = (cnt4 + 63) >> 6;
                 const int pn4 = prev_n4;
-                for (int r = 0; r < nr; ++r) {
-                    const int g = lv + 64 * r;
-                    const bool live = g < cnt4;
-                    const int i = (live ? g : cnt4 - 1) << 2;
-                    const Y4Map mc = map_y4(fd.left_start + i, n4);
-                    const bool in = i < plen;
-                    const int ii = in ? i : 0;
-                    const int q = fd.prev_end + ii;  // in [2 pn4, 4 pn4) whenever `in`
-                    const bool pc = q >= 3 * pn4;
-                    int pidx = (pc ? (4 * pn4 - 4 - q) : (q - 2 * pn4)) >> 2;
-                    pidx = in ? pidx : 0;
-                    const int ridx = in ? ((plen - 4 - ii) >> 2) : 0;
-                    const float4 hv = h4[mc.idx4];
-                    const float4 pv = t4[pidx];
-                    const float4 wl = s4[ii >> 2];
-                    const float4 wr = s4[ridx];
-                    const float4 v = apply_y4(hv, mc.rev, mc.neg);
-                    const float4 t = apply_y4(pv, pc, false);
-                    float o0 = ola(v.x, wl.x, t.x, wr.w);
-                    float o1 = ola(v.y, wl.y, t.y, wr.z);
-                    float o2 = ola(v.z, wl.z, t.z, wr.y);
-                    float o3 = ola(v.w, wl.w, t.w, wr.x);
-                    o0 = in ? o0 : v.x;
-                    o1 = in ? o1 : v.y;
-                    o2 = in ? o2 : v.z;
-                    o3 = in ? o3 : v.w;
-                    if (a.clip) clip_group(o0, o1, o2, o3, clip_peak);
-                    if (live) {
-                        if (ilv) {
-                            out_t *d = dst + (int64_t)(4 * g) * ostep;
-                            store_pcm(d, kS16 ? (out_t)to_s16(o0) : (out_t)o0);
-                            store_pcm(d + ostep, kS16 ? (out_t)to_s16(o1) : (out_t)o1);
-                            store_pcm(d + 2 * ostep, kS16 ? (out_t)to_s16(o2) : (out_t)o2);
-                            store_pcm(d + 3 * ostep, kS16 ? (out_t)to_s16(o3) : (out_t)o3);
-                        } else if (kS16) {
-                            store_nt(reinterpret_cast<uint2 *>(dst) + g, pack_s16(o0, o1), pack_s16(o2, o3));
+                // The window values (and, for 8192 decoders, the tail) come from global memory: a round that asks for its values and
+                // uses them at once waits a whole trip to the L2 -- sixteen trips in a row for an 8192 block.  Four rounds' loads are
+                // issued together, then their arithmetic and stores (lanes past the end clamp their reads and skip the store).
+#ifndef VPZ_BIG_OLA_ROUNDS
+#define VPZ_BIG_OLA_ROUNDS 4
+#endif
+                constexpr int kU = VPZ_BIG_OLA_ROUNDS;
+                for (int r0 = 0; r0 < nr; r0 += kU) {
+                    float4 hv[kU], pv[kU], wl[kU], wr[kU];
+                    bool in_[kU], live_[kU], pc_[kU];
+                    Y4Map mc_[kU];
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const int g = lv + 64 * (r0 + u);
+                        const bool live = g < cnt4;
+                        const int i = (live ? g : cnt4 - 1) << 2;
+                        const Y4Map mc = map_y4(fd.left_start + i, n4);
+                        const bool in = i < plen;
+                        const int ii = in ? i : 0;
+                        const int q = fd.prev_end + ii;  // in [2 pn4, 4 pn4) whenever `in`
+                        const bool pc = q >= 3 * pn4;
+                        int pidx = (pc ? (4 * pn4 - 4 - q) : (q - 2 * pn4)) >> 2;
+                        pidx = in ? pidx : 0;
+                        const int ridx = in ? ((plen - 4 - ii) >> 2) : 0;
+                        hv[u] = h4[mc.idx4];
+                        if (kTailG) {  // (one base in scalar registers + a 32-bit offset per lane)
+                            const VPZ_GLOBAL char *tb = (const VPZ_GLOBAL char *)t4g;
+                            pv[u] = *(const VPZ_GLOBAL float4 *)(tb + (uint32_t)pidx * 16u);
                         } else {
-                            store_pcm4(reinterpret_cast<float4 *>(dst) + g, make_float4(o0, o1, o2, o3));
+                            pv[u] = t4[pidx];
+                        }
+                        wl[u] = s4[ii >> 2];
+                        wr[u] = s4[ridx];
+                        in_[u] = in;
+                        live_[u] = live;
+                        pc_[u] = pc;
+                        mc_[u] = mc;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) {
+                        const int g = lv + 64 * (r0 + u);
+                        const float4 v = apply_y4(hv[u], mc_[u].rev, mc_[u].neg);
+                        const float4 t = apply_y4(pv[u], pc_[u], false);
+                        float o0 = ola(v.x, wl[u].x, t.x, wr[u].w);
+                        float o1 = ola(v.y, wl[u].y, t.y, wr[u].z);
+                        float o2 = ola(v.z, wl[u].z, t.z, wr[u].y);
+                        float o3 = ola(v.w, wl[u].w, t.w, wr[u].x);
+                        o0 = in_[u] ? o0 : v.x;
+                        o1 = in_[u] ? o1 : v.y;
+                        o2 = in_[u] ? o2 : v.z;
+                        o3 = in_[u] ? o3 : v.w;
+                        if (a.clip) clip_group(o0, o1, o2, o3, clip_peak);
+                        if (live_[u]) {
+                            if (ilv) {
+                                out_t *d = dst + (int64_t)(4 * g) * ostep;
+                                store_pcm(d, kS16 ? (out_t)to_s16(o0) : (out_t)o0);
+                                store_pcm(d + ostep, kS16 ? (out_t)to_s16(o1) : (out_t)o1);
+                                store_pcm(d + 2 * ostep, kS16 ? (out_t)to_s16(o2) : (out_t)o2);
+                                store_pcm(d + 3 * ostep, kS16 ? (out_t)to_s16(o3) : (out_t)o3);
+                            } else if (kS16) {
+                                store_nt(reinterpret_cast<uint2 *>(dst) + g, pack_s16(o0, o1), pack_s16(o2, o3));
+                            } else {
+                                store_pcm4(reinterpret_cast<float4 *>(dst) + g, make_float4(o0, o1, o2, o3));
+                            }
                         }
                     }
                 }
@@ -382,10 +437,18 @@ __global__ __launch_bounds__(kBigMaxThreads, 1) void synth_big_kernel(SynthArgs 
             if (n4 >= 256) {
                 const float4 *s4 = reinterpret_cast<const float4 *>(hcur + n4);
                 float4 *d4 = reinterpret_cast<float4 *>(tail);
-                for (int i = lane; i < (n4 >> 2); i += 64) d4[i] = s4[i];
+                if (kTailG) {
+                    int lt = lane;
+                    asm volatile("" : "+v"(lt));  // (no 64-bit address of these stores may be kept in registers across the frame loop)
+                    const VPZ_GLOBAL char *db = (const VPZ_GLOBAL char *)d4;
+                    for (int i = lt; i < (n4 >> 2); i += 64) *(VPZ_GLOBAL float4 *)(db + (uint32_t)i * 16u) = s4[i];
+                } else {
+                    for (int i = lane; i < (n4 >> 2); i += 64) d4[i] = s4[i];
+                }
             } else {
                 for (int i = lane; i < n4; i += 64) tail[i] = hcur[n4 + i];
             }
+            tail_written();
             prev_n4 = n4;
             __builtin_amdgcn_wave_barrier();
         }
@@ -399,6 +462,7 @@ __global__ __launch_bounds__(kBigMaxThreads, 1) void synth_big_kernel(SynthArgs 
 
     if ((run.flags & kRunSaveState) && prev_n4 > 0) {
         float *st = a.state_h + (size_t)(run.state_slot ^ 1) * a.state_slot_floats + ((size_t)run.stream * C + ch) * half1;
+        tail_wanted();
         for (int i = lane; i < prev_n4; i += 64) st[i] = tail[i];
     }
     if (a.clip && __any(clip_peak > 0.99999994f) && lane == 0) atomicMax(&a.clipped[run.stream], run.clip_epoch);
@@ -417,9 +481,9 @@ bool synth_big_supported(int size0, int size1)
 // The kernel's dynamic LDS goes beyond the 64 KB a launch may ask for by default: the limit is raised to what the largest pair needs --
 // ONE value whatever the decoder, so that contexts launching from several host threads (the dispatcher's lanes) never lower it under each other
 template <typename K>
-static hipError_t big_prepare(K kernel, int lds)
+static hipError_t big_prepare(K kernel, int lds, bool tail_g)
 {
-    const int most = big_layout(8192, 8192).total;
+    const int most = tail_g ? big_layout(8192, 8192).total : big_layout(4096, 4096).total;  // (per instantiation: its largest pair)
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds > most ? lds : most);
 }
 
@@ -431,10 +495,17 @@ hipError_t launch_synth_big(const SynthArgs &args, bool has_floor, hipStream_t s
     const int grid = (int)((items + waves - 1) / waves);
     const int lds = big_layout(args.size0, args.size1).total;
     hipError_t e = hipSuccess;
+    const bool tail_g = args.size1 == 8192;
+    if (tail_g && !args.big_tail) return hipErrorInvalidValue;
 #define VPZ_LAUNCH_BIG(F, S)                                                                                  \
     do {                                                                                                      \
-        e = big_prepare(synth_big_kernel<F, S>, lds);                                                         \
-        if (e == hipSuccess) hipLaunchKernelGGL((synth_big_kernel<F, S>), dim3(grid), dim3(64 * waves), lds, stream, args); \
+        if (tail_g) {                                                                                         \
+            e = big_prepare(synth_big_kernel<F, S, true>, lds, true);                                               \
+            if (e == hipSuccess) hipLaunchKernelGGL((synth_big_kernel<F, S, true>), dim3(grid), dim3(64 * waves), lds, stream, args); \
+        } else {                                                                                              \
+            e = big_prepare(synth_big_kernel<F, S, false>, lds, false);                                              \
+            if (e == hipSuccess) hipLaunchKernelGGL((synth_big_kernel<F, S, false>), dim3(grid), dim3(64 * waves), lds, stream, args); \
+        }                                                                                                     \
     } while (0)
     if (has_floor) {
         if (args.s16) VPZ_LAUNCH_BIG(true, true);
@@ -447,16 +518,27 @@ hipError_t launch_synth_big(const SynthArgs &args, bool has_floor, hipStream_t s
     return e != hipSuccess ? e : hipGetLastError();
 }
 
+// floats of SynthArgs.big_tail a launch of n_items (runs x channels) needs: a quarter block per item for an 8192 decoder, else none
+int64_t synth_big_tail_floats(int size1, int64_t n_items) { return size1 == 8192 ? n_items * (size1 >> 2) : 0; }
+
 // wavefronts (= channel-blocks in flight) the chip keeps resident under synth_big_kernel
 int synth_big_resident_waves(bool has_floor, int num_cu, int size0, int size1)
 {
     const int lds = big_layout(size0, size1).total;
     int per_cu = 0;
-    hipError_t e = has_floor ? big_prepare(synth_big_kernel<true, false>, lds) : big_prepare(synth_big_kernel<false, false>, lds);
     const int waves = big_waves(size1);
-    if (e == hipSuccess)
-        e = has_floor ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_big_kernel<true, false>, 64 * waves, lds)
-                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_big_kernel<false, false>, 64 * waves, lds);
+    hipError_t e;
+    if (size1 == 8192) {
+        e = has_floor ? big_prepare(synth_big_kernel<true, false, true>, lds, true) : big_prepare(synth_big_kernel<false, false, true>, lds, true);
+        if (e == hipSuccess)
+            e = has_floor ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_big_kernel<true, false, true>, 64 * waves, lds)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_big_kernel<false, false, true>, 64 * waves, lds);
+    } else {
+        e = has_floor ? big_prepare(synth_big_kernel<true, false, false>, lds, false) : big_prepare(synth_big_kernel<false, false, false>, lds, false);
+        if (e == hipSuccess)
+            e = has_floor ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_big_kernel<true, false, false>, 64 * waves, lds)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, synth_big_kernel<false, false, false>, 64 * waves, lds);
+    }
     if (e != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 1;

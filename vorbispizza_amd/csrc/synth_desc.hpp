@@ -202,6 +202,7 @@ struct SynthArgs {
     const float2 *tw_long;      // fast tables of size1 (BlockTables::d_fast)
     const float2 *tw_short;     // fast tables of size0
     const float *slope0, *slope1;
+    float *big_tail;            // synth_big_kernel, 8192 decoders: [run x channel][2048] the upper half of the wave's previous h
     float *out;
     const int64_t *stream_out_off;  // nullptr => 0
     int64_t channel_stride;

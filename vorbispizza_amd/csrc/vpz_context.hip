@@ -166,9 +166,12 @@ int get_tables(Context *ctx, int n, BlockTables **out)
             double a = two_pi * (double)j / 1024.0;
             fast[kFast8192W1Offset + j] = make_float2((float)cos(a), (float)sin(a));
         }
-        for (int j = 0; j < 1024; ++j) {
+        // (the upper half is the lower one times i, to the bit: imdct8192_wave reads the lower half only and turns the value)
+        for (int j = 0; j < 512; ++j) {
             double a = two_pi * (double)j / 2048.0;
-            fast[kFast8192W2Offset + j] = make_float2((float)cos(a), (float)sin(a));
+            const float2 w = make_float2((float)cos(a), (float)sin(a));
+            fast[kFast8192W2Offset + j] = w;
+            fast[kFast8192W2Offset + 512 + j] = make_float2(-w.y, w.x);
         }
     }
     if (n == 512 || n == 1024) {

@@ -42,6 +42,7 @@ hipError_t launch_synth_pairs(const SynthArgs &args, bool has_floor, bool interl
 bool synth_big_supported(int size0, int size1);
 hipError_t launch_synth_big(const SynthArgs &args, bool has_floor, hipStream_t stream);
 int synth_big_resident_waves(bool has_floor, int num_cu, int size0, int size1);
+int64_t synth_big_tail_floats(int size1, int64_t n_items);
 hipError_t launch_generic_floor(const GenericFrame *frames, int n_frames, int channels, int half1, float *spec,
                                 const uint8_t *post_counts, const uint8_t *curve_y, const float *inv_db,
                                 hipStream_t stream);
@@ -193,6 +194,7 @@ struct Decoder {
     DevBuf b_in_res16;              // VPZ_RESIDUE_I16: the int16 values as they came over the link, widened into b_in_res
     int residue_format = VPZ_RESIDUE_F32;
     DevBuf b_ybuf;                                    // any-block-size path
+    DevBuf b_bigtail;                                 // synth_big_kernel, 8192 decoders: the waves' tails (SynthArgs.big_tail)
     bool generic = false;  // a block size the fused kernels do not take (64, 128): three-pass path (synth_kernels.hip)
     bool big = false;      // the long block is 4096 or 8192 samples: synth_big_kernel (synth_big.hip; VPZ_NO_BIG=1: the three-pass path)
     // type-0 floors (Floor0.cs)
@@ -686,7 +688,7 @@ void vpz_decoder_destroy(vpz_decoder *d)
     }
     if (D.d_f0_bark) (void)hipFree(D.d_f0_bark);
     if (D.d_f0_w) (void)hipFree(D.d_f0_w);
-    DevBuf *bufs[] = {&D.b_f0curve, &D.b_in_amp, &D.b_in_coeff, &D.b_ybuf, &D.b_curve, &D.b_temp, &D.b_cposts, &D.b_ccount, &D.b_in_res, &D.b_in_res16, &D.b_in_posts,
+    DevBuf *bufs[] = {&D.b_f0curve, &D.b_in_amp, &D.b_in_coeff, &D.b_ybuf, &D.b_bigtail, &D.b_curve, &D.b_temp, &D.b_cposts, &D.b_ccount, &D.b_in_res, &D.b_in_res16, &D.b_in_posts,
                       &D.b_in_counts, &D.b_out, &D.arenas[0].dev, &D.arenas[1].dev};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -2242,6 +2244,14 @@ struct SynthCall {
         a.f0_stride = D.f0_k;
         a.spec_i16 = spec_i16 ? 1 : 0;
         a.state_h = D.d_state_h;
+        if (D.big && !use_dual) {
+            const int64_t tf = synth_big_tail_floats(D.size1, (int64_t)n_runs * C);
+            if (tf > 0) {
+                const int grc = grow(ctx, D.b_bigtail, sizeof(float) * (size_t)tf);
+                if (grc != VPZ_OK) return grc;
+            }
+            a.big_tail = static_cast<float *>(D.b_bigtail.p);
+        }
         a.state_slot_floats = (int64_t)D.n_streams * C * half1;
         a.tw_long = D.t1->d_fast;
         a.tw_short = D.t0->d_fast;
