@@ -245,28 +245,36 @@ __global__ __launch_bounds__(kThreads) void imdct4096_kernel(const float *__rest
     }
 }
 
-// N = 8192: one wavefront per channel-block, two 16-byte loads per lane and point; the two big twiddle tables stay
-// in global memory (every entry is read once per block), the 512-point stage tables and w1 in LDS
-__global__ __launch_bounds__(kThreads) void imdct8192_kernel(const float *__restrict__ spectra, float *__restrict__ out,
-                                                            long count, const float2 *__restrict__ tables,
-                                                            const int64_t *__restrict__ src_off,
-                                                            const int64_t *__restrict__ dst_off)
+// N = 8192: one wavefront per channel-block, two 16-byte loads per lane and point.  Every table is in LDS -- the 2048-entry
+// twiddle table and the read half of the level-2 table too: read from global memory inside the butterflies they were some twenty
+// trips to the L2 per block, one behind the other (synth_big.hip has the measurements) --, at the price of one wave: seven waves
+// of 16 KB beside 28.5 KB of tables, one workgroup per CU.
+constexpr int kWaves8192 = 7;
+constexpr int kThreads8192 = 64 * kWaves8192;
+__global__ __launch_bounds__(kThreads8192) void imdct8192_kernel(const float *__restrict__ spectra, float *__restrict__ out,
+                                                                long count, const float2 *__restrict__ tables,
+                                                                const int64_t *__restrict__ src_off,
+                                                                const int64_t *__restrict__ dst_off)
 {
     __shared__ float2 s_twAB[512];
     __shared__ float2 s_twBC[64];
     __shared__ float2 s_w1[512];
-    __shared__ float2 s_h[kWavesPerGroup][2048];
-    for (int i = threadIdx.x; i < 512; i += kThreads) {
+    __shared__ float2 s_tw[2048];
+    __shared__ float2 s_w2[512];
+    __shared__ float2 s_h[kWaves8192][2048];
+    for (int i = threadIdx.x; i < 512; i += kThreads8192) {
         s_twAB[i] = tables[kFast8192TwABOffset + i];
         s_w1[i] = tables[kFast8192W1Offset + i];
+        s_w2[i] = tables[kFast8192W2Offset + i];
     }
+    for (int i = threadIdx.x; i < 2048; i += kThreads8192) s_tw[i] = tables[kFast8192TwOffset + i];
     if (threadIdx.x < 64) s_twBC[threadIdx.x] = tables[kFast8192TwBCOffset + threadIdx.x];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long stride = (long)gridDim.x * kWavesPerGroup;
-    for (long blk = (long)blockIdx.x * kWavesPerGroup + wave; blk < count; blk += stride) {
+    const long stride = (long)gridDim.x * kWaves8192;
+    for (long blk = (long)blockIdx.x * kWaves8192 + wave; blk < count; blk += stride) {
         const float4 *src = reinterpret_cast<const float4 *>(spectra + (src_off ? src_off[blk] : blk * 4096));
         float4 lo[8], hi[8];
 #pragma unroll
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(kThreads) void imdct8192_kernel(const float *__rest
             lo[m] = src[2 * (lane + 64 * m)];
             hi[m] = src[2 * (lane + 64 * m) + 1];
         }
-        imdct8192_wave(lo, hi, s_h[wave], tables + kFast8192TwOffset, tables + kFast8192W2Offset, s_w1, s_twAB, s_twBC, lane);
+        imdct8192_wave(lo, hi, s_h[wave], s_tw, s_w2, s_w1, s_twAB, s_twBC, lane);
         store_full_block<8192, 64>(reinterpret_cast<const float *>(s_h[wave]), out + (dst_off ? dst_off[blk] : blk * 8192), lane);
     }
 }
@@ -283,14 +291,14 @@ __global__ __launch_bounds__(kThreads) void imdct8192_kernel(const float *__rest
 // occupancy), so that every workgroup gets the same share of the batch and there is no partial
 // last round of workgroups.
 template <typename K>
-static int resident_groups(K kernel, int num_cu)
+static int resident_groups(K kernel, int num_cu, int threads = kThreads)
 {
     int per_cu = 0;
     if (const char *e = getenv("VPZ_IMDCT_GROUPS_PER_CU")) {  // tuning experiments only
         per_cu = atoi(e);
         if (per_cu > 0) return num_cu * per_cu;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 2;
     }
@@ -358,9 +366,9 @@ hipError_t launch_imdct_fast_8192(const float *spectra, float *out, int64_t coun
 {
     if (count <= 0) return hipSuccess;
     int &resident = ctx->resident[kResident8192];  // (per context: the contexts of one process may sit on different devices)
-    if (!resident) resident = resident_groups(imdct8192_kernel, ctx->num_cu);
-    const int grid = grid_for((count + kWavesPerGroup - 1) / kWavesPerGroup, resident);
-    hipLaunchKernelGGL(imdct8192_kernel, dim3(grid), dim3(kThreads), 0, stream, spectra, out, (long)count, tw, src_off,
+    if (!resident) resident = resident_groups(imdct8192_kernel, ctx->num_cu, kThreads8192);
+    const int grid = grid_for((count + kWaves8192 - 1) / kWaves8192, resident);
+    hipLaunchKernelGGL(imdct8192_kernel, dim3(grid), dim3(kThreads8192), 0, stream, spectra, out, (long)count, tw, src_off,
                        dst_off);
     return hipGetLastError();
 }

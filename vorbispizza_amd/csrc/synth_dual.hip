@@ -45,7 +45,10 @@ namespace vpz {
 
 constexpr bool kPairs = VPZ_DUAL_PAIRS != 0;
 constexpr int kDualWaves = VPZ_DUAL_WAVES;
-constexpr int kDualWavesPerSimd = VPZ_DUAL_WAVES >= 10 ? 3 : 2;  // 4-wave workgroups: two per CU (LDS); 10-wave ones: one
+#ifndef VPZ_DUAL_WPS
+#define VPZ_DUAL_WPS (VPZ_DUAL_WAVES >= 10 ? 3 : 2)
+#endif
+constexpr int kDualWavesPerSimd = VPZ_DUAL_WPS;  // 4-wave workgroups: two per CU (LDS); 10-wave ones: one
 constexpr int kDualThreads = 64 * kDualWaves;
 
 // Both channels' Floor1 curves at once (render_floor_indices_fast, phase by phase for the two records): the phases are
