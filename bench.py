@@ -924,7 +924,7 @@ def main():
         ge.build()
     if distributed:
         sharding.barrier()
-    from vorbispizza_amd import Context, Decoder, capi
+    from vorbispizza_amd import Context, Decoder, capi, make_packets
 
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
@@ -1048,7 +1048,46 @@ def main():
             dt_n, _ = time_decoder(ctx, dec_n, torch, pk_n, res_n, posts_n, counts_n, samples6, 6, 40, 3)
             extras["configs[3] support not declared"] = fused_entry(samples6 * 6, dt_n, byt_full)
             dec_n.close()
-            del res_n, posts_n, counts_n, res6, posts, counts
+            # ... and as planar [6][1024] packets (what residue types 0 / 1 hand over): the pair route -- the stereo kernel, a workgroup per
+            # pair of channels (synth_pairs.hip); on the Residue2 vector above the decoder keeps group mode
+            res_p = res6.reshape(args.extras_frames6, 1024, 6).transpose(1, 2).contiguous().reshape(-1)
+            pk_p = pk.copy()
+            pk_p["flags"] &= np.uint8(~capi.PKT_INTERLEAVED & 0xFF)
+            dec_p = Decoder(ctx, 6, 256, 2048, floors=floors, mappings=mappings)
+            dt_p, _ = time_decoder(ctx, dec_p, torch, pk_p, res_p, posts, counts, samples6, 6, 40, 3)
+            extras["configs[3] planar packets (pair route)"] = fused_entry(samples6 * 6, dt_p, byt)
+            dec_p.close()
+            del res_n, posts_n, counts_n, res6, res_p, posts, counts
+            torch.cuda.empty_cache()
+            # the other long block sizes the reference takes (Mdct.cs:15-19): 4096 and 8192, mixed with their short blocks, stereo, already
+            # floored (configs[2]'s shape) -- synth_big_kernel, one pass over HBM
+            big = {}
+            import helpers
+            for size0, size1 in ((512, 4096), (1024, 8192)):
+                frames_b = args.extras_frames * 2048 // size1
+                flags_b = helpers.markov_block_flags(frames_b, seed=3)
+                halves = np.where(flags_b & 1, size1 // 2, size0 // 2).astype(np.int64)
+                offs_b = np.concatenate([[0], np.cumsum(halves * 2)])
+                pk_b = make_packets(frames_b)
+                pk_b["flags"] = flags_b | capi.PKT_NO_FLOOR
+                pk_b["granule"] = -1
+                pk_b["residue_offset"] = offs_b[:-1]
+                g = torch.Generator(device=device).manual_seed(size1)
+                res_b = torch.randn(int(offs_b[-1]), generator=g, device=device) * 2.0 ** -8
+                dec_b = Decoder(ctx, 2, size0, size1)
+                cap_b = int(halves.sum()) + 2 * size1
+                out_b = torch.empty(2 * cap_b, device=device)
+                dec_b.reset(-1)
+                smp_b = int(dec_b.synth_raw(pk_b, res_b, None, None, out_b, None, cap_b, capi.OUT_PLANAR, cap_b, capi.MEM_DEVICE)[0])
+                del out_b
+                dt_b, _ = time_decoder(ctx, dec_b, torch, pk_b, res_b, None, None, smp_b, 2, 20, 3)
+                byt_b = 4 * int(offs_b[-1]) + 4 * smp_b * 2
+                big["%d/%d" % (size0, size1)] = {"ms_per_step": round(dt_b * 1e3, 3), "frac_of_8TBps": round(byt_b / dt_b / 1e9 / HBM_PEAK_GBS, 4),
+                                                 "bytes": byt_b, "frames": frames_b}
+                time_decoder.last_spread = None
+                dec_b.close()
+                del res_b
+            extras["long blocks of 4096 / 8192 samples, stereo, mixed with short blocks (synth_big_kernel)"] = big
             torch.cuda.empty_cache()
             # configs[4], one GPU's share: 128 stereo streams (64 x 3test.ogg + 64 x issue6test.ogg)
             dt, tot, t_front, _ = time_real_streams(ctx, torch, device, 64, steps=40, warmup=3)

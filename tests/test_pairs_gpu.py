@@ -134,3 +134,33 @@ def test_setups_whose_steps_do_not_pair_the_channels_keep_their_route(ctx):
         with env(VPZ_NO_PAIRS=1, VPZ_NO_GROUP=1):
             b = run(ctx, pk, res, posts, counts, n_streams, channels, FLOORS, mappings, layout=capi.OUT_PLANAR, splits=2)
         same_bits(a, b, "%d channels, %r / %r" % (channels, steps0, steps1))
+
+
+def test_the_route_that_runs_is_the_route_asked_for(ctx, capfd):
+    """VPZ_HOST_PROFILE=1 makes every synth call name its route on stderr: the pairs when forced (VPZ_PAIRS=1) in either input layout; left
+    to itself the decoder takes them for planar packets to planar PCM and keeps group mode for the Residue2 vector and for interleaved
+    PCM; beyond eight channels (no group mode) the pairs for planar packets, the separate coupling pass for the Residue2 vector;
+    VPZ_NO_PAIRS=1: never; a stereo stream: the stereo kernel as before."""
+    from vorbispizza_amd import capi
+    mappings6 = [{"coupling": [(0, 1), (2, 3)], "channel_floor": [f] * 6} for f in (0, 1)]
+    mappings10 = [{"coupling": [(0, 1), (9, 2)], "channel_floor": [f] * 10} for f in (0, 1)]
+    mappings2 = [{"coupling": [(0, 1)], "channel_floor": [f] * 2} for f in (0, 1)]
+    cases = [  # channels, mappings, interleaved in, layout, env, route
+        (6, mappings6, True, capi.OUT_PLANAR, dict(VPZ_PAIRS=1), "pairs"),
+        (6, mappings6, True, capi.OUT_INTERLEAVED, dict(VPZ_PAIRS=1), "pairs"),
+        (6, mappings6, False, capi.OUT_PLANAR, dict(VPZ_PAIRS=None), "pairs"),
+        (6, mappings6, True, capi.OUT_PLANAR, dict(VPZ_PAIRS=None), "group"),
+        (6, mappings6, False, capi.OUT_INTERLEAVED, dict(VPZ_PAIRS=None), "group"),
+        (6, mappings6, False, capi.OUT_PLANAR, dict(VPZ_PAIRS=None, VPZ_NO_PAIRS=1), "group"),
+        (10, mappings10, False, capi.OUT_PLANAR, dict(VPZ_PAIRS=None), "pairs"),
+        (10, mappings10, True, capi.OUT_PLANAR, dict(VPZ_PAIRS=None), "separate"),
+        (2, mappings2, True, capi.OUT_PLANAR, dict(VPZ_PAIRS=None), "stereo"),
+    ]
+    for channels, mappings, ilv, layout, kv, route in cases:
+        pk, res, posts, counts = stream_major_batch(2, 12, channels, seed=7800 + channels, floor=True, interleaved=ilv)
+        pk["mapping"] = pk["flags"] & 1
+        capfd.readouterr()
+        with env(**dict(dict(VPZ_NO_PAIRS=None, VPZ_NO_GROUP=None, VPZ_NO_DUAL=None), VPZ_HOST_PROFILE=1, **kv)):
+            run(ctx, pk, res, posts, counts, 2, channels, FLOORS, mappings, layout=layout)
+        err = capfd.readouterr().err
+        assert "route %s," % route in err, (channels, ilv, layout, kv, route, err[-300:])

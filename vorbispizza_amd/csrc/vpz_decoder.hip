@@ -2373,7 +2373,7 @@ static int synth_impl(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     D.packet_samples.assign((size_t)n_packets, 0);
     if (n_packets == 0) return VPZ_OK;
 
-    static const bool host_profile = getenv("VPZ_HOST_PROFILE") != nullptr;
+    const bool host_profile = getenv("VPZ_HOST_PROFILE") != nullptr;  // (per call: the tests switch it on for single calls)
     auto tick = [] { return std::chrono::steady_clock::now(); };
     const auto t_begin = tick();
     SynthCall call(D, n_packets, packets, residue, posts, post_counts, mem_space, pcm_out, stream_out_offset,
@@ -2432,8 +2432,10 @@ static int synth_impl(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     if (host_profile) {
         const auto t_end = tick();
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        fprintf(stderr, "[vpz host] packets %lld: arena wait %.1f us, pass1 %.1f us (%s), runs %.1f us, uploads+launch %.1f us\n",
-                (long long)n_packets, us(t_begin, t_arena), us(t_arena, t_pass1), was_parallel ? "parallel" : "serial",
+        // (route: which kernel synthesises -- the tests read it to know that the route they ask for is the one that ran)
+        const char *route = D.generic ? "generic" : call.use_dual ? (D.pairs ? "pairs" : "stereo") : D.big ? "big" : call.use_group ? "group" : "separate";
+        fprintf(stderr, "[vpz host] packets %lld: route %s, arena wait %.1f us, pass1 %.1f us (%s), runs %.1f us, uploads+launch %.1f us\n",
+                (long long)n_packets, route, us(t_begin, t_arena), us(t_arena, t_pass1), was_parallel ? "parallel" : "serial",
                 us(t_pass1, t_pass2), us(t_pass2, t_end));
     }
     return VPZ_OK;  // (window mismatches are per-packet conditions: vpz_decoder_last_packet_status)
