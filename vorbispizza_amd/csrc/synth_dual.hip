@@ -175,6 +175,56 @@ __device__ __forceinline__ void floor0_multiply(float2 (&x)[8], float *row, cons
     __builtin_amdgcn_wave_barrier();
 }
 
+// Both channels at once: every global load of the two curves (and the bark indices) is issued before the first value is used -- copied
+// in a loop, 64 values per trip, a curve of 256 bark bands was four trips to the L2 one behind the other, per channel and pass.
+// do0 / do1: the channel has a type-0 floor (wave-uniform).  k_count <= kFloor0MaxBark = 1024: at most 16 values per lane.
+__device__ __forceinline__ void floor0_multiply_x2(float2 (&x0)[8], float2 (&x1)[8], float *row0, float *row1, const float *curve0,
+                                                   const float *curve1, int k_count, const uint16_t *bark0, const uint16_t *bark1,
+                                                   bool do0, bool do1, int lpb, int lane)
+{
+    const VPZ_GLOBAL float *c0 = (const VPZ_GLOBAL float *)(do0 ? curve0 : curve1), *c1 = (const VPZ_GLOBAL float *)(do1 ? curve1 : curve0);
+    const VPZ_GLOBAL uint4 *p0 = (const VPZ_GLOBAL uint4 *)((do0 ? bark0 : bark1) + (lane & (lpb - 1)) * 16);
+    const VPZ_GLOBAL uint4 *p1 = (const VPZ_GLOBAL uint4 *)((do1 ? bark1 : bark0) + (lane & (lpb - 1)) * 16);
+    float v0[16], v1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = lane + 64 * j;
+        const int ii = i < k_count ? i : 0;  // (unconditional loads: a lane past the end reads the head again and stores nothing)
+        v0[j] = c0[ii];
+        v1[j] = c1[ii];
+    }
+    const uint4 a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = lane + 64 * j;
+        if (i < k_count) {
+            if (do0) row0[i] = v0[j];
+            if (do1) row1[i] = v1[j];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t w0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const uint32_t w1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float t0[16], t1[16];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        t0[2 * m] = do0 ? row0[w0[m] & 0xFFFFu] : 1.0f;
+        t0[2 * m + 1] = do0 ? row0[w0[m] >> 16] : 1.0f;
+        t1[2 * m] = do1 ? row1[w1[m] & 0xFFFFu] : 1.0f;
+        t1[2 * m + 1] = do1 ? row1[w1[m] >> 16] : 1.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (do0) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { x0[m].x *= t0[2 * m]; x0[m].y *= t0[2 * m + 1]; }
+    }
+    if (do1) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { x1[m].x *= t1[2 * m]; x1[m].y *= t1[2 * m + 1]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // kIlvIn : every packet of the batch is the Residue2-interleaved vector [bin][2] (else: every packet planar [2][bin])
 // kOut   : 0 planar output, 1 interleaved
 // kI16   : the residue is 16-bit integers (VPZ_RESIDUE_I16, ABI v5): half the bytes per value from HBM, widened in registers
@@ -796,12 +846,11 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                     const int lpb0 = is_long ? 64 : 8;
                     const int f0s = __builtin_amdgcn_readlane(kv, 7);  // (a.f0_stride)
                     const int kc = min(f0s, kFloor0MaxBark);
-                    if (f0L)
-                        floor0_multiply(xL, hL, a.f0_curve + (size_t)(fd.rec + cA()) * f0s, kc,
-                                        a.f0_bark + ((size_t)__builtin_amdgcn_readlane(cpa, 0) * 2 + (is_long ? 1 : 0)) * 1024, lpb0, ln);
-                    if (f0R)
-                        floor0_multiply(xR, hR, a.f0_curve + (size_t)(fd.rec + cB()) * f0s, kc,
-                                        a.f0_bark + ((size_t)__builtin_amdgcn_readlane(cpb, 0) * 2 + (is_long ? 1 : 0)) * 1024, lpb0, ln);
+                    // (a channel without a type-0 floor: its pointers are the other channel's, its values are not touched)
+                    const size_t fl_l = f0L ? (size_t)__builtin_amdgcn_readlane(cpa, 0) : 0, fl_r = f0R ? (size_t)__builtin_amdgcn_readlane(cpb, 0) : 0;
+                    floor0_multiply_x2(xL, xR, hL, hR, a.f0_curve + (size_t)(fd.rec + cA()) * f0s, a.f0_curve + (size_t)(fd.rec + cB()) * f0s, kc,
+                                       a.f0_bark + (fl_l * 2 + (is_long ? 1 : 0)) * 1024, a.f0_bark + (fl_r * 2 + (is_long ? 1 : 0)) * 1024,
+                                       f0L, f0R, lpb0, ln);
                 }
                 }
             }
