@@ -79,7 +79,8 @@ def test_the_kernel_for_4096_and_8192_blocks_keeps_its_budget(kernels):
 
 
 @pytest.mark.parametrize("flags", [["-DVPZ_STAMPS"], ["-DVPZ_WAVE_TIMES"], ["-DVPZ_TUNING"], ["-DVPZ_STAMPS", "-DVPZ_WAVE_TIMES", "-DVPZ_TUNING"],
-                                   ["-DVPZ_DUAL_STEADY_BIT", "-DVPZ_GROUP_STEADY_BIT", "-DVPZ_PAIR_STORES_NT"]])
+                                   ["-DVPZ_DUAL_STEADY_BIT", "-DVPZ_GROUP_STEADY_BIT", "-DVPZ_PAIR_STORES_NT"],
+                                   ["-DVPZ_DUAL_TAIL_REGS", "-DVPZ_DUAL_MIRROR_VALU"], ["-DVPZ_DUAL_NO_SLOPE_REGS", "-DVPZ_DUAL_NO_TW_REGS"]])
 def test_the_diagnostic_builds_still_parse(flags):
     """The build switches of the fused kernels (phase stamps, wave clocks, tuning switches, the alternatives kept for A/B runs) are
     compiled only when somebody needs them -- and rot unseen: a syntax-only device pass of the three translation units per set."""

@@ -62,6 +62,20 @@ __device__ __forceinline__ float lane_mirror64(float v, int lane)
 {
     return __int_as_float(__builtin_amdgcn_ds_bpermute((63 - lane) << 2, __float_as_int(v)));
 }
+// Two values mirrored at once WITHOUT the LDS pipe (ds_bpermute goes through it; the stereo kernel keeps it ~70 % busy): lane bits 0..3
+// by a row-mirroring DPP move, bit 4 by two v_permlane16_swap, bit 5 by two v_permlane32_swap (each swap pair hands both registers
+// back with the rows / halves exchanged).  Pure data movement: the values of lane_mirror64.
+__device__ __forceinline__ void lane_mirror64_x2(float a, float b, float &ma, float &mb)
+{
+    unsigned ua = __builtin_amdgcn_update_dpp(0u, __float_as_uint(a), 0x140, 0xF, 0xF, false);  // row_mirror
+    unsigned ub = __builtin_amdgcn_update_dpp(0u, __float_as_uint(b), 0x140, 0xF, 0xF, false);
+    auto r = __builtin_amdgcn_permlane16_swap(ua, ub, false, false);   // (A0 B0 A2 B2) (A1 B1 A3 B3)
+    r = __builtin_amdgcn_permlane16_swap(r[1], r[0], false, false);    // (A1 A0 A3 A2) (B1 B0 B3 B2)
+    r = __builtin_amdgcn_permlane32_swap(r[0], r[1], false, false);    // (Alo Blo) (Ahi Bhi)
+    r = __builtin_amdgcn_permlane32_swap(r[1], r[0], false, false);    // (Ahi Alo) (Bhi Blo)
+    ma = __uint_as_float(r[0]);
+    mb = __uint_as_float(r[1]);
+}
 // value held by lane (lane ^ 7): mirror inside each group of 8 lanes
 __device__ __forceinline__ float lane_mirror8(float v, int lane)
 {
@@ -342,6 +356,90 @@ __device__ __forceinline__ void imdct2048_wave_x2(const float2 (&xa)[8], const f
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const float ha = lane_mirror64(wa[7 - q], lane), hb = lane_mirror64(wb[7 - q], lane);
+        scratch_a[lane + 64 * q] = make_float2(za[q].x, ha);
+        scratch_b[lane + 64 * q] = make_float2(zb[q].x, hb);
+    }
+}
+
+// ... with the three twiddle sets in REGISTERS (a lane reads the same 22 entries for every 2048 block: tw[m] = s_tw[lane + 64 m],
+// twAB[p] = s_twAB[64 p + lane], twBC[q] = s_twBC[8 (lane & 7) + q]; entries 0 of the last two are not used): the stereo kernel keeps
+// them across the frames of a run -- 11 KB less through the CU's LDS pipe per pass.  Operations and their order: imdct2048_wave_x2's.
+// kBCRegs false: the third set stays in LDS (s_twBC) -- for the variants that need its 14 registers for something worth more.
+template <bool kBCRegs>
+__device__ __forceinline__ void imdct2048_wave_x2_regs(const float2 (&xa)[8], const float2 (&xb)[8], float2 *scratch_a, float2 *scratch_b,
+                                                       const float2 (&tw)[8], const float2 (&twAB)[8], const float2 (&twBC)[8],
+                                                       const float2 *s_twBC, int lane)
+{
+    float2 za[8], zb[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+#ifndef VPZ_DUAL_MIRROR_VALU  // (-DVPZ_DUAL_MIRROR_VALU: lane_mirror64_x2, measured equal -- profiles/r5_ab_lds_diet.txt)
+        const float ra = lane_mirror64(xa[7 - m].y, lane), rb = lane_mirror64(xb[7 - m].y, lane);
+#else
+        float ra, rb;
+        lane_mirror64_x2(xa[7 - m].y, xb[7 - m].y, ra, rb);
+#endif
+        za[m] = cmul(make_float2(ra, xa[m].x), tw[m]);
+        zb[m] = cmul(make_float2(rb, xb[m].x), tw[m]);
+    }
+    {   // dft512_wave_x2
+        float2 *sa = scratch_a, *sb = scratch_b;
+        radix8_inverse(za);
+        radix8_inverse(zb);
+#pragma unroll
+        for (int p = 1; p < 8; ++p) {
+            za[p] = cmul(za[p], twAB[p]);
+            zb[p] = cmul(zb[p], twAB[p]);
+        }
+        const int l0 = lane & 7, pp = lane >> 3;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            sa[72 * p + lane] = za[p];
+            sb[72 * p + lane] = zb[p];
+        }
+#pragma unroll
+        for (int l1 = 0; l1 < 8; ++l1) {
+            za[l1] = sa[72 * pp + l0 + 8 * l1];
+            zb[l1] = sb[72 * pp + l0 + 8 * l1];
+        }
+        radix8_inverse(za);
+        radix8_inverse(zb);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            const float2 w = kBCRegs ? twBC[q] : s_twBC[l0 * 8 + q];
+            za[q] = cmul(za[q], w);
+            zb[q] = cmul(zb[q], w);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sa[66 * l0 + pp + 8 * q] = za[q];
+            sb[66 * l0 + pp + 8 * q] = zb[q];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            za[r] = sa[66 * r + lane];
+            zb[r] = sb[66 * r + lane];
+        }
+        radix8_inverse(za);
+        radix8_inverse(zb);
+    }
+    float wa[8], wb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float2 a = cmul(za[q], tw[q]), b = cmul(zb[q], tw[q]);
+        za[q].x = a.x;
+        wa[q] = -a.y;
+        zb[q].x = b.x;
+        wb[q] = -b.y;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#ifndef VPZ_DUAL_MIRROR_VALU  // (-DVPZ_DUAL_MIRROR_VALU: lane_mirror64_x2, measured equal -- profiles/r5_ab_lds_diet.txt)
+        const float ha = lane_mirror64(wa[7 - q], lane), hb = lane_mirror64(wb[7 - q], lane);
+#else
+        float ha, hb;
+        lane_mirror64_x2(wa[7 - q], wb[7 - q], ha, hb);
+#endif
         scratch_a[lane + 64 * q] = make_float2(za[q].x, ha);
         scratch_b[lane + 64 * q] = make_float2(zb[q].x, hb);
     }

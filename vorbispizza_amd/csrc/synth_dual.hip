@@ -486,6 +486,36 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     if (!active) return;  // the only workgroup barrier is behind us: waves run free from here
 
     const int half1 = a.size1 >> 1;
+#ifndef VPZ_DUAL_NO_SLOPE_REGS
+    // The steady state's window values -- the same eight 16-byte pieces of the long slope for every such frame of this lane -- are read
+    // ONCE here and kept in 32 registers: 8 KB less through the CU's LDS pipe per pass (it is ~70 % busy under this kernel and what bounds it)
+    float4 swl[4], swr[4];
+    {
+        const float4 *s4 = reinterpret_cast<const float4 *>(s_slope1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            swl[r] = s4[lane + 64 * r];
+            swr[r] = s4[255 - (lane + 64 * r)];
+        }
+    }
+#endif
+#ifndef VPZ_DUAL_NO_TW_REGS
+    // ... and the 2048-point transform's twiddles of this lane (22 entries of three tables, the same for every long block): 44 registers,
+    // 11 KB less through the LDS pipe per pass
+    // (the variants that keep the tail in registers as well -- see kTailRegs below -- leave the third set in LDS: 256 registers is all there is)
+#if defined(VPZ_DUAL_TAIL_REGS) && !defined(VPZ_DUAL_NO_SLOPE_REGS)
+    constexpr bool kBCRegs = kHasFloor || kPairs;
+#else
+    constexpr bool kBCRegs = true;
+#endif
+    float2 rtw[8], rtwAB[8], rtwBC[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        rtw[m] = s_twL[lane + 64 * m];
+        rtwAB[m] = s_twAB[64 * m + lane];
+        rtwBC[m] = kBCRegs ? s_twBC[8 * (lane & 7) + m] : make_float2(0.0f, 0.0f);
+    }
+#endif
     float *hL = s_work[wave][0], *hR = s_work[wave][1];
     float *tailL = s_tail[wave][0], *tailR = s_tail[wave][1];
     int prev_n4 = 0;  // n/4 of the previous block (0: none yet)
@@ -493,6 +523,34 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
     const bool defer = run.pre_kind == kPreNeighbour && run.count > 0 && wave > 0;
     float4 stashL0, stashL1, stashR0, stashR1;  // h[0:512) of the deferred frame, both channels
     stashL0 = stashL1 = stashR0 = stashR1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // The tail of a 2048 block in REGISTERS (no-floor stereo variants: they have the room): lane l keeps 16-byte pieces l and l + 64 of
+    // both channels' tails -- what the steady state's first two output rounds read as they are and its last two mirrored (lane 63 - l's
+    // pieces) --, so a steady frame neither writes its tail to LDS nor reads the previous one from there: 12 KB less through the LDS pipe
+    // per pass.  Everything else (other geometries, short blocks, the neighbour's hand-over, the saved state) wants the rows in LDS:
+    // flush_tail() puts them there first.
+    // MEASURED AND NOT ADOPTED (kernel time under rocprofv3, builds alternating, profiles/r5_ab_lds_diet.txt): 222.6-224.6 us with the
+    // tail in registers (and the third twiddle set back in LDS: 256 registers is all there is) against 219.2-220.5 without.
+    // -DVPZ_DUAL_TAIL_REGS builds it; bit-equal (tests/test_dual_gpu.py, test_full_size_gpu.py under that build).
+#if defined(VPZ_DUAL_TAIL_REGS) && !defined(VPZ_DUAL_NO_SLOPE_REGS)
+    constexpr bool kTailRegs = !kHasFloor && !kPairs;
+#else
+    constexpr bool kTailRegs = false;
+#endif
+    float4 tl0, tl1, tr0, tr1;
+    tl0 = tl1 = tr0 = tr1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    bool tail_regs = false;  // (wave-uniform) the current tail is in tl0 .. tr1 and NOT in s_tail
+    auto flush_tail = [&]() {
+        if (!kTailRegs || !tail_regs) return;
+        int lq = lane;
+        asm volatile("" : "+v"(lq));
+        float4 *dl = reinterpret_cast<float4 *>(tailL), *dr = reinterpret_cast<float4 *>(tailR);
+        dl[lq] = tl0;
+        dl[lq + 64] = tl1;
+        dr[lq] = tr0;
+        dr[lq + 64] = tr1;
+        __builtin_amdgcn_wave_barrier();
+        tail_regs = false;
+    };
     bool published = false;
     auto publish = [&]() {  // this wave's s_tail rows hold the upper half of its run's last block from here on
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -861,7 +919,11 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
 #pragma unroll
                 for (int m = 0; m < 8; ++m) { h2L[ln + 64 * m] = xL[m]; h2R[ln + 64 * m] = xR[m]; }
             } else if (is_long) {
+#ifdef VPZ_DUAL_NO_TW_REGS
                 imdct2048_wave_x2(xL, xR, reinterpret_cast<float2 *>(hL), reinterpret_cast<float2 *>(hR), s_twL, s_twAB, s_twBC, ln);
+#else
+                imdct2048_wave_x2_regs<kBCRegs>(xL, xR, reinterpret_cast<float2 *>(hL), reinterpret_cast<float2 *>(hR), rtw, rtwAB, rtwBC, s_twBC, ln);
+#endif
             } else {
                 imdct256_wave8_x2(xL, xR, reinterpret_cast<float2 *>(hL), reinterpret_cast<float2 *>(hR), s_twS, s_twBC, ln);
             }
@@ -962,8 +1024,44 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         const float4 *tL4 = reinterpret_cast<const float4 *>(ptL), *tR4 = reinterpret_cast<const float4 *>(ptR);
         int lf = lane;
         asm volatile("" : "+v"(lf));  // (no address of the epilogue may be computed ahead of the frame loop)
+        const bool reg_steady = kTailRegs && tail_regs && !deferred_pass && !batch && fi >= 0 && !first_deferred && !drain && aligned &&
+                                is_long && (fd.flags & kFrameSlope1) && fd.left_start == 0 && fd.packet_len == 1024 && fd.prev_end == 1024 &&
+                                fd.out_count == 1024 && prev_n4 == 512 && a.size1 == 2048;
+        if (kTailRegs && tail_regs && !reg_steady && !deferred_pass && !first_deferred) flush_tail();  // (whoever reads the tail below reads LDS)
         if (VPZ_ABLATE(a) & 1) {
             // (tuning only: no window / overlap-add / stores)
+#ifndef VPZ_DUAL_NO_SLOPE_REGS
+        } else if (reg_steady) {
+            // the steady state with the previous tail in registers: rounds 0, 1 over this lane's own pieces, rounds 2, 3 over lane
+            // 63 - l's (tL4[255 - g] = piece 127 - l, 63 - l); same operations and operands as the LDS form below
+            float4 ml1, mr1, ml0, mr0;
+            lane_mirror64_x2(tl1.x, tr1.x, ml1.x, mr1.x);
+            lane_mirror64_x2(tl1.y, tr1.y, ml1.y, mr1.y);
+            lane_mirror64_x2(tl1.z, tr1.z, ml1.z, mr1.z);
+            lane_mirror64_x2(tl1.w, tr1.w, ml1.w, mr1.w);
+            lane_mirror64_x2(tl0.x, tr0.x, ml0.x, mr0.x);
+            lane_mirror64_x2(tl0.y, tr0.y, ml0.y, mr0.y);
+            lane_mirror64_x2(tl0.z, tr0.z, ml0.z, mr0.z);
+            lane_mirror64_x2(tl0.w, tr0.w, ml0.w, mr0.w);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int g = lf + 64 * r;
+                const float4 wl = swl[r], wr = swr[r];
+                if (r < 2) {
+                    const float4 hl = hL4[127 - g], hr = hR4[127 - g];
+                    const float4 pl = r == 0 ? tl0 : tl1, pr = r == 0 ? tr0 : tr1;
+                    emit4(g, ola(-hl.w, wl.x, pl.x, wr.w), ola(-hl.z, wl.y, pl.y, wr.z), ola(-hl.y, wl.z, pl.z, wr.y),
+                          ola(-hl.x, wl.w, pl.w, wr.x), ola(-hr.w, wl.x, pr.x, wr.w), ola(-hr.z, wl.y, pr.y, wr.z),
+                          ola(-hr.y, wl.z, pr.z, wr.y), ola(-hr.x, wl.w, pr.w, wr.x));
+                } else {
+                    const float4 hl = hL4[g - 128], hr = hR4[g - 128];
+                    const float4 pl = r == 2 ? ml1 : ml0, pr = r == 2 ? mr1 : mr0;
+                    emit4(g, ola(hl.x, wl.x, pl.w, wr.w), ola(hl.y, wl.y, pl.z, wr.z), ola(hl.z, wl.z, pl.y, wr.y),
+                          ola(hl.w, wl.w, pl.x, wr.x), ola(hr.x, wl.x, pr.w, wr.w), ola(hr.y, wl.y, pr.z, wr.z),
+                          ola(hr.z, wl.z, pr.y, wr.y), ola(hr.w, wl.w, pr.x, wr.x));
+                }
+            }
+#endif
         } else if (batch && fi >= 0) {  // [census: cold]
             // ---- a batch of short blocks: 128 * bsz contiguous samples.  Sample i of block f is y_f[i] over the previous
             // block's y[128 + i] (both windows short): y_f[i] = -h_f[63 - i] (i < 64), h_f[i - 64] otherwise; the partner
@@ -1021,11 +1119,17 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 // long after long with long windows on both sides (the steady state of every stream): first half of the
                 // output = negated mirror of h[0:512) over the straight previous tail, second half = h[0:512) straight over
                 // the mirrored tail; the window values are read once for both channels
+#ifdef VPZ_DUAL_NO_SLOPE_REGS
                 const float4 *s4 = reinterpret_cast<const float4 *>(s_slope1);
+#endif
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int g = lf + 64 * r;
+#ifdef VPZ_DUAL_NO_SLOPE_REGS
                     const float4 wl = s4[g], wr = s4[255 - g];
+#else
+                    const float4 wl = swl[r], wr = swr[r];
+#endif
                     if (r < 2) {
                         const float4 hl = hL4[127 - g], pl = tL4[g], hr = hR4[127 - g], pr = tR4[g];
                         emit4(g, ola(-hl.w, wl.x, pl.x, wr.w), ola(-hl.z, wl.y, pl.y, wr.z), ola(-hl.y, wl.z, pl.z, wr.y),
@@ -1099,10 +1203,18 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                 const float4 *sl = reinterpret_cast<const float4 *>(hL + 512), *sr = reinterpret_cast<const float4 *>(hR + 512);
                 float4 *dl = reinterpret_cast<float4 *>(tailL), *dr = reinterpret_cast<float4 *>(tailR);
                 const float4 a0 = sl[lf], a1 = sl[lf + 64], b0 = sr[lf], b1 = sr[lf + 64];
-                dl[lf] = a0;
-                dl[lf + 64] = a1;
-                dr[lf] = b0;
-                dr[lf + 64] = b1;
+                if (kTailRegs && a.size1 == 2048) {  // (kept in registers; flush_tail() for whoever wants the rows)
+                    tl0 = a0;
+                    tl1 = a1;
+                    tr0 = b0;
+                    tr1 = b1;
+                    tail_regs = true;
+                } else {
+                    dl[lf] = a0;
+                    dl[lf + 64] = a1;
+                    dr[lf] = b0;
+                    dr[lf + 64] = b1;
+                }
             } else {
                 const int o = (batch ? 128 * (bsz - 1) : 0) + 64 + lf;  // (a batch: its last block)
                 const float tl = hL[o], tr = hR[o];
@@ -1112,7 +1224,10 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
             prev_n4 = n4;
             __builtin_amdgcn_wave_barrier();
         }
-        if (it + 1 == iters_real) publish();  // the run's last tail is in place: the next wave of the workgroup may overlap with it
+        if (it + 1 == iters_real) {  // the run's last tail is in place (in LDS): the next wave of the workgroup may overlap with it
+            flush_tail();
+            publish();
+        }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             va[m] = na[m];
