@@ -236,7 +236,13 @@ static int arena_begin(Context *ctx, PinnedArena &A, size_t need)
         VPZ_HIP_TRY(ctx, hipEventSynchronize(A.uploaded));
         A.pending = false;
     }
-    if (!A.uploaded) VPZ_HIP_TRY(ctx, hipEventCreateWithFlags(&A.uploaded, hipEventDisableTiming));
+    // (the event says "the arena's last readers are done", nothing about memory: without the system-scope fence a default event
+    // carries -- a write-back and invalidation of the device's caches behind every call -- the next call's kernels follow this
+    // call's without that pause; VPZ_ARENA_EVENT_FENCE=1 restores the default event for A/B runs)
+    if (!A.uploaded) {
+        static const bool fence = getenv("VPZ_ARENA_EVENT_FENCE") && atoi(getenv("VPZ_ARENA_EVENT_FENCE"));
+        VPZ_HIP_TRY(ctx, hipEventCreateWithFlags(&A.uploaded, hipEventDisableTiming | (fence ? 0u : (unsigned)hipEventDisableSystemFence)));
+    }
     if (A.cap < need) {
         if (A.base) VPZ_HIP_TRY(ctx, hipHostFree(A.base));
         A.base = nullptr;
@@ -2420,8 +2426,14 @@ static int synth_impl(vpz_decoder *d, int64_t n_packets, const vpz_packet *packe
     if ((rc = call.stage_inputs()) != VPZ_OK) return rc;
     if ((rc = call.launch()) != VPZ_OK) return rc;
     if (call.zero_copy) {  // the kernels read the arena itself: it is free again when they are done
-        VPZ_HIP_TRY(ctx, hipEventRecord(call.A->uploaded, ctx->stream));
-        call.A->pending = true;
+#ifdef VPZ_TUNING  // (timing experiments only, WRONG in general: no event behind the call -- what does the queue's barrier packet cost?)
+        static const bool no_event = getenv("VPZ_UNSAFE_NO_ARENA_EVENT") != nullptr;
+        if (!no_event)
+#endif
+        {
+            VPZ_HIP_TRY(ctx, hipEventRecord(call.A->uploaded, ctx->stream));
+            call.A->pending = true;
+        }
     }
     if ((rc = call.copy_back()) != VPZ_OK) return rc;
     early_guard.completed = mem_space == VPZ_MEM_HOST;  // (copy_back has waited for the stream)
