@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
                               (int)(uint32_t)cs, (int)(uint32_t)(cs >> 32), a.clip};
 #pragma unroll
         for (int i = 0; i < 17; ++i)
-            if (kPairs || i < 8 || i >= 13) kv = lane == i ? vals[i] : kv;
+            if (kPairs || i < 8 || i >= 14) kv = lane == i ? vals[i] : kv;
         asm volatile("" : "+v"(kv));
     }
     // (pairs: the block sizes come from the parked values as well -- the frame loop has no scalar register to keep them in)
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
         const int nblk = size_of(fd.flags);
         const bool is_long = nblk == 2048;
         const int n4 = is_long ? 512 : 64;
-        const bool no_floor = !kHasFloor || (fd.flags & kFrameNoFloor) || __builtin_amdgcn_readlane(kv, 13) == 0;  // (a.ccount == nullptr, parked)
+        const bool no_floor = !kHasFloor || (fd.flags & kFrameNoFloor) || (kPairs ? __builtin_amdgcn_readlane(kv, 13) == 0 : a.ccount == nullptr);
         const int slot = fi - fi0;
         // ABI v4: point groups m >= 8 - skip lie beyond the residue's support -- zeros by the setup header's word (their loads
         // stay: the vector is in memory with its zeros; what is saved is the arithmetic).  Halves are all this path looks at.
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(kDualThreads, kDualWavesPerSimd) void synth_dual_ke
 #pragma unroll
                     for (int f = 0; f < 8; ++f) {
                         const int ff = f < bsz ? f : 0;
-                        const int32_t *posts = (const int32_t *)parked64(4);  // (a.cposts: a floored frame has them)
+                        const int32_t *posts = kPairs ? (const int32_t *)parked64(4) : a.cposts;
                         cps[f][0] = posts[(size_t)(fd.rec + nC() * ff + cA()) * 64 + ln];
                         cps[f][1] = posts[(size_t)(fd.rec + nC() * ff + cB()) * 64 + ln];
                     }
